@@ -1,0 +1,305 @@
+/*
+ * CPU oracle (test infrastructure only, see orc_common.h) for the per-token
+ * glue operators of the decode path: RMSNorm, RoPE, SiLU*mul, argmax, KV-cache
+ * scatter, FP8 e4m3 codec and paged-attention decode.
+ *
+ * Follows:
+ *   crates/core/kernels/layernorm.cu:59-129,232-270   rms_norm_bf16 / fused_add_rms_norm_bf16
+ *   crates/core/kernels/rope.cu:18-114                 rotary_embedding_neox_bf16
+ *   crates/core/kernels/activations.cu:33-35,148-164   silu, silu_and_mul_separate_bf16
+ *   crates/core/kernels/sampling.cu:47-94              argmax_bf16
+ *   crates/core/kernels/cache_ops.cu:28-62             reshape_and_cache_bf16
+ *   crates/core/kernels/paged_attention.cu:558-954     paged_attention_v2 + reduce
+ *   crates/core/src/kv_cache/quantization.rs:287-303,408-452  FP8 quantise / CPU codec
+ * The reference holds no golden vectors for these operators (only shape and
+ * self-consistency tests), so apart from the FP8 known answers
+ * (kv_cache/quantization.rs:654-692) parity here is "unpinned": the oracle is a
+ * line-by-line restatement of the kernels' arithmetic in f32.
+ */
+#include "orc_common.h"
+#include <float.h>
+#include <stdlib.h>
+
+/* out = bf16(x * inv_rms * w), inv_rms = 1/sqrt(sum(x^2)/H + eps); gemma_plus_one
+ * selects the (1 + w) weight convention of Gemma (layers/normalization.rs:17-205). */
+void orc_rms_norm_bf16(const uint16_t *x, const uint16_t *w, float eps, int64_t tokens, int64_t H,
+                       int gemma_plus_one, uint16_t *out) {
+    for (int64_t t = 0; t < tokens; t++) {
+        const uint16_t *xr = x + t * H;
+        float var = 0.0f;
+        for (int64_t i = 0; i < H; i++) {
+            float v = orc_bf16_to_f32(xr[i]);
+            var += v * v;
+        }
+        float inv = 1.0f / sqrtf(var / (float)H + eps);
+        for (int64_t i = 0; i < H; i++) {
+            float wv = w ? orc_bf16_to_f32(w[i]) : 1.0f;
+            if (gemma_plus_one) wv = 1.0f + wv;
+            out[t * H + i] = orc_f32_to_bf16(orc_bf16_to_f32(xr[i]) * inv * wv);
+        }
+    }
+}
+
+/* residual = bf16(residual + x); out = bf16(residual * inv_rms * w); the variance
+ * is taken over the unrounded f32 sums (layernorm.cu:246-251). */
+void orc_fused_add_rms_norm_bf16(const uint16_t *x, uint16_t *residual, const uint16_t *w, float eps,
+                                 int64_t tokens, int64_t H, uint16_t *out) {
+    for (int64_t t = 0; t < tokens; t++) {
+        float var = 0.0f;
+        for (int64_t i = 0; i < H; i++) {
+            float r = orc_bf16_to_f32(residual[t * H + i]) + orc_bf16_to_f32(x[t * H + i]);
+            residual[t * H + i] = orc_f32_to_bf16(r);
+            var += r * r;
+        }
+        float inv = 1.0f / sqrtf(var / (float)H + eps);
+        for (int64_t i = 0; i < H; i++) {
+            float r = orc_bf16_to_f32(residual[t * H + i]);
+            out[t * H + i] = orc_f32_to_bf16(r * inv * orc_bf16_to_f32(w[i]));
+        }
+    }
+}
+
+/* NeoX RoPE in place on [tokens, heads, head_size] bf16; cos_sin [max_pos, rot_dim]
+ * f32 = cos[rot/2] then sin[rot/2]. */
+void orc_rope_neox_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin,
+                        int64_t tokens, int rot_dim, int head_size, int n_heads, int n_kv_heads) {
+    int half = rot_dim / 2;
+    for (int64_t t = 0; t < tokens; t++) {
+        const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
+        for (int pass = 0; pass < 2; pass++) {
+            uint16_t *base = pass == 0 ? q : k;
+            int nh = pass == 0 ? n_heads : n_kv_heads;
+            if (!base) continue;
+            for (int h = 0; h < nh; h++) {
+                uint16_t *a = base + (t * nh + h) * head_size;
+                for (int i = 0; i < half; i++) {
+                    float xv = orc_bf16_to_f32(a[i]), yv = orc_bf16_to_f32(a[half + i]);
+                    float c = cs[i], s = cs[half + i];
+                    a[i] = orc_f32_to_bf16(xv * c - yv * s);
+                    a[half + i] = orc_f32_to_bf16(yv * c + xv * s);
+                }
+            }
+        }
+    }
+}
+
+void orc_silu_and_mul_bf16(const uint16_t *gate, const uint16_t *up, int64_t n, uint16_t *out) {
+    for (int64_t i = 0; i < n; i++) {
+        float g = orc_bf16_to_f32(gate[i]), u = orc_bf16_to_f32(up[i]);
+        float s = g / (1.0f + expf(-g));
+        out[i] = orc_f32_to_bf16(s * u);
+    }
+}
+
+/* argmax per row; ties: the reference's merge keeps the incumbent on equality and
+ * its order over threads is unspecified, so only the VALUE is comparable on ties.
+ * This returns the first index of the maximum. */
+void orc_argmax_bf16(const uint16_t *logits, int64_t rows, int64_t vocab, int32_t *out_idx) {
+    for (int64_t r = 0; r < rows; r++) {
+        float best = -FLT_MAX;
+        int32_t bi = 0;
+        for (int64_t i = 0; i < vocab; i++) {
+            float v = orc_bf16_to_f32(logits[r * vocab + i]);
+            if (v > best) { best = v; bi = (int32_t)i; }
+        }
+        out_idx[r] = bi;
+    }
+}
+
+/* ---- FP8 e4m3fn ---- */
+float orc_fp8_e4m3_decode(uint8_t b) {
+    int sign = b & 0x80, exp = (b >> 3) & 0xF, man = b & 7;
+    float v;
+    if (exp == 0xF && man == 7) v = NAN;
+    else if (exp == 0) v = ldexpf((float)man / 8.0f, -6);
+    else v = ldexpf(1.0f + (float)man / 8.0f, exp - 7);
+    return sign ? -v : v;
+}
+
+/* Round-to-nearest-even, saturating to +-448 (the hardware conversion the GPU
+ * path uses: crates/core/kernels/fp8_quant.cu static quant). */
+uint8_t orc_fp8_e4m3_encode_rne(float f) {
+    uint8_t sign = signbit(f) ? 0x80 : 0;
+    float a = fabsf(f);
+    if (isnan(a)) return (uint8_t)(sign | 0x7F);
+    if (a >= 448.0f) return (uint8_t)(sign | 0x7E);
+    if (a < ldexpf(1.0f, -10)) { /* below half the smallest subnormal (2^-9): 0, tie 2^-10 -> even 0 */
+        return sign;
+    }
+    int e;
+    float m = frexpf(a, &e); /* a = m * 2^e, m in [0.5,1) */
+    int exp = e - 1;         /* a = (2m) * 2^exp, 2m in [1,2) */
+    if (exp < -6) {          /* subnormal: units of 2^-9 */
+        float q = a * 512.0f;
+        float r = nearbyintf(q); /* RNE in default rounding mode */
+        int qi = (int)r;
+        if (qi >= 8) return (uint8_t)(sign | 0x08);
+        return (uint8_t)(sign | qi);
+    }
+    float frac = (2.0f * m - 1.0f) * 8.0f; /* in [0,8) */
+    int qi = (int)nearbyintf(frac);
+    int be = exp + 7;
+    if (qi == 8) { qi = 0; be++; }
+    if (be > 15 || (be == 15 && qi == 7)) return (uint8_t)(sign | 0x7E);
+    return (uint8_t)(sign | (be << 3) | qi);
+}
+
+/* The reference's CPU encoder (mantissa truncation, kv_cache/quantization.rs:408-430). */
+uint8_t orc_fp8_e4m3_encode_trunc(float val) {
+    if (val == 0.0f) return 0;
+    uint8_t sign = val < 0.0f ? 0x80 : 0;
+    float a = fabsf(val);
+    if (a > 448.0f) a = 448.0f;
+    if (a < 1.0f / 512.0f) return sign;
+    uint32_t bits;
+    memcpy(&bits, &a, 4);
+    int e = (int)((bits >> 23) & 0xFF) - 127 + 7;
+    if (e < 0) e = 0;
+    if (e > 15) e = 15;
+    return (uint8_t)(sign | (e << 3) | ((bits & 0x7FFFFF) >> 20));
+}
+
+/* KV FP8 store as the GPU path does it: f32(x)/scale, clamp +-448, round to bf16,
+ * then bf16 -> e4m3 RNE (cache_engine.rs:202-223, quantization.rs:287-303,459-473). */
+uint8_t orc_kv_fp8_quant(uint16_t x_bf16, float scale) {
+    float v = orc_bf16_to_f32(x_bf16) / scale;
+    if (v > 448.0f) v = 448.0f;
+    if (v < -448.0f) v = -448.0f;
+    return orc_fp8_e4m3_encode_rne(orc_round_bf16(v));
+}
+
+/* Scatter K/V rows [tokens, kv_heads*head_dim] into the paged cache
+ * [blocks, block_size, kv_heads, head_dim]; slot < 0 skips.  kv_dtype 0 = bf16
+ * copy, 1 = FP8 e4m3 with per-tensor scales. */
+void orc_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
+                           const int32_t *slots, int64_t tokens, int kv_heads, int head_dim,
+                           int block_size, int kv_dtype, float k_scale, float v_scale) {
+    int64_t row = (int64_t)kv_heads * head_dim;
+    for (int64_t t = 0; t < tokens; t++) {
+        int32_t slot = slots[t];
+        if (slot < 0) continue;
+        int64_t dst = (int64_t)slot * row; /* block*bs*row + off*row == slot*row */
+        (void)block_size;
+        for (int64_t i = 0; i < row; i++) {
+            if (kv_dtype == 0) {
+                ((uint16_t *)k_cache)[dst + i] = key[t * row + i];
+                ((uint16_t *)v_cache)[dst + i] = value[t * row + i];
+            } else {
+                ((uint8_t *)k_cache)[dst + i] = orc_kv_fp8_quant(key[t * row + i], k_scale);
+                ((uint8_t *)v_cache)[dst + i] = orc_kv_fp8_quant(value[t * row + i], v_scale);
+            }
+        }
+    }
+}
+
+static inline float kv_load(const void *cache, int64_t idx, int kv_dtype, float scale) {
+    if (kv_dtype == 0) return orc_bf16_to_f32(((const uint16_t *)cache)[idx]);
+    return orc_fp8_e4m3_decode(((const uint8_t *)cache)[idx]) * scale;
+}
+
+/* Paged-attention decode, V2 structure: per (seq, head) the window
+ * [start, seq_len) is cut into partitions of partition_size tokens, each
+ * normalised locally with 1/(sum + 1e-6), then merged with the log-sum-exp
+ * rule and a second 1/(sum + 1e-6) (paged_attention.cu:750-953).  A single
+ * partition is copied through unchanged (:846-855).  out is bf16. */
+void orc_paged_attention_v2(const uint16_t *q, const void *k_cache, const void *v_cache,
+                            const int32_t *block_tables, const int32_t *seq_lens, float scale,
+                            int64_t num_seqs, int num_heads, int num_kv_heads, int max_blocks_per_seq,
+                            int head_dim, int block_size, int partition_size, int window, int kv_dtype,
+                            float k_scale, float v_scale, uint16_t *out) {
+    int qpk = num_heads / num_kv_heads;
+    int64_t tok_stride = (int64_t)num_kv_heads * head_dim;
+    for (int64_t s = 0; s < num_seqs; s++) {
+        int seq_len = seq_lens[s];
+        if (seq_len == 0) continue;
+        int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
+        int eff = seq_len - start;
+        int nparts = (eff + partition_size - 1) / partition_size;
+        for (int h = 0; h < num_heads; h++) {
+            int kvh = h / qpk;
+            const uint16_t *qv = q + (s * num_heads + h) * head_dim;
+            float *logits = (float *)malloc(sizeof(float) * (size_t)partition_size);
+            float gmax = -FLT_MAX;
+            float *all_max = (float *)malloc(sizeof(float) * (size_t)nparts);
+            float *all_sum = (float *)malloc(sizeof(float) * (size_t)nparts);
+            float *all_tmp = (float *)malloc(sizeof(float) * (size_t)nparts * head_dim);
+            for (int p = 0; p < nparts; p++) {
+                int t0 = start + p * partition_size;
+                int t1 = t0 + partition_size < seq_len ? t0 + partition_size : seq_len;
+                float m = -FLT_MAX;
+                for (int t = t0; t < t1; t++) {
+                    int blk = block_tables[s * max_blocks_per_seq + t / block_size];
+                    int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * head_dim;
+                    float qk = 0.0f;
+                    for (int d = 0; d < head_dim; d++)
+                        qk += orc_bf16_to_f32(qv[d]) * kv_load(k_cache, base + d, kv_dtype, k_scale);
+                    float l = qk * scale;
+                    logits[t - t0] = l;
+                    if (l > m) m = l;
+                }
+                float sum = 0.0f;
+                for (int t = t0; t < t1; t++) {
+                    float e = expf(logits[t - t0] - m);
+                    logits[t - t0] = e;
+                    sum += e;
+                }
+                float inv = 1.0f / (sum + 1e-6f);
+                for (int d = 0; d < head_dim; d++) {
+                    float a = 0.0f;
+                    for (int t = t0; t < t1; t++) {
+                        int blk = block_tables[s * max_blocks_per_seq + t / block_size];
+                        int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * head_dim;
+                        a += (logits[t - t0] * inv) * kv_load(v_cache, base + d, kv_dtype, v_scale);
+                    }
+                    all_tmp[(int64_t)p * head_dim + d] = a;
+                }
+                all_max[p] = m;
+                all_sum[p] = sum;
+                if (m > gmax) gmax = m;
+            }
+            uint16_t *o = out + (s * num_heads + h) * head_dim;
+            if (nparts == 1) {
+                for (int d = 0; d < head_dim; d++) o[d] = orc_f32_to_bf16(all_tmp[d]);
+            } else {
+                float gsum = 0.0f;
+                for (int p = 0; p < nparts; p++) {
+                    all_sum[p] = all_sum[p] * expf(all_max[p] - gmax);
+                    gsum += all_sum[p];
+                }
+                float inv = 1.0f / (gsum + 1e-6f);
+                for (int d = 0; d < head_dim; d++) {
+                    float a = 0.0f;
+                    for (int p = 0; p < nparts; p++) a += all_tmp[(int64_t)p * head_dim + d] * all_sum[p];
+                    o[d] = orc_f32_to_bf16(a * inv);
+                }
+            }
+            free(all_tmp); free(all_sum); free(all_max); free(logits);
+        }
+    }
+}
+
+/* Q6_K super-block (210 B / 256 weights): ql[128], qh[64], scales i8[16], f16 d
+ * (crates/core/kernels/gather_dequant.cu:52-82). */
+void orc_q6k_dequant(const uint8_t *data, int64_t n_blocks, float *out) {
+    for (int64_t b = 0; b < n_blocks; b++) {
+        const uint8_t *blk = data + b * 210;
+        const uint8_t *ql = blk, *qh = blk + 128;
+        const int8_t *sc = (const int8_t *)(blk + 192);
+        float d = orc_f16_to_f32((uint16_t)(blk[208] | (blk[209] << 8)));
+        float *y = out + b * 256;
+        for (int half = 0; half < 2; half++) {
+            for (int l = 0; l < 32; l++) {
+                int is = l / 16;
+                int q1 = (int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                int q2 = (int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                int q4 = (int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                y[l] = d * (float)sc[is] * (float)q1;
+                y[l + 32] = d * (float)sc[is + 2] * (float)q2;
+                y[l + 64] = d * (float)sc[is + 4] * (float)q3;
+                y[l + 96] = d * (float)sc[is + 6] * (float)q4;
+            }
+            y += 128; ql += 64; qh += 32; sc += 8;
+        }
+    }
+}

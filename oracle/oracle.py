@@ -1,0 +1,302 @@
+"""ctypes front-end of the CPU oracle (oracle/_build/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg.  Nothing under vllm_rust_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "liborc.so"
+
+IQ_TYPES = {"iq2_xs": 17, "iq3_xxs": 18, "iq3_s": 21, "iq2_s": 22, "iq4_xs": 23}
+IQ_TYPE_SIZE = {17: 74, 22: 82, 18: 98, 21: 110, 23: 136}
+
+
+def build() -> Path:
+    """Compile the oracle with gcc (no GPU toolchain involved)."""
+    subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def _load() -> C.CDLL:
+    if not _LIB_PATH.exists():
+        build()
+    return C.CDLL(str(_LIB_PATH))
+
+
+_lib = _load()
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+for _name, _res, _args in [
+    ("orc_iq_type_size", C.c_int, [C.c_int]),
+    ("orc_iq_dequant", C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_iq_subdots", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_quantize_q8_1", None, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("orc_iq_mmvq_q8", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_iq_mmvq_q8_mt", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_awq_to_gptq_u32", C.c_uint32, [C.c_uint32]),
+    ("orc_repack_awq_nibbles", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_awq_to_gptq_qweight", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_int4_dequant", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_int4_gemv_f32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_int4_gemv_bf16", C.c_int, [C.c_void_p] * 5 + [C.c_int64] * 4 + [C.c_void_p]),
+    ("orc_f32_to_bf16_array", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_bf16_to_f32_array", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_f32_to_f16_array", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_f16_to_f32_array", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_rms_norm_bf16", None, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    ("orc_fused_add_rms_norm_bf16", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_rope_neox_bf16", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("orc_silu_and_mul_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_argmax_bf16", None, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_fp8_e4m3_decode", C.c_float, [C.c_uint8]),
+    ("orc_fp8_e4m3_encode_rne", C.c_uint8, [C.c_float]),
+    ("orc_fp8_e4m3_encode_trunc", C.c_uint8, [C.c_float]),
+    ("orc_kv_fp8_quant", C.c_uint8, [C.c_uint16, C.c_float]),
+    ("orc_reshape_and_cache", None, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
+    ("orc_paged_attention_v2", None, [C.c_void_p] * 5 + [C.c_float, C.c_int64] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
+    ("orc_q6k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+]:
+    _f = getattr(_lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+# ---------------------------------------------------------------- conversions
+def f32_to_bf16(x) -> np.ndarray:
+    x = _c(x, np.float32)
+    out = np.empty(x.shape, np.uint16)
+    _lib.orc_f32_to_bf16_array(_p(x), x.size, _p(out))
+    return out
+
+
+def bf16_to_f32(x) -> np.ndarray:
+    x = _c(x, np.uint16)
+    out = np.empty(x.shape, np.float32)
+    _lib.orc_bf16_to_f32_array(_p(x), x.size, _p(out))
+    return out
+
+
+def f32_to_f16(x) -> np.ndarray:
+    x = _c(x, np.float32)
+    out = np.empty(x.shape, np.uint16)
+    _lib.orc_f32_to_f16_array(_p(x), x.size, _p(out))
+    return out
+
+
+def f16_to_f32(x) -> np.ndarray:
+    x = _c(x, np.uint16)
+    out = np.empty(x.shape, np.float32)
+    _lib.orc_f16_to_f32_array(_p(x), x.size, _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- I-quants
+def iq_dequant(ggml_type: int, data) -> np.ndarray:
+    data = _c(data, np.uint8).reshape(-1)
+    ts = IQ_TYPE_SIZE[ggml_type]
+    assert data.size % ts == 0
+    nb = data.size // ts
+    out = np.empty(nb * 256, np.float32)
+    rc = _lib.orc_iq_dequant(ggml_type, _p(data), nb, _p(out))
+    assert rc == 0
+    return out
+
+
+def quantize_q8_1(x):
+    x = _c(x, np.float32)
+    m, n_in = x.shape
+    assert n_in % 32 == 0
+    aq = np.empty((m, n_in), np.int8)
+    ad = np.empty((m, n_in // 32), np.float32)
+    _lib.orc_quantize_q8_1(_p(x), m, n_in, _p(aq), _p(ad))
+    return aq, ad
+
+
+def iq_subdots(ggml_type: int, w, aq, n_out: int, n_in: int) -> np.ndarray:
+    w = _c(w, np.uint8).reshape(-1)
+    aq = _c(aq, np.int8)
+    m = aq.shape[0]
+    out = np.empty((n_out, m, n_in // 32), np.int32)
+    rc = _lib.orc_iq_subdots(ggml_type, _p(w), _p(aq), n_out, n_in, m, _p(out))
+    assert rc == 0
+    return out
+
+
+def iq_mmvq_q8(ggml_type: int, w, aq, ad, n_out: int, n_in: int, threads: bool = False) -> np.ndarray:
+    w = _c(w, np.uint8).reshape(-1)
+    aq = _c(aq, np.int8)
+    ad = _c(ad, np.float32)
+    m = aq.shape[0]
+    y = np.empty((m, n_out), np.float32)
+    fn = _lib.orc_iq_mmvq_q8_mt if threads else _lib.orc_iq_mmvq_q8
+    rc = fn(ggml_type, _p(w), _p(aq), _p(ad), n_out, n_in, m, _p(y))
+    assert rc == 0
+    return y
+
+
+def iq_matmul(ggml_type: int, w, x, n_out: int, n_in: int) -> np.ndarray:
+    """q8_1_mmvq_cpu: quantise X to q8_1, integer dots, f32 accumulate."""
+    aq, ad = quantize_q8_1(np.asarray(x, np.float32).reshape(-1, n_in))
+    return iq_mmvq_q8(ggml_type, w, aq, ad, n_out, n_in)
+
+
+# ---------------------------------------------------------------- int4 (AWQ / GPTQ)
+def awq_to_gptq_u32(w: int) -> int:
+    return int(_lib.orc_awq_to_gptq_u32(w & 0xFFFFFFFF))
+
+
+def repack_awq_nibbles(words) -> np.ndarray:
+    words = _c(words, np.uint32)
+    out = np.empty_like(words)
+    _lib.orc_repack_awq_nibbles(_p(words), words.size, _p(out))
+    return out
+
+
+def awq_to_gptq_qweight(awq, K: int, N: int) -> np.ndarray:
+    awq = _c(awq, np.uint32)
+    assert awq.shape == (K, N // 8)
+    out = np.empty((K // 8, N), np.uint32)
+    rc = _lib.orc_awq_to_gptq_qweight(_p(awq), K, N, _p(out))
+    assert rc == 0
+    return out
+
+
+def int4_dequant(qweight, scales_f32, qzeros, K: int, N: int, group: int) -> np.ndarray:
+    qweight = _c(qweight, np.uint32)
+    scales_f32 = _c(scales_f32, np.float32)
+    qz = _c(qzeros, np.uint32) if qzeros is not None else None
+    w = np.empty((K, N), np.float32)
+    rc = _lib.orc_int4_dequant(_p(qweight), _p(scales_f32), _p(qz) if qz is not None else None, K, N, group, _p(w))
+    assert rc == 0
+    return w
+
+
+def int4_gemv_f32(x, qweight, scales_f32, qzeros, K: int, N: int, group: int) -> np.ndarray:
+    x = _c(x, np.float32).reshape(-1, K)
+    qweight = _c(qweight, np.uint32)
+    scales_f32 = _c(scales_f32, np.float32)
+    qz = _c(qzeros, np.uint32) if qzeros is not None else None
+    y = np.empty((x.shape[0], N), np.float32)
+    rc = _lib.orc_int4_gemv_f32(_p(x), _p(qweight), _p(scales_f32), _p(qz) if qz is not None else None,
+                                x.shape[0], K, N, group, _p(y))
+    assert rc == 0
+    return y
+
+
+def int4_gemv_bf16(x_bf16, qweight, scales_bf16, qzeros, bias_bf16, K: int, N: int, group: int) -> np.ndarray:
+    x = _c(x_bf16, np.uint16).reshape(-1, K)
+    qweight = _c(qweight, np.uint32)
+    sc = _c(scales_bf16, np.uint16)
+    qz = _c(qzeros, np.uint32) if qzeros is not None else None
+    bs = _c(bias_bf16, np.uint16) if bias_bf16 is not None else None
+    y = np.empty((x.shape[0], N), np.uint16)
+    rc = _lib.orc_int4_gemv_bf16(_p(x), _p(qweight), _p(sc), _p(qz) if qz is not None else None,
+                                 _p(bs) if bs is not None else None, x.shape[0], K, N, group, _p(y))
+    assert rc == 0
+    return y
+
+
+# ---------------------------------------------------------------- glue ops
+def rms_norm_bf16(x_bf16, w_bf16, eps: float, gemma_plus_one: bool = False) -> np.ndarray:
+    x = _c(x_bf16, np.uint16)
+    tokens, H = x.shape
+    w = _c(w_bf16, np.uint16) if w_bf16 is not None else None
+    out = np.empty_like(x)
+    _lib.orc_rms_norm_bf16(_p(x), _p(w) if w is not None else None, eps, tokens, H, int(gemma_plus_one), _p(out))
+    return out
+
+
+def fused_add_rms_norm_bf16(x_bf16, residual_bf16, w_bf16, eps: float):
+    x = _c(x_bf16, np.uint16)
+    res = _c(residual_bf16, np.uint16).copy()
+    tokens, H = x.shape
+    w = _c(w_bf16, np.uint16)
+    out = np.empty_like(x)
+    _lib.orc_fused_add_rms_norm_bf16(_p(x), _p(res), _p(w), eps, tokens, H, _p(out))
+    return out, res
+
+
+def rope_neox_bf16(positions, q_bf16, k_bf16, cos_sin, rot_dim: int, head_size: int, n_heads: int, n_kv_heads: int):
+    pos = _c(positions, np.int32)
+    q = _c(q_bf16, np.uint16).copy()
+    k = _c(k_bf16, np.uint16).copy() if k_bf16 is not None else None
+    cs = _c(cos_sin, np.float32)
+    _lib.orc_rope_neox_bf16(_p(pos), _p(q), _p(k) if k is not None else None, _p(cs), pos.size, rot_dim, head_size,
+                            n_heads, n_kv_heads)
+    return q, k
+
+
+def silu_and_mul_bf16(gate_bf16, up_bf16) -> np.ndarray:
+    g = _c(gate_bf16, np.uint16)
+    u = _c(up_bf16, np.uint16)
+    out = np.empty_like(g)
+    _lib.orc_silu_and_mul_bf16(_p(g), _p(u), g.size, _p(out))
+    return out
+
+
+def argmax_bf16(logits_bf16) -> np.ndarray:
+    lg = _c(logits_bf16, np.uint16)
+    rows, vocab = lg.shape
+    out = np.empty(rows, np.int32)
+    _lib.orc_argmax_bf16(_p(lg), rows, vocab, _p(out))
+    return out
+
+
+def fp8_e4m3_decode(b: int) -> float:
+    return float(_lib.orc_fp8_e4m3_decode(b))
+
+
+def fp8_e4m3_encode_rne(v: float) -> int:
+    return int(_lib.orc_fp8_e4m3_encode_rne(v))
+
+
+def fp8_e4m3_encode_trunc(v: float) -> int:
+    return int(_lib.orc_fp8_e4m3_encode_trunc(v))
+
+
+def reshape_and_cache(key_bf16, value_bf16, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int,
+                      kv_dtype: int = 0, k_scale: float = 1.0, v_scale: float = 1.0) -> None:
+    key = _c(key_bf16, np.uint16)
+    val = _c(value_bf16, np.uint16)
+    sl = _c(slots, np.int32)
+    assert k_cache.flags.c_contiguous and v_cache.flags.c_contiguous
+    _lib.orc_reshape_and_cache(_p(key), _p(val), _p(k_cache), _p(v_cache), _p(sl), sl.size, kv_heads, head_dim,
+                               block_size, kv_dtype, k_scale, v_scale)
+
+
+def paged_attention_v2(q_bf16, k_cache, v_cache, block_tables, seq_lens, scale: float, num_heads: int,
+                       num_kv_heads: int, head_dim: int, block_size: int, partition_size: int, window: int = 0,
+                       kv_dtype: int = 0, k_scale: float = 1.0, v_scale: float = 1.0) -> np.ndarray:
+    q = _c(q_bf16, np.uint16)
+    bt = _c(block_tables, np.int32)
+    sl = _c(seq_lens, np.int32)
+    num_seqs = sl.size
+    out = np.zeros((num_seqs, num_heads * head_dim), np.uint16)
+    _lib.orc_paged_attention_v2(_p(q), _p(k_cache), _p(v_cache), _p(bt), _p(sl), scale, num_seqs, num_heads,
+                                num_kv_heads, bt.shape[1], head_dim, block_size, partition_size, window, kv_dtype,
+                                k_scale, v_scale, _p(out))
+    return out
+
+
+def q6k_dequant(data) -> np.ndarray:
+    data = _c(data, np.uint8).reshape(-1)
+    assert data.size % 210 == 0
+    nb = data.size // 210
+    out = np.empty(nb * 256, np.float32)
+    _lib.orc_q6k_dequant(_p(data), nb, _p(out))
+    return out

@@ -1,0 +1,104 @@
+"""FP8 known answers (kv_cache/quantization.rs:654-692) and self-checks of the
+glue-operator oracle against float64 numpy."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def test_fp8_known_answers():
+    assert orc.fp8_e4m3_encode_trunc(0.0) == 0 and orc.fp8_e4m3_decode(0) == 0.0
+    for enc in (orc.fp8_e4m3_encode_trunc, orc.fp8_e4m3_encode_rne):
+        assert orc.fp8_e4m3_decode(enc(1.0)) == 1.0
+        assert orc.fp8_e4m3_decode(enc(-2.0)) == -2.0
+        assert orc.fp8_e4m3_decode(enc(1000.0)) == 448.0        # clamp
+        assert orc.fp8_e4m3_decode(enc(-1000.0)) == -448.0
+
+
+def test_fp8_rne_exhaustive_round_trip_and_midpoints():
+    vals = [orc.fp8_e4m3_decode(b) for b in range(0x7F)]        # 0 .. 448, increasing
+    assert all(vals[i] < vals[i + 1] for i in range(len(vals) - 1))
+    for b, v in enumerate(vals):
+        assert orc.fp8_e4m3_encode_rne(v) == b
+        assert orc.fp8_e4m3_encode_rne(-v) == (b | 0x80)
+    for b in range(0x7E):
+        mid = (vals[b] + vals[b + 1]) / 2.0
+        assert orc.fp8_e4m3_encode_rne(mid) == (b if b % 2 == 0 else b + 1)   # ties to even
+        assert orc.fp8_e4m3_encode_rne(np.nextafter(np.float32(mid), np.float32(1e9))) == b + 1
+        assert orc.fp8_e4m3_encode_rne(np.nextafter(np.float32(mid), np.float32(-1e9))) == b
+
+
+def test_rms_norm_and_fused_add():
+    rng = np.random.default_rng(1)
+    x = orc.f32_to_bf16(rng.standard_normal((3, 256)).astype(np.float32))
+    w = orc.f32_to_bf16(rng.standard_normal(256).astype(np.float32))
+    out = orc.bf16_to_f32(orc.rms_norm_bf16(x, w, 1e-6))
+    xf, wf = orc.bf16_to_f32(x).astype(np.float64), orc.bf16_to_f32(w).astype(np.float64)
+    ref = xf / np.sqrt((xf ** 2).mean(-1, keepdims=True) + 1e-6) * wf
+    assert np.abs(out - ref).max() <= 2 ** -7 * np.abs(ref).max()
+    res = orc.f32_to_bf16(rng.standard_normal((3, 256)).astype(np.float32))
+    out2, res2 = orc.fused_add_rms_norm_bf16(x, res, w, 1e-6)
+    assert np.array_equal(res2, orc.f32_to_bf16(orc.bf16_to_f32(x) + orc.bf16_to_f32(res)))
+
+
+def test_rope_rotation_preserves_norm():
+    rng = np.random.default_rng(2)
+    T, H, KVH, D = 2, 4, 2, 64
+    q = orc.f32_to_bf16(rng.standard_normal((T, H * D)).astype(np.float32))
+    k = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    pos = np.array([3, 17], np.int32)
+    inv = 1.0 / (10000.0 ** (np.arange(0, D, 2) / D))
+    ang = np.arange(32)[:, None] * inv[None, :]
+    cs = np.concatenate([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
+    q2, k2 = orc.rope_neox_bf16(pos, q, k, cs, D, D, H, KVH)
+    n0 = np.linalg.norm(orc.bf16_to_f32(q).reshape(T, H, D), axis=-1)
+    n1 = np.linalg.norm(orc.bf16_to_f32(q2).reshape(T, H, D), axis=-1)
+    assert np.allclose(n0, n1, rtol=1e-2)
+
+
+def test_paged_attention_matches_dense_softmax():
+    rng = np.random.default_rng(3)
+    S, H, KVH, D, BS = 2, 4, 2, 64, 16
+    seq_lens = np.array([37, 150], np.int32)
+    nblk = 32
+    kc = orc.f32_to_bf16(rng.standard_normal((nblk, BS, KVH, D)).astype(np.float32))
+    vc = orc.f32_to_bf16(rng.standard_normal((nblk, BS, KVH, D)).astype(np.float32))
+    bt = np.stack([rng.permutation(nblk)[:10] for _ in range(S)]).astype(np.int32)
+    q = orc.f32_to_bf16(rng.standard_normal((S, H * D)).astype(np.float32))
+    scale = 1.0 / np.sqrt(D)
+    for window in (0, 64):
+        out = orc.bf16_to_f32(orc.paged_attention_v2(q, kc, vc, bt, seq_lens, scale, H, KVH, D, BS, 64, window))
+        kf, vf, qf = orc.bf16_to_f32(kc).astype(np.float64), orc.bf16_to_f32(vc).astype(np.float64), orc.bf16_to_f32(q).astype(np.float64)
+        for s in range(S):
+            L = int(seq_lens[s]); start = L - window if (window and L > window) else 0
+            toks = np.arange(start, L)
+            kk = kf[bt[s, toks // BS], toks % BS]; vv = vf[bt[s, toks // BS], toks % BS]
+            for h in range(H):
+                lg = kk[:, h // 2] @ qf[s, h * D:(h + 1) * D] * scale
+                p = np.exp(lg - lg.max()); p /= p.sum()
+                ref = p @ vv[:, h // 2]
+                assert np.abs(out[s, h * D:(h + 1) * D] - ref).max() <= 2e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_kv_fp8_cache_round_trip():
+    rng = np.random.default_rng(4)
+    KVH, D, BS = 2, 32, 16
+    k = orc.f32_to_bf16(rng.standard_normal((3, KVH * D)).astype(np.float32))
+    v = orc.f32_to_bf16(rng.standard_normal((3, KVH * D)).astype(np.float32))
+    kc = np.zeros((4, BS, KVH, D), np.uint8); vc = np.zeros_like(kc)
+    ks = float(np.abs(orc.bf16_to_f32(k)).max() * 1.5 / 448.0)
+    orc.reshape_and_cache(k, v, kc, vc, np.array([5, -1, 40], np.int32), KVH, D, BS, 1, ks, ks)
+    row = kc.reshape(-1, KVH * D)
+    dec = np.array([orc.fp8_e4m3_decode(int(b)) for b in row[5]], np.float32) * np.float32(ks)
+    assert np.abs(dec - orc.bf16_to_f32(k[0])).max() <= 0.07 * np.abs(orc.bf16_to_f32(k[0])).max()
+    assert not row[6].any() and row[40].any()
+
+
+def test_q6k_dequant_structure():
+    blk = np.zeros(210, np.uint8)
+    blk[192:208] = 1                       # scales = 1
+    blk[208:210] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+    out = orc.q6k_dequant(blk)
+    assert (out == -32.0).all()            # q = 0 - 32
+    blk[0] = 0x21; blk[128] = 0b00_01_00_11
+    out = orc.q6k_dequant(blk)
+    assert out[0] == (1 | (3 << 4)) - 32 and out[64] == (2 | (1 << 4)) - 32
