@@ -1,0 +1,170 @@
+/*
+ * libvmx -- MI355X (gfx950) quantized-inference hot path, C ABI.
+ *
+ * Every entry point takes raw device pointers, explicit shapes and a HIP
+ * stream (passed as void*, NULL = the null stream).  No entry point allocates,
+ * synchronises or reads device memory on the host unless its comment says so,
+ * so all "forward" calls may be captured into a hipGraph.  Return value: 0 on
+ * success, a negative VMX_E* code otherwise; vmx_last_error() returns a
+ * thread-local message for the last failure.  Nothing aborts.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative
+ * to the vasia123/vllm-rust tree).
+ */
+#ifndef VMX_H
+#define VMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMX_OK 0
+#define VMX_EINVAL (-1)   /* shape / dtype / alignment precondition violated */
+#define VMX_ELAUNCH (-2)  /* HIP runtime reported an error */
+#define VMX_ENOMEM (-3)   /* allocation failed (create/load-time calls only) */
+#define VMX_EUNSUPPORTED (-4)
+
+/* GGML tensor type ids accepted by the I-quant entry points
+ * (crates/core/src/quantization/gguf/iq/mod.rs:55-75). */
+#define VMX_GGML_IQ2_XS 17
+#define VMX_GGML_IQ3_XXS 18
+#define VMX_GGML_IQ3_S 21
+#define VMX_GGML_IQ2_S 22
+#define VMX_GGML_IQ4_XS 23
+
+/* Activation / storage dtypes. */
+#define VMX_F32 0
+#define VMX_BF16 1
+#define VMX_F16 2
+
+/* KV-cache dtypes (crates/core/src/kv_cache/quantization.rs:16). */
+#define VMX_KV_AUTO 0     /* same 16-bit type as the activations */
+#define VMX_KV_FP8_E4M3 1
+
+/* ------------------------------------------------------------------ runtime */
+
+/* Select `device` for the calling thread and load the code object.  Idempotent. */
+int vmx_init(int device);
+int vmx_abi_version(void);
+const char *vmx_last_error(void);
+
+/* ------------------------------------------------------------ GGUF I-quants */
+
+/* Bytes per 256-weight super-block, or -1 (iq/mod.rs:85-93). */
+int vmx_iq_type_size(int ggml_type);
+
+/* Replaces dequantize_iq{2_xs,2_s,3_xxs,3_s,4_xs}_f32
+ * (crates/core/kernels/iq_dequant.cu:182-194; launcher iq/mod.rs:382-436):
+ * n_blocks super-blocks -> n_blocks*256 f32. */
+int vmx_iq_dequantize_f32(int ggml_type, const void *blocks, float *out, int64_t n_blocks, void *stream);
+
+/* Replaces quantize_q8_1_rows (iq_dequant.cu:253-267; launcher iq/mod.rs:797-817):
+ * x f32 [total_blocks*32] -> aq int8 [total_blocks*32], ad f32 [total_blocks]. */
+int vmx_quantize_q8_1_rows(const float *x, int8_t *aq, float *ad, int64_t total_blocks, void *stream);
+
+/* Replaces mmvq_iq*_f32 (iq_dequant.cu:388-423; launcher iq/mod.rs:819-843):
+ * y[m, n_out] = sum_g w_d * a_d * int_dot.  Preconditions as the reference:
+ * 1 <= m <= 16, n_in % 256 == 0. */
+int vmx_iq_mmvq_f32(int ggml_type, const void *w, const int8_t *aq, const float *ad, float *y, int n_out,
+                    int n_in, int m, void *stream);
+
+/* Replaces iq_matmul / IqMatmulOp::cuda_fwd (iq/mod.rs:759-877): quantise x to
+ * q8_1 into `workspace`, then MMVQ.  workspace >= vmx_iq_matmul_workspace_bytes. */
+size_t vmx_iq_matmul_workspace_bytes(int n_in, int m);
+int vmx_iq_matmul_f32(int ggml_type, const void *w, const float *x, float *y, int n_out, int n_in, int m,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Parity aid: the integer sub-dots the MMVQ kernel accumulates,
+ * out[(o*m + mi)*(n_in/32) + g] (int32), for bit-exact comparison with
+ * cpu_dot_iq* (iq/mod.rs:556-658). */
+int vmx_iq_subdots_i32(int ggml_type, const void *w, const int8_t *aq, int32_t *out, int n_out, int n_in,
+                       int m, void *stream);
+
+/* Replaces gather_dequant_q6k_f32 (crates/core/kernels/gather_dequant.cu:31-83):
+ * out[i, :] = dequant(row ids[i]) of a Q6_K table [num_embeddings, dim];
+ * out-of-range ids leave zeros. */
+int vmx_gather_dequant_q6k_f32(const void *blocks, const int32_t *ids, float *out, int num_ids, int dim,
+                               int num_embeddings, void *stream);
+
+/* ------------------------------------------------------- AWQ / GPTQ int4 */
+
+/* Replaces awq_to_gptq_qweight_int4 (crates/core/kernels/marlin_gemm.cu:491;
+ * CPU form awq_marlin.rs:170-240): AWQ [K, N/8] -> GPTQ-sequential [K/8, N]. */
+int vmx_awq_to_gptq_qweight(const uint32_t *awq, uint32_t *out, int K, int N, void *stream);
+
+/* Replaces awq_marlin_repack_int4 used on qzeros (marlin_gemm.cu:431;
+ * awq_marlin.rs:126-151): per-word nibble reorder, shape preserved. */
+int vmx_awq_repack_nibbles(const uint32_t *in, uint32_t *out, int64_t n_words, void *stream);
+
+/* Load-time repack into the gfx950 tile stream consumed by vmx_int4_gemm_bf16.
+ * Takes the tensors exactly as the reference's MarlinLinear holds them after
+ * AwqMarlinLinear::load_weights (awq_marlin.rs:580-667) minus the final
+ * transpose: qweight GPTQ-sequential [K/8, N]; scales bf16 [K/group, N];
+ * qzeros [K/group, N/8] sequential nibbles, or NULL for the symmetric GPTQ
+ * zero point 8 (marlin_gemm.cu:43-48).  Needs K % 128 == 0, N % 16 == 0,
+ * group % 128 == 0 (or group == K).  `packed` needs vmx_int4_packed_bytes. */
+size_t vmx_int4_packed_bytes(int K, int N, int group);
+int vmx_int4_pack(const uint32_t *qweight, const uint16_t *scales_bf16, const uint32_t *qzeros, void *packed,
+                  int K, int N, int group, void *stream);
+
+/* Replaces the awq_gemv_int4_*_bf16 family and marlin_gemm_int4(_zp)_bf16 for
+ * small M (crates/core/kernels/awq_gemv.cu:46-665; dispatcher
+ * marlin_cuda.rs:337-640): y[m,n] = bf16(sum_k x[m,k]*(nib-zp)*scale + bias),
+ * f32 accumulation.  1 <= M <= 16.  workspace >= vmx_int4_gemm_workspace_bytes
+ * (split-K partial sums); bias bf16 [N] or NULL. */
+size_t vmx_int4_gemm_workspace_bytes(int M, int N, int K);
+int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *packed, const uint16_t *bias, int M, int N,
+                       int K, int group, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces awq_marlin_dequant_int4_bf16 (crates/core/kernels/awq_marlin_dequant.cu:35-69):
+ * tile stream -> dense bf16 [K, N] (prefill path and parity aid). */
+int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K, int N, int group, void *stream);
+
+/* ----------------------------------------------------------- glue operators */
+
+/* Replaces rms_norm_bf16 / fused_add_rms_norm_bf16 (crates/core/kernels/layernorm.cu:59-129,232-270;
+ * launchers cuda_kernels.rs rms_norm_cuda).  residual may be NULL (plain norm); when given it
+ * is updated in place with bf16(residual + x) first.  weight_plus_one selects Gemma's (1+w). */
+int vmx_rms_norm_bf16(uint16_t *out, const uint16_t *x, uint16_t *residual, const uint16_t *weight, float eps,
+                      int tokens, int hidden, int weight_plus_one, void *stream);
+
+/* Replaces rotary_embedding_neox_bf16 (crates/core/kernels/rope.cu:94-114): in place on
+ * q [tokens, heads*head_size], k [tokens, kv_heads*head_size] (k may be NULL). */
+int vmx_rope_neox_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin_cache,
+                       int tokens, int rot_dim, int head_size, int num_heads, int num_kv_heads, void *stream);
+
+/* Replaces silu_and_mul_separate_bf16 (crates/core/kernels/activations.cu:148-164). */
+int vmx_silu_and_mul_bf16(uint16_t *out, const uint16_t *gate, const uint16_t *up, int64_t n, void *stream);
+
+/* Replaces argmax_bf16 (crates/core/kernels/sampling.cu:47-94): ids i32 [rows].  Among equal
+ * maxima the smallest index wins (the reference leaves ties to its shuffle order).
+ * workspace >= vmx_argmax_workspace_bytes (per-slice partial results). */
+size_t vmx_argmax_workspace_bytes(int rows, int vocab);
+int vmx_argmax_bf16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* Replaces reshape_and_cache_bf16 and the FP8 quantise branch of CacheEngine::write_batch
+ * (crates/core/kernels/cache_ops.cu:28-62; kv_cache/cache_engine.rs:196-247):
+ * caches [blocks, block_size, kv_heads, head_dim]; kv_dtype VMX_KV_AUTO (bf16 copy) or
+ * VMX_KV_FP8_E4M3 (k_scale/v_scale: device f32[1]). */
+int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
+                          const int32_t *slot_mapping, int tokens, int kv_heads, int head_dim, int block_size,
+                          int kv_dtype, const float *k_scale, const float *v_scale, void *stream);
+
+/* Replaces paged_attention_v2_* + paged_attention_v2_reduce_* (crates/core/kernels/paged_attention.cu:558-954;
+ * launcher signature cuda_kernels.rs:641-658): decode attention for q [seqs, heads, head_dim] bf16 over the
+ * paged cache.  window = 0 means full causal.  workspace >= vmx_paged_attention_workspace_bytes. */
+size_t vmx_paged_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim, int max_seq_len);
+int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                             const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs,
+                             int num_heads, int num_kv_heads, int max_blocks_per_seq, int max_seq_len,
+                             int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
+                             const float *v_scale, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMX_H */

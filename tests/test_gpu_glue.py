@@ -1,0 +1,149 @@
+"""GPU parity of the glue operators and paged-attention decode against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import vllm_rust_amd as vmx
+    assert torch.cuda.is_available()
+    vmx.init(0)
+    return vmx, torch
+
+
+def _bf(torch, a_u16):
+    return torch.from_numpy(np.ascontiguousarray(a_u16).view(np.int16)).cuda().view(torch.bfloat16)
+
+
+def _u16(torch, t):
+    return t.cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def _close_bf16(got_u16, ref_u16, orc, ulps=1):
+    g, r = orc.bf16_to_f32(got_u16), orc.bf16_to_f32(ref_u16)
+    tol = np.maximum(np.abs(r), 1e-30) * (2.0 ** -7) * ulps + 1e-7
+    bad = np.abs(g - r) > tol
+    assert not bad.any(), (g[bad][:5], r[bad][:5])
+
+
+@pytest.mark.parametrize("hidden", [1024, 3840, 4096])
+def test_rms_norm_and_fused_add(gpu, hidden):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(hidden)
+    x = orc.f32_to_bf16(rng.standard_normal((3, hidden)).astype(np.float32) * 3)
+    w = orc.f32_to_bf16(rng.standard_normal(hidden).astype(np.float32))
+    res = orc.f32_to_bf16(rng.standard_normal((3, hidden)).astype(np.float32))
+    for plus_one in (False, True):
+        got = _u16(torch, vmx.rms_norm(_bf(torch, x), _bf(torch, w), 1e-6, weight_plus_one=plus_one))
+        _close_bf16(got, orc.rms_norm_bf16(x, w, 1e-6, plus_one), orc)
+    r_dev = _bf(torch, res)
+    got = _u16(torch, vmx.rms_norm(_bf(torch, x), _bf(torch, w), 1e-6, residual=r_dev))
+    ref_out, ref_res = orc.fused_add_rms_norm_bf16(x, res, w, 1e-6)
+    assert np.array_equal(_u16(torch, r_dev), ref_res)       # the add itself is bit-exact
+    _close_bf16(got, ref_out, orc)
+
+
+def test_rope_neox(gpu):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(2)
+    T, H, KVH, D = 5, 32, 8, 128
+    q = orc.f32_to_bf16(rng.standard_normal((T, H * D)).astype(np.float32))
+    k = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    pos = np.array([0, 3, 17, 255, 1000], np.int32)
+    inv = 1.0 / (1e6 ** (np.arange(0, D, 2) / D))
+    ang = np.arange(1024)[:, None] * inv[None, :]
+    cs = np.concatenate([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
+    qd, kd = _bf(torch, q), _bf(torch, k)
+    vmx.rope_neox(torch.from_numpy(pos).cuda(), qd, kd, torch.from_numpy(cs).cuda(), D, D, H, KVH)
+    rq, rk = orc.rope_neox_bf16(pos, q, k, cs, D, D, H, KVH)
+    _close_bf16(_u16(torch, qd), rq, orc)     # fma contraction may move the last bit
+    _close_bf16(_u16(torch, kd), rk, orc)
+
+
+def test_silu_and_mul(gpu):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(3)
+    g = orc.f32_to_bf16(rng.standard_normal((2, 12288)).astype(np.float32) * 4)
+    u = orc.f32_to_bf16(rng.standard_normal((2, 12288)).astype(np.float32))
+    got = _u16(torch, vmx.silu_and_mul(_bf(torch, g), _bf(torch, u)))
+    _close_bf16(got, orc.silu_and_mul_bf16(g, u), orc)
+
+
+def test_argmax(gpu):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(4)
+    for vocab in (151936, 262144, 1000, 7):
+        lg = orc.f32_to_bf16(rng.standard_normal((3, vocab)).astype(np.float32))
+        got = vmx.argmax(_bf(torch, lg)).cpu().numpy()
+        ref = orc.argmax_bf16(lg)
+        vals = orc.bf16_to_f32(lg)
+        # bf16 logits tie often: compare VALUES (sampling.cu:20-30 leaves the index on ties open),
+        # and our documented rule (smallest index) equals the oracle's first-max.
+        assert np.array_equal(vals[np.arange(3), got], vals[np.arange(3), ref])
+        assert np.array_equal(got, ref)
+    neg = orc.f32_to_bf16(np.full((1, 100), -5.0, np.float32)); neg[0, 63] = orc.f32_to_bf16(np.float32(-1.0))
+    assert vmx.argmax(_bf(torch, neg)).item() == 63
+
+
+@pytest.mark.parametrize("kv_dtype", [0, 1])
+def test_reshape_and_cache(gpu, kv_dtype):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(5)
+    KVH, D, BS, NB = 8, 128, 16, 6
+    k = orc.f32_to_bf16(rng.standard_normal((4, KVH * D)).astype(np.float32) * 2)
+    v = orc.f32_to_bf16(rng.standard_normal((4, KVH * D)).astype(np.float32) * 2)
+    slots = np.array([5, -1, 40, 95], np.int32)
+    dt = np.uint16 if kv_dtype == 0 else np.uint8
+    kc_ref = np.zeros((NB, BS, KVH, D), dt); vc_ref = np.zeros_like(kc_ref)
+    ks = float(np.abs(orc.bf16_to_f32(k)).max() * 1.5 / 448.0); vs = float(np.abs(orc.bf16_to_f32(v)).max() * 1.5 / 448.0)
+    orc.reshape_and_cache(k, v, kc_ref, vc_ref, slots, KVH, D, BS, kv_dtype, ks, vs)
+    tdt = torch.int16 if kv_dtype == 0 else torch.uint8
+    kc = torch.zeros((NB, BS, KVH, D), dtype=tdt, device="cuda"); vc = torch.zeros_like(kc)
+    sk = torch.tensor([ks], dtype=torch.float32, device="cuda"); sv = torch.tensor([vs], dtype=torch.float32, device="cuda")
+    vmx.reshape_and_cache(_bf(torch, k), _bf(torch, v), kc, vc, torch.from_numpy(slots).cuda(), KVH, D, BS, kv_dtype, sk, sv)
+    assert np.array_equal(kc.cpu().numpy().view(dt), kc_ref)       # byte-exact, FP8 included
+    assert np.array_equal(vc.cpu().numpy().view(dt), vc_ref)
+
+
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (16, 1, 512), (4, 4, 64)])
+@pytest.mark.parametrize("kv_dtype", [0, 1])
+def test_paged_attention(gpu, H, KVH, D, kv_dtype):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(H + D + kv_dtype)
+    BS, NB, MB = 16, 80, 40
+    seq_lens = np.array([1, 37, 256, 257, 600], np.int32)
+    S = len(seq_lens)
+    kf = rng.standard_normal((NB, BS, KVH, D)).astype(np.float32)
+    vf = rng.standard_normal((NB, BS, KVH, D)).astype(np.float32)
+    ks = vs = 1.0
+    if kv_dtype == 0:
+        kc, vc = orc.f32_to_bf16(kf), orc.f32_to_bf16(vf)
+        kcd = torch.from_numpy(kc.view(np.int16)).cuda(); vcd = torch.from_numpy(vc.view(np.int16)).cuda()
+    else:
+        ks = float(np.abs(kf).max() * 1.5 / 448.0); vs = float(np.abs(vf).max() * 1.5 / 448.0)
+        enc = np.vectorize(orc.fp8_e4m3_encode_rne, otypes=[np.uint8])
+        kc, vc = enc(kf / ks), enc(vf / vs)
+        kcd = torch.from_numpy(kc).cuda(); vcd = torch.from_numpy(vc).cuda()
+    bt = np.stack([rng.permutation(NB)[:MB] for _ in range(S)]).astype(np.int32)
+    q = orc.f32_to_bf16(rng.standard_normal((S, H * D)).astype(np.float32))
+    scale = float(1.0 / np.sqrt(D))
+    sk = torch.tensor([ks], dtype=torch.float32, device="cuda"); sv = torch.tensor([vs], dtype=torch.float32, device="cuda")
+    for window in (0, 100):
+        got = _u16(torch, vmx.paged_attention(_bf(torch, q), kcd, vcd, torch.from_numpy(bt).cuda(), torch.from_numpy(seq_lens).cuda(),
+                                              scale, H, KVH, D, BS, int(seq_lens.max()), window, kv_dtype, sk, sv))
+        for psize in (256, 64):   # 256 = this library's partitioning; 64 = the reference's for ctx <= 4096
+            ref = orc.paged_attention_v2(q, kc, vc, bt, seq_lens, scale, H, KVH, D, BS, psize, window, kv_dtype, ks, vs)
+            g, r = orc.bf16_to_f32(got), orc.bf16_to_f32(ref)
+            # f32 accumulate within 1e-3 relative (north star) + one bf16 ulp of the stored output
+            assert np.abs(g - r).max() <= (1e-3 + 2 ** -7) * np.abs(r).max(), (window, psize)
+            rel = np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum())
+            assert rel <= 1e-3 + 2 ** -8

@@ -1,0 +1,169 @@
+"""GPU parity of the I-quant kernels against the CPU oracle and the reference's
+golden vectors; restates gguf/iq/cuda_tests.rs and adds bit-exact integer checks."""
+import numpy as np
+import pytest
+
+from tests.helpers import IQ_NAMES, load_iq_fixture, ramp, random_iq_blocks, tile_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import vllm_rust_amd as vmx
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    vmx.init(0)
+    return vmx, torch
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-12)))
+
+
+@pytest.mark.parametrize("name", IQ_NAMES)
+def test_dequant_matches_golden_and_oracle(gpu, name):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    f, raw, gold = load_iq_fixture(name)
+    tid = f["ggml_type_id"]
+    out = vmx.iq_dequantize(tid, _dev(torch, raw), f["n_blocks"]).cpu().numpy()
+    assert np.abs(out - gold).max() <= 1e-4            # cuda_tests.rs:51
+    assert np.array_equal(out, orc.iq_dequant(tid, raw))   # same f32 expression order
+    # random valid blocks, many of them (grid-stride path)
+    rng = np.random.default_rng(tid)
+    rb = random_iq_blocks(rng, f["type_size"], 5000)
+    out = vmx.iq_dequantize(tid, _dev(torch, rb), 5000).cpu().numpy()
+    ref = orc.iq_dequant(tid, rb)
+    assert np.array_equal(out, ref)
+
+
+def test_quantize_q8_1_bit_exact(gpu):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((5, 4096)).astype(np.float32)
+    x[1, 64:96] = 0.0                                   # all-zero block
+    x[2, :32] = np.float32(120.0) * (np.arange(32) % 2)  # outliers
+    x[3, 5] = 1e-30
+    aq, ad = vmx.quantize_q8_1(_dev(torch, x))
+    raq, rad = orc.quantize_q8_1(x)
+    assert np.array_equal(ad.cpu().numpy(), rad)
+    assert np.array_equal(aq.cpu().numpy(), raq)
+
+
+@pytest.mark.parametrize("name", IQ_NAMES)
+def test_integer_subdots_bit_exact(gpu, name):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    f, raw, _ = load_iq_fixture(name)
+    tid, ts, nb = f["ggml_type_id"], f["type_size"], f["n_blocks"]
+    rng = np.random.default_rng(7)
+    for w_raw, n_out, n_in in [(raw, nb, 256), (random_iq_blocks(rng, ts, 37 * 3), 37, 768)]:
+        for m in (1, 3):
+            x = (rng.standard_normal((m, n_in)) * 2).astype(np.float32)
+            aq, ad = orc.quantize_q8_1(x)
+            got = vmx.iq_subdots(tid, _dev(torch, w_raw), _dev(torch, aq), n_out, n_in).cpu().numpy()
+            assert np.array_equal(got, orc.iq_subdots(tid, w_raw, aq, n_out, n_in))
+
+
+@pytest.mark.parametrize("name", IQ_NAMES)
+def test_mmvq_matches_cpu_mmvq_fixture(gpu, name):
+    """cuda_tests.rs:61-107: [n_blocks, 256] weight, m in {1,4,16}, rel-L2 <= 1e-3."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    f, raw, _ = load_iq_fixture(name)
+    tid, nb = f["ggml_type_id"], f["n_blocks"]
+    w = _dev(torch, raw)
+    for m in (1, 4, 16):
+        x = ramp(m, 256, 23, 11, 0.03)
+        got = vmx.iq_matmul(tid, w, _dev(torch, x), nb, 256).cpu().numpy()
+        ref = orc.iq_matmul(tid, raw, x, nb, 256)
+        assert (ref.astype(np.float64) ** 2).sum() > 1e-6
+        assert rel_l2(got, ref) <= 1e-3, (name, m)
+
+
+def test_mmvq_multi_superblock(gpu):
+    """cuda_tests.rs:115-176: tiled IQ3_XXS fixture at nb256 = 1,2,3,6,8,16."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    f, raw, _ = load_iq_fixture("iq3_xxs")
+    tid, ts, nb = f["ggml_type_id"], f["type_size"], f["n_blocks"]
+    for n_out, n_in in [(6, 256), (3, 512), (2, 768), (1, 1536), (1, 2048), (1, 4096)]:
+        w_raw = tile_blocks(raw, ts, nb, n_out * n_in // 256)
+        for m in (1, 4, 16):
+            x = ramp(m, n_in, 23, 11, 0.03)
+            got = vmx.iq_matmul(tid, _dev(torch, w_raw), _dev(torch, x), n_out, n_in).cpu().numpy()
+            ref = orc.iq_matmul(tid, w_raw, x, n_out, n_in)
+            assert rel_l2(got, ref) <= 1e-3, (n_in, m)
+
+
+@pytest.mark.parametrize("name", IQ_NAMES)
+@pytest.mark.parametrize("m", [1, 2, 5, 8, 13, 16])
+def test_mmvq_random_blocks_all_m(gpu, name, m):
+    """Ragged n_out (not a multiple of the rows per workgroup), Gemma width 3840."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    tid = orc.IQ_TYPES[name]; ts = orc.IQ_TYPE_SIZE[tid]
+    rng = np.random.default_rng(100 + m)
+    n_out, n_in = 203, 3840
+    w_raw = random_iq_blocks(rng, ts, n_out * n_in // 256)
+    x = rng.standard_normal((m, n_in)).astype(np.float32)
+    got = vmx.iq_matmul(tid, _dev(torch, w_raw), _dev(torch, x), n_out, n_in).cpu().numpy()
+    ref = orc.iq_matmul(tid, w_raw, x, n_out, n_in)
+    assert rel_l2(got, ref) <= 1e-3
+
+
+def test_mmvq_full_size_rows_subset(gpu):
+    """Bench shape 14336 x 4096 (benches/iq_dequant_bench.rs:27): rows are independent,
+    so a random subset of output rows is checked against the oracle run on those rows."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    tid, ts = 18, 98
+    rng = np.random.default_rng(5)
+    n_out, n_in = 14336, 4096
+    w_raw = random_iq_blocks(rng, ts, n_out * n_in // 256)
+    x = rng.standard_normal((1, n_in)).astype(np.float32)
+    got = vmx.iq_matmul(tid, _dev(torch, w_raw), _dev(torch, x), n_out, n_in).cpu().numpy()
+    rows = np.sort(rng.choice(n_out, 64, replace=False)); rows[0] = 0; rows[-1] = n_out - 1
+    row_bytes = n_in // 256 * ts
+    sub = np.concatenate([w_raw[r * row_bytes:(r + 1) * row_bytes] for r in rows])
+    ref = orc.iq_matmul(tid, sub, x, len(rows), n_in)
+    assert rel_l2(got[:, rows], ref) <= 1e-3
+    # linearity in the (pre-quantised) activations' scales: y(2*ad) == 2*y(ad) exactly
+    aq, ad = vmx.quantize_q8_1(_dev(torch, x))
+    y1 = vmx.iq_mmvq(tid, _dev(torch, w_raw), aq, ad, n_out, n_in)
+    y2 = vmx.iq_mmvq(tid, _dev(torch, w_raw), aq, ad * 2, n_out, n_in)
+    assert torch.equal(y2, y1 * 2)
+
+
+def test_preconditions_surface_as_errors(gpu):
+    vmx, torch = gpu
+    from vllm_rust_amd._lib import VmxError
+    w = torch.zeros(98 * 16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(VmxError, match="exceeds IQ_GEMV_MAX_M"):
+        vmx.iq_matmul(18, w, torch.zeros((17, 256), device="cuda"), 1, 256)
+    with pytest.raises(VmxError, match="not a multiple of 256"):
+        vmx.iq_matmul(18, w, torch.zeros((1, 320), device="cuda"), 1, 320)
+    with pytest.raises(VmxError, match="unsupported ggml type"):
+        vmx.iq_dequantize(12, w, 1)
+
+
+def test_gather_dequant_q6k(gpu):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(9)
+    rows, dim = 50, 768
+    blk = rng.integers(0, 256, size=(rows * dim // 256, 210), dtype=np.uint8)
+    blk[:, 209] = rng.integers(0x2C, 0x34, size=blk.shape[0]); blk[:, 208] = 0
+    table = orc.q6k_dequant(blk.reshape(-1)).reshape(rows, dim)
+    ids = np.array([3, 49, 0, 77, -1, 3], np.int32)
+    got = vmx.gather_dequant_q6k(_dev(torch, blk.reshape(-1)), _dev(torch, ids), dim, rows).cpu().numpy()
+    for i, t in enumerate(ids):
+        exp = table[t] if 0 <= t < rows else np.zeros(dim, np.float32)
+        assert np.array_equal(got[i], exp)      # gguf/mod.rs:2112-2154: gather == full dequant, bit-exact

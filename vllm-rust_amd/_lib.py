@@ -1,0 +1,78 @@
+"""ctypes binding of lib/libvmx.so (the C ABI declared in include/vmx.h).
+
+The library is the product: if it is missing this module raises at import and
+nothing in the package falls back to another implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libvmx.so"
+
+if not LIB_PATH.exists():
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C {_PKG / 'csrc'}` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path"
+    )
+
+lib = C.CDLL(str(LIB_PATH))
+
+_i, _i64, _f, _p, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+_SIGS = {
+    "vmx_init": (_i, [_i]),
+    "vmx_abi_version": (_i, []),
+    "vmx_last_error": (C.c_char_p, []),
+    "vmx_iq_type_size": (_i, [_i]),
+    "vmx_iq_dequantize_f32": (_i, [_i, _p, _p, _i64, _p]),
+    "vmx_quantize_q8_1_rows": (_i, [_p, _p, _p, _i64, _p]),
+    "vmx_iq_mmvq_f32": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_iq_matmul_workspace_bytes": (_sz, [_i, _i]),
+    "vmx_iq_matmul_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "vmx_iq_subdots_i32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_gather_dequant_q6k_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "vmx_awq_to_gptq_qweight": (_i, [_p, _p, _i, _i, _p]),
+    "vmx_awq_repack_nibbles": (_i, [_p, _p, _i64, _p]),
+    "vmx_int4_packed_bytes": (_sz, [_i, _i, _i]),
+    "vmx_int4_pack": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_int4_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "vmx_int4_gemm_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "vmx_int4_dequant_bf16": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vmx_rms_norm_bf16": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _p]),
+    "vmx_rope_neox_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vmx_silu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _p]),
+    "vmx_argmax_workspace_bytes": (_sz, [_i, _i]),
+    "vmx_argmax_bf16": (_i, [_p, _p, _i, _i, _p, _sz, _p]),
+    "vmx_reshape_and_cache": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "vmx_paged_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "vmx_paged_attention_bf16": (_i, [_p] * 6 + [_f] + [_i] * 9 + [_p, _p, _p, _sz, _p]),
+}
+
+
+def _bind():
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+
+
+_bind()
+
+
+class VmxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vmx error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise VmxError(rc, lib.vmx_last_error().decode("utf-8", "replace"))
+
+
+def declared_symbols():
+    """Names bound above; tests compare this with the prototypes in include/vmx.h."""
+    return sorted(_SIGS)

@@ -1,0 +1,279 @@
+// Per-token glue operators of the decode path for gfx950: RMSNorm (+ fused residual add),
+// NeoX RoPE, SiLU*mul, argmax, KV-cache scatter (bf16 copy or FP8 e4m3 quantise).
+// Semantics: crates/core/kernels/{layernorm.cu:59-129,232-270, rope.cu:18-114,
+// activations.cu:33-35,148-164, sampling.cu:47-94, cache_ops.cu:28-62} and the FP8 branch of
+// crates/core/src/kv_cache/cache_engine.rs:196-247.  All are HBM/launch-bound: 16-byte
+// vector accesses, one pass over the data, wave64 butterflies for the reductions.
+#include "vmx_internal.h"
+#include <float.h>
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4 v, float f[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f[2 * j] = __uint_as_float(w[j] << 16);
+        f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+    }
+}
+
+__device__ __forceinline__ uint4 pack8(const float f[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = (uint32_t)vmx_f32_to_bf16(f[2 * j]) | ((uint32_t)vmx_f32_to_bf16(f[2 * j + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// One workgroup per token.  hidden % 8 == 0.  With `residual`: residual = bf16(residual + x),
+// variance over the unrounded f32 sums, normalisation from the rounded residual (layernorm.cu:246-268).
+__global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ x,
+                                                        uint16_t *__restrict__ residual, const uint16_t *__restrict__ weight,
+                                                        float eps, int hidden, int plus_one) {
+    __shared__ float red[4];
+    const int64_t row = (int64_t)blockIdx.x * hidden;
+    const int nvec = hidden >> 3;
+    float var = 0.f;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        float a[8];
+        unpack8(*reinterpret_cast<const uint4 *>(x + row + 8 * i), a);
+        if (residual) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4 *>(residual + row + 8 * i), r);
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = r[j] + a[j];
+            *reinterpret_cast<uint4 *>(residual + row + 8 * i) = pack8(a);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) var += a[j] * a[j];
+    }
+    var = vmx_block_sum_256(var, red);
+    const float inv = rsqrtf(var / (float)hidden + eps);
+    const uint16_t *src = residual ? residual : x;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        float a[8], w[8];
+        unpack8(*reinterpret_cast<const uint4 *>(src + row + 8 * i), a);
+        if (weight) unpack8(*reinterpret_cast<const uint4 *>(weight + 8 * i), w);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float wj = weight ? w[j] : 1.0f;
+            if (plus_one) wj = 1.0f + wj;
+            a[j] = a[j] * inv * wj;
+        }
+        *reinterpret_cast<uint4 *>(out + row + 8 * i) = pack8(a);
+    }
+}
+
+// One workgroup per token; thread i -> (head, pair index).
+__global__ __launch_bounds__(256) void rope_neox_kernel(const int32_t *__restrict__ positions, uint16_t *__restrict__ q,
+                                                         uint16_t *__restrict__ k, const float *__restrict__ cos_sin, int rot_dim,
+                                                         int head_size, int num_heads, int num_kv_heads) {
+    const int t = blockIdx.x;
+    const int half = rot_dim >> 1;
+    const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
+    const int nq = num_heads * half, nk = k ? num_kv_heads * half : 0;
+    for (int i = threadIdx.x; i < nq + nk; i += 256) {
+        uint16_t *base;
+        int hi, ri;
+        if (i < nq) { hi = i / half; ri = i % half; base = q + ((int64_t)t * num_heads + hi) * head_size; }
+        else { const int j = i - nq; hi = j / half; ri = j % half; base = k + ((int64_t)t * num_kv_heads + hi) * head_size; }
+        const float c = cs[ri], s = cs[half + ri];
+        const float xv = vmx_bf16_to_f32(base[ri]), yv = vmx_bf16_to_f32(base[half + ri]);
+        base[ri] = vmx_f32_to_bf16(xv * c - yv * s);
+        base[half + ri] = vmx_f32_to_bf16(yv * c + xv * s);
+    }
+}
+
+__device__ __forceinline__ float silu(float g) { return g / (1.0f + expf(-g)); }
+
+__global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ gate,
+                                                        const uint16_t *__restrict__ up, int64_t n) {
+    const int64_t nvec = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float g[8], u[8];
+        unpack8(reinterpret_cast<const uint4 *>(gate)[i], g);
+        unpack8(reinterpret_cast<const uint4 *>(up)[i], u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) g[j] = silu(g[j]) * u[j];
+        reinterpret_cast<uint4 *>(out)[i] = pack8(g);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += 256)
+            out[i] = vmx_f32_to_bf16(silu(vmx_bf16_to_f32(gate[i])) * vmx_bf16_to_f32(up[i]));
+}
+
+// Argmax: key = (order-preserving float bits << 32) | ~index, so a u64 max picks the largest
+// value and, among equal values, the smallest index (the reference leaves ties unspecified).
+__device__ __forceinline__ unsigned long long argmax_key(float v, uint32_t idx) {
+    uint32_t b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)b << 32) | (unsigned long long)(~idx);
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// grid (chunks, rows): each workgroup reduces one slice of a row to a key in part[row][chunk].
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t *__restrict__ logits, unsigned long long *__restrict__ part,
+                                                              int vocab) {
+    __shared__ unsigned long long red[4];
+    const int row = blockIdx.y, chunks = gridDim.x;
+    const uint16_t *lg = logits + (int64_t)row * vocab;
+    const int per = (((vocab + chunks - 1) / chunks) + 7) & ~7;
+    const int lo = blockIdx.x * per, hi = min(vocab, lo + per);
+    unsigned long long best = 0;
+    const bool vec_ok = (((uintptr_t)lg) & 15) == 0;
+    int i = lo + threadIdx.x * 8;
+    for (; vec_ok && i + 8 <= hi; i += 256 * 8) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4 *>(lg + i), f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned long long k = argmax_key(f[j], (uint32_t)(i + j));
+            best = k > best ? k : best;
+        }
+    }
+    if (!vec_ok) i = lo + threadIdx.x * 8;
+    for (; i < hi; i += 256 * 8)  // tail (or unaligned row): scalar
+        for (int j = i; j < min(i + 8, hi); j++) {
+            const unsigned long long k = argmax_key(vmx_bf16_to_f32(lg[j]), (uint32_t)j);
+            best = k > best ? k : best;
+        }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = red[0];
+        for (int w = 1; w < 4; w++) b = red[w] > b ? red[w] : b;
+        part[(int64_t)row * chunks + blockIdx.x] = b;
+    }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const unsigned long long *__restrict__ part, int32_t *__restrict__ out,
+                                                           int chunks) {
+    const int row = blockIdx.x;
+    unsigned long long best = 0;
+    for (int c = threadIdx.x; c < chunks; c += 64) {
+        const unsigned long long k = part[(int64_t)row * chunks + c];
+        best = k > best ? k : best;
+    }
+    best = wave_max_u64(best);
+    if (threadIdx.x == 0) out[row] = (int32_t)(~(uint32_t)(best & 0xFFFFFFFFull));
+}
+
+// e4m3fn, round-to-nearest-even, saturating (no inf): the OCP conversion gfx950 has in hardware.
+__device__ __forceinline__ uint8_t f32_to_e4m3(float v) {
+    const uint32_t packed = __builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false);
+    return (uint8_t)(packed & 0xFFu);
+}
+
+// One workgroup per token.  FP8: f32(x)/scale, clamp +-448, round to bf16, then e4m3 RNE
+// (the reference casts the scaled f32 tensor to bf16 before its static-quant kernel).
+__global__ __launch_bounds__(256) void reshape_and_cache_kernel(const uint16_t *__restrict__ key, const uint16_t *__restrict__ value,
+                                                                 void *__restrict__ k_cache, void *__restrict__ v_cache,
+                                                                 const int32_t *__restrict__ slots, int row_elems, int fp8,
+                                                                 const float *__restrict__ k_scale, const float *__restrict__ v_scale) {
+    const int t = blockIdx.x;
+    const int slot = slots[t];
+    if (slot < 0) return;
+    const uint16_t *ks = key + (int64_t)t * row_elems, *vs = value + (int64_t)t * row_elems;
+    const int64_t dst = (int64_t)slot * row_elems;
+    if (!fp8) {
+        for (int i = threadIdx.x; i < (row_elems >> 3); i += 256) {
+            reinterpret_cast<uint4 *>((uint16_t *)k_cache + dst)[i] = reinterpret_cast<const uint4 *>(ks)[i];
+            reinterpret_cast<uint4 *>((uint16_t *)v_cache + dst)[i] = reinterpret_cast<const uint4 *>(vs)[i];
+        }
+    } else {
+        const float ksc = k_scale ? *k_scale : 1.0f, vsc = v_scale ? *v_scale : 1.0f;
+        for (int i = threadIdx.x; i < row_elems; i += 256) {
+            float a = vmx_bf16_to_f32(ks[i]) / ksc, b = vmx_bf16_to_f32(vs[i]) / vsc;
+            a = fminf(fmaxf(a, -448.0f), 448.0f);
+            b = fminf(fmaxf(b, -448.0f), 448.0f);
+            a = vmx_bf16_to_f32(vmx_f32_to_bf16(a));
+            b = vmx_bf16_to_f32(vmx_f32_to_bf16(b));
+            ((uint8_t *)k_cache)[dst + i] = f32_to_e4m3(a);
+            ((uint8_t *)v_cache)[dst + i] = f32_to_e4m3(b);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vmx_rms_norm_bf16(uint16_t *out, const uint16_t *x, uint16_t *residual, const uint16_t *weight, float eps, int tokens,
+                                 int hidden, int weight_plus_one, void *stream) {
+    VMX_REQUIRE(out && x, "rms_norm: null pointer");
+    VMX_REQUIRE(tokens >= 0 && hidden > 0 && hidden % 8 == 0, "rms_norm: hidden (%d) must be a positive multiple of 8", hidden);
+    if (tokens == 0) return VMX_OK;
+    hipLaunchKernelGGL(rms_norm_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), out, x, residual, weight, eps, hidden,
+                       weight_plus_one);
+    VMX_CHECK_LAUNCH("rms_norm");
+    return VMX_OK;
+}
+
+extern "C" int vmx_rope_neox_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin_cache, int tokens,
+                                  int rot_dim, int head_size, int num_heads, int num_kv_heads, void *stream) {
+    VMX_REQUIRE(positions && q && cos_sin_cache, "rope: null pointer");
+    VMX_REQUIRE(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rope: rot_dim %d invalid for head_size %d", rot_dim,
+                head_size);
+    if (tokens <= 0) return VMX_OK;
+    hipLaunchKernelGGL(rope_neox_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), positions, q, k, cos_sin_cache, rot_dim,
+                       head_size, num_heads, num_kv_heads);
+    VMX_CHECK_LAUNCH("rope");
+    return VMX_OK;
+}
+
+extern "C" int vmx_silu_and_mul_bf16(uint16_t *out, const uint16_t *gate, const uint16_t *up, int64_t n, void *stream) {
+    VMX_REQUIRE(out && gate && up && n >= 0, "silu_and_mul: bad arguments");
+    if (n == 0) return VMX_OK;
+    int64_t blocks = ((n >> 3) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, vmx_stream(stream), out, gate, up, n);
+    VMX_CHECK_LAUNCH("silu_and_mul");
+    return VMX_OK;
+}
+
+static int argmax_chunks(int vocab) {
+    int c = (vocab + 4095) / 4096;
+    return c < 1 ? 1 : (c > 64 ? 64 : c);
+}
+
+extern "C" size_t vmx_argmax_workspace_bytes(int rows, int vocab) {
+    if (rows <= 0 || vocab <= 0) return 0;
+    return (size_t)rows * argmax_chunks(vocab) * sizeof(unsigned long long);
+}
+
+extern "C" int vmx_argmax_bf16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+    VMX_REQUIRE(out_ids && logits && workspace, "argmax: null pointer");
+    VMX_REQUIRE(rows >= 0 && vocab > 0, "argmax: bad shape");
+    VMX_REQUIRE(workspace_bytes >= vmx_argmax_workspace_bytes(rows, vocab), "argmax: workspace too small");
+    if (rows == 0) return VMX_OK;
+    const int chunks = argmax_chunks(vocab);
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(chunks, rows), dim3(256), 0, vmx_stream(stream), logits,
+                       (unsigned long long *)workspace, vocab);
+    VMX_CHECK_LAUNCH("argmax(partial)");
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, vmx_stream(stream), (const unsigned long long *)workspace, out_ids,
+                       chunks);
+    VMX_CHECK_LAUNCH("argmax(final)");
+    return VMX_OK;
+}
+
+extern "C" int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
+                                     const int32_t *slot_mapping, int tokens, int kv_heads, int head_dim, int block_size, int kv_dtype,
+                                     const float *k_scale, const float *v_scale, void *stream) {
+    VMX_REQUIRE(key && value && k_cache && v_cache && slot_mapping, "reshape_and_cache: null pointer");
+    VMX_REQUIRE(kv_heads > 0 && head_dim > 0 && (kv_heads * head_dim) % 8 == 0 && block_size > 0, "reshape_and_cache: bad geometry");
+    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3, "reshape_and_cache: unsupported kv dtype %d", kv_dtype);
+    if (tokens <= 0) return VMX_OK;
+    hipLaunchKernelGGL(reshape_and_cache_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), key, value, k_cache, v_cache,
+                       slot_mapping, kv_heads * head_dim, kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0, k_scale, v_scale);
+    VMX_CHECK_LAUNCH("reshape_and_cache");
+    return VMX_OK;
+}

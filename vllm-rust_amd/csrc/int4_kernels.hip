@@ -1,0 +1,387 @@
+// AWQ / GPTQ int4 kernels for gfx950: load-time repacks and the small-M
+// dequant-fused GEMM that replaces the reference's awq_gemv_* / marlin_gemm_int4*
+// kernels (crates/core/kernels/awq_gemv.cu:46-665, marlin_gemm.cu:67-187,301-430).
+//
+// Arithmetic contract (awq_gemv.cu:70-117): y[m,n] = bf16(sum_k x[m,k] * ((nib - zp) * s) + bias),
+// bf16 x and s, f32 accumulation.  This kernel evaluates the same sum re-associated per
+// quantisation group on the matrix cores:
+//     sum_k x*(nib - zp)*s = s * ( sum_k x*(128 + nib)  -  (128 + zp) * sum_k x )
+// 0x4300|nib is the bf16 value 128+nib exactly, so a packed word unpacks to an MFMA
+// B-fragment with one and-or per pair of weights; products are exact in f32 and only the
+// summation order differs from the reference.
+//
+// HBM layout ("tile stream", built once at load by vmx_int4_pack):
+//   W  [N/16][K/128][64][4] u32 : for column tile nt and k-block kb one contiguous 1 KiB unit;
+//       lane l of a wave reads its dwordx4 at l*16.  Word i of lane l holds the 8 weights
+//       k = kb*128 + 32*i + 8*(l>>4) + j (j = 0..7) of column nt*16 + (l&15), weight j at
+//       nibble position {0,4,1,5,2,6,3,7}[j], so (w >> 4t) & 0x000F000F yields weights 2t, 2t+1.
+//   SZ [N/16][G][16] u32 : low half = bf16 scale bits, high half = bf16 bits of 128 + zp.
+// One wave-load is therefore 1 KiB contiguous = 16 columns x one 128-deep group slice,
+// and feeds four v_mfma_f32_16x16x32_bf16 (A = activations, rows = m).
+#include "vmx_internal.h"
+
+namespace {
+
+constexpr int KB = 128;     // k-values per unit
+constexpr int NT = 16;      // columns per unit
+constexpr int UNIT_WORDS = 256;
+
+__host__ __device__ inline size_t sz_offset_bytes(int K, int N) { return ((size_t)K * N / 2 + 255) & ~(size_t)255; }
+
+// ---------------------------------------------------------------- repacks
+// AWQ [K, N/8] (interleaved along N) -> GPTQ-sequential [K/8, N] (awq_marlin.rs:170-240).
+__global__ __launch_bounds__(256) void awq_to_gptq_kernel(const uint32_t *__restrict__ awq, uint32_t *__restrict__ out, int K,
+                                                           int N) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [K/8, N]
+    if (idx >= (int64_t)(K / 8) * N) return;
+    const int n = (int)(idx % N), kb = (int)(idx / N);
+    const int shift = ((n & 1) * 16) + ((n & 7) >> 1) * 4;  // {0,16,4,20,8,24,12,28}[n%8]
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t src = awq[(int64_t)(kb * 8 + i) * (N / 8) + (n >> 3)];
+        word |= ((src >> shift) & 0xFu) << (4 * i);
+    }
+    out[idx] = word;
+}
+
+__global__ __launch_bounds__(256) void awq_nibble_reorder_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                                  int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = in[i];
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int shift = ((j & 1) * 16) + (j >> 1) * 4;
+        r |= ((w >> shift) & 0xFu) << (4 * j);
+    }
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(256) void int4_pack_w_kernel(const uint32_t *__restrict__ qweight, uint32_t *__restrict__ W, int K,
+                                                           int N) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over K*N/8 output words
+    if (idx >= (int64_t)K * N / 8) return;
+    const int i = (int)(idx & 3), l = (int)((idx >> 2) & 63);
+    const int64_t unit = idx >> 8;
+    const int kblocks = K / KB;
+    const int kb = (int)(unit % kblocks), nt = (int)(unit / kblocks);
+    const int n = nt * NT + (l & 15);
+    const int c = 4 * i + (l >> 4);  // 8-wide k chunk inside the unit
+    const uint32_t src = qweight[(int64_t)(kb * 16 + c) * N + n];
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int pos = (j >> 1) + 4 * (j & 1);  // {0,4,1,5,2,6,3,7}[j]
+        r |= ((src >> (4 * j)) & 0xFu) << (4 * pos);
+    }
+    W[idx] = r;
+}
+
+__global__ __launch_bounds__(256) void int4_pack_sz_kernel(const uint16_t *__restrict__ scales, const uint32_t *__restrict__ qzeros,
+                                                            uint32_t *__restrict__ SZ, int G, int N) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [N/16][G][16]
+    if (idx >= (int64_t)G * N) return;
+    const int nl = (int)(idx & 15);
+    const int g = (int)((idx >> 4) % G), nt = (int)((idx >> 4) / G);
+    const int n = nt * NT + nl;
+    uint32_t zp = 8;
+    if (qzeros) zp = (qzeros[(int64_t)g * (N / 8) + (n >> 3)] >> (4 * (n & 7))) & 0xFu;
+    SZ[idx] = (uint32_t)scales[(int64_t)g * N + n] | ((0x4300u | zp) << 16);
+}
+
+// tile stream -> dense bf16 [K, N]; value bf16((nib - zp) * scale) as awq_marlin_dequant.cu:35-69.
+__global__ __launch_bounds__(256) void int4_dequant_kernel(const uint32_t *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                            uint16_t *__restrict__ dense, int K, int N, int group) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)K * N / 8) return;
+    const int i = (int)(idx & 3), l = (int)((idx >> 2) & 63);
+    const int64_t unit = idx >> 8;
+    const int kblocks = K / KB, G = K / group;
+    const int kb = (int)(unit % kblocks), nt = (int)(unit / kblocks);
+    const int n = nt * NT + (l & 15);
+    const int k0 = kb * KB + 32 * i + 8 * (l >> 4);
+    const uint32_t sz = SZ[((int64_t)nt * G + k0 / group) * 16 + (l & 15)];
+    const float s = vmx_bf16_to_f32((uint16_t)(sz & 0xFFFFu));
+    const int zp = (int)((sz >> 16) & 0xFu);
+    const uint32_t w = W[idx];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int pos = (j >> 1) + 4 * (j & 1);
+        const int nib = (int)((w >> (4 * pos)) & 0xFu);
+        dense[(int64_t)(k0 + j) * N + n] = vmx_f32_to_bf16((float)(nib - zp) * s);
+    }
+}
+
+// ---------------------------------------------------------------- small-M GEMM
+// Workgroup = 4 waves = one 16-column tile x (4*UPW) consecutive k-blocks; wave w owns k-blocks
+// [w*UPW, (w+1)*UPW) of the workgroup's slice.  All weight units of a wave are requested before
+// the activations are staged, so their HBM latency overlaps the prologue.
+//   blockIdx.x = ks * n_tiles + nt   (ks = split-K slice; neighbouring workgroups stream
+//                                     neighbouring tiles of the same slice)
+// Output: splits == 1 -> y bf16 (+bias); else partial[ks][M][N] f32, summed by int4_reduce_kernel.
+template <int UPW>
+__global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                         const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+                                                         uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N,
+                                                         int K, int group, int splits) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int KS = 4 * UPW * KB;       // k-values per workgroup
+    constexpr int XROW = KS + 8;           // bf16 per staged row (+16 B pad against bank conflicts)
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                  // [M][XROW]
+    float *sumx = reinterpret_cast<float *>(smem + (size_t)M * XROW * 2);  // [4*UPW][16]
+    float *red = sumx + 4 * UPW * 16;                                   // [4][64][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = N / NT, kblocks = K / KB, G = K / group;
+    const int nt = blockIdx.x % n_tiles, ks = blockIdx.x / n_tiles;
+    const int kb_wg = ks * 4 * UPW;        // first k-block of this workgroup
+    const int nl = lane & 15, h = lane >> 4;
+
+    // 1. request this wave's weight units and scale/zero words
+    uint4 wreg[UPW];
+    uint32_t szreg[UPW];
+#pragma unroll
+    for (int u = 0; u < UPW; u++) {
+        const int kb = kb_wg + wave * UPW + u;
+        if (kb < kblocks) {
+            wreg[u] = W[((int64_t)nt * kblocks + kb) * 64 + lane];
+            szreg[u] = SZ[((int64_t)nt * G + (kb * KB) / group) * 16 + nl];
+        } else {
+            wreg[u] = make_uint4(0, 0, 0, 0);
+            szreg[u] = 0;
+        }
+    }
+
+    // 2. stage x[0..M)[slice] into LDS, with per-(k-block,row) sums
+    {
+        constexpr int CPR = KS / 8;  // 16-byte chunks per row
+        const int total = M * CPR;
+        for (int c0 = 0; c0 < total; c0 += 256) {
+            const int c = c0 + tid;
+            float s = 0.f;
+            int mrow = 0, cc = 0;
+            if (c < total) {
+                mrow = c / CPR;
+                cc = c % CPR;
+                const int k = kb_wg * KB + cc * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (k < K) v = *reinterpret_cast<const uint4 *>(x + (int64_t)mrow * K + k);
+                *reinterpret_cast<uint4 *>(xs + mrow * XROW + cc * 8) = v;
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) s += __uint_as_float(vv[j] << 16) + __uint_as_float(vv[j] & 0xFFFF0000u);
+            }
+            // 16 consecutive chunks = one (row, k-block)
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            if (c < total && (lane & 15) == 0) sumx[(cc >> 4) * 16 + mrow] = s;
+        }
+        // rows >= M of sumx are never read for a live output
+    }
+    __syncthreads();
+
+    // 3. unpack + MFMA
+    vmx_f32x4 fin = {0.f, 0.f, 0.f, 0.f};
+    const bool arow = nl < M;
+#pragma unroll
+    for (int u = 0; u < UPW; u++) {
+        const int kbl = wave * UPW + u;  // k-block inside the workgroup slice
+        if (kb_wg + kbl < kblocks) {     // wave-uniform
+            vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t w4[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t w = w4[i];
+                uint4 bu;
+                bu.x = (w & 0x000F000Fu) | 0x43004300u;
+                bu.y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+                bu.z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+                bu.w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+                uint4 au = make_uint4(0, 0, 0, 0);
+                if (arow) au = *reinterpret_cast<const uint4 *>(xs + nl * XROW + kbl * KB + 32 * i + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au),
+                                                              __builtin_bit_cast(vmx_bf16x8, bu), acc, 0, 0, 0);
+            }
+            const float s = __uint_as_float(szreg[u] << 16);
+            const float zo = __uint_as_float(szreg[u] & 0xFFFF0000u);
+            const float4 sx = *reinterpret_cast<const float4 *>(sumx + kbl * 16 + 4 * h);
+            fin[0] += s * (acc[0] - zo * sx.x);
+            fin[1] += s * (acc[1] - zo * sx.y);
+            fin[2] += s * (acc[2] - zo * sx.z);
+            fin[3] += s * (acc[3] - zo * sx.w);
+        }
+    }
+
+    // 4. sum the 4 waves, write out.  Lane holds rows m = 4h + r, column n = nt*16 + nl.
+    *reinterpret_cast<float4 *>(red + (wave * 64 + lane) * 4) = make_float4(fin[0], fin[1], fin[2], fin[3]);
+    __syncthreads();
+    if (wave == 0) {
+        float4 a = *reinterpret_cast<const float4 *>(red + lane * 4);
+#pragma unroll
+        for (int wv = 1; wv < 4; wv++) {
+            const float4 b = *reinterpret_cast<const float4 *>(red + (wv * 64 + lane) * 4);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const float out4[4] = {a.x, a.y, a.z, a.w};
+        const int n = nt * NT + nl;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int mrow = 4 * h + r;
+            if (mrow < M) {
+                if (splits == 1) {
+                    float v = out4[r];
+                    if (bias) v += vmx_bf16_to_f32(bias[n]);
+                    y[(int64_t)mrow * N + n] = vmx_f32_to_bf16(v);
+                } else {
+                    partial[((int64_t)ks * M + mrow) * N + n] = out4[r];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void int4_reduce_kernel(const float *__restrict__ partial, const uint16_t *__restrict__ bias,
+                                                           uint16_t *__restrict__ y, int M, int N, int splits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    float v = 0.f;
+    for (int s = 0; s < splits; s++) v += partial[(int64_t)s * M * N + i];
+    if (bias) v += vmx_bf16_to_f32(bias[i % N]);
+    y[i] = vmx_f32_to_bf16(v);
+}
+
+struct GemmPlan { int upw; int splits; };
+
+// Pick units-per-wave so the grid has roughly >= 6 workgroups per CU where the shape allows it.
+inline GemmPlan plan_gemm(int N, int K) {
+    const int n_tiles = N / NT, kblocks = K / KB;
+    int upw = 8;
+    while (upw > 1) {
+        const int splits = (kblocks + 4 * upw - 1) / (4 * upw);
+        if ((int64_t)n_tiles * splits >= 768) break;
+        upw >>= 1;
+    }
+    // do not leave most of a workgroup idle on short K
+    while (upw > 1 && 4 * upw > kblocks) upw >>= 1;
+    GemmPlan p;
+    p.upw = upw;
+    p.splits = (kblocks + 4 * upw - 1) / (4 * upw);
+    return p;
+}
+
+inline size_t gemm_lds_bytes(int M, int upw) {
+    return (size_t)M * (4 * upw * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + 4 * 64 * 4 * 4;
+}
+
+}  // namespace
+
+extern "C" int vmx_awq_to_gptq_qweight(const uint32_t *awq, uint32_t *out, int K, int N, void *stream) {
+    VMX_REQUIRE(awq && out, "awq_to_gptq_qweight: null pointer");
+    VMX_REQUIRE(K > 0 && K % 8 == 0, "awq_to_gptq_qweight: in_features (%d) must be divisible by 8", K);
+    VMX_REQUIRE(N > 0 && N % 8 == 0, "awq_to_gptq_qweight: out_features (%d) must be divisible by 8", N);
+    const int64_t total = (int64_t)(K / 8) * N;
+    hipLaunchKernelGGL(awq_to_gptq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vmx_stream(stream), awq, out, K, N);
+    VMX_CHECK_LAUNCH("awq_to_gptq_qweight");
+    return VMX_OK;
+}
+
+extern "C" int vmx_awq_repack_nibbles(const uint32_t *in, uint32_t *out, int64_t n_words, void *stream) {
+    VMX_REQUIRE(in && out && n_words >= 0, "awq_repack_nibbles: bad arguments");
+    if (n_words == 0) return VMX_OK;
+    hipLaunchKernelGGL(awq_nibble_reorder_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, vmx_stream(stream), in, out,
+                       n_words);
+    VMX_CHECK_LAUNCH("awq_repack_nibbles");
+    return VMX_OK;
+}
+
+static int check_int4_shape(const char *who, int K, int N, int group) {
+    VMX_REQUIRE(K > 0 && K % KB == 0, "%s: K (%d) must be a multiple of 128", who, K);
+    VMX_REQUIRE(N > 0 && N % NT == 0, "%s: N (%d) must be a multiple of 16", who, N);
+    VMX_REQUIRE(group > 0 && group % KB == 0 && K % group == 0, "%s: group_size (%d) must be a multiple of 128 dividing K (%d)", who,
+                group, K);
+    return VMX_OK;
+}
+
+extern "C" size_t vmx_int4_packed_bytes(int K, int N, int group) {
+    if (K <= 0 || N <= 0 || group <= 0) return 0;
+    return sz_offset_bytes(K, N) + (size_t)(K / group) * N * 4;
+}
+
+extern "C" int vmx_int4_pack(const uint32_t *qweight, const uint16_t *scales_bf16, const uint32_t *qzeros, void *packed, int K, int N,
+                             int group, void *stream) {
+    VMX_REQUIRE(qweight && scales_bf16 && packed, "int4_pack: null pointer");
+    if (int rc = check_int4_shape("int4_pack", K, N, group)) return rc;
+    uint32_t *W = (uint32_t *)packed;
+    uint32_t *SZ = (uint32_t *)((char *)packed + sz_offset_bytes(K, N));
+    const int64_t words = (int64_t)K * N / 8;
+    hipLaunchKernelGGL(int4_pack_w_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, vmx_stream(stream), qweight, W, K, N);
+    VMX_CHECK_LAUNCH("int4_pack(W)");
+    const int G = K / group;
+    const int64_t szn = (int64_t)G * N;
+    hipLaunchKernelGGL(int4_pack_sz_kernel, dim3((unsigned)((szn + 255) / 256)), dim3(256), 0, vmx_stream(stream), scales_bf16, qzeros,
+                       SZ, G, N);
+    VMX_CHECK_LAUNCH("int4_pack(SZ)");
+    return VMX_OK;
+}
+
+extern "C" int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K, int N, int group, void *stream) {
+    VMX_REQUIRE(packed && dense, "int4_dequant: null pointer");
+    if (int rc = check_int4_shape("int4_dequant", K, N, group)) return rc;
+    const uint32_t *W = (const uint32_t *)packed;
+    const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    const int64_t words = (int64_t)K * N / 8;
+    hipLaunchKernelGGL(int4_dequant_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, vmx_stream(stream), W, SZ, dense, K, N,
+                       group);
+    VMX_CHECK_LAUNCH("int4_dequant");
+    return VMX_OK;
+}
+
+extern "C" size_t vmx_int4_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % KB || N % NT) return 0;
+    const GemmPlan p = plan_gemm(N, K);
+    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *packed, const uint16_t *bias, int M, int N, int K,
+                                  int group, void *workspace, size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(y && x && packed, "int4_gemm: null pointer");
+    VMX_REQUIRE(M >= 1 && M <= 16, "int4_gemm: M (%d) must be in 1..16 (larger M takes the dequant + GEMM path)", M);
+    if (int rc = check_int4_shape("int4_gemm", K, N, group)) return rc;
+    const GemmPlan p = plan_gemm(N, K);
+    const size_t need = p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+    VMX_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), "int4_gemm: workspace %zu B < required %zu B", workspace_bytes,
+                need);
+    const uint4 *W = (const uint4 *)packed;
+    const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    const size_t lds = gemm_lds_bytes(M, p.upw);
+    VMX_REQUIRE(lds <= 160 * 1024, "int4_gemm: LDS need %zu B exceeds 160 KiB", lds);
+    const dim3 grid((unsigned)((N / NT) * p.splits)), block(256);
+    hipStream_t st = vmx_stream(stream);
+    float *partial = (float *)workspace;
+#define LAUNCH(U)                                                                                                          \
+    do {                                                                                                                   \
+        if (lds > 64 * 1024)                                                                                               \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              (int)lds));                                                                  \
+        hipLaunchKernelGGL((int4_gemm_kernel<U>), grid, block, lds, st, W, SZ, x, bias, y, partial, M, N, K, group, p.splits); \
+    } while (0)
+    switch (p.upw) {
+        case 8: LAUNCH(8); break;
+        case 4: LAUNCH(4); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(1); break;
+    }
+#undef LAUNCH
+    VMX_CHECK_LAUNCH("int4_gemm");
+    if (p.splits > 1) {
+        const int64_t total = (int64_t)M * N;
+        hipLaunchKernelGGL(int4_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, bias, y, M, N,
+                           p.splits);
+        VMX_CHECK_LAUNCH("int4_reduce");
+    }
+    return VMX_OK;
+}

@@ -1,0 +1,477 @@
+// GGUF I-quant kernels for gfx950: block dequantisation, q8_1 activation
+// quantisation and the q8_1 MMVQ (matrix x quantised-vector) decode kernel.
+//
+// Semantics follow crates/core/kernels/iq_dequant.cu (dequantize_iq*_f32 :42-194,
+// quantize_q8_1_rows :253-267, vec_dot_iq*_q8_1 :274-386, mmvq_iq*_f32 :388-423)
+// and their CPU restatement crates/core/src/quantization/gguf/iq/mod.rs:136-725.
+// The structure is gfx950's own: wave64, codebooks staged in LDS, v_dot4_i32_i8
+// for the integer dots, rows streamed straight into VGPRs with several rows in
+// flight per wave, signs applied with a carry-free xor/add (codebook bytes are
+// never 0, so two's-complement negation of a byte cannot carry into its neighbour).
+#include "vmx_internal.h"
+
+#define IQ_TABLE_QUAL static __device__ const
+#include "_gen/iq_tables_gen.h"
+
+namespace {
+
+constexpr int QK_K = 256;
+
+// ---- unaligned little-endian loads (block sizes 74/82/98/110 are only 2-byte aligned)
+struct __attribute__((packed, aligned(2))) u32_a2 { uint32_t v; };
+struct __attribute__((packed, aligned(2))) u16_a2 { uint16_t v; };
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return reinterpret_cast<const u32_a2 *>(p)->v; }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return reinterpret_cast<const u16_a2 *>(p)->v; }
+
+template <int T> struct IqTraits;
+template <> struct IqTraits<17> { static constexpr int TS = 74;  static constexpr int LDS_WORDS = 1024; };
+template <> struct IqTraits<22> { static constexpr int TS = 82;  static constexpr int LDS_WORDS = 2048; };
+template <> struct IqTraits<18> { static constexpr int TS = 98;  static constexpr int LDS_WORDS = 256; };
+template <> struct IqTraits<21> { static constexpr int TS = 110; static constexpr int LDS_WORDS = 512; };
+template <> struct IqTraits<23> { static constexpr int TS = 136; static constexpr int LDS_WORDS = 4; };
+
+// Stage the type's codebook in LDS (as u32 words).  Ends with a barrier.
+template <int T> __device__ __forceinline__ void load_codebook(uint32_t *lds) {
+    constexpr int W = IqTraits<T>::LDS_WORDS;
+    const uint32_t *src;
+    if constexpr (T == 17) src = reinterpret_cast<const uint32_t *>(iq2xs_grid);
+    else if constexpr (T == 22) src = reinterpret_cast<const uint32_t *>(iq2s_grid);
+    else if constexpr (T == 18) src = iq3xxs_grid;
+    else if constexpr (T == 21) src = iq3s_grid;
+    else src = reinterpret_cast<const uint32_t *>(kvalues_iq4nl);
+    for (int i = threadIdx.x; i < W; i += blockDim.x) lds[i] = src[i];
+    __syncthreads();
+}
+
+// 4 sign bits -> 0x01 in each byte whose bit is set.
+__device__ __forceinline__ uint32_t spread4(uint32_t bits4) { return __umul24(bits4 & 0xFu, 0x00204081u) & 0x01010101u; }
+
+// Negate the bytes of g selected by the 4 sign bits.  g's bytes are in 1..127.
+__device__ __forceinline__ int sign4(uint32_t g, uint32_t bits4) {
+    uint32_t lsb = spread4(bits4);
+    uint32_t mask = (lsb << 8) - lsb;  // 0xFF per selected byte
+    return (int)((g ^ mask) + lsb);
+}
+
+// ggml's ksigns_iq2xs[i] = i | (parity(i) << 7) for i in 0..127.
+__device__ __forceinline__ uint32_t ksign(uint32_t i7) { return i7 | ((__popc(i7) & 1u) << 7); }
+
+// Eight 4-bit indices of `q4` through the 16-entry int8 table T[0..3] (as 4 words):
+// lo = entries of the low nibbles, hi = of the high nibbles.
+__device__ __forceinline__ void table16(uint32_t q4, const uint32_t T[4], int &lo, int &hi) {
+    auto look = [&](uint32_t idx) -> int {  // idx: 4 bytes, each 0..15
+        uint32_t sel = idx & 0x07070707u;
+        uint32_t a = __builtin_amdgcn_perm(T[1], T[0], sel);
+        uint32_t b = __builtin_amdgcn_perm(T[3], T[2], sel);
+        uint32_t hb = (idx >> 3) & 0x01010101u;
+        uint32_t m = (hb << 8) - hb;
+        return (int)((b & m) | (a & ~m));
+    };
+    lo = look(q4 & 0x0F0F0F0Fu);
+    hi = look((q4 >> 4) & 0x0F0F0F0Fu);
+}
+
+struct SubScale { int ls0, ls1; };
+
+// Decode sub-block ib (0..7) of super-block b into 8 words of 4 signed int8
+// (word k = weights 4k..4k+3) plus the sub-block's integer scale fields.
+template <int T>
+__device__ __forceinline__ void decode_sub(const uint8_t *b, int ib, const uint32_t *cb, int q[8], SubScale &sc) {
+    sc.ls0 = sc.ls1 = 0;
+    if constexpr (T == 17) {  // IQ2_XS: qs u16[32]@2, scales u8[8]@66
+        uint32_t w0 = ld32(b + 2 + 8 * ib), w1 = ld32(b + 2 + 8 * ib + 4);
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            uint32_t v = ((l < 2 ? w0 : w1) >> (16 * (l & 1))) & 0xFFFFu;
+            uint2 g = reinterpret_cast<const uint2 *>(cb)[v & 511u];
+            uint32_t s8 = ksign(v >> 9);
+            q[2 * l] = sign4(g.x, s8);
+            q[2 * l + 1] = sign4(g.y, s8 >> 4);
+        }
+        uint32_t s = b[66 + ib];
+        sc.ls0 = s & 0xF; sc.ls1 = s >> 4;
+    } else if constexpr (T == 22) {  // IQ2_S: qs u8[32]@2, signs u8[32]@34, qh u8[8]@66, scales u8[8]@74
+        uint32_t qs = ld32(b + 2 + 4 * ib), sg = ld32(b + 34 + 4 * ib), qh = b[66 + ib];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            uint32_t idx = ((qs >> (8 * l)) & 0xFFu) | ((qh << (8 - 2 * l)) & 0x300u);
+            uint2 g = reinterpret_cast<const uint2 *>(cb)[idx];
+            uint32_t s8 = (sg >> (8 * l)) & 0xFFu;
+            q[2 * l] = sign4(g.x, s8);
+            q[2 * l + 1] = sign4(g.y, s8 >> 4);
+        }
+        uint32_t s = b[74 + ib];
+        sc.ls0 = s & 0xF; sc.ls1 = s >> 4;
+    } else if constexpr (T == 18) {  // IQ3_XXS: qs u8[64]@2, scales_and_signs u32[8]@66
+        uint32_t w0 = ld32(b + 2 + 8 * ib), w1 = ld32(b + 2 + 8 * ib + 4), aux = ld32(b + 66 + 4 * ib);
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            uint32_t pair = ((l < 2 ? w0 : w1) >> (16 * (l & 1))) & 0xFFFFu;
+            uint32_t s8 = ksign((aux >> (7 * l)) & 127u);
+            q[2 * l] = sign4(cb[pair & 0xFFu], s8);
+            q[2 * l + 1] = sign4(cb[pair >> 8], s8 >> 4);
+        }
+        sc.ls0 = (int)(aux >> 28);
+    } else if constexpr (T == 21) {  // IQ3_S: qs u8[64]@2, qh u8[8]@66, signs u8[32]@74, scales u8[4]@106
+        uint32_t w0 = ld32(b + 2 + 8 * ib), w1 = ld32(b + 2 + 8 * ib + 4), sg = ld32(b + 74 + 4 * ib);
+        uint32_t qh = b[66 + ib];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            uint32_t pair = ((l < 2 ? w0 : w1) >> (16 * (l & 1))) & 0xFFFFu;
+            uint32_t i1 = (pair & 0xFFu) | ((qh << (8 - 2 * l)) & 256u);
+            uint32_t i2 = (pair >> 8) | ((qh << (7 - 2 * l)) & 256u);
+            uint32_t s8 = (sg >> (8 * l)) & 0xFFu;
+            q[2 * l] = sign4(cb[i1], s8);
+            q[2 * l + 1] = sign4(cb[i2], s8 >> 4);
+        }
+        sc.ls0 = (b[106 + (ib >> 1)] >> (4 * (ib & 1))) & 0xF;
+    } else {  // IQ4_XS: scales_h u16@2, scales_l u8[4]@4, qs u8[128]@8
+        uint32_t Tb[4] = {cb[0], cb[1], cb[2], cb[3]};
+        const uint2 *qp = reinterpret_cast<const uint2 *>(b + 8 + 16 * ib);  // blocks are 8-byte multiples
+        uint2 a = qp[0], c = qp[1];
+        uint32_t w[4] = {a.x, a.y, c.x, c.y};
+#pragma unroll
+        for (int j = 0; j < 4; j++) table16(w[j], Tb, q[j], q[j + 4]);
+        uint32_t sh = ld16(b + 2);
+        sc.ls0 = (int)(((b[4 + (ib >> 1)] >> (4 * (ib & 1))) & 0xFu) | (((sh >> (2 * ib)) & 3u) << 4));
+    }
+}
+
+// Integer scale step of vec_dot_iq*_q8_1 (C truncating division).
+template <int T> __device__ __forceinline__ int scale_int(int s0, int s1, const SubScale &sc) {
+    if constexpr (T == 17 || T == 22) return (s0 * sc.ls0 + s1 * sc.ls1 + (s0 + s1) / 2) / 4;
+    else if constexpr (T == 18) { int s = s0 + s1; return (sc.ls0 * s + s / 2) / 2; }
+    else if constexpr (T == 21) return (s0 + s1) * (1 + 2 * sc.ls0);
+    else return (s0 + s1) * (sc.ls0 - 32);
+}
+
+__device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+__device__ __forceinline__ int subdot_halves(const int q[8], const int u[8], int &s1) {
+    int s0 = 0;
+    s1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { s0 = dot4(q[k], u[k], s0); s1 = dot4(q[k + 4], u[k + 4], s1); }
+    return s0;
+}
+
+// ------------------------------------------------------------------ dequant
+// One thread per 32-weight sub-block; 8 float4 stores per thread.
+template <int T>
+__global__ __launch_bounds__(256) void iq_dequant_kernel(const uint8_t *__restrict__ blocks, float *__restrict__ out,
+                                                          int64_t n_blocks) {
+    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
+    load_codebook<T>(cb);
+    const int64_t total = n_blocks * 8;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = s >> 3;
+        const int ib = (int)(s & 7);
+        const uint8_t *b = blocks + blk * IqTraits<T>::TS;
+        const float d = vmx_f16_to_f32((uint16_t)ld16(b));
+        int q[8];
+        SubScale sc;
+        decode_sub<T>(b, ib, cb, q, sc);
+        float db0, db1;
+        if constexpr (T == 17 || T == 22) {
+            db0 = d * (0.5f + (float)sc.ls0) * 0.25f;
+            db1 = d * (0.5f + (float)sc.ls1) * 0.25f;
+        } else if constexpr (T == 18) {
+            db0 = db1 = d * (0.5f + (float)sc.ls0) * 0.5f;
+        } else if constexpr (T == 21) {
+            db0 = db1 = d * (float)(1 + 2 * sc.ls0);
+        } else {
+            db0 = db1 = d * (float)(sc.ls0 - 32);
+        }
+        float4 *y = reinterpret_cast<float4 *>(out + blk * QK_K + ib * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float db = k < 4 ? db0 : db1;
+            const int w = q[k];
+            float4 v;
+            v.x = db * (float)(int8_t)(w & 0xFF);
+            v.y = db * (float)(int8_t)((w >> 8) & 0xFF);
+            v.z = db * (float)(int8_t)((w >> 16) & 0xFF);
+            v.w = db * (float)(int8_t)((w >> 24) & 0xFF);
+            y[k] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ q8_1
+// 8 lanes per 32-value block: one float4 load, one packed int8x4 store per lane.
+__global__ __launch_bounds__(256) void quantize_q8_1_kernel(const float *__restrict__ x, int8_t *__restrict__ aq,
+                                                             float *__restrict__ ad, int64_t total_blocks) {
+    const int64_t lane4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index of a 4-value group
+    const int64_t blk = lane4 >> 3;
+    const bool live = blk < total_blocks;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) v = reinterpret_cast<const float4 *>(x)[lane4];
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d = amax / 127.0f;
+    uint32_t packed = 0;
+    if (amax != 0.0f) {
+        int q0 = (int)roundf(v.x / d), q1 = (int)roundf(v.y / d), q2 = (int)roundf(v.z / d), q3 = (int)roundf(v.w / d);
+        packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) |
+                 ((uint32_t)(q3 & 0xFF) << 24);
+    }
+    if (live) {
+        reinterpret_cast<uint32_t *>(aq)[lane4] = packed;
+        if ((lane4 & 7) == 0) ad[blk] = d;
+    }
+}
+
+// ------------------------------------------------------------------ MMVQ
+// One wave owns R consecutive output rows per step; lane g walks the row's
+// 32-weight sub-blocks (g, g+64, ...).  The R rows' sub-blocks are decoded
+// first (R independent load chains in flight), then every activation row is
+// dotted against all of them.  Accumulation: acc += (w_d * a_d) * (float)sub,
+// lanes summed by a 64-wide butterfly.
+template <int T, int MT, int R>
+__global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
+                                                       const float *__restrict__ ad, float *__restrict__ y, int n_out,
+                                                       int n_in, int m) {
+    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
+    load_codebook<T>(cb);
+    constexpr int TS = IqTraits<T>::TS;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nb256 = n_in >> 8, nblk32 = n_in >> 5;
+    const int waves_total = gridDim.x * 4;
+    for (int row0 = (blockIdx.x * 4 + wave) * R; row0 < n_out; row0 += waves_total * R) {
+        float acc[R][MT];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) acc[r][mi] = 0.0f;
+
+        for (int g = lane; g < nblk32; g += 64) {
+            const int sb = g >> 3, ib = g & 7;
+            int q[R][8];
+            SubScale sc[R];
+            float wd[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int row = min(row0 + r, n_out - 1);  // clamp: duplicates are discarded at the store
+                const uint8_t *b = w + ((int64_t)row * nb256 + sb) * TS;
+                wd[r] = vmx_f16_to_f32((uint16_t)ld16(b));
+                decode_sub<T>(b, ib, cb, q[r], sc[r]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                if (mi < m) {
+                    const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)mi * n_in + g * 32);
+                    const int4 ua = up[0], ub = up[1];
+                    const int u[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+                    const float da = ad[(int64_t)mi * nblk32 + g];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        int s1;
+                        const int s0 = subdot_halves(q[r], u, s1);
+                        const int sub = scale_int<T>(s0, s1, sc[r]);
+                        acc[r][mi] += (wd[r] * da) * (float)sub;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                const float v = vmx_wave_sum(acc[r][mi]);
+                if (lane == 0 && mi < m && row0 + r < n_out) y[(int64_t)mi * n_out + row0 + r] = v;
+            }
+    }
+}
+
+// Integer sub-dots only (parity aid): out[(o*m + mi)*nblk32 + g].
+template <int T>
+__global__ __launch_bounds__(256) void iq_subdots_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
+                                                          int32_t *__restrict__ out, int n_out, int n_in, int m) {
+    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
+    load_codebook<T>(cb);
+    const int nb256 = n_in >> 8, nblk32 = n_in >> 5;
+    const int64_t total = (int64_t)n_out * nblk32;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i / nblk32), g = (int)(i % nblk32);
+        const uint8_t *b = w + ((int64_t)o * nb256 + (g >> 3)) * IqTraits<T>::TS;
+        int q[8];
+        SubScale sc;
+        decode_sub<T>(b, g & 7, cb, q, sc);
+        for (int mi = 0; mi < m; mi++) {
+            const int *up = reinterpret_cast<const int *>(aq + (int64_t)mi * n_in + g * 32);
+            int u[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) u[k] = up[k];
+            int s1;
+            const int s0 = subdot_halves(q, u, s1);
+            out[((int64_t)o * m + mi) * nblk32 + g] = scale_int<T>(s0, s1, sc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Q6_K gather
+// One 64-thread workgroup per (id, super-block): thread t -> half t/32, l = t%32, 4 outputs.
+__global__ __launch_bounds__(64) void gather_q6k_kernel(const uint8_t *__restrict__ blocks, const int32_t *__restrict__ ids,
+                                                         float *__restrict__ out, int num_ids, int blocks_per_row,
+                                                         int num_embeddings) {
+    const int gb = blockIdx.x;
+    if (gb >= num_ids * blocks_per_row) return;
+    const int out_row = gb / blocks_per_row, bir = gb % blocks_per_row;
+    const int id = ids[out_row];
+    const int t = threadIdx.x, half = t >> 5, l = t & 31;
+    float *yo = out + ((int64_t)out_row * blocks_per_row + bir) * QK_K + 128 * half;
+    if (id < 0 || id >= num_embeddings) {
+        yo[l] = 0.f; yo[l + 32] = 0.f; yo[l + 64] = 0.f; yo[l + 96] = 0.f;
+        return;
+    }
+    const uint8_t *b = blocks + ((int64_t)id * blocks_per_row + bir) * 210;
+    const uint8_t *ql = b + 64 * half, *qh = b + 128 + 32 * half;
+    const int8_t *sc = reinterpret_cast<const int8_t *>(b + 192) + 8 * half;
+    const float d = vmx_f16_to_f32((uint16_t)ld16(b + 208));
+    const int is = l >> 4;
+    const int q1 = (int)((ql[l] & 0xF) | ((qh[l] & 3) << 4)) - 32;
+    const int q2 = (int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+    const int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+    const int q4 = (int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+    yo[l] = d * (float)sc[is] * (float)q1;
+    yo[l + 32] = d * (float)sc[is + 2] * (float)q2;
+    yo[l + 64] = d * (float)sc[is + 4] * (float)q3;
+    yo[l + 96] = d * (float)sc[is + 6] * (float)q4;
+}
+
+inline int grid_for(int64_t work_items, int per_block, int cap) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+template <int T>
+int launch_mmvq(const uint8_t *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, hipStream_t st) {
+    // rows per workgroup = 4 waves * R; cap the grid and stride the rest.
+    if (m == 1) {
+        constexpr int R = 2;
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 1, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+    } else if (m == 2) {
+        constexpr int R = 2;
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 2, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+    } else if (m <= 4) {
+        constexpr int R = 2;
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 4, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+    } else if (m <= 8) {
+        constexpr int R = 1;
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 8, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+    } else {
+        constexpr int R = 1;
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 16, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+    }
+    VMX_CHECK_LAUNCH("iq_mmvq");
+    return VMX_OK;
+}
+
+}  // namespace
+
+#define IQ_DISPATCH(type, CALL)                                   \
+    switch (type) {                                               \
+        case 17: CALL(17); break;                                 \
+        case 22: CALL(22); break;                                 \
+        case 18: CALL(18); break;                                 \
+        case 21: CALL(21); break;                                 \
+        case 23: CALL(23); break;                                 \
+        default:                                                  \
+            vmx_set_error("unsupported ggml type id %d", type);  \
+            return VMX_EUNSUPPORTED;                              \
+    }
+
+extern "C" int vmx_iq_type_size(int t) {
+    switch (t) {
+        case 17: return 74;
+        case 22: return 82;
+        case 18: return 98;
+        case 21: return 110;
+        case 23: return 136;
+        default: return -1;
+    }
+}
+
+extern "C" int vmx_iq_dequantize_f32(int ggml_type, const void *blocks, float *out, int64_t n_blocks, void *stream) {
+    VMX_REQUIRE(blocks && out, "iq_dequantize: null pointer");
+    VMX_REQUIRE(n_blocks >= 0, "iq_dequantize: n_blocks %lld < 0", (long long)n_blocks);
+    if (n_blocks == 0) return VMX_OK;
+    const int grid = grid_for(n_blocks * 8, 256, 16384);
+#define CALL(T) hipLaunchKernelGGL((iq_dequant_kernel<T>), dim3(grid), dim3(256), 0, vmx_stream(stream), (const uint8_t *)blocks, out, n_blocks)
+    IQ_DISPATCH(ggml_type, CALL)
+#undef CALL
+    VMX_CHECK_LAUNCH("iq_dequantize");
+    return VMX_OK;
+}
+
+extern "C" int vmx_quantize_q8_1_rows(const float *x, int8_t *aq, float *ad, int64_t total_blocks, void *stream) {
+    VMX_REQUIRE(x && aq && ad, "quantize_q8_1: null pointer");
+    VMX_REQUIRE(total_blocks >= 0, "quantize_q8_1: total_blocks < 0");
+    if (total_blocks == 0) return VMX_OK;
+    const int64_t groups = total_blocks * 8;
+    hipLaunchKernelGGL(quantize_q8_1_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, vmx_stream(stream), x, aq, ad,
+                       total_blocks);
+    VMX_CHECK_LAUNCH("quantize_q8_1");
+    return VMX_OK;
+}
+
+extern "C" int vmx_iq_mmvq_f32(int ggml_type, const void *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in,
+                               int m, void *stream) {
+    VMX_REQUIRE(w && aq && ad && y, "iq_mmvq: null pointer");
+    VMX_REQUIRE(m >= 1 && m <= 16, "iq_matmul: m %d exceeds IQ_GEMV_MAX_M (16)", m);
+    VMX_REQUIRE(n_in > 0 && n_in % QK_K == 0, "iq_matmul: n_in %d not a multiple of 256", n_in);
+    VMX_REQUIRE(n_out > 0, "iq_matmul: n_out %d", n_out);
+#define CALL(T) { int rc = launch_mmvq<T>((const uint8_t *)w, aq, ad, y, n_out, n_in, m, vmx_stream(stream)); if (rc) return rc; }
+    IQ_DISPATCH(ggml_type, CALL)
+#undef CALL
+    return VMX_OK;
+}
+
+extern "C" size_t vmx_iq_matmul_workspace_bytes(int n_in, int m) {
+    if (n_in <= 0 || m <= 0) return 0;
+    size_t q = ((size_t)m * n_in + 255) & ~(size_t)255;
+    return q + (size_t)m * (n_in / 32) * sizeof(float);
+}
+
+extern "C" int vmx_iq_matmul_f32(int ggml_type, const void *w, const float *x, float *y, int n_out, int n_in, int m,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(w && x && y && workspace, "iq_matmul: null pointer");
+    VMX_REQUIRE(m >= 1 && m <= 16, "iq_matmul: m %d exceeds IQ_GEMV_MAX_M (16)", m);
+    VMX_REQUIRE(n_in > 0 && n_in % QK_K == 0, "iq_matmul: n_in %d not a multiple of 256", n_in);
+    VMX_REQUIRE(workspace_bytes >= vmx_iq_matmul_workspace_bytes(n_in, m), "iq_matmul: workspace too small");
+    int8_t *aq = (int8_t *)workspace;
+    float *ad = (float *)((char *)workspace + (((size_t)m * n_in + 255) & ~(size_t)255));
+    int rc = vmx_quantize_q8_1_rows(x, aq, ad, (int64_t)m * (n_in / 32), stream);
+    if (rc) return rc;
+    return vmx_iq_mmvq_f32(ggml_type, w, aq, ad, y, n_out, n_in, m, stream);
+}
+
+extern "C" int vmx_iq_subdots_i32(int ggml_type, const void *w, const int8_t *aq, int32_t *out, int n_out, int n_in, int m,
+                                  void *stream) {
+    VMX_REQUIRE(w && aq && out, "iq_subdots: null pointer");
+    VMX_REQUIRE(n_in > 0 && n_in % QK_K == 0 && n_out > 0 && m >= 1, "iq_subdots: bad shape");
+    const int grid = grid_for((int64_t)n_out * (n_in / 32), 256, 4096);
+#define CALL(T) hipLaunchKernelGGL((iq_subdots_kernel<T>), dim3(grid), dim3(256), 0, vmx_stream(stream), (const uint8_t *)w, aq, out, n_out, n_in, m)
+    IQ_DISPATCH(ggml_type, CALL)
+#undef CALL
+    VMX_CHECK_LAUNCH("iq_subdots");
+    return VMX_OK;
+}
+
+extern "C" int vmx_gather_dequant_q6k_f32(const void *blocks, const int32_t *ids, float *out, int num_ids, int dim,
+                                          int num_embeddings, void *stream) {
+    VMX_REQUIRE(blocks && ids && out, "gather_dequant_q6k: null pointer");
+    VMX_REQUIRE(dim > 0 && dim % QK_K == 0, "gather_dequant_q6k: dim %d not a multiple of 256", dim);
+    VMX_REQUIRE(num_ids >= 0 && num_embeddings > 0, "gather_dequant_q6k: bad counts");
+    if (num_ids == 0) return VMX_OK;
+    const int bpr = dim / QK_K;
+    hipLaunchKernelGGL(gather_q6k_kernel, dim3(num_ids * bpr), dim3(64), 0, vmx_stream(stream), (const uint8_t *)blocks, ids, out,
+                       num_ids, bpr, num_embeddings);
+    VMX_CHECK_LAUNCH("gather_dequant_q6k");
+    return VMX_OK;
+}

@@ -1,0 +1,81 @@
+// Internal helpers shared by the libvmx translation units (host + device).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/vmx.h"
+
+// ---------------------------------------------------------------- host side
+void vmx_set_error(const char *fmt, ...);
+
+#define VMX_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            vmx_set_error(__VA_ARGS__);   \
+            return VMX_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define VMX_CHECK_LAUNCH(what)                                                     \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            vmx_set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+            return VMX_ELAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define VMX_CHECK_HIP(expr)                                                        \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            vmx_set_error("%s: %s", #expr, hipGetErrorString(e__));               \
+            return VMX_ELAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+static inline hipStream_t vmx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------- device side
+#define VMX_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 vmx_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float vmx_f32x4;
+
+__device__ __forceinline__ float vmx_bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// Round-to-nearest-even; a plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32).
+__device__ __forceinline__ uint16_t vmx_f32_to_bf16(float f) {
+    __bf16 b = static_cast<__bf16>(f);
+    return __builtin_bit_cast(uint16_t, b);
+}
+
+__device__ __forceinline__ float vmx_f16_to_f32(uint16_t h) {
+    return static_cast<float>(__builtin_bit_cast(_Float16, h));
+}
+
+__device__ __forceinline__ float vmx_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float vmx_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Sum over a 256-thread workgroup (4 waves); `red` is 4 floats of LDS.  Ends synchronised.
+__device__ __forceinline__ float vmx_block_sum_256(float v, float *red) {
+    v = vmx_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}

@@ -1,0 +1,162 @@
+"""Thin torch-tensor front-ends over the C ABI (one per entry point).
+
+Every function takes CUDA(HIP) tensors, validates only what ctypes cannot, and
+launches on torch's current stream.  Shape/dtype preconditions are enforced by
+the library itself and surface as VmxError with the library's message.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib
+
+__all__ = [
+    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots",
+    "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
+    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention",
+]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def init(device: int = 0) -> None:
+    check(lib.vmx_init(device))
+    torch.cuda.set_device(device)
+
+
+def iq_type_size(ggml_type: int) -> int:
+    return lib.vmx_iq_type_size(ggml_type)
+
+
+def iq_dequantize(ggml_type: int, blocks: torch.Tensor, n_blocks: int) -> torch.Tensor:
+    out = torch.empty(n_blocks * 256, dtype=torch.float32, device=blocks.device)
+    check(lib.vmx_iq_dequantize_f32(ggml_type, _ptr(blocks), _ptr(out), n_blocks, _stream()))
+    return out
+
+
+def quantize_q8_1(x: torch.Tensor):
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    m, n_in = x.shape
+    aq = torch.empty((m, n_in), dtype=torch.int8, device=x.device)
+    ad = torch.empty((m, n_in // 32), dtype=torch.float32, device=x.device)
+    check(lib.vmx_quantize_q8_1_rows(_ptr(x), _ptr(aq), _ptr(ad), m * (n_in // 32), _stream()))
+    return aq, ad
+
+
+def iq_mmvq(ggml_type: int, w: torch.Tensor, aq: torch.Tensor, ad: torch.Tensor, n_out: int, n_in: int, out=None):
+    m = aq.shape[0]
+    y = out if out is not None else torch.empty((m, n_out), dtype=torch.float32, device=w.device)
+    check(lib.vmx_iq_mmvq_f32(ggml_type, _ptr(w), _ptr(aq), _ptr(ad), _ptr(y), n_out, n_in, m, _stream()))
+    return y
+
+
+def iq_matmul(ggml_type: int, w: torch.Tensor, x: torch.Tensor, n_out: int, n_in: int, workspace=None):
+    m = x.shape[0]
+    need = lib.vmx_iq_matmul_workspace_bytes(n_in, max(m, 1))
+    ws = workspace if workspace is not None else torch.empty(max(need, 1), dtype=torch.uint8, device=w.device)
+    y = torch.empty((m, n_out), dtype=torch.float32, device=w.device)
+    check(lib.vmx_iq_matmul_f32(ggml_type, _ptr(w), _ptr(x), _ptr(y), n_out, n_in, m, _ptr(ws), ws.numel(), _stream()))
+    return y
+
+
+def iq_subdots(ggml_type: int, w: torch.Tensor, aq: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
+    m = aq.shape[0]
+    out = torch.empty((n_out, m, n_in // 32), dtype=torch.int32, device=w.device)
+    check(lib.vmx_iq_subdots_i32(ggml_type, _ptr(w), _ptr(aq), _ptr(out), n_out, n_in, m, _stream()))
+    return out
+
+
+def gather_dequant_q6k(blocks: torch.Tensor, ids: torch.Tensor, dim: int, num_embeddings: int) -> torch.Tensor:
+    out = torch.empty((ids.numel(), dim), dtype=torch.float32, device=blocks.device)
+    check(lib.vmx_gather_dequant_q6k_f32(_ptr(blocks), _ptr(ids), _ptr(out), ids.numel(), dim, num_embeddings, _stream()))
+    return out
+
+
+def awq_to_gptq_qweight(awq: torch.Tensor, K: int, N: int) -> torch.Tensor:
+    out = torch.empty((K // 8, N), dtype=torch.int32, device=awq.device)
+    check(lib.vmx_awq_to_gptq_qweight(_ptr(awq), _ptr(out), K, N, _stream()))
+    return out
+
+
+def awq_repack_nibbles(words: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(words)
+    check(lib.vmx_awq_repack_nibbles(_ptr(words), _ptr(out), words.numel(), _stream()))
+    return out
+
+
+def int4_pack(qweight: torch.Tensor, scales_bf16: torch.Tensor, qzeros, K: int, N: int, group: int) -> torch.Tensor:
+    nbytes = lib.vmx_int4_packed_bytes(K, N, group)
+    packed = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=qweight.device)
+    check(lib.vmx_int4_pack(_ptr(qweight), _ptr(scales_bf16), _ptr(qzeros), _ptr(packed), K, N, group, _stream()))
+    return packed
+
+
+def int4_gemm(x_bf16: torch.Tensor, packed: torch.Tensor, bias, N: int, K: int, group: int, workspace=None, out=None):
+    M = x_bf16.shape[0]
+    need = lib.vmx_int4_gemm_workspace_bytes(max(M, 1), N, K)
+    ws = workspace if workspace is not None else torch.empty(max(need, 1), dtype=torch.uint8, device=packed.device)
+    y = out if out is not None else torch.empty((M, N), dtype=torch.bfloat16, device=packed.device)
+    check(lib.vmx_int4_gemm_bf16(_ptr(y), _ptr(x_bf16), _ptr(packed), _ptr(bias), M, N, K, group, _ptr(ws), ws.numel(),
+                                 _stream()))
+    return y
+
+
+def int4_dequant(packed: torch.Tensor, K: int, N: int, group: int) -> torch.Tensor:
+    dense = torch.empty((K, N), dtype=torch.bfloat16, device=packed.device)
+    check(lib.vmx_int4_dequant_bf16(_ptr(packed), _ptr(dense), K, N, group, _stream()))
+    return dense
+
+
+def rms_norm(x: torch.Tensor, weight, eps: float, residual=None, weight_plus_one: bool = False) -> torch.Tensor:
+    """x bf16 [tokens, hidden]; with `residual` it is updated in place (fused add)."""
+    out = torch.empty_like(x)
+    tokens, hidden = x.shape
+    check(lib.vmx_rms_norm_bf16(_ptr(out), _ptr(x), _ptr(residual), _ptr(weight), eps, tokens, hidden, int(weight_plus_one),
+                                _stream()))
+    return out
+
+
+def rope_neox(positions: torch.Tensor, q: torch.Tensor, k, cos_sin: torch.Tensor, rot_dim: int, head_size: int,
+              num_heads: int, num_kv_heads: int) -> None:
+    check(lib.vmx_rope_neox_bf16(_ptr(positions), _ptr(q), _ptr(k), _ptr(cos_sin), positions.numel(), rot_dim, head_size,
+                                 num_heads, num_kv_heads, _stream()))
+
+
+def silu_and_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(gate)
+    check(lib.vmx_silu_and_mul_bf16(_ptr(out), _ptr(gate), _ptr(up), gate.numel(), _stream()))
+    return out
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    rows, vocab = logits.shape
+    ws = torch.empty(max(lib.vmx_argmax_workspace_bytes(rows, vocab), 8), dtype=torch.uint8, device=logits.device)
+    out = torch.empty(rows, dtype=torch.int32, device=logits.device)
+    check(lib.vmx_argmax_bf16(_ptr(out), _ptr(logits), rows, vocab, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def reshape_and_cache(key, value, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int,
+                      kv_dtype: int = 0, k_scale=None, v_scale=None) -> None:
+    check(lib.vmx_reshape_and_cache(_ptr(key), _ptr(value), _ptr(k_cache), _ptr(v_cache), _ptr(slots), slots.numel(),
+                                    kv_heads, head_dim, block_size, kv_dtype, _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
+def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, scale: float, num_heads: int, num_kv_heads: int,
+                    head_dim: int, block_size: int, max_seq_len: int, window: int = 0, kv_dtype: int = 0, k_scale=None,
+                    v_scale=None, workspace=None) -> torch.Tensor:
+    num_seqs = seq_lens.numel()
+    need = lib.vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len)
+    ws = workspace if workspace is not None else torch.empty(max(need, 8), dtype=torch.uint8, device=q.device)
+    out = torch.zeros((num_seqs, num_heads * head_dim), dtype=torch.bfloat16, device=q.device)
+    check(lib.vmx_paged_attention_bf16(_ptr(out), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(block_tables), _ptr(seq_lens),
+                                       scale, num_seqs, num_heads, num_kv_heads, block_tables.shape[1], max_seq_len, head_dim,
+                                       block_size, window, kv_dtype, _ptr(k_scale), _ptr(v_scale), _ptr(ws), ws.numel(),
+                                       _stream()))
+    return out
