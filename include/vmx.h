@@ -164,6 +164,86 @@ int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cac
                              int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
                              const float *v_scale, void *workspace, size_t workspace_bytes, void *stream);
 
+
+/* Replaces the cuBLAS half_matmul_pooled used for the (tied) lm_head on the decode path
+ * (crates/core/src/models/qwen3_quantized.rs:1258-1302; cuda_kernels.rs half_matmul_pooled):
+ * y[m, n] = bf16(sum_k x[m,k] * W[n,k] + bias[n]), W bf16 [N, K] row-major, 1 <= M <= 16.
+ * The reference's arithmetic lives in a third-party library, so parity is tolerance-only. */
+int vmx_dense_gemv_bf16(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N,
+                        int K, void *stream);
+
+/* Replaces embedding_lookup_bf16 (crates/core/kernels/activations.cu embedding_lookup_*):
+ * out[t, :] = table[ids[t], :]; out-of-range ids give a zero row. */
+int vmx_embedding_lookup_bf16(uint16_t *out, const uint16_t *table, const int32_t *ids, int tokens, int hidden,
+                              int vocab, void *stream);
+
+/* ------------------------------------------------------- whole-token decoder */
+
+/* Engine-facing surface of the quantized Qwen3-family decoder: the C form of
+ * ModelForward::forward_decode_batch for QuantizedQwen3ForCausalLM
+ * (crates/core/src/engine/model_forward.rs:22-138, models/qwen3_quantized.rs:557-1302).
+ * create/load calls allocate and may synchronise; vmx_qwen3_decode is a fixed launch
+ * sequence (no allocation, no host reads) and may be captured into a hipGraph. */
+typedef struct vmx_qwen3_config {
+    int hidden_size, num_layers, num_heads, num_kv_heads, head_dim, intermediate_size, vocab_size;
+    float rms_norm_eps;
+    int max_position;        /* rows of the cos/sin cache */
+    int group_size;          /* AWQ/GPTQ group size (multiple of 128) */
+    int qk_norm;             /* 1: per-head RMSNorm on q and k (Qwen3) */
+    int tie_word_embeddings; /* 1: lm_head shares the embedding table */
+    int kv_cache_dtype;      /* VMX_KV_AUTO (bf16) or VMX_KV_FP8_E4M3 */
+    int block_size, num_blocks; /* paged KV cache geometry, per layer */
+    int max_batch;           /* 1..16 */
+    int max_seq_len;         /* sizes the split-KV workspace */
+} vmx_qwen3_config;
+
+typedef struct vmx_qwen3 vmx_qwen3;
+
+/* tensor ids for vmx_qwen3_load_tensor */
+#define VMX_T_EMBED 0       /* bf16 [vocab, hidden] */
+#define VMX_T_LM_HEAD 1     /* bf16 [vocab, hidden] (untied models) */
+#define VMX_T_FINAL_NORM 2  /* bf16 [hidden] */
+#define VMX_T_COS_SIN 3     /* f32 [max_position, head_dim]: cos[hd/2] | sin[hd/2] per row */
+#define VMX_T_INPUT_LN 4    /* per layer: bf16 [hidden] */
+#define VMX_T_POST_LN 5
+#define VMX_T_Q_NORM 6      /* bf16 [head_dim] */
+#define VMX_T_K_NORM 7
+#define VMX_T_KV_SCALES 8   /* f32 [2] = {k_scale, v_scale} (FP8 KV cache) */
+
+/* linear slots for vmx_qwen3_load_awq_linear */
+#define VMX_L_Q 0
+#define VMX_L_K 1
+#define VMX_L_V 2
+#define VMX_L_O 3
+#define VMX_L_GATE 4
+#define VMX_L_UP 5
+#define VMX_L_DOWN 6
+
+int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out);
+void vmx_qwen3_destroy(vmx_qwen3 *m);
+
+/* Copy one non-quantized tensor (device or host pointer) into the model. */
+int vmx_qwen3_load_tensor(vmx_qwen3 *m, int which, int layer, const void *src, size_t bytes, void *stream);
+
+/* Load one AWQ projection as the checkpoint stores it (QuantizedWeightLoader::load_linear for AWQ,
+ * crates/core/src/quantization/weight_loader.rs:597-714): qweight u32 [K, N/8], qzeros u32 [K/g, N/8]
+ * (both AWQ-interleaved), scales f16 [K/g, N].  Runs the reference's load-time pipeline
+ * (awq_marlin.rs:580-667) on the device and repacks into the tile stream; q|k|v and gate|up are
+ * merged into one linear each once all their parts have arrived. */
+int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
+                              const uint16_t *scales_f16, void *stream);
+
+/* One decode step: input_ids/positions/slot_mapping/seq_lens i32 [batch], block_tables i32
+ * [batch, max_blocks_per_seq] (all device).  Writes greedy token ids to out_ids (device i32 [batch],
+ * may be NULL) and, if logits_out != NULL, bf16 logits [batch, vocab] there. */
+int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+                     const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq,
+                     int max_seq_len, int32_t *out_ids, uint16_t *logits_out, void *stream);
+
+/* Parity aid: read back an internal activation of the last step (0 = residual stream h,
+ * 1 = final normed x, 2 = logits), bf16. */
+int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,151 @@
+"""End-to-end parity of the whole-token decoder against the composed CPU oracle on a tiny
+Qwen3-shaped model with random AWQ weights, plus hipGraph capture/replay equivalence."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import vllm_rust_amd as vmx
+    assert torch.cuda.is_available()
+    vmx.init(0)
+    return vmx, torch
+
+
+def _tiny_spec(**kw):
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    base = dict(hidden_size=256, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64, intermediate_size=512,
+                vocab_size=1000, max_position=512, num_blocks=32, max_batch=4, max_seq_len=300)
+    base.update(kw)
+    return Qwen3Spec(**base)
+
+
+def _u16(torch, t):
+    return t.cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_decode_steps_match_oracle(gpu, tied):
+    from oracle import oracle as orc
+    from tests.model_oracle import OracleQwen3
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache
+    vmx, torch = gpu
+    spec = _tiny_spec(tie_word_embeddings=tied)
+    model = QuantizedQwen3ForCausalLM(spec)
+    ck = model.load_synthetic(seed=3, keep_host_copy=True)
+    ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta))
+    rng = np.random.default_rng(0)
+    B, MB = 3, 8
+    bt = np.stack([rng.permutation(spec.num_blocks)[:MB] for _ in range(B)]).astype(np.int32)
+    # make block tables disjoint across sequences
+    bt = np.arange(B * MB, dtype=np.int32).reshape(B, MB)[:, ::-1].copy()
+    ids = rng.integers(0, spec.vocab_size, size=B).astype(np.int32)
+    for step in range(6):
+        pos = np.full(B, step, np.int32)
+        slots = (bt[np.arange(B), pos // spec.block_size] * spec.block_size + pos % spec.block_size).astype(np.int32)
+        seq_lens = pos + 1
+        logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        out = model.forward_decode_batch(torch.from_numpy(ids).cuda(), torch.from_numpy(pos).cuda(), torch.from_numpy(slots).cuda(),
+                                         torch.from_numpy(bt).cuda(), torch.from_numpy(seq_lens).cuda(), logits=logits)
+        torch.cuda.synchronize()
+        ref_logits, ref_h, _ = ref.decode(ids, pos, slots, bt, seq_lens)
+        got = orc.bf16_to_f32(_u16(torch, logits)); exp = orc.bf16_to_f32(ref_logits)
+        got_h = orc.bf16_to_f32(_u16(torch, model.debug_read(0, (B, spec.hidden_size)))); exp_h = orc.bf16_to_f32(ref_h)
+        # bf16 rounding noise compounds through the layers: compare with a relative-L2 bound
+        rel_h = np.sqrt(((got_h - exp_h) ** 2).sum() / (exp_h ** 2).sum())
+        rel_l = np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum())
+        assert rel_h <= 2e-2 and rel_l <= 2e-2, (step, rel_h, rel_l)
+        # greedy token: equal whenever the oracle's top-2 margin exceeds the observed logit error
+        o = out.cpu().numpy()
+        for b in range(B):
+            srt = np.sort(exp[b])[::-1]
+            if srt[0] - srt[1] > 4 * np.abs(got[b] - exp[b]).max():
+                assert o[b] == int(np.argmax(exp[b]))
+            assert got[b, o[b]] == got[b].max()
+        ids = o.astype(np.int32) % spec.vocab_size
+    model.close()
+
+
+def test_graph_replay_equals_eager(gpu):
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
+    vmx, torch = gpu
+    spec = _tiny_spec()
+    model = QuantizedQwen3ForCausalLM(spec)
+    model.load_synthetic(seed=5)
+    B, MB = 2, 8
+    bt = torch.arange(B * MB, dtype=torch.int32, device="cuda").reshape(B, MB)
+    ids = torch.tensor([5, 77], dtype=torch.int32, device="cuda")
+    pos = torch.zeros(B, dtype=torch.int32, device="cuda")
+    slots = torch.empty(B, dtype=torch.int32, device="cuda")
+    seq_lens = torch.empty(B, dtype=torch.int32, device="cuda")
+    out = torch.empty(B, dtype=torch.int32, device="cuda")
+    logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+
+    def set_step(p):
+        pos.fill_(p)
+        slots.copy_(bt[:, p // spec.block_size] * spec.block_size + p % spec.block_size)
+        seq_lens.fill_(p + 1)
+
+    # eager reference run
+    eager = []
+    cur = ids.clone()
+    for p in range(5):
+        set_step(p)
+        model.forward_decode_batch(cur, pos, slots, bt, seq_lens, out_ids=out, logits=logits)
+        torch.cuda.synchronize()
+        eager.append((out.clone(), logits.clone()))
+        cur = out.clone()
+    # captured run over the same inputs (the KV cache is rewritten with identical values)
+    cur = ids.clone()
+    g = torch.cuda.CUDAGraph()
+    set_step(0)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        model.forward_decode_batch(cur, pos, slots, bt, seq_lens, out_ids=out, logits=logits)  # warm-up on the side stream
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        model.forward_decode_batch(cur, pos, slots, bt, seq_lens, out_ids=out, logits=logits)
+    for p in range(5):
+        set_step(p)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[p][0]) and torch.equal(logits, eager[p][1]), p
+        cur.copy_(out)
+    model.close()
+
+
+def test_decode_preconditions(gpu):
+    from vllm_rust_amd._lib import VmxError
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    vmx, torch = gpu
+    with pytest.raises(VmxError, match="max_batch"):
+        QuantizedQwen3ForCausalLM(_tiny_spec(max_batch=17))
+    with pytest.raises(VmxError, match="multiple of 128"):
+        QuantizedQwen3ForCausalLM(_tiny_spec(hidden_size=200))
+    m = QuantizedQwen3ForCausalLM(_tiny_spec())
+    z = torch.zeros(4, dtype=torch.int32, device="cuda")
+    with pytest.raises(VmxError, match="not fully loaded"):
+        m.forward_decode_batch(z[:1], z[:1], z[:1], z[:1].reshape(1, 1), z[:1])
+    m.close()
+
+
+def test_dense_gemv_and_embedding(gpu):
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(8)
+    for M, N, K in [(1, 1000, 256), (3, 5003, 4096), (16, 777, 1024)]:
+        x = orc.f32_to_bf16(rng.standard_normal((M, K)).astype(np.float32))
+        W = orc.f32_to_bf16(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
+        xd = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16)
+        Wd = torch.from_numpy(W.view(np.int16)).cuda().view(torch.bfloat16)
+        got = orc.bf16_to_f32(_u16(torch, vmx.dense_gemv(xd, Wd)))
+        ref = orc.bf16_to_f32(x).astype(np.float64) @ orc.bf16_to_f32(W).astype(np.float64).T
+        assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max() + 1e-5
+    table = torch.randn((50, 64), device="cuda").to(torch.bfloat16)
+    ids = torch.tensor([3, 49, 50, -1, 0], dtype=torch.int32, device="cuda")
+    out = vmx.embedding_lookup(table, ids)
+    assert torch.equal(out[0], table[3]) and torch.equal(out[1], table[49]) and torch.equal(out[4], table[0])
+    assert not out[2].any() and not out[3].any()

@@ -48,7 +48,25 @@ _SIGS = {
     "vmx_reshape_and_cache": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vmx_paged_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vmx_paged_attention_bf16": (_i, [_p] * 6 + [_f] + [_i] * 9 + [_p, _p, _p, _sz, _p]),
+    "vmx_dense_gemv_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_embedding_lookup_bf16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "vmx_qwen3_create": (_i, [_p, _p]),
+    "vmx_qwen3_destroy": (None, [_p]),
+    "vmx_qwen3_load_tensor": (_i, [_p, _i, _i, _p, _sz, _p]),
+    "vmx_qwen3_load_awq_linear": (_i, [_p, _i, _i, _p, _p, _p, _p]),
+    "vmx_qwen3_decode": (_i, [_p] * 6 + [_i, _i, _i, _p, _p, _p]),
+    "vmx_qwen3_debug_read": (_i, [_p, _i, _p, _sz, _p]),
 }
+
+
+class Qwen3Config(C.Structure):
+    """struct vmx_qwen3_config (include/vmx.h)."""
+    _fields_ = [
+        ("hidden_size", _i), ("num_layers", _i), ("num_heads", _i), ("num_kv_heads", _i), ("head_dim", _i),
+        ("intermediate_size", _i), ("vocab_size", _i), ("rms_norm_eps", _f), ("max_position", _i), ("group_size", _i),
+        ("qk_norm", _i), ("tie_word_embeddings", _i), ("kv_cache_dtype", _i), ("block_size", _i), ("num_blocks", _i),
+        ("max_batch", _i), ("max_seq_len", _i),
+    ]
 
 
 def _bind():

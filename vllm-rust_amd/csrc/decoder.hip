@@ -1,0 +1,475 @@
+// Whole-token decode executor for the Qwen3-family quantized decoder (AWQ / GPTQ int4 linears,
+// bf16 norms and lm_head, paged KV cache), mirroring the reference's
+// QuantizedQwen3ForCausalLM::forward_decode_batch (crates/core/src/models/qwen3_quantized.rs:
+// attention :694-927, MLP :532-552, layer :1036-1088, lm_head :1258-1302) behind a C ABI.
+//
+// Operator order and rounding points are the reference's: every linear output, residual sum,
+// norm output, rotated q/k and activation product is rounded to bf16 exactly where the
+// reference's separate kernels round it.  What differs is the launch structure: the linears
+// leave split-K partial sums in f32 and the next vector kernel folds "sum partials -> bf16 ->
+// (+bias) -> residual add -> RMSNorm" (or "-> per-head norm -> RoPE -> KV-cache write", or
+// "-> SiLU*mul") into one pass, so a layer is 10 launches instead of the reference's ~17, and the
+// whole step is a fixed launch sequence without allocation or host reads (hipGraph-capturable).
+#include "vmx_kernels.h"
+
+#include <new>
+#include <vector>
+
+int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
+                          hipStream_t st);
+
+namespace {
+
+__device__ __forceinline__ float round_bf16(float v) { return vmx_bf16_to_f32(vmx_f32_to_bf16(v)); }
+
+__device__ __forceinline__ float sum_partials(const float *__restrict__ partial, int splits, int64_t slice_stride, int64_t idx) {
+    float v = 0.f;
+    for (int s = 0; s < splits; s++) v += partial[s * slice_stride + idx];
+    return v;
+}
+
+// One workgroup per token.  h (bf16 residual stream, in/out), optional incoming linear output as
+// f32 partials [splits][tokens][hidden]:  o = bf16(sum partials); h = bf16(h + o);
+// x = bf16(h * rsqrt(mean(h^2) + eps) * w)   (add_bf16 then rms_norm_bf16: variance over the ROUNDED h).
+__global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x,
+                                                          const float *__restrict__ partial, int splits, int tokens,
+                                                          const uint16_t *__restrict__ w, float eps, int hidden) {
+    __shared__ float red[4];
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *hv = reinterpret_cast<float *>(smem);  // [hidden] rounded residual values
+    const int t = blockIdx.x;
+    const int64_t row = (int64_t)t * hidden;
+    const int64_t slice = (int64_t)tokens * hidden;
+    float var = 0.f;
+    for (int i = threadIdx.x; i < hidden; i += 256) {
+        float hval = vmx_bf16_to_f32(h[row + i]);
+        if (partial) {
+            const float o = round_bf16(sum_partials(partial, splits, slice, row + i));
+            hval = round_bf16(hval + o);
+            h[row + i] = vmx_f32_to_bf16(hval);
+        }
+        hv[i] = hval;
+        var += hval * hval;
+    }
+    var = vmx_block_sum_256(var, red);
+    const float inv = rsqrtf(var / (float)hidden + eps);
+    for (int i = threadIdx.x; i < hidden; i += 256) x[row + i] = vmx_f32_to_bf16(hv[i] * inv * vmx_bf16_to_f32(w[i]));
+}
+
+// grid (heads_q + 2*heads_kv, tokens), block 64.  Takes the merged qkv linear output as f32
+// partials [splits][tokens][(Hq + 2*Hkv) * hd]; per head: bf16 round, optional per-head RMSNorm
+// (bf16 round), NeoX RoPE (bf16 round); q -> q_out, k and v -> paged cache (bf16 or FP8 e4m3).
+__global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ partial, int splits, int tokens,
+                                                       uint16_t *__restrict__ q_out, void *__restrict__ k_cache,
+                                                       void *__restrict__ v_cache, const uint16_t *__restrict__ q_norm_w,
+                                                       const uint16_t *__restrict__ k_norm_w, float eps,
+                                                       const float *__restrict__ cos_sin, const int32_t *__restrict__ positions,
+                                                       const int32_t *__restrict__ slots, int Hq, int Hkv, int hd, int rot_dim,
+                                                       int fp8, const float *__restrict__ k_scale, const float *__restrict__ v_scale) {
+    __shared__ float vals[512];
+    const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const int ntot = (Hq + 2 * Hkv) * hd;
+    const int64_t slice = (int64_t)tokens * ntot;
+    const int64_t base = (int64_t)t * ntot + (int64_t)head * hd;
+    const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
+    float ss = 0.f;
+    for (int i = lane; i < hd; i += 64) {
+        const float v = round_bf16(sum_partials(partial, splits, slice, base + i));
+        vals[i] = v;
+        ss += v * v;
+    }
+    const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
+    if (nw) {  // per-head RMSNorm, output rounded to bf16 (rms_norm_bf16 on the [.., hd] view)
+        ss = vmx_wave_sum(ss);
+        const float inv = rsqrtf(ss / (float)hd + eps);
+        for (int i = lane; i < hd; i += 64) vals[i] = round_bf16(vals[i] * inv * vmx_bf16_to_f32(nw[i]));
+    }
+    __syncthreads();
+    if (is_q || is_k) {  // NeoX rotation of the first rot_dim dims
+        const int half = rot_dim >> 1;
+        const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
+        for (int i = lane; i < half; i += 64) {
+            const float xv = vals[i], yv = vals[half + i], c = cs[i], s = cs[half + i];
+            vals[i] = round_bf16(xv * c - yv * s);
+            vals[half + i] = round_bf16(yv * c + xv * s);
+        }
+        __syncthreads();
+    }
+    if (is_q) {
+        for (int i = lane; i < hd; i += 64) q_out[((int64_t)t * Hq + head) * hd + i] = vmx_f32_to_bf16(vals[i]);
+        return;
+    }
+    const int slot = slots[t];
+    if (slot < 0) return;
+    const int kvh = is_k ? head - Hq : head - Hq - Hkv;
+    const int64_t dst = ((int64_t)slot * Hkv + kvh) * hd;
+    void *cache = is_k ? k_cache : v_cache;
+    if (!fp8) {
+        for (int i = lane; i < hd; i += 64) ((uint16_t *)cache)[dst + i] = vmx_f32_to_bf16(vals[i]);
+    } else {
+        const float sc = is_k ? (k_scale ? *k_scale : 1.f) : (v_scale ? *v_scale : 1.f);
+        for (int i = lane; i < hd; i += 64) {
+            float a = vals[i] / sc;
+            a = fminf(fmaxf(a, -448.0f), 448.0f);
+            a = round_bf16(a);
+            ((uint8_t *)cache)[dst + i] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, a, 0, false) & 0xFFu);
+        }
+    }
+}
+
+// a[t, i] = bf16(silu(bf16(gate)) * bf16(up)) from the merged gate|up linear output (f32 partials
+// [splits][tokens][2*inter], gate columns first).
+__global__ __launch_bounds__(256) void gateup_act_kernel(const float *__restrict__ partial, int splits, int tokens,
+                                                          uint16_t *__restrict__ act, int inter) {
+    const int64_t total = (int64_t)tokens * inter;
+    const int64_t slice = (int64_t)tokens * 2 * inter;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / inter, c = i % inter;
+        const float g = round_bf16(sum_partials(partial, splits, slice, t * 2 * inter + c));
+        const float u = round_bf16(sum_partials(partial, splits, slice, t * 2 * inter + inter + c));
+        act[i] = vmx_f32_to_bf16((g / (1.0f + expf(-g))) * u);
+    }
+}
+
+__global__ __launch_bounds__(256) void f16_to_bf16_into_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int64_t n,
+                                                                int cols, int ldo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[(i / cols) * ldo + (i % cols)] = vmx_f32_to_bf16(vmx_f16_to_f32(in[i]));
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ table,
+                                                     const int32_t *__restrict__ ids, int hidden, int vocab) {
+    const int t = blockIdx.x;
+    const int id = ids[t];
+    const bool ok = id >= 0 && id < vocab;
+    const uint4 *src = reinterpret_cast<const uint4 *>(table + (int64_t)(ok ? id : 0) * hidden);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (int64_t)t * hidden);
+    for (int i = threadIdx.x; i < (hidden >> 3); i += 256) dst[i] = ok ? src[i] : make_uint4(0, 0, 0, 0);
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        bytes = n;
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e != hipSuccess) {
+            vmx_set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+            return VMX_ENOMEM;
+        }
+        return VMX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+// Mirrors `trait QuantizedLinear` (crates/core/src/quantization/config.rs:147-190) for the AWQ/GPTQ
+// int4 tile stream: load_weights (one-time repack) + forward (here: split-K partial sums).
+struct Int4Linear {
+    int in_features = 0, out_features = 0, group = 128;
+    DevBuf packed;
+    bool loaded = false;
+    int splits() const { return vmx_int4_splits(out_features, in_features); }
+    int forward_partial(const uint16_t *x, float *partial, int M, hipStream_t st) const {
+        return vmx_int4_gemm_partial(packed.p, x, partial, M, out_features, in_features, group, st);
+    }
+};
+
+// Merged GPTQ-sequential staging of several AWQ linears that share the input (q|k|v, gate|up).
+struct MergeStage {
+    DevBuf qweight, qzeros, scales;
+    int filled = 0;
+};
+
+struct Layer {
+    Int4Linear qkv, o, gate_up, down;
+    MergeStage qkv_stage, gu_stage;
+    DevBuf input_ln, post_ln, q_norm, k_norm;
+    DevBuf k_cache, v_cache, kv_scales;  // kv_scales: f32[2] = {k_scale, v_scale}
+};
+
+}  // namespace
+
+struct vmx_qwen3 {
+    vmx_qwen3_config cfg;
+    std::vector<Layer> layers;
+    DevBuf embed, lm_head, final_norm, cos_sin;
+    bool lm_head_tied = false;
+    DevBuf h, x, q, attn, act, partial, logits, attn_ws, argmax_ws;
+    int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
+};
+
+namespace {
+
+int make_linear(Int4Linear &l, int K, int N, int group) {
+    l.in_features = K;
+    l.out_features = N;
+    l.group = group;
+    return l.packed.alloc(vmx_int4_packed_bytes(K, N, group));
+}
+
+int stage_alloc(MergeStage &s, int K, int Ntot, int group) {
+    if (s.qweight.p) return VMX_OK;
+    if (int rc = s.qweight.alloc((size_t)(K / 8) * Ntot * 4)) return rc;
+    if (int rc = s.qzeros.alloc((size_t)(K / group) * (Ntot / 8) * 4)) return rc;
+    return s.scales.alloc((size_t)(K / group) * Ntot * 2);
+}
+
+void stage_free(MergeStage &s) {
+    s.qweight.release();
+    s.qzeros.release();
+    s.scales.release();
+}
+
+// AWQ checkpoint tensors of one projection -> columns [col0, col0+N) of the staging tensors
+// (the reference's AwqMarlinLinear::load_weights steps: awq_marlin.rs:621-656).
+int stage_put(MergeStage &s, const uint32_t *qweight, const uint32_t *qzeros, const uint16_t *scales_f16, int K, int N, int group,
+              int Ntot, int col0, hipStream_t st) {
+    if (int rc = vmx_awq_convert_into(qweight, qzeros, (uint32_t *)s.qweight.p, (uint32_t *)s.qzeros.p, K, N, group, Ntot, col0, st))
+        return rc;
+    const int64_t n = (int64_t)(K / group) * N;
+    hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scales_f16,
+                       (uint16_t *)s.scales.p + col0, n, N, Ntot);
+    VMX_CHECK_LAUNCH("scales f16->bf16");
+    return VMX_OK;
+}
+
+int stage_pack(MergeStage &s, Int4Linear &l, hipStream_t st) {
+    int rc = vmx_int4_pack((const uint32_t *)s.qweight.p, (const uint16_t *)s.scales.p, (const uint32_t *)s.qzeros.p, l.packed.p,
+                           l.in_features, l.out_features, l.group, st);
+    if (rc) return rc;
+    VMX_CHECK_HIP(hipStreamSynchronize(st));  // load time: staging is freed right after
+    stage_free(s);
+    l.loaded = true;
+    return VMX_OK;
+}
+
+}  // namespace
+
+extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
+    VMX_REQUIRE(cfg && out, "qwen3_create: null pointer");
+    const vmx_qwen3_config &c = *cfg;
+    VMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 128 == 0, "qwen3_create: hidden_size (%d) must be a multiple of 128", c.hidden_size);
+    VMX_REQUIRE(c.intermediate_size > 0 && c.intermediate_size % 128 == 0, "qwen3_create: intermediate_size (%d) must be a multiple of 128",
+                c.intermediate_size);
+    VMX_REQUIRE(c.num_layers > 0 && c.num_heads > 0 && c.num_kv_heads > 0 && c.num_heads % c.num_kv_heads == 0,
+                "qwen3_create: bad head counts");
+    VMX_REQUIRE(c.head_dim == 64 || c.head_dim == 128 || c.head_dim == 256 || c.head_dim == 512, "qwen3_create: head_dim %d unsupported",
+                c.head_dim);
+    VMX_REQUIRE(c.max_batch >= 1 && c.max_batch <= 16, "qwen3_create: max_batch (%d) must be in 1..16", c.max_batch);
+    VMX_REQUIRE(c.group_size > 0 && c.group_size % 128 == 0, "qwen3_create: group_size (%d) must be a multiple of 128", c.group_size);
+    VMX_REQUIRE(c.block_size > 0 && c.num_blocks > 0 && c.max_seq_len > 0 && c.vocab_size > 0 && c.max_position > 0,
+                "qwen3_create: bad cache/vocab geometry");
+    VMX_REQUIRE(c.kv_cache_dtype == VMX_KV_AUTO || c.kv_cache_dtype == VMX_KV_FP8_E4M3, "qwen3_create: unsupported kv dtype");
+    vmx_qwen3 *m = new (std::nothrow) vmx_qwen3();
+    VMX_REQUIRE(m, "qwen3_create: out of host memory");
+    m->cfg = c;
+    m->layers.resize(c.num_layers);
+    const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = c.max_batch;
+    const int NQKV = m->qkv_n(), NO = c.num_heads * hd;
+    int rc = VMX_OK;
+#define TRY(e) do { if (!rc) rc = (e); } while (0)
+    TRY(m->embed.alloc((size_t)c.vocab_size * H * 2));
+    m->lm_head_tied = c.tie_word_embeddings != 0;
+    if (!m->lm_head_tied) TRY(m->lm_head.alloc((size_t)c.vocab_size * H * 2));
+    TRY(m->final_norm.alloc((size_t)H * 2));
+    TRY(m->cos_sin.alloc((size_t)c.max_position * hd * 4));
+    const size_t kv_elem = c.kv_cache_dtype == VMX_KV_FP8_E4M3 ? 1 : 2;
+    const size_t kv_bytes = (size_t)c.num_blocks * c.block_size * c.num_kv_heads * hd * kv_elem;
+    size_t max_partial = 0;
+    for (auto &L : m->layers) {
+        TRY(make_linear(L.qkv, H, NQKV, c.group_size));
+        TRY(make_linear(L.o, NO, H, c.group_size));
+        TRY(make_linear(L.gate_up, H, 2 * I, c.group_size));
+        TRY(make_linear(L.down, I, H, c.group_size));
+        TRY(L.input_ln.alloc((size_t)H * 2));
+        TRY(L.post_ln.alloc((size_t)H * 2));
+        TRY(L.q_norm.alloc((size_t)hd * 2));
+        TRY(L.k_norm.alloc((size_t)hd * 2));
+        TRY(L.k_cache.alloc(kv_bytes));
+        TRY(L.v_cache.alloc(kv_bytes));
+        TRY(L.kv_scales.alloc(8));
+        if (!rc) {
+            const float ones[2] = {1.0f, 1.0f};
+            if (hipMemcpy(L.kv_scales.p, ones, 8, hipMemcpyHostToDevice) != hipSuccess) rc = VMX_ELAUNCH;
+        }
+    }
+    if (!rc) {
+        const Layer &L = m->layers[0];
+        const size_t cands[4] = {(size_t)L.qkv.splits() * NQKV, (size_t)L.o.splits() * H, (size_t)L.gate_up.splits() * 2 * I,
+                                 (size_t)L.down.splits() * H};
+        for (size_t v : cands) max_partial = v > max_partial ? v : max_partial;
+    }
+    TRY(m->partial.alloc(max_partial * B * 4));
+    TRY(m->h.alloc((size_t)B * H * 2));
+    TRY(m->x.alloc((size_t)B * H * 2));
+    TRY(m->q.alloc((size_t)B * NO * 2));
+    TRY(m->attn.alloc((size_t)B * NO * 2));
+    TRY(m->act.alloc((size_t)B * I * 2));
+    TRY(m->logits.alloc((size_t)B * c.vocab_size * 2));
+    TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, hd, c.max_seq_len)));
+    TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
+#undef TRY
+    if (rc) {
+        vmx_qwen3_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return VMX_OK;
+}
+
+extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
+    if (!m) return;
+    for (auto &L : m->layers) {
+        for (DevBuf *b : {&L.qkv.packed, &L.o.packed, &L.gate_up.packed, &L.down.packed, &L.input_ln, &L.post_ln, &L.q_norm, &L.k_norm,
+                          &L.k_cache, &L.v_cache, &L.kv_scales})
+            b->release();
+        stage_free(L.qkv_stage);
+        stage_free(L.gu_stage);
+    }
+    for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial,
+                      &m->logits, &m->attn_ws, &m->argmax_ws})
+        b->release();
+    delete m;
+}
+
+extern "C" int vmx_qwen3_load_tensor(vmx_qwen3 *m, int which, int layer, const void *src, size_t bytes, void *stream) {
+    VMX_REQUIRE(m && src, "qwen3_load_tensor: null pointer");
+    DevBuf *dst = nullptr;
+    switch (which) {
+        case VMX_T_EMBED: dst = &m->embed; break;
+        case VMX_T_LM_HEAD: dst = m->lm_head_tied ? nullptr : &m->lm_head; break;
+        case VMX_T_FINAL_NORM: dst = &m->final_norm; break;
+        case VMX_T_COS_SIN: dst = &m->cos_sin; break;
+        default: break;
+    }
+    if (!dst && which >= VMX_T_INPUT_LN && which <= VMX_T_KV_SCALES) {
+        VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "qwen3_load_tensor: layer %d out of range", layer);
+        Layer &L = m->layers[layer];
+        DevBuf *tab[5] = {&L.input_ln, &L.post_ln, &L.q_norm, &L.k_norm, &L.kv_scales};
+        dst = tab[which - VMX_T_INPUT_LN];
+    }
+    VMX_REQUIRE(dst, "qwen3_load_tensor: tensor id %d not loadable on this model", which);
+    VMX_REQUIRE(bytes == dst->bytes, "qwen3_load_tensor: tensor %d expects %zu bytes, got %zu", which, dst->bytes, bytes);
+    VMX_CHECK_HIP(hipMemcpyAsync(dst->p, src, bytes, hipMemcpyDefault, vmx_stream(stream)));
+    return VMX_OK;
+}
+
+extern "C" int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
+                                         const uint16_t *scales_f16, void *stream) {
+    VMX_REQUIRE(m && qweight && qzeros && scales_f16, "qwen3_load_awq_linear: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "qwen3_load_awq_linear: layer %d out of range", layer);
+    const vmx_qwen3_config &c = m->cfg;
+    Layer &L = m->layers[layer];
+    hipStream_t st = vmx_stream(stream);
+    const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, g = c.group_size;
+    const int NQ = c.num_heads * hd, NKV = c.num_kv_heads * hd;
+    MergeStage single;
+    switch (slot) {
+        case VMX_L_Q: case VMX_L_K: case VMX_L_V: {
+            const int Ntot = m->qkv_n();
+            if (int rc = stage_alloc(L.qkv_stage, H, Ntot, g)) return rc;
+            const int N = slot == VMX_L_Q ? NQ : NKV;
+            const int col0 = slot == VMX_L_Q ? 0 : (slot == VMX_L_K ? NQ : NQ + NKV);
+            if (int rc = stage_put(L.qkv_stage, qweight, qzeros, scales_f16, H, N, g, Ntot, col0, st)) return rc;
+            L.qkv_stage.filled |= 1 << (slot - VMX_L_Q);
+            if (L.qkv_stage.filled == 7) return stage_pack(L.qkv_stage, L.qkv, st);
+            return VMX_OK;
+        }
+        case VMX_L_GATE: case VMX_L_UP: {
+            if (int rc = stage_alloc(L.gu_stage, H, 2 * I, g)) return rc;
+            if (int rc = stage_put(L.gu_stage, qweight, qzeros, scales_f16, H, I, g, 2 * I, slot == VMX_L_GATE ? 0 : I, st)) return rc;
+            L.gu_stage.filled |= slot == VMX_L_GATE ? 1 : 2;
+            if (L.gu_stage.filled == 3) return stage_pack(L.gu_stage, L.gate_up, st);
+            return VMX_OK;
+        }
+        case VMX_L_O: {
+            if (int rc = stage_alloc(single, NQ, H, g)) return rc;
+            int rc = stage_put(single, qweight, qzeros, scales_f16, NQ, H, g, H, 0, st);
+            if (!rc) rc = stage_pack(single, L.o, st);
+            stage_free(single);
+            return rc;
+        }
+        case VMX_L_DOWN: {
+            if (int rc = stage_alloc(single, I, H, g)) return rc;
+            int rc = stage_put(single, qweight, qzeros, scales_f16, I, H, g, H, 0, st);
+            if (!rc) rc = stage_pack(single, L.down, st);
+            stage_free(single);
+            return rc;
+        }
+        default:
+            vmx_set_error("qwen3_load_awq_linear: unknown slot %d", slot);
+            return VMX_EINVAL;
+    }
+}
+
+// One decode step for `batch` sequences (one new token each).  Pure launch sequence.
+extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+                                const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq,
+                                int max_seq_len, int32_t *out_ids, uint16_t *logits_out, void *stream) {
+    VMX_REQUIRE(m && input_ids && positions && slot_mapping && block_tables && seq_lens, "qwen3_decode: null pointer");
+    const vmx_qwen3_config &c = m->cfg;
+    VMX_REQUIRE(batch >= 1 && batch <= c.max_batch, "qwen3_decode: batch %d exceeds max_batch %d", batch, c.max_batch);
+    VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "qwen3_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
+                c.max_seq_len);
+    for (const Layer &L : m->layers)
+        VMX_REQUIRE(L.qkv.loaded && L.o.loaded && L.gate_up.loaded && L.down.loaded, "qwen3_decode: weights not fully loaded");
+    hipStream_t st = vmx_stream(stream);
+    const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = batch;
+    const int Hq = c.num_heads, Hkv = c.num_kv_heads, NQKV = m->qkv_n();
+    uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p, *attn = (uint16_t *)m->attn.p,
+             *act = (uint16_t *)m->act.p;
+    float *partial = (float *)m->partial.p;
+    const size_t h_lds = (size_t)H * 4;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
+
+    hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
+    const float *pending = nullptr;  // linear output not yet folded into the residual stream
+    int pending_splits = 0;
+    for (const Layer &L : m->layers) {
+        hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, pending, pending_splits, B,
+                           (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
+        if (int rc = L.qkv.forward_partial(x, partial, B, st)) return rc;
+        const float *ks = (const float *)L.kv_scales.p;
+        hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, partial, L.qkv.splits(), B, q, L.k_cache.p,
+                           L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
+                           c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
+                           slot_mapping, Hq, Hkv, hd, hd, fp8, ks, ks + 1);
+        if (int rc = vmx_paged_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, scale, B, Hq, Hkv,
+                                              max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
+                                              m->attn_ws.p, m->attn_ws.bytes, stream))
+            return rc;
+        if (int rc = L.o.forward_partial(attn, partial, B, st)) return rc;
+        hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, partial, L.o.splits(), B,
+                           (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
+        if (int rc = L.gate_up.forward_partial(x, partial, B, st)) return rc;
+        int64_t blocks = ((int64_t)B * I + 255) / 256;
+        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, partial,
+                           L.gate_up.splits(), B, act, I);
+        if (int rc = L.down.forward_partial(act, partial, B, st)) return rc;
+        pending = partial;
+        pending_splits = L.down.splits();
+    }
+    hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, pending, pending_splits, B,
+                       (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H);
+    VMX_CHECK_LAUNCH("qwen3_decode");
+    uint16_t *logits = logits_out ? logits_out : (uint16_t *)m->logits.p;
+    const uint16_t *head = (const uint16_t *)(m->lm_head_tied ? m->embed.p : m->lm_head.p);
+    if (int rc = vmx_dense_gemv_launch(logits, x, head, nullptr, B, c.vocab_size, H, st)) return rc;
+    if (out_ids)
+        if (int rc = vmx_argmax_bf16(out_ids, logits, B, c.vocab_size, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
+    return VMX_OK;
+}
+
+// Parity aid: copies of internal activations after the last vmx_qwen3_decode call.
+extern "C" int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t bytes, void *stream) {
+    VMX_REQUIRE(m && dst, "qwen3_debug_read: null pointer");
+    DevBuf *src = which == 0 ? &m->h : which == 1 ? &m->x : which == 2 ? &m->logits : nullptr;
+    VMX_REQUIRE(src && bytes <= src->bytes, "qwen3_debug_read: bad request");
+    VMX_CHECK_HIP(hipMemcpyAsync(dst, src->p, bytes, hipMemcpyDefault, vmx_stream(stream)));
+    return VMX_OK;
+}

@@ -24,14 +24,13 @@ namespace {
 
 constexpr int KB = 128;     // k-values per unit
 constexpr int NT = 16;      // columns per unit
-constexpr int UNIT_WORDS = 256;
 
 __host__ __device__ inline size_t sz_offset_bytes(int K, int N) { return ((size_t)K * N / 2 + 255) & ~(size_t)255; }
 
 // ---------------------------------------------------------------- repacks
 // AWQ [K, N/8] (interleaved along N) -> GPTQ-sequential [K/8, N] (awq_marlin.rs:170-240).
 __global__ __launch_bounds__(256) void awq_to_gptq_kernel(const uint32_t *__restrict__ awq, uint32_t *__restrict__ out, int K,
-                                                           int N) {
+                                                           int N, int ldo) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [K/8, N]
     if (idx >= (int64_t)(K / 8) * N) return;
     const int n = (int)(idx % N), kb = (int)(idx / N);
@@ -42,11 +41,12 @@ __global__ __launch_bounds__(256) void awq_to_gptq_kernel(const uint32_t *__rest
         const uint32_t src = awq[(int64_t)(kb * 8 + i) * (N / 8) + (n >> 3)];
         word |= ((src >> shift) & 0xFu) << (4 * i);
     }
-    out[idx] = word;
+    out[(int64_t)kb * ldo + n] = word;
 }
 
+// rows x cols words; out row stride ldo (for writing into a wider, merged tensor)
 __global__ __launch_bounds__(256) void awq_nibble_reorder_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                                  int64_t n) {
+                                                                  int64_t n, int cols, int ldo) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t w = in[i];
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void awq_nibble_reorder_kernel(const uint32_t 
         const int shift = ((j & 1) * 16) + (j >> 1) * 4;
         r |= ((w >> shift) & 0xFu) << (4 * j);
     }
-    out[i] = r;
+    out[(i / cols) * ldo + (i % cols)] = r;
 }
 
 __global__ __launch_bounds__(256) void int4_pack_w_kernel(const uint32_t *__restrict__ qweight, uint32_t *__restrict__ W, int K,
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void int4_dequant_kernel(const uint32_t *__res
 // the activations are staged, so their HBM latency overlaps the prologue.
 //   blockIdx.x = ks * n_tiles + nt   (ks = split-K slice; neighbouring workgroups stream
 //                                     neighbouring tiles of the same slice)
-// Output: splits == 1 -> y bf16 (+bias); else partial[ks][M][N] f32, summed by int4_reduce_kernel.
+// Output: y != NULL (only with splits == 1) -> y bf16 (+bias); else partial[ks][M][N] f32, summed by
+// int4_reduce_kernel or by the consuming kernel.
 template <int UPW>
 __global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                          const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict_
         for (int r = 0; r < 4; r++) {
             const int mrow = 4 * h + r;
             if (mrow < M) {
-                if (splits == 1) {
+                if (y) {
                     float v = out4[r];
                     if (bias) v += vmx_bf16_to_f32(bias[n]);
                     y[(int64_t)mrow * N + n] = vmx_f32_to_bf16(v);
@@ -284,16 +285,16 @@ extern "C" int vmx_awq_to_gptq_qweight(const uint32_t *awq, uint32_t *out, int K
     VMX_REQUIRE(K > 0 && K % 8 == 0, "awq_to_gptq_qweight: in_features (%d) must be divisible by 8", K);
     VMX_REQUIRE(N > 0 && N % 8 == 0, "awq_to_gptq_qweight: out_features (%d) must be divisible by 8", N);
     const int64_t total = (int64_t)(K / 8) * N;
-    hipLaunchKernelGGL(awq_to_gptq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vmx_stream(stream), awq, out, K, N);
+    hipLaunchKernelGGL(awq_to_gptq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vmx_stream(stream), awq, out, K, N, N);
     VMX_CHECK_LAUNCH("awq_to_gptq_qweight");
     return VMX_OK;
 }
 
 extern "C" int vmx_awq_repack_nibbles(const uint32_t *in, uint32_t *out, int64_t n_words, void *stream) {
-    VMX_REQUIRE(in && out && n_words >= 0, "awq_repack_nibbles: bad arguments");
+    VMX_REQUIRE(in && out && n_words >= 0 && n_words < ((int64_t)1 << 31), "awq_repack_nibbles: bad arguments");
     if (n_words == 0) return VMX_OK;
     hipLaunchKernelGGL(awq_nibble_reorder_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, vmx_stream(stream), in, out,
-                       n_words);
+                       n_words, (int)n_words, (int)n_words);
     VMX_CHECK_LAUNCH("awq_repack_nibbles");
     return VMX_OK;
 }
@@ -340,6 +341,49 @@ extern "C" int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K,
     return VMX_OK;
 }
 
+// ---- internal (C++) entry points used by the decoder ---------------------------------------
+int vmx_int4_splits(int N, int K) { return plan_gemm(N, K).splits; }
+
+// partial[splits][M][N] f32, also when splits == 1.  Arguments must already satisfy check_int4_shape.
+int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial, int M, int N, int K, int group, hipStream_t st) {
+    const GemmPlan p = plan_gemm(N, K);
+    const uint4 *W = (const uint4 *)packed;
+    const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    const size_t lds = gemm_lds_bytes(M, p.upw);
+    const dim3 grid((unsigned)((N / NT) * p.splits)), block(256);
+#define LAUNCHP(U)                                                                                                        \
+    do {                                                                                                                  \
+        if (lds > 64 * 1024)                                                                                              \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              (int)lds));                                                                 \
+        hipLaunchKernelGGL((int4_gemm_kernel<U>), grid, block, lds, st, W, SZ, x, (const uint16_t *)nullptr, (uint16_t *)nullptr, \
+                           partial, M, N, K, group, p.splits);                                                            \
+    } while (0)
+    switch (p.upw) {
+        case 8: LAUNCHP(8); break;
+        case 4: LAUNCHP(4); break;
+        case 2: LAUNCHP(2); break;
+        default: LAUNCHP(1); break;
+    }
+#undef LAUNCHP
+    VMX_CHECK_LAUNCH("int4_gemm");
+    return VMX_OK;
+}
+
+// AWQ checkpoint tensors -> columns [col0, col0+N) of merged GPTQ-sequential tensors with Ntot columns.
+int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out,
+                         int K, int N, int group, int Ntot, int col0, hipStream_t st) {
+    const int64_t total = (int64_t)(K / 8) * N;
+    hipLaunchKernelGGL(awq_to_gptq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, awq_qweight, qweight_out + col0, K,
+                       N, Ntot);
+    VMX_CHECK_LAUNCH("awq_to_gptq_qweight");
+    const int64_t zw = (int64_t)(K / group) * (N / 8);
+    hipLaunchKernelGGL(awq_nibble_reorder_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, awq_qzeros,
+                       qzeros_out + col0 / 8, zw, N / 8, Ntot / 8);
+    VMX_CHECK_LAUNCH("awq_repack_nibbles");
+    return VMX_OK;
+}
+
 extern "C" size_t vmx_int4_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % KB || N % NT) return 0;
     const GemmPlan p = plan_gemm(N, K);
@@ -367,7 +411,8 @@ extern "C" int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *pa
         if (lds > 64 * 1024)                                                                                               \
             VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)lds));                                                                  \
-        hipLaunchKernelGGL((int4_gemm_kernel<U>), grid, block, lds, st, W, SZ, x, bias, y, partial, M, N, K, group, p.splits); \
+        hipLaunchKernelGGL((int4_gemm_kernel<U>), grid, block, lds, st, W, SZ, x, bias, p.splits == 1 ? y : (uint16_t *)nullptr, \
+                           partial, M, N, K, group, p.splits);                                                             \
     } while (0)
     switch (p.upw) {
         case 8: LAUNCH(8); break;

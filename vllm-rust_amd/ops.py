@@ -13,7 +13,8 @@ from ._lib import check, lib
 __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
-    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention",
+    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention", "dense_gemv",
+    "embedding_lookup",
 ]
 
 
@@ -159,4 +160,20 @@ def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, scale: float, n
                                        scale, num_seqs, num_heads, num_kv_heads, block_tables.shape[1], max_seq_len, head_dim,
                                        block_size, window, kv_dtype, _ptr(k_scale), _ptr(v_scale), _ptr(ws), ws.numel(),
                                        _stream()))
+    return out
+
+
+def dense_gemv(x: torch.Tensor, W: torch.Tensor, bias=None) -> torch.Tensor:
+    """x bf16 [M, K], W bf16 [N, K] -> bf16 [M, N]."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(lib.vmx_dense_gemv_bf16(_ptr(y), _ptr(x), _ptr(W), _ptr(bias), M, N, K, _stream()))
+    return y
+
+
+def embedding_lookup(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    vocab, hidden = table.shape
+    out = torch.empty((ids.numel(), hidden), dtype=torch.bfloat16, device=table.device)
+    check(lib.vmx_embedding_lookup_bf16(_ptr(out), _ptr(table), _ptr(ids), ids.numel(), hidden, vocab, _stream()))
     return out

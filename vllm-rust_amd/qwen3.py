@@ -1,0 +1,169 @@
+"""Host-side driver of the quantized Qwen3 decoder (libvmx `vmx_qwen3_*`).
+
+Mirrors the engine-facing surface of the reference's QuantizedQwen3ForCausalLM
+(crates/core/src/models/qwen3_quantized.rs:557-1302; ModelForward::forward_decode_batch,
+engine/model_forward.rs:66-76): weights are handed over per projection in AWQ checkpoint form,
+a decode step takes token ids + per-sequence positions/slots/block tables and returns greedy
+token ids (and optionally logits).  All arithmetic happens in the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+
+import numpy as np
+import torch
+
+from ._lib import Qwen3Config, check, lib
+
+T_EMBED, T_LM_HEAD, T_FINAL_NORM, T_COS_SIN, T_INPUT_LN, T_POST_LN, T_Q_NORM, T_K_NORM, T_KV_SCALES = range(9)
+L_Q, L_K, L_V, L_O, L_GATE, L_UP, L_DOWN = range(7)
+
+
+@dataclasses.dataclass
+class Qwen3Spec:
+    hidden_size: int
+    num_layers: int
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+    intermediate_size: int
+    vocab_size: int
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    max_position: int = 4096
+    group_size: int = 128
+    qk_norm: bool = True
+    tie_word_embeddings: bool = False
+    kv_cache_dtype: int = 0
+    block_size: int = 16
+    num_blocks: int = 64
+    max_batch: int = 1
+    max_seq_len: int = 1024
+
+    @staticmethod
+    def qwen3_8b(**kw):
+        return Qwen3Spec(4096, 36, 32, 8, 128, 12288, 151936, **kw)
+
+    @staticmethod
+    def qwen3_0_6b(**kw):
+        return Qwen3Spec(1024, 28, 16, 8, 128, 3072, 151936, tie_word_embeddings=True, **kw)
+
+
+def rope_cos_sin_cache(head_dim: int, max_position: int, theta: float) -> np.ndarray:
+    """cos|sin table as the reference builds it (layers/rotary.rs:84-103): f32 inv_freq and
+    angles, cos/sin rounded to bf16 (the model dtype) and widened back to f32."""
+    i = np.arange(0, head_dim, 2, dtype=np.float32)
+    inv_freq = (np.float32(1.0) / np.power(np.float32(theta), i / np.float32(head_dim))).astype(np.float32)
+    t = np.arange(max_position, dtype=np.float32)[:, None]
+    freqs = (t * inv_freq[None, :]).astype(np.float32)
+
+    def bf16_round(a):
+        u = a.astype(np.float32).view(np.uint32)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.view(np.float32)
+
+    return np.concatenate([bf16_round(np.cos(freqs)), bf16_round(np.sin(freqs))], axis=1).astype(np.float32)
+
+
+class QuantizedQwen3ForCausalLM:
+    def __init__(self, spec: Qwen3Spec, device: int = 0):
+        self.spec = spec
+        self.device = torch.device("cuda", device)
+        cfg = Qwen3Config(spec.hidden_size, spec.num_layers, spec.num_heads, spec.num_kv_heads, spec.head_dim,
+                          spec.intermediate_size, spec.vocab_size, spec.rms_norm_eps, spec.max_position, spec.group_size,
+                          int(spec.qk_norm), int(spec.tie_word_embeddings), spec.kv_cache_dtype, spec.block_size,
+                          spec.num_blocks, spec.max_batch, spec.max_seq_len)
+        self._h = C.c_void_p()
+        check(lib.vmx_qwen3_create(C.byref(cfg), C.byref(self._h)))
+        cs = torch.from_numpy(rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta)).to(self.device)
+        self.load_tensor(T_COS_SIN, 0, cs)
+
+    def close(self):
+        if self._h:
+            lib.vmx_qwen3_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def load_tensor(self, which: int, layer: int, t: torch.Tensor) -> None:
+        t = t.contiguous()
+        check(lib.vmx_qwen3_load_tensor(self._h, which, layer, t.data_ptr(), t.numel() * t.element_size(), self._stream()))
+        torch.cuda.current_stream().synchronize()  # `t` may be a temporary
+
+    def load_awq_linear(self, layer: int, slot: int, qweight: torch.Tensor, qzeros: torch.Tensor, scales_f16: torch.Tensor):
+        assert qweight.dtype == torch.int32 and qzeros.dtype == torch.int32 and scales_f16.dtype == torch.float16
+        check(lib.vmx_qwen3_load_awq_linear(self._h, layer, slot, qweight.data_ptr(), qzeros.data_ptr(), scales_f16.data_ptr(),
+                                            self._stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def linear_shapes(self):
+        s = self.spec
+        nq, nkv = s.num_heads * s.head_dim, s.num_kv_heads * s.head_dim
+        return {L_Q: (s.hidden_size, nq), L_K: (s.hidden_size, nkv), L_V: (s.hidden_size, nkv), L_O: (nq, s.hidden_size),
+                L_GATE: (s.hidden_size, s.intermediate_size), L_UP: (s.hidden_size, s.intermediate_size),
+                L_DOWN: (s.intermediate_size, s.hidden_size)}
+
+    def load_synthetic(self, seed: int = 0, keep_host_copy: bool = False):
+        """Random-init weights of the model's architecture in AWQ checkpoint form (seeded).
+        Scales are sized so activations stay O(1) through the stack.  Returns the host copy of the
+        checkpoint when keep_host_copy (tiny test models only)."""
+        s = self.spec
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        ck = {}
+
+        def keep(name, t):
+            if keep_host_copy:
+                ck[name] = t.cpu()
+
+        emb = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.5).to(torch.bfloat16)
+        self.load_tensor(T_EMBED, 0, emb); keep("embed", emb)
+        if not s.tie_word_embeddings:
+            head = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.05).to(torch.bfloat16)
+            self.load_tensor(T_LM_HEAD, 0, head); keep("lm_head", head)
+            del head
+        del emb
+        fn = (1.0 + 0.1 * torch.randn(s.hidden_size, device=self.device, generator=g)).to(torch.bfloat16)
+        self.load_tensor(T_FINAL_NORM, 0, fn); keep("final_norm", fn)
+        for li in range(s.num_layers):
+            for which, n, name in ((T_INPUT_LN, s.hidden_size, "input_ln"), (T_POST_LN, s.hidden_size, "post_ln"),
+                                   (T_Q_NORM, s.head_dim, "q_norm"), (T_K_NORM, s.head_dim, "k_norm")):
+                w = (1.0 + 0.1 * torch.randn(n, device=self.device, generator=g)).to(torch.bfloat16)
+                self.load_tensor(which, li, w); keep(f"{li}.{name}", w)
+            for slot, (K, N) in self.linear_shapes().items():
+                qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=self.device, generator=g)
+                qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // s.group_size, N // 8), dtype=torch.int32, device=self.device,
+                                   generator=g)
+                # uniform int4 minus zero point has std ~6.5; aim for unit-variance outputs
+                sc = (torch.rand((K // s.group_size, N), device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (6.5 * math.sqrt(K)))
+                sc = sc.to(torch.float16)
+                self.load_awq_linear(li, slot, qw, qz, sc)
+                keep(f"{li}.{slot}.qweight", qw); keep(f"{li}.{slot}.qzeros", qz); keep(f"{li}.{slot}.scales", sc)
+        return ck
+
+    def forward_decode_batch(self, input_ids, positions, slot_mapping, block_tables, seq_lens, max_seq_len=None,
+                             out_ids=None, logits=None):
+        """All arguments are int32 CUDA tensors; returns out_ids (int32 [B])."""
+        B = input_ids.numel()
+        if out_ids is None:
+            out_ids = torch.empty(B, dtype=torch.int32, device=self.device)
+        msl = int(max_seq_len if max_seq_len is not None else self.spec.max_seq_len)
+        check(lib.vmx_qwen3_decode(self._h, input_ids.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(),
+                                   block_tables.data_ptr(), seq_lens.data_ptr(), B, block_tables.shape[1], msl,
+                                   out_ids.data_ptr(), None if logits is None else logits.data_ptr(), self._stream()))
+        return out_ids
+
+    def debug_read(self, which: int, shape) -> torch.Tensor:
+        t = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
+        check(lib.vmx_qwen3_debug_read(self._h, which, t.data_ptr(), t.numel() * 2, self._stream()))
+        torch.cuda.current_stream().synchronize()
+        return t
