@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: greedy decode tok/s of a Qwen3-8B-shaped AWQ int4 model on MI355X.
+
+A "step" is one decode token for the whole batch (batch = 1 per GPU: BASELINE.json configs[1],
+"Qwen3-8B AWQ int4 TP=1 on one MI355X, packed-int GEMM decode, batch=1 seq=1").  Weights are a
+seeded random-init AWQ checkpoint of the Qwen3-8B architecture (no network, no model files); a
+256-token prompt is first pushed through the same decode path (untimed), then W warm-up and K
+timed steps are replayed from one hipGraph (decode step + device-side step bookkeeping), with all
+inputs resident in HBM.
+
+With --gpus N > 1 each rank (one process per GPU, launched by torch.distributed.run) runs an
+independent replica of the same job ("replicas only": data-parallel serving, no exchange step on
+the data path); value is the sum over ranks, time is the max over ranks.
+
+Prints one JSON line on rank 0 with `roofline` (the int4 linear kernel, timed with HIP events on
+its launch stream over an eager re-run of the timed steps) and `cpu_baseline` (the CPU oracle's
+int4 GEMV, OpenMP over output columns, on a bounded sample of the same per-token work).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def cpu_baseline(spec, budget_s=12.0):
+    """Time the oracle's int4 GEMV (bf16 in/out, f32 accumulate; the arithmetic of the reference's
+    CPU-side scalar reference) on the projections of ONE decoder layer, repeated while the budget
+    lasts, and convert to tokens/s for the full model (layers x per-layer time + bf16 lm_head)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    H, I = spec.hidden_size, spec.intermediate_size
+    nq, nkv = spec.num_heads * spec.head_dim, spec.num_kv_heads * spec.head_dim
+    shapes = [(H, nq), (H, nkv), (H, nkv), (nq, H), (H, I), (H, I), (I, H)]
+    mats = []
+    for K, N in shapes:
+        qw = rng.integers(0, 2 ** 32, size=(K // 8, N), dtype=np.uint32)
+        qz = rng.integers(0, 2 ** 32, size=(K // spec.group_size, N // 8), dtype=np.uint32)
+        sc = orc.f32_to_bf16((rng.random((K // spec.group_size, N), dtype=np.float32) * 0.01))
+        x = orc.f32_to_bf16(rng.standard_normal((1, K)).astype(np.float32))
+        mats.append((x, qw, sc, qz, K, N))
+    cores = len(os.sched_getaffinity(0))
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    t_layer, reps = 0.0, 0
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for x, qw, sc, qz, K, N in mats:
+            orc.int4_gemv_bf16(x, qw, sc, qz, None, K, N, spec.group_size)
+        t_layer += time.perf_counter() - t0
+        reps += 1
+        if time.perf_counter() - t_start > budget_s or reps >= 8:
+            break
+    t_layer /= reps
+    # lm_head: dense bf16 [V, H] dot in numpy (float32), timed on a 1/16 slice of the vocabulary
+    Vs = spec.vocab_size // 16
+    W = rng.standard_normal((Vs, H)).astype(np.float32)
+    xv = rng.standard_normal(H).astype(np.float32)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        W @ xv
+    t_head = (time.perf_counter() - t0) / 3 * 16
+    tok_s = 1.0 / (spec.num_layers * t_layer + t_head)
+    return {"value": round(tok_s, 3), "unit": "tok/s", "cores": cores, "kind": "port",
+            "sample": f"oracle int4 GEMV of one decoder layer's 7 projections x{reps} ({t_layer * 1e3:.1f} ms/layer), scaled to "
+                      f"{spec.num_layers} layers + numpy f32 lm_head on 1/16 of the vocabulary ({t_head * 1e3:.1f} ms)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--prompt", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (invalidates the number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import vllm_rust_amd as vmx
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    vmx.init(local_rank)
+
+    K_steps, W_steps = args.steps, args.warmup
+    total_tokens = args.prompt + W_steps + 2 * K_steps + 8
+    block_size = 16
+    n_blocks = (total_tokens + block_size - 1) // block_size + 1
+    spec = Qwen3Spec.qwen3_8b(max_position=max(4096, total_tokens + 1), num_blocks=n_blocks, block_size=block_size, max_batch=1,
+                              max_seq_len=total_tokens + 1)
+    if args.layers:
+        spec.num_layers = args.layers
+    model = QuantizedQwen3ForCausalLM(spec, device=local_rank)
+    model.load_synthetic(seed=1234 + rank)
+
+    dev = model.device
+    B = 1
+    bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(B, n_blocks).contiguous()
+    ids = torch.tensor([11], dtype=torch.int32, device=dev)
+    pos = torch.zeros(B, dtype=torch.int32, device=dev)
+    slots = (bt[:, 0] * block_size).to(torch.int32).contiguous()
+    seq_lens = torch.ones(B, dtype=torch.int32, device=dev)
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+
+    def step():
+        model.forward_decode_batch(ids, pos, slots, bt, seq_lens, max_seq_len=spec.max_seq_len, out_ids=out)
+        model.advance(ids, out, pos, slots, seq_lens, bt)
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        step()  # first call outside capture (lazy module load)
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+        # prompt: the remaining prompt tokens through the decode path (positions 1 .. prompt-1)
+        for _ in range(args.prompt - 1):
+            graph.replay()
+        for _ in range(W_steps):
+            graph.replay()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(side):
+        for _ in range(K_steps):
+            graph.replay()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pos_after = int(pos.item())
+    assert pos_after == args.prompt + W_steps + K_steps, (pos_after, args.prompt, W_steps, K_steps)
+    if dist_on:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel (int4 linear), eager re-run of K steps with HIP events
+    roofline = None
+    if rank == 0:
+        n_lin = 4 * spec.num_layers
+        with torch.cuda.stream(side):
+            model.profile_begin(n_lin * K_steps)
+            for _ in range(K_steps):
+                step()
+            launches, us, alg = model.profile_end()
+        torch.cuda.synchronize()
+        per_launch_bytes = alg / max(launches, 1)
+        per_launch_us = us / max(launches, 1)
+        achieved = alg / us / 1e3 if us > 0 else 0.0  # bytes/us -> GB/s
+        roofline = {"bound": "hbm", "kernel": "int4_gemm_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": launches, "avg_launch_us": round(per_launch_us, 3),
+                    "alg_bytes_per_launch": round(per_launch_bytes)}
+
+    if rank == 0:
+        tok_s = world * B * K_steps / elapsed
+        line = {
+            "metric": "decode tok/s (greedy, batch=1 per GPU) + %HBM-peak of the int4 linear kernel, Qwen3-8B AWQ",
+            "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": K_steps, "warmup": W_steps,
+            "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int4 weights x bf16 activations, f32 accumulate", "data": "synthetic",
+            "config": {"workload": "Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, 256-token prompt then timed tokens, bf16 KV",
+                       "layers": spec.num_layers, "hidden": spec.hidden_size, "vocab": spec.vocab_size,
+                       "parallelism": "tp1" if world == 1 else f"dp{world} replicas (tp1 each)",
+                       "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
+                       "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
+            "roofline": roofline,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(spec),
+        }
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

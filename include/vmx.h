@@ -240,6 +240,19 @@ int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *posi
                      const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq,
                      int max_seq_len, int32_t *out_ids, uint16_t *logits_out, void *stream);
 
+/* Device-side step bookkeeping so consecutive steps replay from one graph: input_ids <- next_ids,
+ * positions += 1, seq_lens = positions + 1, slot_mapping from block_tables (what the reference's
+ * engine computes on the host per step: crates/core/src/engine/helpers.rs execute_batched_decode). */
+int vmx_decode_advance(int32_t *input_ids, const int32_t *next_ids, int32_t *positions, int32_t *slot_mapping,
+                       int32_t *seq_lens, const int32_t *block_tables, int batch, int max_blocks_per_seq,
+                       int block_size, void *stream);
+
+/* Measurement aid (eager mode only, not under graph capture): bracket every int4 linear launch of the
+ * following decode steps with HIP events on the launch stream; _end synchronises and returns the number
+ * of launches, their summed duration in microseconds and their summed algorithmic bytes. */
+int vmx_qwen3_profile_begin(vmx_qwen3 *m, int max_launches);
+int vmx_qwen3_profile_end(vmx_qwen3 *m, int *launches, double *total_us, double *alg_bytes);
+
 /* Parity aid: read back an internal activation of the last step (0 = residual stream h,
  * 1 = final normed x, 2 = logits), bf16. */
 int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t bytes, void *stream);

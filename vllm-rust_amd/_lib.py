@@ -8,6 +8,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# torch ships its own HIP runtime; it must be the one already resident when libvmx.so (linked against
+# libamdhip64 by soname) is loaded, otherwise the process ends up with a runtime that sees no device.
+import torch  # noqa: F401  (plumbing: device memory, streams)
+
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "libvmx.so"
 
@@ -56,6 +60,9 @@ _SIGS = {
     "vmx_qwen3_load_awq_linear": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "vmx_qwen3_decode": (_i, [_p] * 6 + [_i, _i, _i, _p, _p, _p]),
     "vmx_qwen3_debug_read": (_i, [_p, _i, _p, _sz, _p]),
+    "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
+    "vmx_qwen3_profile_begin": (_i, [_p, _i]),
+    "vmx_qwen3_profile_end": (_i, [_p, _p, _p, _p]),
 }
 
 

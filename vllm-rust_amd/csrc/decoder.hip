@@ -193,8 +193,16 @@ struct Layer {
 
 }  // namespace
 
+struct GemmProfile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;  // pairs: start, stop
+    size_t used = 0;
+    double alg_bytes = 0.0;      // algorithmic bytes of the bracketed launches
+};
+
 struct vmx_qwen3 {
     vmx_qwen3_config cfg;
+    GemmProfile prof;
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
@@ -203,6 +211,26 @@ struct vmx_qwen3 {
 };
 
 namespace {
+
+// Algorithmic bytes of one int4 linear launch: packed nibbles + bf16 scales + 4-bit zeros + bf16 in/out.
+double int4_alg_bytes(const Int4Linear &l, int M) {
+    const double K = l.in_features, N = l.out_features, G = K / l.group;
+    return K * N / 2 + G * N * 2 + G * N / 2 + (double)M * K * 2 + (double)M * N * 2;
+}
+
+// forward_partial, bracketed by events when profiling is on (eager mode only).
+int run_linear(vmx_qwen3 *m, const Int4Linear &l, const uint16_t *x, float *partial, int M, hipStream_t st) {
+    GemmProfile &p = m->prof;
+    const bool rec = p.on && p.used + 2 <= p.ev.size();
+    if (rec) VMX_CHECK_HIP(hipEventRecord(p.ev[p.used], st));
+    if (int rc = l.forward_partial(x, partial, M, st)) return rc;
+    if (rec) {
+        VMX_CHECK_HIP(hipEventRecord(p.ev[p.used + 1], st));
+        p.used += 2;
+        p.alg_bytes += int4_alg_bytes(l, M);
+    }
+    return VMX_OK;
+}
 
 int make_linear(Int4Linear &l, int K, int N, int group) {
     l.in_features = K;
@@ -330,6 +358,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.qkv_stage);
         stage_free(L.gu_stage);
     }
+    for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial,
                       &m->logits, &m->attn_ws, &m->argmax_ws})
         b->release();
@@ -433,7 +462,7 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     for (const Layer &L : m->layers) {
         hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, pending, pending_splits, B,
                            (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
-        if (int rc = L.qkv.forward_partial(x, partial, B, st)) return rc;
+        if (int rc = run_linear(m, L.qkv, x, partial, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
         hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, partial, L.qkv.splits(), B, q, L.k_cache.p,
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
@@ -443,14 +472,14 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
                                               max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
                                               m->attn_ws.p, m->attn_ws.bytes, stream))
             return rc;
-        if (int rc = L.o.forward_partial(attn, partial, B, st)) return rc;
+        if (int rc = run_linear(m, L.o, attn, partial, B, st)) return rc;
         hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, partial, L.o.splits(), B,
                            (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
-        if (int rc = L.gate_up.forward_partial(x, partial, B, st)) return rc;
+        if (int rc = run_linear(m, L.gate_up, x, partial, B, st)) return rc;
         int64_t blocks = ((int64_t)B * I + 255) / 256;
         hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, partial,
                            L.gate_up.splits(), B, act, I);
-        if (int rc = L.down.forward_partial(act, partial, B, st)) return rc;
+        if (int rc = run_linear(m, L.down, act, partial, B, st)) return rc;
         pending = partial;
         pending_splits = L.down.splits();
     }
@@ -471,5 +500,66 @@ extern "C" int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t b
     DevBuf *src = which == 0 ? &m->h : which == 1 ? &m->x : which == 2 ? &m->logits : nullptr;
     VMX_REQUIRE(src && bytes <= src->bytes, "qwen3_debug_read: bad request");
     VMX_CHECK_HIP(hipMemcpyAsync(dst, src->p, bytes, hipMemcpyDefault, vmx_stream(stream)));
+    return VMX_OK;
+}
+
+// ---- measurement aid: time every int4 linear launch of subsequent EAGER decode steps with HIP
+// events on the launch stream.  Not for use under graph capture.
+extern "C" int vmx_qwen3_profile_begin(vmx_qwen3 *m, int max_launches) {
+    VMX_REQUIRE(m && max_launches > 0, "qwen3_profile_begin: bad arguments");
+    GemmProfile &p = m->prof;
+    while (p.ev.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        VMX_CHECK_HIP(hipEventCreate(&e));
+        p.ev.push_back(e);
+    }
+    p.used = 0;
+    p.alg_bytes = 0.0;
+    p.on = true;
+    return VMX_OK;
+}
+
+// Synchronises the last recorded event; returns launches, summed duration (us) and summed algorithmic bytes.
+extern "C" int vmx_qwen3_profile_end(vmx_qwen3 *m, int *launches, double *total_us, double *alg_bytes) {
+    VMX_REQUIRE(m && launches && total_us && alg_bytes, "qwen3_profile_end: null pointer");
+    GemmProfile &p = m->prof;
+    p.on = false;
+    double us = 0.0;
+    if (p.used) VMX_CHECK_HIP(hipEventSynchronize(p.ev[p.used - 1]));
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float ms = 0.f;
+        VMX_CHECK_HIP(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        us += (double)ms * 1e3;
+    }
+    *launches = (int)(p.used / 2);
+    *total_us = us;
+    *alg_bytes = p.alg_bytes;
+    return VMX_OK;
+}
+
+namespace {
+// ids <- next token; position, seq_len += 1; slot from the block table (host-side engine bookkeeping of
+// the reference, done on the device so that consecutive steps can be replayed from one graph).
+__global__ void decode_advance_kernel(int32_t *ids, const int32_t *next_ids, int32_t *positions, int32_t *slots, int32_t *seq_lens,
+                                      const int32_t *block_tables, int batch, int max_blocks_per_seq, int block_size) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int p = positions[b] + 1;
+    ids[b] = next_ids[b];
+    positions[b] = p;
+    seq_lens[b] = p + 1;
+    const int blk = min(p / block_size, max_blocks_per_seq - 1);
+    slots[b] = block_tables[b * max_blocks_per_seq + blk] * block_size + p % block_size;
+}
+}  // namespace
+
+extern "C" int vmx_decode_advance(int32_t *input_ids, const int32_t *next_ids, int32_t *positions, int32_t *slot_mapping,
+                                  int32_t *seq_lens, const int32_t *block_tables, int batch, int max_blocks_per_seq, int block_size,
+                                  void *stream) {
+    VMX_REQUIRE(input_ids && next_ids && positions && slot_mapping && seq_lens && block_tables, "decode_advance: null pointer");
+    VMX_REQUIRE(batch >= 1 && max_blocks_per_seq >= 1 && block_size >= 1, "decode_advance: bad shape");
+    hipLaunchKernelGGL(decode_advance_kernel, dim3((batch + 63) / 64), dim3(64), 0, vmx_stream(stream), input_ids, next_ids, positions,
+                       slot_mapping, seq_lens, block_tables, batch, max_blocks_per_seq, block_size);
+    VMX_CHECK_LAUNCH("decode_advance");
     return VMX_OK;
 }

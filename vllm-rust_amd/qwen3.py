@@ -167,3 +167,16 @@ class QuantizedQwen3ForCausalLM:
         check(lib.vmx_qwen3_debug_read(self._h, which, t.data_ptr(), t.numel() * 2, self._stream()))
         torch.cuda.current_stream().synchronize()
         return t
+
+    def advance(self, input_ids, next_ids, positions, slot_mapping, seq_lens, block_tables) -> None:
+        check(lib.vmx_decode_advance(input_ids.data_ptr(), next_ids.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(),
+                                     seq_lens.data_ptr(), block_tables.data_ptr(), input_ids.numel(), block_tables.shape[1],
+                                     self.spec.block_size, self._stream()))
+
+    def profile_begin(self, max_launches: int) -> None:
+        check(lib.vmx_qwen3_profile_begin(self._h, max_launches))
+
+    def profile_end(self):
+        n, us, by = C.c_int(), C.c_double(), C.c_double()
+        check(lib.vmx_qwen3_profile_end(self._h, C.byref(n), C.byref(us), C.byref(by)))
+        return n.value, us.value, by.value
