@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int PART = 256;  // tokens per partition = threads per workgroup
+constexpr int PART = 64;  // tokens per partition = lanes of the wave that owns it
 
 template <bool FP8> struct KvElem;
 template <> struct KvElem<false> { using T = uint16_t; };
@@ -59,24 +59,69 @@ template <bool FP8> __device__ __forceinline__ void load2(const void *base, int6
     }
 }
 
-// grid (kv_heads, seqs, partitions); block 256.  QPK = query heads per KV head (compile time).
-// LDS: stat | q f32 [QPK][HD] | logits f32 [QPK][PART]; the cross-wave sums reuse the q/logits region.
+// Raw (unconverted) cache accesses, so that many rows can wait in registers cheaply.
+template <bool FP8> struct Raw8 { using T = uint4; };
+template <> struct Raw8<true> { using T = uint2; };
+
+template <bool FP8> __device__ __forceinline__ typename Raw8<FP8>::T load8_raw(const void *base, int64_t idx) {
+    if constexpr (!FP8) return *reinterpret_cast<const uint4 *>((const uint16_t *)base + idx);
+    else return *reinterpret_cast<const uint2 *>((const uint8_t *)base + idx);
+}
+
+template <bool FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8>::T v, float scale, float f[8]) {
+    if constexpr (!FP8) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f[2 * j] = __uint_as_float(w[j] << 16);
+            f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+        }
+    } else {
+        f[0] = __builtin_amdgcn_cvt_f32_fp8(v.x, 0) * scale;
+        f[1] = __builtin_amdgcn_cvt_f32_fp8(v.x, 1) * scale;
+        f[2] = __builtin_amdgcn_cvt_f32_fp8(v.x, 2) * scale;
+        f[3] = __builtin_amdgcn_cvt_f32_fp8(v.x, 3) * scale;
+        f[4] = __builtin_amdgcn_cvt_f32_fp8(v.y, 0) * scale;
+        f[5] = __builtin_amdgcn_cvt_f32_fp8(v.y, 1) * scale;
+        f[6] = __builtin_amdgcn_cvt_f32_fp8(v.y, 2) * scale;
+        f[7] = __builtin_amdgcn_cvt_f32_fp8(v.y, 3) * scale;
+    }
+}
+
+template <bool FP8> __device__ __forceinline__ uint32_t load2_raw(const void *base, int64_t idx) {
+    if constexpr (!FP8) return *reinterpret_cast<const uint32_t *>((const uint16_t *)base + idx);
+    else return *reinterpret_cast<const uint16_t *>((const uint8_t *)base + idx);
+}
+
+template <bool FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale, float &a, float &b) {
+    if constexpr (!FP8) {
+        a = __uint_as_float(w << 16);
+        b = __uint_as_float(w & 0xFFFF0000u);
+    } else {
+        a = __builtin_amdgcn_cvt_f32_fp8(w, 0) * scale;
+        b = __builtin_amdgcn_cvt_f32_fp8(w, 1) * scale;
+    }
+}
+
+// grid (kv_heads, seqs, partitions); block 64: ONE wave per (sequence, KV head, 64-token partition),
+// serving all QPK query heads of the KV head.  Everything the wave needs from HBM is requested up
+// front so a partition costs about one memory round trip:
+//   phase 1  token per lane: the lane's K row arrives as 16-byte pieces (up to 16 in flight) and is
+//            dotted against the q vectors, which are read with scalar loads (wave-uniform addresses);
+//   phase 2  softmax over the 64 lanes with butterflies (no LDS);
+//   phase 3  dim per lane: V rows (one coalesced row per wave-instruction, requested before phase 1
+//            for head_dim <= 128) are weighted by p[t], broadcast from lane t with v_readlane.
 template <int HD, int QPK, bool FP8>
-__global__ __launch_bounds__(256) void paged_attn_partition_kernel(
+__global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
     const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
     const int32_t *__restrict__ seq_lens, float scale, int num_heads, int num_kv_heads, int max_blocks_per_seq, int block_size,
     int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int A_FLOATS = QPK * HD + QPK * PART, B_FLOATS = 4 * QPK * HD;
-    float *stat = reinterpret_cast<float *>(smem);   // [QPK][2] max, sum (+pad to 16 B)
-    float *q_s = stat + ((2 * QPK + 3) & ~3);        // [QPK][HD]
-    float *lg = q_s + QPK * HD;                      // [QPK][PART]
-    float *red = q_s;                                // [4][QPK][HD] cross-wave sums; reuses q_s/lg after a barrier
-    static_assert(A_FLOATS > 0 && B_FLOATS > 0, "");
+    __shared__ int64_t tok_base[PART];
+    __shared__ __align__(16) float p_s[PART * QPK];  // [token][head] softmax weights
 
     const int kvh = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const int seq_len = seq_lens[seq];
     if (seq_len == 0) return;
     const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
@@ -88,105 +133,117 @@ __global__ __launch_bounds__(256) void paged_attn_partition_kernel(
     const int64_t tok_stride = (int64_t)num_kv_heads * HD;
     const int head0 = kvh * QPK;
 
-    for (int i = tid; i < QPK * HD; i += 256)
-        q_s[i] = vmx_bf16_to_f32(q[((int64_t)seq * num_heads + head0 + i / HD) * HD + i % HD]);
-    __syncthreads();
+    // this lane's token row (lanes past the end re-read the last valid row; their logits are masked)
+    const int t = t0 + min(lane, ntok - 1);
+    const int blk = block_tables[(int64_t)seq * max_blocks_per_seq + t / block_size];
+    const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD;
+    tok_base[lane] = base;
 
-    // ---- phase 1: token per lane
-    {
-        float acc[QPK];
+    constexpr int NP = HD >= 128 ? HD / 128 : 1;       // V: pairs of dims per lane
+    constexpr int VB = NP == 1 ? 32 : (NP == 2 ? 16 : 8);   // V rows requested per batch (32 registers)
+    constexpr bool V_EARLY = true;                      // first V batch is requested before the K pass
+    const bool lane_live = (HD >= 128) || (lane < 32);
+
+    __syncthreads();
+    // q rows of this KV head's query group: addresses are wave-uniform, so the reads below become
+    // scalar loads and the dot products take q from SGPRs (no LDS traffic, no VGPRs for q).
+    const uint16_t *qg = q + ((int64_t)seq * num_heads + head0) * HD;
+
+    uint32_t vraw[VB][NP];
+    auto load_v_batch = [&](int b0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int h = 0; h < QPK; h++) acc[h] = 0.f;
-        if (tid < ntok) {
-            const int t = t0 + tid;
-            const int blk = block_tables[(int64_t)seq * max_blocks_per_seq + t / block_size];
-            const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD;
-#pragma unroll 4
-            for (int c = 0; c < HD / 8; c++) {
-                float kf[8];
-                load8<FP8>(k_cache, base + 8 * c, ksc, kf);
+        for (int j = 0; j < VB; j++) {
+            const int64_t rb = tok_base[min(b0 + j, ntok - 1)];
 #pragma unroll
-                for (int h = 0; h < QPK; h++) {
-                    const float4 qa = *reinterpret_cast<const float4 *>(q_s + h * HD + 8 * c);
-                    const float4 qb = *reinterpret_cast<const float4 *>(q_s + h * HD + 8 * c + 4);
-                    acc[h] += kf[0] * qa.x + kf[1] * qa.y + kf[2] * qa.z + kf[3] * qa.w + kf[4] * qb.x + kf[5] * qb.y +
-                              kf[6] * qb.z + kf[7] * qb.w;
-                }
+            for (int p = 0; p < NP; p++) {
+                vraw[j][p] = 0;
+                if (lane_live) vraw[j][p] = load2_raw<FP8>(v_cache, rb + 2 * lane + 128 * p);
             }
         }
-#pragma unroll
-        for (int h = 0; h < QPK; h++) lg[h * PART + tid] = tid < ntok ? acc[h] * scale : -FLT_MAX;
-    }
-    __syncthreads();
+    };
+    if (V_EARLY) load_v_batch(0);
 
-    // ---- phase 2: softmax per head (wave w takes heads w, w+4, ...)
-    for (int h = wave; h < QPK; h += 4) {
-        float v[4], m = -FLT_MAX;
+    // ---- phase 1
+    float acc[QPK];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { v[j] = lg[h * PART + lane + 64 * j]; m = fmaxf(m, v[j]); }
-        m = vmx_wave_max(m);
-        float s = 0.f;
+    for (int h = 0; h < QPK; h++) acc[h] = 0.f;
+    constexpr int KCH = HD / 8 < 16 ? HD / 8 : 16;  // K pieces in flight
+    for (int c0 = 0; c0 < HD / 8; c0 += KCH) {
+        typename Raw8<FP8>::T kraw[KCH];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float e = (lane + 64 * j < ntok) ? __expf(v[j] - m) : 0.f;
-            v[j] = e;
-            s += e;
+        for (int c = 0; c < KCH; c++) kraw[c] = load8_raw<FP8>(k_cache, base + 8 * (c0 + c));
+#pragma unroll
+        for (int c = 0; c < KCH; c++) {
+            float kf[8];
+            cvt8<FP8>(kraw[c], ksc, kf);
+#pragma unroll
+            for (int h = 0; h < QPK; h++) {
+                const uint4 qv = *reinterpret_cast<const uint4 *>(qg + h * HD + 8 * (c0 + c));
+                const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+                float a = acc[h];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    a = fmaf(kf[2 * j], __uint_as_float(qw[j] << 16), a);
+                    a = fmaf(kf[2 * j + 1], __uint_as_float(qw[j] & 0xFFFF0000u), a);
+                }
+                acc[h] = a;
+            }
         }
-        s = vmx_wave_sum(s);
-        const float inv = 1.0f / (s + 1e-6f);
-#pragma unroll
-        for (int j = 0; j < 4; j++) lg[h * PART + lane + 64 * j] = v[j] * inv;
-        if (lane == 0) { stat[2 * h] = m; stat[2 * h + 1] = s; }
     }
+
+    // ---- phase 2: p[h] = exp(l - max) / (sum + 1e-6) for this lane's token
+    float pr[QPK];
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        const float l = lane < ntok ? acc[h] * scale : -FLT_MAX;
+        const float m = vmx_wave_max(l);
+        const float e = lane < ntok ? __expf(l - m) : 0.f;
+        const float ssum = vmx_wave_sum(e);
+        pr[h] = e * (1.0f / (ssum + 1e-6f));
+        p_s[lane * QPK + h] = pr[h];
+        if (lane == 0) {
+            const int64_t mo = ((int64_t)seq * num_heads + head0 + h) * max_parts + part;
+            max_logits[mo] = m;
+            exp_sums[mo] = ssum;
+        }
+    }
+
     __syncthreads();
 
-    // ---- phase 3: dim per lane; wave w takes tokens w, w+4, ...
-    constexpr int DPL = HD / 64;  // dims per lane (HD >= 128: pairs), handled as DPL/2 pairs
-    constexpr int NP = DPL >= 2 ? DPL / 2 : 1;
+    // ---- phase 3
     float o[QPK][NP][2];
 #pragma unroll
     for (int h = 0; h < QPK; h++)
 #pragma unroll
         for (int p = 0; p < NP; p++) o[h][p][0] = o[h][p][1] = 0.f;
-    const bool lane_live = (HD >= 128) || (lane < 32);  // HD = 64: 32 lanes x 2 dims
-    for (int i = wave; i < ntok; i += 4) {
-        const int t = t0 + i;
-        const int blk = block_tables[(int64_t)seq * max_blocks_per_seq + t / block_size];
-        const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD;
-        float va[NP], vb[NP];
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            va[p] = vb[p] = 0.f;
-            if (lane_live) load2<FP8>(v_cache, base + 2 * lane + 128 * p, vsc, va[p], vb[p]);
-        }
+    for (int b0 = 0; b0 < PART; b0 += VB) {
+        if (b0 >= ntok) break;
+        if (!V_EARLY || b0 > 0) load_v_batch(b0);
 #pragma unroll
-        for (int h = 0; h < QPK; h++) {
-            const float pr = lg[h * PART + i];
+        for (int j = 0; j < VB; j++) {
+            if (b0 + j < ntok) {  // wave-uniform
+                float va[NP], vb[NP];
 #pragma unroll
-            for (int p = 0; p < NP; p++) { o[h][p][0] += pr * va[p]; o[h][p][1] += pr * vb[p]; }
+                for (int p = 0; p < NP; p++) cvt2<FP8>(vraw[j][p], vsc, va[p], vb[p]);
+#pragma unroll
+                for (int h = 0; h < QPK; h++) {
+                    const float w = p_s[(b0 + j) * QPK + h];  // same address in every lane: LDS broadcast
+#pragma unroll
+                    for (int p = 0; p < NP; p++) { o[h][p][0] += w * va[p]; o[h][p][1] += w * vb[p]; }
+                }
+                asm volatile("" ::: "memory");  // do not hoist the weights of later tokens (register pressure)
+            }
         }
     }
-    __syncthreads();  // every wave is done reading lg before red overwrites it
     if (lane_live) {
 #pragma unroll
         for (int h = 0; h < QPK; h++)
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                red[(wave * QPK + h) * HD + 2 * lane + 128 * p] = o[h][p][0];
-                red[(wave * QPK + h) * HD + 2 * lane + 128 * p + 1] = o[h][p][1];
+                float *dst = tmp_out + (((int64_t)seq * num_heads + head0 + h) * max_parts + part) * HD + 2 * lane + 128 * p;
+                *reinterpret_cast<float2 *>(dst) = make_float2(o[h][p][0], o[h][p][1]);
             }
-    }
-    __syncthreads();
-    for (int i = tid; i < QPK * HD; i += 256) {
-        const int h = i / HD, d = i % HD;
-        const float v = red[(0 * QPK + h) * HD + d] + red[(1 * QPK + h) * HD + d] + red[(2 * QPK + h) * HD + d] +
-                        red[(3 * QPK + h) * HD + d];
-        tmp_out[(((int64_t)seq * num_heads + head0 + h) * max_parts + part) * HD + d] = v;
-    }
-    if (tid < QPK) {
-        const int64_t mo = ((int64_t)seq * num_heads + head0 + tid) * max_parts + part;
-        max_logits[mo] = stat[2 * tid];
-        exp_sums[mo] = stat[2 * tid + 1];
     }
 }
 
@@ -220,20 +277,11 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
     }
 }
 
-template <int HD, int QPK, bool FP8> size_t part_lds_bytes() {
-    const size_t a = (size_t)QPK * HD + (size_t)QPK * PART, b = (size_t)4 * QPK * HD;
-    return (((size_t)2 * QPK + 3) & ~(size_t)3) * sizeof(float) + (a > b ? a : b) * sizeof(float);
-}
-
 template <int HD, int QPK, bool FP8>
 int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const uint16_t *q, const void *kc,
                 const void *vc, const int32_t *bt, const int32_t *sl, float scale, int H, int KVH, int mbps, int bs, int max_parts,
                 int window, const float *ks, const float *vs) {
-    const size_t lds = part_lds_bytes<HD, QPK, FP8>();
-    if (lds > 64 * 1024)
-        VMX_CHECK_HIP(hipFuncSetAttribute((const void *)paged_attn_partition_kernel<HD, QPK, FP8>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((paged_attn_partition_kernel<HD, QPK, FP8>), grid, dim3(256), lds, st, tmp_out, exp_sums, max_logits, q, kc, vc,
+    hipLaunchKernelGGL((paged_attn_partition_kernel<HD, QPK, FP8>), grid, dim3(64), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
                        bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs);
     VMX_CHECK_LAUNCH("paged_attention(partition)");
     return VMX_OK;

@@ -28,32 +28,90 @@ __device__ __forceinline__ float sum_partials(const float *__restrict__ partial,
     return v;
 }
 
+constexpr int SMAX = 8;  // most split-K slices any linear produces (int4 plan: K/128 / 4 <= ... checked at create)
+
+// 8 consecutive f32 sums of the split-K slices at element offset idx (multiple of 8); all loads independent.
+__device__ __forceinline__ void sum_partials8(const float *__restrict__ partial, int splits, int64_t slice_stride, int64_t idx,
+                                              float out[8]) {
+    float4 a[SMAX], b[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        if (s < splits) {
+            a[s] = *reinterpret_cast<const float4 *>(partial + s * slice_stride + idx);
+            b[s] = *reinterpret_cast<const float4 *>(partial + s * slice_stride + idx + 4);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        if (s < splits) {
+            out[0] += a[s].x; out[1] += a[s].y; out[2] += a[s].z; out[3] += a[s].w;
+            out[4] += b[s].x; out[5] += b[s].y; out[6] += b[s].z; out[7] += b[s].w;
+        }
+    }
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4 v, float f[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f[2 * j] = __uint_as_float(w[j] << 16);
+        f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+    }
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float f[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = (uint32_t)vmx_f32_to_bf16(f[2 * j]) | ((uint32_t)vmx_f32_to_bf16(f[2 * j + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // One workgroup per token.  h (bf16 residual stream, in/out), optional incoming linear output as
 // f32 partials [splits][tokens][hidden]:  o = bf16(sum partials); h = bf16(h + o);
 // x = bf16(h * rsqrt(mean(h^2) + eps) * w)   (add_bf16 then rms_norm_bf16: variance over the ROUNDED h).
+// Thread t owns the 8-element chunks t, t+256, ... (CH of them, hidden <= CH*2048) in registers.
+template <int CH>
 __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x,
                                                           const float *__restrict__ partial, int splits, int tokens,
                                                           const uint16_t *__restrict__ w, float eps, int hidden) {
     __shared__ float red[4];
-    extern __shared__ __align__(16) unsigned char smem[];
-    float *hv = reinterpret_cast<float *>(smem);  // [hidden] rounded residual values
     const int t = blockIdx.x;
     const int64_t row = (int64_t)t * hidden;
     const int64_t slice = (int64_t)tokens * hidden;
+    const int nchunk = hidden >> 3;
+    float hv[CH][8];
     float var = 0.f;
-    for (int i = threadIdx.x; i < hidden; i += 256) {
-        float hval = vmx_bf16_to_f32(h[row + i]);
-        if (partial) {
-            const float o = round_bf16(sum_partials(partial, splits, slice, row + i));
-            hval = round_bf16(hval + o);
-            h[row + i] = vmx_f32_to_bf16(hval);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int ci = threadIdx.x + 256 * c;
+        if (ci < nchunk) {
+            unpack_bf16x8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
+            if (partial) {
+                float o[8];
+                sum_partials8(partial, splits, slice, row + 8 * ci, o);
+#pragma unroll
+                for (int j = 0; j < 8; j++) hv[c][j] = round_bf16(hv[c][j] + round_bf16(o[j]));
+                *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack_bf16x8(hv[c]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) var += hv[c][j] * hv[c][j];
         }
-        hv[i] = hval;
-        var += hval * hval;
     }
     var = vmx_block_sum_256(var, red);
     const float inv = rsqrtf(var / (float)hidden + eps);
-    for (int i = threadIdx.x; i < hidden; i += 256) x[row + i] = vmx_f32_to_bf16(hv[i] * inv * vmx_bf16_to_f32(w[i]));
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int ci = threadIdx.x + 256 * c;
+        if (ci < nchunk) {
+            float wv[8], o[8];
+            unpack_bf16x8(*reinterpret_cast<const uint4 *>(w + 8 * ci), wv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = hv[c][j] * inv * wv[j];
+            *reinterpret_cast<uint4 *>(x + row + 8 * ci) = pack_bf16x8(o);
+        }
+    }
 }
 
 // grid (heads_q + 2*heads_kv, tokens), block 64.  Takes the merged qkv linear output as f32
@@ -146,6 +204,14 @@ __global__ __launch_bounds__(256) void embed_kernel(uint16_t *__restrict__ out, 
     const uint4 *src = reinterpret_cast<const uint4 *>(table + (int64_t)(ok ? id : 0) * hidden);
     uint4 *dst = reinterpret_cast<uint4 *>(out + (int64_t)t * hidden);
     for (int i = threadIdx.x; i < (hidden >> 3); i += 256) dst[i] = ok ? src[i] : make_uint4(0, 0, 0, 0);
+}
+
+void launch_resid_norm(hipStream_t st, uint16_t *h, uint16_t *x, const float *partial, int splits, int tokens, const uint16_t *w,
+                       float eps, int hidden) {
+    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
+    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
+    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
+    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
 }
 
 struct DevBuf {
@@ -280,7 +346,8 @@ int stage_pack(MergeStage &s, Int4Linear &l, hipStream_t st) {
 extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     VMX_REQUIRE(cfg && out, "qwen3_create: null pointer");
     const vmx_qwen3_config &c = *cfg;
-    VMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 128 == 0, "qwen3_create: hidden_size (%d) must be a multiple of 128", c.hidden_size);
+    VMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 128 == 0 && c.hidden_size <= 16384,
+                "qwen3_create: hidden_size (%d) must be a multiple of 128, at most 16384", c.hidden_size);
     VMX_REQUIRE(c.intermediate_size > 0 && c.intermediate_size % 128 == 0, "qwen3_create: intermediate_size (%d) must be a multiple of 128",
                 c.intermediate_size);
     VMX_REQUIRE(c.num_layers > 0 && c.num_heads > 0 && c.num_kv_heads > 0 && c.num_heads % c.num_kv_heads == 0,
@@ -330,6 +397,10 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
         const size_t cands[4] = {(size_t)L.qkv.splits() * NQKV, (size_t)L.o.splits() * H, (size_t)L.gate_up.splits() * 2 * I,
                                  (size_t)L.down.splits() * H};
         for (size_t v : cands) max_partial = v > max_partial ? v : max_partial;
+        if (L.qkv.splits() > SMAX || L.o.splits() > SMAX || L.gate_up.splits() > SMAX || L.down.splits() > SMAX) {
+            vmx_set_error("qwen3_create: a linear needs more than %d split-K slices (K too large)", SMAX);
+            rc = VMX_EUNSUPPORTED;
+        }
     }
     TRY(m->partial.alloc(max_partial * B * 4));
     TRY(m->h.alloc((size_t)B * H * 2));
@@ -448,11 +519,10 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
         VMX_REQUIRE(L.qkv.loaded && L.o.loaded && L.gate_up.loaded && L.down.loaded, "qwen3_decode: weights not fully loaded");
     hipStream_t st = vmx_stream(stream);
     const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = batch;
-    const int Hq = c.num_heads, Hkv = c.num_kv_heads, NQKV = m->qkv_n();
+    const int Hq = c.num_heads, Hkv = c.num_kv_heads;
     uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p, *attn = (uint16_t *)m->attn.p,
              *act = (uint16_t *)m->act.p;
     float *partial = (float *)m->partial.p;
-    const size_t h_lds = (size_t)H * 4;
     const float scale = 1.0f / sqrtf((float)hd);
     const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
 
@@ -460,8 +530,7 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     const float *pending = nullptr;  // linear output not yet folded into the residual stream
     int pending_splits = 0;
     for (const Layer &L : m->layers) {
-        hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, pending, pending_splits, B,
-                           (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
+        launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
         if (int rc = run_linear(m, L.qkv, x, partial, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
         hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, partial, L.qkv.splits(), B, q, L.k_cache.p,
@@ -473,8 +542,7 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
                                               m->attn_ws.p, m->attn_ws.bytes, stream))
             return rc;
         if (int rc = run_linear(m, L.o, attn, partial, B, st)) return rc;
-        hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, partial, L.o.splits(), B,
-                           (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
+        launch_resid_norm(st, h, x, partial, L.o.splits(), B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
         if (int rc = run_linear(m, L.gate_up, x, partial, B, st)) return rc;
         int64_t blocks = ((int64_t)B * I + 255) / 256;
         hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, partial,
@@ -483,8 +551,7 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
         pending = partial;
         pending_splits = L.down.splits();
     }
-    hipLaunchKernelGGL(resid_norm_kernel, dim3(B), dim3(256), h_lds, st, h, x, pending, pending_splits, B,
-                       (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H);
+    launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H);
     VMX_CHECK_LAUNCH("qwen3_decode");
     uint16_t *logits = logits_out ? logits_out : (uint16_t *)m->logits.p;
     const uint16_t *head = (const uint16_t *)(m->lm_head_tied ? m->embed.p : m->lm_head.p);

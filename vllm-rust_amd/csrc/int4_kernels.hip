@@ -268,6 +268,8 @@ inline GemmPlan plan_gemm(int N, int K) {
     }
     // do not leave most of a workgroup idle on short K
     while (upw > 1 && 4 * upw > kblocks) upw >>= 1;
+    // consumers that fold the split-K sum into their prologue read at most 8 slices
+    while (upw < 8 && (kblocks + 4 * upw - 1) / (4 * upw) > 8) upw <<= 1;
     GemmPlan p;
     p.upw = upw;
     p.splits = (kblocks + 4 * upw - 1) / (4 * upw);
