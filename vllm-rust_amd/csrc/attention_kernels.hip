@@ -12,7 +12,7 @@
 // dots it against the q vectors held in LDS, which are read as broadcasts); phase 2 is a
 // per-head softmax over the 256 logits; phase 3 is dim-per-lane (a wave reads one V row as one
 // coalesced access and the four waves split the tokens).
-#include "vmx_internal.h"
+#include "vmx_kernels.h"
 #include <float.h>
 
 namespace {
@@ -287,35 +287,32 @@ int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, floa
     return VMX_OK;
 }
 
+static int parts_for_impl(int max_seq_len) { return max_seq_len <= 0 ? 1 : (max_seq_len + PART - 1) / PART; }
 }  // namespace
 
-static int parts_for(int max_seq_len) { return max_seq_len <= 0 ? 1 : (max_seq_len + PART - 1) / PART; }
 
 extern "C" size_t vmx_paged_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim, int max_seq_len) {
     if (num_seqs <= 0 || num_heads <= 0 || head_dim <= 0) return 0;
-    const size_t P = (size_t)parts_for(max_seq_len);
+    const size_t P = (size_t)parts_for_impl(max_seq_len);
     return (size_t)num_seqs * num_heads * P * ((size_t)head_dim + 2) * sizeof(float);
 }
 
-extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
-                                        const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
-                                        int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size,
-                                        int window, int kv_dtype, const float *k_scale, const float *v_scale, void *workspace,
-                                        size_t workspace_bytes, void *stream) {
-    VMX_REQUIRE(out && q && k_cache && v_cache && block_tables && seq_lens && workspace, "paged_attention: null pointer");
-    VMX_REQUIRE(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
-                "paged_attention: num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
-    VMX_REQUIRE(block_size > 0 && max_blocks_per_seq > 0 && window >= 0, "paged_attention: bad cache geometry");
-    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3, "paged_attention: unsupported kv dtype %d", kv_dtype);
-    VMX_REQUIRE(workspace_bytes >= vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len),
-                "paged_attention: workspace too small");
-    if (num_seqs == 0) return VMX_OK;
-    const int P = parts_for(max_seq_len);
+// Internal: launch only the per-partition kernel; the caller merges the partitions (either with
+// paged_attn_reduce_kernel or inside the prologue of the consuming linear).
+int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void *v_cache, const int32_t *block_tables,
+                              const int32_t *seq_lens, float scale, int num_seqs, int num_heads, int num_kv_heads,
+                              int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window, int kv_dtype,
+                              const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st) {
+    const int P = parts_for_impl(max_seq_len);
     const int qpk = num_heads / num_kv_heads;
     float *tmp_out = (float *)workspace;
     float *exp_sums = tmp_out + (size_t)num_seqs * num_heads * P * head_dim;
     float *max_logits = exp_sums + (size_t)num_seqs * num_heads * P;
-    hipStream_t st = vmx_stream(stream);
+    out->tmp_out = tmp_out;
+    out->exp_sums = exp_sums;
+    out->max_logits = max_logits;
+    out->max_parts = P;
+    out->part_tokens = PART;
     const dim3 grid(num_kv_heads, num_seqs, P);
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
     int rc = VMX_EUNSUPPORTED;
@@ -341,9 +338,30 @@ extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const 
     }
 #undef BY_QPK
 #undef ARGS
-    if (rc) return rc;
-    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, tmp_out, exp_sums, max_logits,
-                       seq_lens, num_heads, head_dim, P, window);
+    return rc;
+}
+
+extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                        const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
+                                        int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size,
+                                        int window, int kv_dtype, const float *k_scale, const float *v_scale, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(out && q && k_cache && v_cache && block_tables && seq_lens && workspace, "paged_attention: null pointer");
+    VMX_REQUIRE(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+                "paged_attention: num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
+    VMX_REQUIRE(block_size > 0 && max_blocks_per_seq > 0 && window >= 0, "paged_attention: bad cache geometry");
+    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3, "paged_attention: unsupported kv dtype %d", kv_dtype);
+    VMX_REQUIRE(workspace_bytes >= vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len),
+                "paged_attention: workspace too small");
+    if (num_seqs == 0) return VMX_OK;
+    hipStream_t st = vmx_stream(stream);
+    VmxAttnParts parts;
+    if (int rc = vmx_paged_attention_parts(q, k_cache, v_cache, block_tables, seq_lens, scale, num_seqs, num_heads, num_kv_heads,
+                                           max_blocks_per_seq, max_seq_len, head_dim, block_size, window, kv_dtype, k_scale, v_scale,
+                                           workspace, &parts, st))
+        return rc;
+    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts.tmp_out, parts.exp_sums,
+                       parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
 }

@@ -242,6 +242,10 @@ struct Int4Linear {
     int forward_partial(const uint16_t *x, float *partial, int M, hipStream_t st) const {
         return vmx_int4_gemm_partial(packed.p, x, partial, M, out_features, in_features, group, st);
     }
+    // activations produced in the prologue (mode/xsrc: VmxXSource in vmx_kernels.h)
+    int forward_fused(int mode, const VmxXSource &xsrc, float *partial, int M, hipStream_t st) const {
+        return vmx_int4_gemm_fused(packed.p, mode, &xsrc, partial, M, out_features, in_features, group, st);
+    }
 };
 
 // Merged GPTQ-sequential staging of several AWQ linears that share the input (q|k|v, gate|up).
@@ -272,7 +276,7 @@ struct vmx_qwen3 {
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
-    DevBuf h, x, q, attn, act, partial, logits, attn_ws, argmax_ws;
+    DevBuf h, x, q, partial, partial_b, logits, attn_ws, argmax_ws;
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
 };
 
@@ -284,12 +288,12 @@ double int4_alg_bytes(const Int4Linear &l, int M) {
     return K * N / 2 + G * N * 2 + G * N / 2 + (double)M * K * 2 + (double)M * N * 2;
 }
 
-// forward_partial, bracketed by events when profiling is on (eager mode only).
-int run_linear(vmx_qwen3 *m, const Int4Linear &l, const uint16_t *x, float *partial, int M, hipStream_t st) {
+// forward_fused, bracketed by events when profiling is on (eager mode only).
+int run_linear(vmx_qwen3 *m, const Int4Linear &l, int mode, const VmxXSource &xsrc, float *partial, int M, hipStream_t st) {
     GemmProfile &p = m->prof;
     const bool rec = p.on && p.used + 2 <= p.ev.size();
     if (rec) VMX_CHECK_HIP(hipEventRecord(p.ev[p.used], st));
-    if (int rc = l.forward_partial(x, partial, M, st)) return rc;
+    if (int rc = l.forward_fused(mode, xsrc, partial, M, st)) return rc;
     if (rec) {
         VMX_CHECK_HIP(hipEventRecord(p.ev[p.used + 1], st));
         p.used += 2;
@@ -403,11 +407,10 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
         }
     }
     TRY(m->partial.alloc(max_partial * B * 4));
+    TRY(m->partial_b.alloc(max_partial * B * 4));
     TRY(m->h.alloc((size_t)B * H * 2));
     TRY(m->x.alloc((size_t)B * H * 2));
     TRY(m->q.alloc((size_t)B * NO * 2));
-    TRY(m->attn.alloc((size_t)B * NO * 2));
-    TRY(m->act.alloc((size_t)B * I * 2));
     TRY(m->logits.alloc((size_t)B * c.vocab_size * 2));
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, hd, c.max_seq_len)));
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
@@ -430,7 +433,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.gu_stage);
     }
     for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial,
+    for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->partial, &m->partial_b,
                       &m->logits, &m->attn_ws, &m->argmax_ws})
         b->release();
     delete m;
@@ -520,35 +523,44 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     hipStream_t st = vmx_stream(stream);
     const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = batch;
     const int Hq = c.num_heads, Hkv = c.num_kv_heads;
-    uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p, *attn = (uint16_t *)m->attn.p,
-             *act = (uint16_t *)m->act.p;
-    float *partial = (float *)m->partial.p;
+    uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p;
+    float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;  // ping-pong: each linear reads one, writes the other
     const float scale = 1.0f / sqrtf((float)hd);
     const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
+    (void)I;
 
     hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
-    const float *pending = nullptr;  // linear output not yet folded into the residual stream
+    const float *pending = nullptr;  // down-projection output (f32 slices in PB) not yet folded into the residual stream
     int pending_splits = 0;
     for (const Layer &L : m->layers) {
-        launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
-        if (int rc = run_linear(m, L.qkv, x, partial, B, st)) return rc;
+        // q|k|v = linear(rms_norm(h += pending))            [norm fused into the linear's prologue]
+        VmxXSource xn = {};
+        xn.h = h; xn.part = pending; xn.part_splits = pending_splits; xn.norm_w = (const uint16_t *)L.input_ln.p; xn.eps = c.rms_norm_eps;
+        if (int rc = run_linear(m, L.qkv, 2, xn, PA, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
-        hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, partial, L.qkv.splits(), B, q, L.k_cache.p,
+        hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, L.qkv.splits(), B, q, L.k_cache.p,
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                            c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
                            slot_mapping, Hq, Hkv, hd, hd, fp8, ks, ks + 1);
-        if (int rc = vmx_paged_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, scale, B, Hq, Hkv,
-                                              max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
-                                              m->attn_ws.p, m->attn_ws.bytes, stream))
+        VmxAttnParts ap;
+        if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, scale, B, Hq, Hkv,
+                                               max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
+                                               m->attn_ws.p, &ap, st))
             return rc;
-        if (int rc = run_linear(m, L.o, attn, partial, B, st)) return rc;
-        launch_resid_norm(st, h, x, partial, L.o.splits(), B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
-        if (int rc = run_linear(m, L.gate_up, x, partial, B, st)) return rc;
-        int64_t blocks = ((int64_t)B * I + 255) / 256;
-        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, partial,
-                           L.gate_up.splits(), B, act, I);
-        if (int rc = run_linear(m, L.down, act, partial, B, st)) return rc;
-        pending = partial;
+        // o = linear(merge(attention partitions))           [partition merge fused into the prologue]
+        VmxXSource xa = {};
+        xa.part = ap.tmp_out; xa.exp_sums = ap.exp_sums; xa.max_logits = ap.max_logits; xa.seq_lens = seq_lens; xa.head_dim = hd;
+        xa.max_parts = ap.max_parts; xa.window = 0; xa.part_tokens = ap.part_tokens;
+        if (int rc = run_linear(m, L.o, 3, xa, PB, B, st)) return rc;
+        // gate|up = linear(rms_norm(h += o))
+        VmxXSource xp = {};
+        xp.h = h; xp.part = PB; xp.part_splits = L.o.splits(); xp.norm_w = (const uint16_t *)L.post_ln.p; xp.eps = c.rms_norm_eps;
+        if (int rc = run_linear(m, L.gate_up, 2, xp, PA, B, st)) return rc;
+        // down = linear(silu(gate) * up)                    [activation fused into the prologue]
+        VmxXSource xg = {};
+        xg.part = PA; xg.part_splits = L.gate_up.splits();
+        if (int rc = run_linear(m, L.down, 1, xg, PB, B, st)) return rc;
+        pending = PB;
         pending_splits = L.down.splits();
     }
     launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H);
