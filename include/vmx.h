@@ -253,6 +253,10 @@ int vmx_decode_advance(int32_t *input_ids, const int32_t *next_ids, int32_t *pos
 int vmx_qwen3_profile_begin(vmx_qwen3 *m, int max_launches);
 int vmx_qwen3_profile_end(vmx_qwen3 *m, int *launches, double *total_us, double *alg_bytes);
 
+/* Measurement aid: stream `bytes` from p with the int4 linear's access shape (upw 1 KiB units per wave,
+ * all requested up front) and discard them; gives the HBM floor for a launch of that size. */
+int vmx_debug_stream_read(const void *p, size_t bytes, int upw, void *sink, void *stream);
+
 /* Parity aid: read back an internal activation of the last step (0 = residual stream h,
  * 1 = final normed x, 2 = logits), bf16. */
 int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t bytes, void *stream);

@@ -341,6 +341,14 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
     return rc;
 }
 
+int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
+                              int head_dim, int window, hipStream_t st) {
+    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,
+                       parts->max_logits, seq_lens, num_heads, head_dim, parts->max_parts, window);
+    VMX_CHECK_LAUNCH("paged_attention(reduce)");
+    return VMX_OK;
+}
+
 extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
                                         const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
                                         int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size,

@@ -12,6 +12,7 @@
 // whole step is a fixed launch sequence without allocation or host reads (hipGraph-capturable).
 #include "vmx_kernels.h"
 
+#include <stdlib.h>
 #include <new>
 #include <vector>
 
@@ -28,7 +29,7 @@ __device__ __forceinline__ float sum_partials(const float *__restrict__ partial,
     return v;
 }
 
-constexpr int SMAX = 8;  // most split-K slices any linear produces (int4 plan: K/128 / 4 <= ... checked at create)
+constexpr int SMAX = 4;  // most split-K slices any linear produces (int4 plan: K/128 / 4 <= ... checked at create)
 
 // 8 consecutive f32 sums of the split-K slices at element offset idx (multiple of 8); all loads independent.
 __device__ __forceinline__ void sum_partials8(const float *__restrict__ partial, int splits, int64_t slice_stride, int64_t idx,
@@ -242,10 +243,7 @@ struct Int4Linear {
     int forward_partial(const uint16_t *x, float *partial, int M, hipStream_t st) const {
         return vmx_int4_gemm_partial(packed.p, x, partial, M, out_features, in_features, group, st);
     }
-    // activations produced in the prologue (mode/xsrc: VmxXSource in vmx_kernels.h)
-    int forward_fused(int mode, const VmxXSource &xsrc, float *partial, int M, hipStream_t st) const {
-        return vmx_int4_gemm_fused(packed.p, mode, &xsrc, partial, M, out_features, in_features, group, st);
-    }
+
 };
 
 // Merged GPTQ-sequential staging of several AWQ linears that share the input (q|k|v, gate|up).
@@ -276,7 +274,7 @@ struct vmx_qwen3 {
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
-    DevBuf h, x, q, partial, partial_b, logits, attn_ws, argmax_ws;
+    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws;
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
 };
 
@@ -288,12 +286,12 @@ double int4_alg_bytes(const Int4Linear &l, int M) {
     return K * N / 2 + G * N * 2 + G * N / 2 + (double)M * K * 2 + (double)M * N * 2;
 }
 
-// forward_fused, bracketed by events when profiling is on (eager mode only).
-int run_linear(vmx_qwen3 *m, const Int4Linear &l, int mode, const VmxXSource &xsrc, float *partial, int M, hipStream_t st) {
+// forward_partial, bracketed by events when profiling is on (eager mode only).
+int run_linear(vmx_qwen3 *m, const Int4Linear &l, const uint16_t *xin, float *partial, int M, hipStream_t st) {
     GemmProfile &p = m->prof;
     const bool rec = p.on && p.used + 2 <= p.ev.size();
     if (rec) VMX_CHECK_HIP(hipEventRecord(p.ev[p.used], st));
-    if (int rc = l.forward_fused(mode, xsrc, partial, M, st)) return rc;
+    if (int rc = l.forward_partial(xin, partial, M, st)) return rc;
     if (rec) {
         VMX_CHECK_HIP(hipEventRecord(p.ev[p.used + 1], st));
         p.used += 2;
@@ -411,6 +409,8 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     TRY(m->h.alloc((size_t)B * H * 2));
     TRY(m->x.alloc((size_t)B * H * 2));
     TRY(m->q.alloc((size_t)B * NO * 2));
+    TRY(m->attn.alloc((size_t)B * NO * 2));
+    TRY(m->act.alloc((size_t)B * I * 2));
     TRY(m->logits.alloc((size_t)B * c.vocab_size * 2));
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, hd, c.max_seq_len)));
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
@@ -433,7 +433,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.gu_stage);
     }
     for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->partial, &m->partial_b,
+    for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
                       &m->logits, &m->attn_ws, &m->argmax_ws})
         b->release();
     delete m;
@@ -527,16 +527,15 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;  // ping-pong: each linear reads one, writes the other
     const float scale = 1.0f / sqrtf((float)hd);
     const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
-    (void)I;
 
     hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
     const float *pending = nullptr;  // down-projection output (f32 slices in PB) not yet folded into the residual stream
     int pending_splits = 0;
+    uint16_t *attn = (uint16_t *)m->attn.p, *act = (uint16_t *)m->act.p;
     for (const Layer &L : m->layers) {
-        // q|k|v = linear(rms_norm(h += pending))            [norm fused into the linear's prologue]
-        VmxXSource xn = {};
-        xn.h = h; xn.part = pending; xn.part_splits = pending_splits; xn.norm_w = (const uint16_t *)L.input_ln.p; xn.eps = c.rms_norm_eps;
-        if (int rc = run_linear(m, L.qkv, 2, xn, PA, B, st)) return rc;
+        // h += pending; x = rms_norm(h);  q|k|v = linear(x)
+        launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
+        if (int rc = run_linear(m, L.qkv, x, PA, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
         hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, L.qkv.splits(), B, q, L.k_cache.p,
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
@@ -547,19 +546,15 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
                                                max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
                                                m->attn_ws.p, &ap, st))
             return rc;
-        // o = linear(merge(attention partitions))           [partition merge fused into the prologue]
-        VmxXSource xa = {};
-        xa.part = ap.tmp_out; xa.exp_sums = ap.exp_sums; xa.max_logits = ap.max_logits; xa.seq_lens = seq_lens; xa.head_dim = hd;
-        xa.max_parts = ap.max_parts; xa.window = 0; xa.part_tokens = ap.part_tokens;
-        if (int rc = run_linear(m, L.o, 3, xa, PB, B, st)) return rc;
-        // gate|up = linear(rms_norm(h += o))
-        VmxXSource xp = {};
-        xp.h = h; xp.part = PB; xp.part_splits = L.o.splits(); xp.norm_w = (const uint16_t *)L.post_ln.p; xp.eps = c.rms_norm_eps;
-        if (int rc = run_linear(m, L.gate_up, 2, xp, PA, B, st)) return rc;
-        // down = linear(silu(gate) * up)                    [activation fused into the prologue]
-        VmxXSource xg = {};
-        xg.part = PA; xg.part_splits = L.gate_up.splits();
-        if (int rc = run_linear(m, L.down, 1, xg, PB, B, st)) return rc;
+        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st)) return rc;
+        if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
+        // h += o; x = rms_norm(h);  gate|up = linear(x);  act = silu(gate) * up;  down = linear(act)
+        launch_resid_norm(st, h, x, PB, L.o.splits(), B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
+        if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
+        int64_t blocks = ((int64_t)B * I + 255) / 256;
+        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA,
+                           L.gate_up.splits(), B, act, I);
+        if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;
         pending = PB;
         pending_splits = L.down.splits();
     }

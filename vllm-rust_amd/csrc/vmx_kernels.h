@@ -3,21 +3,6 @@
 #include "vmx_internal.h"
 
 // int4_kernels.hip
-// Where a fused int4 linear takes its activations from (see XMode in int4_kernels.hip).
-struct VmxXSource {
-    const uint16_t *x;
-    const float *part;
-    int part_splits;
-    uint16_t *h;
-    const uint16_t *norm_w;
-    float eps;
-    const float *exp_sums;
-    const float *max_logits;
-    const int32_t *seq_lens;
-    int head_dim, max_parts, window, part_tokens;
-};
-int vmx_int4_gemm_fused(const void *packed, int mode, const VmxXSource *xsrc, float *partial, int M, int N, int K, int group,
-                        hipStream_t st);
 int vmx_int4_splits(int N, int K);
 int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial, int M, int N, int K, int group, hipStream_t st);
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
@@ -32,3 +17,5 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
                               const int32_t *seq_lens, float scale, int num_seqs, int num_heads, int num_kv_heads,
                               int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window, int kv_dtype,
                               const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st);
+int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
+                              int head_dim, int window, hipStream_t st);
