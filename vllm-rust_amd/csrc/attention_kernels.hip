@@ -6,58 +6,16 @@
 // the log-sum-exp rule; GQA kv_head = head / (H / KVH); sliding window start = seq_len - window;
 // FP8 e4m3 caches dequantised as float(byte) * scale.
 //
-// Structure (gfx950's own): one workgroup = one (sequence, KV head, partition of 256 tokens) and
-// serves ALL query heads of that KV head, so each K/V byte is read from HBM once instead of once
-// per query head.  Phase 1 is token-per-lane (each lane streams one K row in 16-byte pieces and
-// dots it against the q vectors held in LDS, which are read as broadcasts); phase 2 is a
-// per-head softmax over the 256 logits; phase 3 is dim-per-lane (a wave reads one V row as one
-// coalesced access and the four waves split the tokens).
+// Structure (gfx950's own): one wave = one (sequence, KV head, partition) and serves ALL query heads
+// of that KV head, so each K/V byte is read from HBM once instead of once per query head; QK^T runs
+// on the matrix cores over 16-token tiles, PV on the vector ALU with one V row per wave access
+// (details at the kernel).  At most 64 partitions per sequence; a second kernel (or the consumer)
+// merges them.
 #include "vmx_kernels.h"
 #include <float.h>
 
 namespace {
 
-constexpr int PART = 64;  // tokens per partition = lanes of the wave that owns it
-
-template <bool FP8> struct KvElem;
-template <> struct KvElem<false> { using T = uint16_t; };
-template <> struct KvElem<true> { using T = uint8_t; };
-
-// 8 consecutive cache elements -> f32
-template <bool FP8> __device__ __forceinline__ void load8(const void *base, int64_t idx, float scale, float f[8]) {
-    if constexpr (!FP8) {
-        const uint4 v = *reinterpret_cast<const uint4 *>((const uint16_t *)base + idx);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            f[2 * j] = __uint_as_float(w[j] << 16);
-            f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
-        }
-    } else {
-        const uint2 v = *reinterpret_cast<const uint2 *>((const uint8_t *)base + idx);
-        f[0] = __builtin_amdgcn_cvt_f32_fp8(v.x, 0) * scale;
-        f[1] = __builtin_amdgcn_cvt_f32_fp8(v.x, 1) * scale;
-        f[2] = __builtin_amdgcn_cvt_f32_fp8(v.x, 2) * scale;
-        f[3] = __builtin_amdgcn_cvt_f32_fp8(v.x, 3) * scale;
-        f[4] = __builtin_amdgcn_cvt_f32_fp8(v.y, 0) * scale;
-        f[5] = __builtin_amdgcn_cvt_f32_fp8(v.y, 1) * scale;
-        f[6] = __builtin_amdgcn_cvt_f32_fp8(v.y, 2) * scale;
-        f[7] = __builtin_amdgcn_cvt_f32_fp8(v.y, 3) * scale;
-    }
-}
-
-// 2 consecutive cache elements -> f32
-template <bool FP8> __device__ __forceinline__ void load2(const void *base, int64_t idx, float scale, float &a, float &b) {
-    if constexpr (!FP8) {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>((const uint16_t *)base + idx);
-        a = __uint_as_float(w << 16);
-        b = __uint_as_float(w & 0xFFFF0000u);
-    } else {
-        const uint32_t w = *reinterpret_cast<const uint16_t *>((const uint8_t *)base + idx);
-        a = __builtin_amdgcn_cvt_f32_fp8(w, 0) * scale;
-        b = __builtin_amdgcn_cvt_f32_fp8(w, 1) * scale;
-    }
-}
 
 // Raw (unconverted) cache accesses, so that many rows can wait in registers cheaply.
 template <bool FP8> struct Raw8 { using T = uint4; };
@@ -103,148 +61,162 @@ template <bool FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale
     }
 }
 
-// grid (kv_heads, seqs, partitions); block 64: ONE wave per (sequence, KV head, 64-token partition),
-// serving all QPK query heads of the KV head.  Everything the wave needs from HBM is requested up
-// front so a partition costs about one memory round trip:
-//   phase 1  token per lane: the lane's K row arrives as 16-byte pieces (up to 16 in flight) and is
-//            dotted against the q vectors, which are read with scalar loads (wave-uniform addresses);
-//   phase 2  softmax over the 64 lanes with butterflies (no LDS);
-//   phase 3  dim per lane: V rows (one coalesced row per wave-instruction, requested before phase 1
-//            for head_dim <= 128) are weighted by p[t], broadcast from lane t with v_readlane.
+// grid (kv_heads, seqs, partitions); block 64: ONE wave per (sequence, KV head, partition), serving
+// all QPK (<= 16) query heads of the KV head.  A partition is `tiles_per_part` tiles of 16 tokens,
+// walked with an online softmax (running max / sum / rescaled accumulator).  Per tile:
+//   QK^T  one v_mfma_f32_16x16x32_bf16 per 32 head dims: A = the q rows of the group (row = head),
+//         B = K^T (column = token); lane (token, dim group) feeds 16-byte pieces of its token's K row
+//         straight from the cache, so the 16x16 logit tile costs HD/32 matrix instructions and no
+//         cross-lane reduction.  bf16 products are exact in f32, as in the reference's FMA chain.
+//   softmax over the tile's 16 tokens with 4 butterfly steps inside each 16-lane row group;
+//   PV    dim per lane: a V row is one coalesced wave access; p[head][token] is broadcast from the
+//         lane that holds it with v_readlane (wave-uniform, no LDS).
+// Everything a tile needs from HBM (K pieces, V rows, q) is requested before its arithmetic starts;
+// with several tiles per partition the next tile's block-table entry is fetched one tile ahead.
 template <int HD, int QPK, bool FP8>
 __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
     const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
     const int32_t *__restrict__ seq_lens, float scale, int num_heads, int num_kv_heads, int max_blocks_per_seq, int block_size,
-    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr) {
-    __shared__ int64_t tok_base[PART];
-    __shared__ __align__(16) float p_s[PART * QPK];  // [token][head] softmax weights
-
+    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part) {
+    constexpr int KSTEPS = HD / 32;                 // MFMA k-steps per tile
+    constexpr int NP = HD >= 128 ? HD / 128 : 1;    // V: pairs of dims per lane
+    constexpr int HG = (QPK + 3) / 4;               // 16-lane row groups that hold live heads
     const int kvh = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, tl = lane & 15, dg = lane >> 4;
     const int seq_len = seq_lens[seq];
     if (seq_len == 0) return;
     const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
-    const int t0 = start + part * PART;
-    if (t0 >= seq_len) return;
-    const int ntok = min(PART, seq_len - t0);
+    const int part_tokens = tiles_per_part * 16;
+    const int p0 = start + part * part_tokens;
+    if (p0 >= seq_len) return;
+    const int p1 = min(p0 + part_tokens, seq_len);
     const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
     const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
+    const float lscale = scale * ksc;
     const int64_t tok_stride = (int64_t)num_kv_heads * HD;
     const int head0 = kvh * QPK;
-
-    // this lane's token row (lanes past the end re-read the last valid row; their logits are masked)
-    const int t = t0 + min(lane, ntok - 1);
-    const int blk = block_tables[(int64_t)seq * max_blocks_per_seq + t / block_size];
-    const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD;
-    tok_base[lane] = base;
-
-    constexpr int NP = HD >= 128 ? HD / 128 : 1;       // V: pairs of dims per lane
-    constexpr int VB = NP == 1 ? 32 : (NP == 2 ? 16 : 8);   // V rows requested per batch (32 registers)
-    constexpr bool V_EARLY = true;                      // first V batch is requested before the K pass
     const bool lane_live = (HD >= 128) || (lane < 32);
 
-    __syncthreads();
-    // q rows of this KV head's query group: addresses are wave-uniform, so the reads below become
-    // scalar loads and the dot products take q from SGPRs (no LDS traffic, no VGPRs for q).
-    const uint16_t *qg = q + ((int64_t)seq * num_heads + head0) * HD;
-
-    uint32_t vraw[VB][NP];
-    auto load_v_batch = [&](int b0) __attribute__((always_inline)) {
+    // q rows as MFMA A fragments: lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)
+    uint4 qa[KSTEPS];
 #pragma unroll
-        for (int j = 0; j < VB; j++) {
-            const int64_t rb = tok_base[min(b0 + j, ntok - 1)];
+    for (int i = 0; i < KSTEPS; i++) {
+        qa[i] = make_uint4(0, 0, 0, 0);
+        if (tl < QPK) qa[i] = *reinterpret_cast<const uint4 *>(q + ((int64_t)seq * num_heads + head0 + tl) * HD + 32 * i + 8 * dg);
+    }
+
+    float m_run[4], s_run[4];  // per head row 4*dg + r (replicated over the 16 lanes of the group)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { m_run[r] = -FLT_MAX; s_run[r] = 0.f; }
+    float o[QPK][NP][2];
+#pragma unroll
+    for (int h = 0; h < QPK; h++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) o[h][p][0] = o[h][p][1] = 0.f;
+
+    for (int t0 = p0; t0 < p1; t0 += 16) {
+        const int ntok = min(16, p1 - t0);
+        // this lane's token (lanes past the end re-read the last valid row; their logits are masked)
+        const int t = t0 + min(tl, ntok - 1);
+        const int blk = block_tables[(int64_t)seq * max_blocks_per_seq + t / block_size];
+        const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD;
+        typename Raw8<FP8>::T kraw[KSTEPS];
+#pragma unroll
+        for (int i = 0; i < KSTEPS; i++) kraw[i] = load8_raw<FP8>(k_cache, base + 32 * i + 8 * dg);
+        // V rows: row base of token j is wave-uniform (broadcast from lane j)
+        uint32_t vraw[16][NP];
+        const uint32_t base_lo = (uint32_t)base, base_hi = (uint32_t)(base >> 32);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int64_t rb = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)base_hi, j) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)base_lo, j));
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 vraw[j][p] = 0;
                 if (lane_live) vraw[j][p] = load2_raw<FP8>(v_cache, rb + 2 * lane + 128 * p);
             }
         }
-    };
-    if (V_EARLY) load_v_batch(0);
 
-    // ---- phase 1
-    float acc[QPK];
+        // ---- logits tile: rows = heads, columns = tokens
+        vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < QPK; h++) acc[h] = 0.f;
-    constexpr int KCH = HD / 8 < 16 ? HD / 8 : 16;  // K pieces in flight
-    for (int c0 = 0; c0 < HD / 8; c0 += KCH) {
-        typename Raw8<FP8>::T kraw[KCH];
-#pragma unroll
-        for (int c = 0; c < KCH; c++) kraw[c] = load8_raw<FP8>(k_cache, base + 8 * (c0 + c));
-#pragma unroll
-        for (int c = 0; c < KCH; c++) {
-            float kf[8];
-            cvt8<FP8>(kraw[c], ksc, kf);
-#pragma unroll
-            for (int h = 0; h < QPK; h++) {
-                const uint4 qv = *reinterpret_cast<const uint4 *>(qg + h * HD + 8 * (c0 + c));
-                const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
-                float a = acc[h];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    a = fmaf(kf[2 * j], __uint_as_float(qw[j] << 16), a);
-                    a = fmaf(kf[2 * j + 1], __uint_as_float(qw[j] & 0xFFFF0000u), a);
-                }
-                acc[h] = a;
+        for (int i = 0; i < KSTEPS; i++) {
+            uint4 kb;
+            if constexpr (!FP8) {
+                kb = kraw[i];
+            } else {  // e4m3 -> bf16 is exact
+                float f[8];
+                cvt8<FP8>(kraw[i], 1.0f, f);
+                kb.x = (uint32_t)vmx_f32_to_bf16(f[0]) | ((uint32_t)vmx_f32_to_bf16(f[1]) << 16);
+                kb.y = (uint32_t)vmx_f32_to_bf16(f[2]) | ((uint32_t)vmx_f32_to_bf16(f[3]) << 16);
+                kb.z = (uint32_t)vmx_f32_to_bf16(f[4]) | ((uint32_t)vmx_f32_to_bf16(f[5]) << 16);
+                kb.w = (uint32_t)vmx_f32_to_bf16(f[6]) | ((uint32_t)vmx_f32_to_bf16(f[7]) << 16);
             }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, qa[i]), __builtin_bit_cast(vmx_bf16x8, kb), acc,
+                                                          0, 0, 0);
         }
-    }
-
-    // ---- phase 2: p[h] = exp(l - max) / (sum + 1e-6) for this lane's token
-    float pr[QPK];
+        // ---- online softmax over the 16 tokens of the tile (lane = token tl, rows 4*dg + r)
+        float pw[4], corr[4];
 #pragma unroll
-    for (int h = 0; h < QPK; h++) {
-        const float l = lane < ntok ? acc[h] * scale : -FLT_MAX;
-        const float m = vmx_wave_max(l);
-        const float e = lane < ntok ? __expf(l - m) : 0.f;
-        const float ssum = vmx_wave_sum(e);
-        pr[h] = e * (1.0f / (ssum + 1e-6f));
-        p_s[lane * QPK + h] = pr[h];
-        if (lane == 0) {
-            const int64_t mo = ((int64_t)seq * num_heads + head0 + h) * max_parts + part;
-            max_logits[mo] = m;
-            exp_sums[mo] = ssum;
+        for (int r = 0; r < 4; r++) {
+            const float l = tl < ntok ? acc[r] * lscale : -FLT_MAX;
+            float mx = l;
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+            const float m_new = fmaxf(m_run[r], mx);
+            const float e = tl < ntok ? __expf(l - m_new) : 0.f;
+            float sm = e;
+            sm += __shfl_xor(sm, 1, 64);
+            sm += __shfl_xor(sm, 2, 64);
+            sm += __shfl_xor(sm, 4, 64);
+            sm += __shfl_xor(sm, 8, 64);
+            corr[r] = __expf(m_run[r] - m_new);  // 0 on the first tile (m_run = -FLT_MAX)
+            s_run[r] = s_run[r] * corr[r] + sm;
+            m_run[r] = m_new;
+            pw[r] = e;
         }
-    }
-
-    __syncthreads();
-
-    // ---- phase 3
-    float o[QPK][NP][2];
+        // ---- PV: o[h] = o[h] * corr[h] + sum_t p[h][t] * V[t]
 #pragma unroll
-    for (int h = 0; h < QPK; h++)
+        for (int h = 0; h < QPK; h++) {
+            const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, corr[h & 3]), 16 * (h >> 2)));
 #pragma unroll
-        for (int p = 0; p < NP; p++) o[h][p][0] = o[h][p][1] = 0.f;
+            for (int p = 0; p < NP; p++) { o[h][p][0] *= c; o[h][p][1] *= c; }
+        }
 #pragma unroll
-    for (int b0 = 0; b0 < PART; b0 += VB) {
-        if (b0 >= ntok) break;
-        if (!V_EARLY || b0 > 0) load_v_batch(b0);
-#pragma unroll
-        for (int j = 0; j < VB; j++) {
-            if (b0 + j < ntok) {  // wave-uniform
+        for (int j = 0; j < 16; j++) {
+            if (j < ntok) {  // wave-uniform
                 float va[NP], vb[NP];
 #pragma unroll
                 for (int p = 0; p < NP; p++) cvt2<FP8>(vraw[j][p], vsc, va[p], vb[p]);
 #pragma unroll
                 for (int h = 0; h < QPK; h++) {
-                    const float w = p_s[(b0 + j) * QPK + h];  // same address in every lane: LDS broadcast
+                    const float w =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pw[h & 3]), 16 * (h >> 2) + j));
 #pragma unroll
                     for (int p = 0; p < NP; p++) { o[h][p][0] += w * va[p]; o[h][p][1] += w * vb[p]; }
                 }
-                asm volatile("" ::: "memory");  // do not hoist the weights of later tokens (register pressure)
             }
         }
     }
-    if (lane_live) {
+
+    // ---- partition result: locally normalised output, max and sum per head
 #pragma unroll
-        for (int h = 0; h < QPK; h++)
+    for (int h = 0; h < QPK; h++) {
+        const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_run[h & 3]), 16 * (h >> 2)));
+        const float mh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run[h & 3]), 16 * (h >> 2)));
+        const float inv = 1.0f / (sh + 1e-6f);
+        const int64_t mo = ((int64_t)seq * num_heads + head0 + h) * max_parts + part;
+        if (lane == 0) { max_logits[mo] = mh; exp_sums[mo] = sh; }
+        if (lane_live) {
 #pragma unroll
-            for (int p = 0; p < NP; p++) {
-                float *dst = tmp_out + (((int64_t)seq * num_heads + head0 + h) * max_parts + part) * HD + 2 * lane + 128 * p;
-                *reinterpret_cast<float2 *>(dst) = make_float2(o[h][p][0], o[h][p][1]);
-            }
+            for (int p = 0; p < NP; p++)
+                *reinterpret_cast<float2 *>(tmp_out + mo * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
+        }
     }
+    (void)HG;
 }
 
 // grid (heads, seqs); block 128.  Merge as paged_attention.cu:840-953 (single partition = copy).
@@ -252,12 +224,12 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
                                                                  const float *__restrict__ exp_sums,
                                                                  const float *__restrict__ max_logits,
                                                                  const int32_t *__restrict__ seq_lens, int num_heads, int head_dim,
-                                                                 int max_parts, int window) {
+                                                                 int max_parts, int window, int part_tokens) {
     const int head = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
     const int seq_len = seq_lens[seq];
     if (seq_len == 0) return;
     const int eff = (window > 0 && seq_len > window) ? window : seq_len;
-    const int np = (eff + PART - 1) / PART;
+    const int np = (eff + part_tokens - 1) / part_tokens;
     const int64_t mo = ((int64_t)seq * num_heads + head) * max_parts;
     const float *tp = tmp_out + mo * head_dim;
     uint16_t *o = out + ((int64_t)seq * num_heads + head) * head_dim;
@@ -280,14 +252,23 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
 template <int HD, int QPK, bool FP8>
 int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const uint16_t *q, const void *kc,
                 const void *vc, const int32_t *bt, const int32_t *sl, float scale, int H, int KVH, int mbps, int bs, int max_parts,
-                int window, const float *ks, const float *vs) {
+                int window, const float *ks, const float *vs, int tiles_per_part) {
     hipLaunchKernelGGL((paged_attn_partition_kernel<HD, QPK, FP8>), grid, dim3(64), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
-                       bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs);
+                       bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part);
     VMX_CHECK_LAUNCH("paged_attention(partition)");
     return VMX_OK;
 }
 
-static int parts_for_impl(int max_seq_len) { return max_seq_len <= 0 ? 1 : (max_seq_len + PART - 1) / PART; }
+// Partition geometry: 16-token tiles; at most 64 partitions per sequence, so a partition is
+// ceil(tiles / 64) tiles.
+static int tiles_per_part_for(int max_seq_len) {
+    const int tiles = max_seq_len <= 0 ? 1 : (max_seq_len + 15) / 16;
+    return (tiles + 63) / 64;
+}
+static int parts_for_impl(int max_seq_len) {
+    const int tiles = max_seq_len <= 0 ? 1 : (max_seq_len + 15) / 16, tpp = tiles_per_part_for(max_seq_len);
+    return (tiles + tpp - 1) / tpp;
+}
 }  // namespace
 
 
@@ -312,12 +293,13 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
     out->exp_sums = exp_sums;
     out->max_logits = max_logits;
     out->max_parts = P;
-    out->part_tokens = PART;
+    const int tpp = tiles_per_part_for(max_seq_len);
+    out->part_tokens = tpp * 16;
     const dim3 grid(num_kv_heads, num_seqs, P);
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
     int rc = VMX_EUNSUPPORTED;
 #define ARGS grid, st, tmp_out, exp_sums, max_logits, q, k_cache, v_cache, block_tables, seq_lens, scale, num_heads, num_kv_heads, \
-             max_blocks_per_seq, block_size, P, window, k_scale, v_scale
+             max_blocks_per_seq, block_size, P, window, k_scale, v_scale, tpp
 #define BY_QPK(HD)                                                                                                         \
     switch (qpk) {                                                                                                         \
         case 1: rc = fp8 ? launch_part<HD, 1, true>(ARGS) : launch_part<HD, 1, false>(ARGS); break;                        \
@@ -344,7 +326,7 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
                               int head_dim, int window, hipStream_t st) {
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,
-                       parts->max_logits, seq_lens, num_heads, head_dim, parts->max_parts, window);
+                       parts->max_logits, seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
 }
@@ -369,7 +351,7 @@ extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const 
                                            workspace, &parts, st))
         return rc;
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts.tmp_out, parts.exp_sums,
-                       parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window);
+                       parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window, parts.part_tokens);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
 }
