@@ -13,7 +13,7 @@ independent replica of the same job ("replicas only": data-parallel serving, no 
 the data path); value is the sum over ranks, time is the max over ranks.
 
 Prints one JSON line on rank 0 with `roofline` (the int4 linear kernel, timed with HIP events on
-its launch stream over an eager re-run of the timed steps) and `cpu_baseline` (the CPU oracle's
+its launch stream over back-to-back replays of the step's linear launches) and `cpu_baseline` (the CPU oracle's
 int4 GEMV, OpenMP over output columns, on a bounded sample of the same per-token work).
 """
 import argparse
@@ -155,23 +155,33 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- roofline of the dominant kernel (int4 linear), eager re-run of K steps with HIP events
+    # ---- roofline of the dominant kernel (int4 linear): the step's linear launches alone (same weights,
+    # same buffers), captured into a graph and replayed back to back between two HIP events recorded on
+    # the stream the kernels run on; duration per launch = elapsed / launches (boundaries included, as in
+    # rocprofv3's back-to-back kernel timestamps).
     roofline = None
     if rank == 0:
-        n_lin = 4 * spec.num_layers
+        launches, alg = model.linears_info(B)
         with torch.cuda.stream(side):
-            model.profile_begin(n_lin * K_steps)
-            for _ in range(K_steps):
-                step()
-            launches, us, alg = model.profile_end()
+            model.linears_only(B)
+            lg = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(lg, stream=side):
+                model.linears_only(B)
+            reps = max(8, K_steps // 4)
+            lg.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(reps):
+                lg.replay()
+            e1.record(side)
         torch.cuda.synchronize()
-        per_launch_bytes = alg / max(launches, 1)
-        per_launch_us = us / max(launches, 1)
+        us = e0.elapsed_time(e1) * 1e3 / reps
         achieved = alg / us / 1e3 if us > 0 else 0.0  # bytes/us -> GB/s
         roofline = {"bound": "hbm", "kernel": "int4_gemm_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "launches": launches, "avg_launch_us": round(per_launch_us, 3),
-                    "alg_bytes_per_launch": round(per_launch_bytes)}
+                    "launches_per_step": launches, "avg_launch_us": round(us / launches, 3),
+                    "alg_bytes_per_launch": round(alg / launches)}
 
     if rank == 0:
         tok_s = world * B * K_steps / elapsed

@@ -247,11 +247,12 @@ int vmx_decode_advance(int32_t *input_ids, const int32_t *next_ids, int32_t *pos
                        int32_t *seq_lens, const int32_t *block_tables, int batch, int max_blocks_per_seq,
                        int block_size, void *stream);
 
-/* Measurement aid (eager mode only, not under graph capture): bracket every int4 linear launch of the
- * following decode steps with HIP events on the launch stream; _end synchronises and returns the number
- * of launches, their summed duration in microseconds and their summed algorithmic bytes. */
-int vmx_qwen3_profile_begin(vmx_qwen3 *m, int max_launches);
-int vmx_qwen3_profile_end(vmx_qwen3 *m, int *launches, double *total_us, double *alg_bytes);
+/* Measurement aid: launch only the int4 linears of one decode step (4 per layer, in step order, on the
+ * model's own buffers and weights).  Replayed back to back between two HIP events on its stream this
+ * gives the kernel's average launch duration; _info returns the launch count and the summed
+ * algorithmic bytes of one such pass. */
+int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream);
+int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, double *alg_bytes);
 
 /* Measurement aid: stream `bytes` from p with the int4 linear's access shape (upw 1 KiB units per wave,
  * all requested up front) and discard them; gives the HBM floor for a launch of that size. */

@@ -62,8 +62,8 @@ _SIGS = {
     "vmx_qwen3_debug_read": (_i, [_p, _i, _p, _sz, _p]),
     "vmx_debug_stream_read": (_i, [_p, _sz, _i, _p, _p]),
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
-    "vmx_qwen3_profile_begin": (_i, [_p, _i]),
-    "vmx_qwen3_profile_end": (_i, [_p, _p, _p, _p]),
+    "vmx_qwen3_linears_only": (_i, [_p, _i, _p]),
+    "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
 }
 
 

@@ -219,12 +219,17 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     (void)HG;
 }
 
-// grid (heads, seqs); block 128.  Merge as paged_attention.cu:840-953 (single partition = copy).
+// grid (heads, seqs); block 128.  Merge as paged_attention.cu:840-953 (single partition = copy):
+// out = sum_p tmp_p * w_p / (sum_p w_p + 1e-6), w_p = exp_sum_p * exp(max_p - gmax).  np <= 64, so the
+// weights are computed by one lane each and shared through LDS; the partition rows are then read
+// with independent loads.
 __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__restrict__ out, const float *__restrict__ tmp_out,
                                                                  const float *__restrict__ exp_sums,
                                                                  const float *__restrict__ max_logits,
                                                                  const int32_t *__restrict__ seq_lens, int num_heads, int head_dim,
                                                                  int max_parts, int window, int part_tokens) {
+    __shared__ float w_s[64];
+    __shared__ float inv_s;
     const int head = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
     const int seq_len = seq_lens[seq];
     if (seq_len == 0) return;
@@ -237,14 +242,21 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
         for (int d = tid; d < head_dim; d += 128) o[d] = vmx_f32_to_bf16(tp[d]);
         return;
     }
-    float gmax = -FLT_MAX;
-    for (int p = 0; p < np; p++) gmax = fmaxf(gmax, max_logits[mo + p]);
-    float gsum = 0.f;
-    for (int p = 0; p < np; p++) gsum += exp_sums[mo + p] * __expf(max_logits[mo + p] - gmax);
-    const float inv = 1.0f / (gsum + 1e-6f);
+    if (tid < 64) {
+        const float mx = tid < np ? max_logits[mo + tid] : -FLT_MAX;
+        const float sm = tid < np ? exp_sums[mo + tid] : 0.f;
+        const float gmax = vmx_wave_max(mx);
+        const float w = tid < np ? sm * __expf(mx - gmax) : 0.f;
+        const float gsum = vmx_wave_sum(w);
+        w_s[tid] = w;
+        if (tid == 0) inv_s = 1.0f / (gsum + 1e-6f);
+    }
+    __syncthreads();
+    const float inv = inv_s;
     for (int d = tid; d < head_dim; d += 128) {
         float acc = 0.f;
-        for (int p = 0; p < np; p++) acc += tp[(int64_t)p * head_dim + d] * (exp_sums[mo + p] * __expf(max_logits[mo + p] - gmax));
+#pragma unroll 8
+        for (int p = 0; p < np; p++) acc += tp[(int64_t)p * head_dim + d] * w_s[p];
         o[d] = vmx_f32_to_bf16(acc * inv);
     }
 }

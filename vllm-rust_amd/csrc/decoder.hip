@@ -261,16 +261,8 @@ struct Layer {
 
 }  // namespace
 
-struct GemmProfile {
-    bool on = false;
-    std::vector<hipEvent_t> ev;  // pairs: start, stop
-    size_t used = 0;
-    double alg_bytes = 0.0;      // algorithmic bytes of the bracketed launches
-};
-
 struct vmx_qwen3 {
     vmx_qwen3_config cfg;
-    GemmProfile prof;
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
@@ -286,18 +278,8 @@ double int4_alg_bytes(const Int4Linear &l, int M) {
     return K * N / 2 + G * N * 2 + G * N / 2 + (double)M * K * 2 + (double)M * N * 2;
 }
 
-// forward_partial, bracketed by events when profiling is on (eager mode only).
-int run_linear(vmx_qwen3 *m, const Int4Linear &l, const uint16_t *xin, float *partial, int M, hipStream_t st) {
-    GemmProfile &p = m->prof;
-    const bool rec = p.on && p.used + 2 <= p.ev.size();
-    if (rec) VMX_CHECK_HIP(hipEventRecord(p.ev[p.used], st));
-    if (int rc = l.forward_partial(xin, partial, M, st)) return rc;
-    if (rec) {
-        VMX_CHECK_HIP(hipEventRecord(p.ev[p.used + 1], st));
-        p.used += 2;
-        p.alg_bytes += int4_alg_bytes(l, M);
-    }
-    return VMX_OK;
+int run_linear(vmx_qwen3 *, const Int4Linear &l, const uint16_t *xin, float *partial, int M, hipStream_t st) {
+    return l.forward_partial(xin, partial, M, st);
 }
 
 int make_linear(Int4Linear &l, int K, int N, int group) {
@@ -432,7 +414,6 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.qkv_stage);
         stage_free(L.gu_stage);
     }
-    for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
                       &m->logits, &m->attn_ws, &m->argmax_ws})
         b->release();
@@ -577,37 +558,36 @@ extern "C" int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t b
     return VMX_OK;
 }
 
-// ---- measurement aid: time every int4 linear launch of subsequent EAGER decode steps with HIP
-// events on the launch stream.  Not for use under graph capture.
-extern "C" int vmx_qwen3_profile_begin(vmx_qwen3 *m, int max_launches) {
-    VMX_REQUIRE(m && max_launches > 0, "qwen3_profile_begin: bad arguments");
-    GemmProfile &p = m->prof;
-    while (p.ev.size() < (size_t)max_launches * 2) {
-        hipEvent_t e;
-        VMX_CHECK_HIP(hipEventCreate(&e));
-        p.ev.push_back(e);
+// ---- measurement aid: the int4 linear launches of one decode step and nothing else (4 per layer, in
+// step order, on the step's own activation buffers and weights).  Replayed back to back between two
+// HIP events this gives the kernel's average launch duration on its own stream.
+extern "C" int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream) {
+    VMX_REQUIRE(m && batch >= 1 && batch <= m->cfg.max_batch, "qwen3_linears_only: bad arguments");
+    hipStream_t st = vmx_stream(stream);
+    const uint16_t *x = (const uint16_t *)m->x.p, *attn = (const uint16_t *)m->attn.p, *act = (const uint16_t *)m->act.p;
+    float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;
+    for (const Layer &L : m->layers) {
+        if (int rc = L.qkv.forward_partial(x, PA, batch, st)) return rc;
+        if (int rc = L.o.forward_partial(attn, PB, batch, st)) return rc;
+        if (int rc = L.gate_up.forward_partial(x, PA, batch, st)) return rc;
+        if (int rc = L.down.forward_partial(act, PB, batch, st)) return rc;
     }
-    p.used = 0;
-    p.alg_bytes = 0.0;
-    p.on = true;
     return VMX_OK;
 }
 
-// Synchronises the last recorded event; returns launches, summed duration (us) and summed algorithmic bytes.
-extern "C" int vmx_qwen3_profile_end(vmx_qwen3 *m, int *launches, double *total_us, double *alg_bytes) {
-    VMX_REQUIRE(m && launches && total_us && alg_bytes, "qwen3_profile_end: null pointer");
-    GemmProfile &p = m->prof;
-    p.on = false;
-    double us = 0.0;
-    if (p.used) VMX_CHECK_HIP(hipEventSynchronize(p.ev[p.used - 1]));
-    for (size_t i = 0; i + 1 < p.used; i += 2) {
-        float ms = 0.f;
-        VMX_CHECK_HIP(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
-        us += (double)ms * 1e3;
-    }
-    *launches = (int)(p.used / 2);
-    *total_us = us;
-    *alg_bytes = p.alg_bytes;
+// Launch count and summed algorithmic bytes (packed nibbles + bf16 scales + 4-bit zeros + bf16
+// activations in and out) of vmx_qwen3_linears_only.
+extern "C" int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, double *alg_bytes) {
+    VMX_REQUIRE(m && launches && alg_bytes, "qwen3_linears_info: null pointer");
+    double by = 0.0;
+    int n = 0;
+    for (const Layer &L : m->layers)
+        for (const Int4Linear *l : {&L.qkv, &L.o, &L.gate_up, &L.down}) {
+            by += int4_alg_bytes(*l, batch);
+            n++;
+        }
+    *launches = n;
+    *alg_bytes = by;
     return VMX_OK;
 }
 

@@ -173,10 +173,10 @@ class QuantizedQwen3ForCausalLM:
                                      seq_lens.data_ptr(), block_tables.data_ptr(), input_ids.numel(), block_tables.shape[1],
                                      self.spec.block_size, self._stream()))
 
-    def profile_begin(self, max_launches: int) -> None:
-        check(lib.vmx_qwen3_profile_begin(self._h, max_launches))
+    def linears_only(self, batch: int = 1) -> None:
+        check(lib.vmx_qwen3_linears_only(self._h, batch, self._stream()))
 
-    def profile_end(self):
-        n, us, by = C.c_int(), C.c_double(), C.c_double()
-        check(lib.vmx_qwen3_profile_end(self._h, C.byref(n), C.byref(us), C.byref(by)))
-        return n.value, us.value, by.value
+    def linears_info(self, batch: int = 1):
+        n, by = C.c_int(), C.c_double()
+        check(lib.vmx_qwen3_linears_info(self._h, batch, C.byref(n), C.byref(by)))
+        return n.value, by.value
