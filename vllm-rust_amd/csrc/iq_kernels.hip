@@ -73,68 +73,94 @@ __device__ __forceinline__ void table16(uint32_t q4, const uint32_t T[4], int &l
 
 struct SubScale { int ls0, ls1; };
 
-// Decode sub-block ib (0..7) of super-block b into 8 words of 4 signed int8
-// (word k = weights 4k..4k+3) plus the sub-block's integer scale fields.
+// Raw bytes of one 32-weight sub-block, fetched before any of them is interpreted so that the loads
+// of several sub-blocks (rows, k positions) can be in flight together.
+struct RawSub {
+    uint32_t a, b, c, e;  // type-specific words (see load_raw)
+    uint32_t x, y;        // small fields (scales, high bits)
+    uint32_t d;           // f16 super-block scale bits
+};
+
+template <int T> __device__ __forceinline__ RawSub load_raw(const uint8_t *b, int ib) {
+    RawSub r;
+    r.a = r.b = r.c = r.e = r.x = r.y = 0;
+    r.d = ld16(b);
+    if constexpr (T == 17) {         // IQ2_XS: qs u16[32]@2, scales u8[8]@66
+        r.a = ld32(b + 2 + 8 * ib); r.b = ld32(b + 2 + 8 * ib + 4); r.x = b[66 + ib];
+    } else if constexpr (T == 22) {  // IQ2_S: qs u8[32]@2, signs u8[32]@34, qh u8[8]@66, scales u8[8]@74
+        r.a = ld32(b + 2 + 4 * ib); r.c = ld32(b + 34 + 4 * ib); r.y = b[66 + ib]; r.x = b[74 + ib];
+    } else if constexpr (T == 18) {  // IQ3_XXS: qs u8[64]@2, scales_and_signs u32[8]@66
+        r.a = ld32(b + 2 + 8 * ib); r.b = ld32(b + 2 + 8 * ib + 4); r.c = ld32(b + 66 + 4 * ib);
+    } else if constexpr (T == 21) {  // IQ3_S: qs u8[64]@2, qh u8[8]@66, signs u8[32]@74, scales u8[4]@106
+        r.a = ld32(b + 2 + 8 * ib); r.b = ld32(b + 2 + 8 * ib + 4); r.c = ld32(b + 74 + 4 * ib);
+        r.y = b[66 + ib]; r.x = b[106 + (ib >> 1)];
+    } else {                         // IQ4_XS: scales_h u16@2, scales_l u8[4]@4, qs u8[128]@8 (8-byte aligned)
+        const uint2 *qp = reinterpret_cast<const uint2 *>(b + 8 + 16 * ib);
+        const uint2 p0 = qp[0], p1 = qp[1];
+        r.a = p0.x; r.b = p0.y; r.c = p1.x; r.e = p1.y;
+        r.y = ld16(b + 2); r.x = b[4 + (ib >> 1)];
+    }
+    return r;
+}
+
+// Decode a fetched sub-block into 8 words of 4 signed int8 (word k = weights 4k..4k+3) plus the
+// sub-block's integer scale fields.  cb = the type's codebook in LDS.
 template <int T>
-__device__ __forceinline__ void decode_sub(const uint8_t *b, int ib, const uint32_t *cb, int q[8], SubScale &sc) {
+__device__ __forceinline__ void decode_raw(const RawSub &r, int ib, const uint32_t *cb, int q[8], SubScale &sc) {
     sc.ls0 = sc.ls1 = 0;
-    if constexpr (T == 17) {  // IQ2_XS: qs u16[32]@2, scales u8[8]@66
-        uint32_t w0 = ld32(b + 2 + 8 * ib), w1 = ld32(b + 2 + 8 * ib + 4);
+    if constexpr (T == 17) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t v = ((l < 2 ? w0 : w1) >> (16 * (l & 1))) & 0xFFFFu;
+            uint32_t v = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
             uint2 g = reinterpret_cast<const uint2 *>(cb)[v & 511u];
             uint32_t s8 = ksign(v >> 9);
             q[2 * l] = sign4(g.x, s8);
             q[2 * l + 1] = sign4(g.y, s8 >> 4);
         }
-        uint32_t s = b[66 + ib];
-        sc.ls0 = s & 0xF; sc.ls1 = s >> 4;
-    } else if constexpr (T == 22) {  // IQ2_S: qs u8[32]@2, signs u8[32]@34, qh u8[8]@66, scales u8[8]@74
-        uint32_t qs = ld32(b + 2 + 4 * ib), sg = ld32(b + 34 + 4 * ib), qh = b[66 + ib];
+        sc.ls0 = r.x & 0xF; sc.ls1 = r.x >> 4;
+    } else if constexpr (T == 22) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t idx = ((qs >> (8 * l)) & 0xFFu) | ((qh << (8 - 2 * l)) & 0x300u);
+            uint32_t idx = ((r.a >> (8 * l)) & 0xFFu) | ((r.y << (8 - 2 * l)) & 0x300u);
             uint2 g = reinterpret_cast<const uint2 *>(cb)[idx];
-            uint32_t s8 = (sg >> (8 * l)) & 0xFFu;
+            uint32_t s8 = (r.c >> (8 * l)) & 0xFFu;
             q[2 * l] = sign4(g.x, s8);
             q[2 * l + 1] = sign4(g.y, s8 >> 4);
         }
-        uint32_t s = b[74 + ib];
-        sc.ls0 = s & 0xF; sc.ls1 = s >> 4;
-    } else if constexpr (T == 18) {  // IQ3_XXS: qs u8[64]@2, scales_and_signs u32[8]@66
-        uint32_t w0 = ld32(b + 2 + 8 * ib), w1 = ld32(b + 2 + 8 * ib + 4), aux = ld32(b + 66 + 4 * ib);
+        sc.ls0 = r.x & 0xF; sc.ls1 = r.x >> 4;
+    } else if constexpr (T == 18) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t pair = ((l < 2 ? w0 : w1) >> (16 * (l & 1))) & 0xFFFFu;
-            uint32_t s8 = ksign((aux >> (7 * l)) & 127u);
+            uint32_t pair = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
+            uint32_t s8 = ksign((r.c >> (7 * l)) & 127u);
             q[2 * l] = sign4(cb[pair & 0xFFu], s8);
             q[2 * l + 1] = sign4(cb[pair >> 8], s8 >> 4);
         }
-        sc.ls0 = (int)(aux >> 28);
-    } else if constexpr (T == 21) {  // IQ3_S: qs u8[64]@2, qh u8[8]@66, signs u8[32]@74, scales u8[4]@106
-        uint32_t w0 = ld32(b + 2 + 8 * ib), w1 = ld32(b + 2 + 8 * ib + 4), sg = ld32(b + 74 + 4 * ib);
-        uint32_t qh = b[66 + ib];
+        sc.ls0 = (int)(r.c >> 28);
+    } else if constexpr (T == 21) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t pair = ((l < 2 ? w0 : w1) >> (16 * (l & 1))) & 0xFFFFu;
-            uint32_t i1 = (pair & 0xFFu) | ((qh << (8 - 2 * l)) & 256u);
-            uint32_t i2 = (pair >> 8) | ((qh << (7 - 2 * l)) & 256u);
-            uint32_t s8 = (sg >> (8 * l)) & 0xFFu;
+            uint32_t pair = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
+            uint32_t i1 = (pair & 0xFFu) | ((r.y << (8 - 2 * l)) & 256u);
+            uint32_t i2 = (pair >> 8) | ((r.y << (7 - 2 * l)) & 256u);
+            uint32_t s8 = (r.c >> (8 * l)) & 0xFFu;
             q[2 * l] = sign4(cb[i1], s8);
             q[2 * l + 1] = sign4(cb[i2], s8 >> 4);
         }
-        sc.ls0 = (b[106 + (ib >> 1)] >> (4 * (ib & 1))) & 0xF;
-    } else {  // IQ4_XS: scales_h u16@2, scales_l u8[4]@4, qs u8[128]@8
+        sc.ls0 = (r.x >> (4 * (ib & 1))) & 0xF;
+    } else {
         uint32_t Tb[4] = {cb[0], cb[1], cb[2], cb[3]};
-        const uint2 *qp = reinterpret_cast<const uint2 *>(b + 8 + 16 * ib);  // blocks are 8-byte multiples
-        uint2 a = qp[0], c = qp[1];
-        uint32_t w[4] = {a.x, a.y, c.x, c.y};
+        const uint32_t w[4] = {r.a, r.b, r.c, r.e};
 #pragma unroll
         for (int j = 0; j < 4; j++) table16(w[j], Tb, q[j], q[j + 4]);
-        uint32_t sh = ld16(b + 2);
-        sc.ls0 = (int)(((b[4 + (ib >> 1)] >> (4 * (ib & 1))) & 0xFu) | (((sh >> (2 * ib)) & 3u) << 4));
+        sc.ls0 = (int)(((r.x >> (4 * (ib & 1))) & 0xFu) | (((r.y >> (2 * ib)) & 3u) << 4));
     }
+}
+
+template <int T>
+__device__ __forceinline__ void decode_sub(const uint8_t *b, int ib, const uint32_t *cb, int q[8], SubScale &sc) {
+    const RawSub r = load_raw<T>(b, ib);
+    decode_raw<T>(r, ib, cb, q, sc);
 }
 
 // Integer scale step of vec_dot_iq*_q8_1 (C truncating division).
@@ -224,11 +250,12 @@ __global__ __launch_bounds__(256) void quantize_q8_1_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------ MMVQ
-// One wave owns R consecutive output rows per step; lane g walks the row's
-// 32-weight sub-blocks (g, g+64, ...).  The R rows' sub-blocks are decoded
-// first (R independent load chains in flight), then every activation row is
-// dotted against all of them.  Accumulation: acc += (w_d * a_d) * (float)sub,
-// lanes summed by a 64-wide butterfly.
+// One wave owns R consecutive output rows per step; lane g walks the row's 32-weight sub-blocks two
+// at a time (g, g+64).  Per step every global load is issued before anything is decoded, in the
+// order the data will be needed back (vmcnt retires in issue order): first the q8_1 activations of
+// the lane's sub-blocks (L2-resident), then the raw weight fields of all R x 2 sub-blocks; only then
+// are the sub-blocks decoded (codebook gathers from LDS) and dotted.  Accumulation:
+// acc += (w_d * a_d) * (float)sub, lanes summed by a 64-wide butterfly.
 template <int T, int MT, int R>
 __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
                                                        const float *__restrict__ ad, float *__restrict__ y, int n_out,
@@ -236,6 +263,8 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
     __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
     load_codebook<T>(cb);
     constexpr int TS = IqTraits<T>::TS;
+    constexpr int G = 2;                      // sub-blocks per lane per step
+    constexpr bool ACT_FIRST = MT <= 2;       // activations of the step kept in registers
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nb256 = n_in >> 8, nblk32 = n_in >> 5;
@@ -247,31 +276,62 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
 #pragma unroll
             for (int mi = 0; mi < MT; mi++) acc[r][mi] = 0.0f;
 
-        for (int g = lane; g < nblk32; g += 64) {
-            const int sb = g >> 3, ib = g & 7;
-            int q[R][8];
-            SubScale sc[R];
-            float wd[R];
+        for (int g0 = lane; g0 < nblk32; g0 += 64 * G) {
+            int4 ua[G][ACT_FIRST ? MT : 1], ub[G][ACT_FIRST ? MT : 1];
+            float da[G][ACT_FIRST ? MT : 1];
+            if constexpr (ACT_FIRST) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int row = min(row0 + r, n_out - 1);  // clamp: duplicates are discarded at the store
-                const uint8_t *b = w + ((int64_t)row * nb256 + sb) * TS;
-                wd[r] = vmx_f16_to_f32((uint16_t)ld16(b));
-                decode_sub<T>(b, ib, cb, q[r], sc[r]);
+                for (int gi = 0; gi < G; gi++) {
+                    const int g = min(g0 + 64 * gi, nblk32 - 1);
+#pragma unroll
+                    for (int mi = 0; mi < MT; mi++) {
+                        const int mm = min(mi, m - 1);
+                        const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)mm * n_in + g * 32);
+                        ua[gi][mi] = up[0];
+                        ub[gi][mi] = up[1];
+                        da[gi][mi] = ad[(int64_t)mm * nblk32 + g];
+                    }
+                }
+            }
+            RawSub raw[R][G];
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) {
+                const int g = min(g0 + 64 * gi, nblk32 - 1);  // a clamped duplicate is discarded below
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int row = min(row0 + r, n_out - 1);
+                    raw[r][gi] = load_raw<T>(w + ((int64_t)row * nb256 + (g >> 3)) * TS, g & 7);
+                }
             }
 #pragma unroll
-            for (int mi = 0; mi < MT; mi++) {
-                if (mi < m) {
-                    const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)mi * n_in + g * 32);
-                    const int4 ua = up[0], ub = up[1];
-                    const int u[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
-                    const float da = ad[(int64_t)mi * nblk32 + g];
+            for (int gi = 0; gi < G; gi++) {
+                const int g = g0 + 64 * gi;
+                const bool live = g < nblk32;
+                const int gc = min(g, nblk32 - 1);
+                int q[R][8];
+                SubScale sc[R];
 #pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        int s1;
-                        const int s0 = subdot_halves(q[r], u, s1);
-                        const int sub = scale_int<T>(s0, s1, sc[r]);
-                        acc[r][mi] += (wd[r] * da) * (float)sub;
+                for (int r = 0; r < R; r++) decode_raw<T>(raw[r][gi], gc & 7, cb, q[r], sc[r]);
+#pragma unroll
+                for (int mi = 0; mi < MT; mi++) {
+                    if (mi < m) {
+                        int4 va, vb;
+                        float dav;
+                        if constexpr (ACT_FIRST) {
+                            va = ua[gi][mi]; vb = ub[gi][mi]; dav = da[gi][mi];
+                        } else {
+                            const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)mi * n_in + gc * 32);
+                            va = up[0]; vb = up[1]; dav = ad[(int64_t)mi * nblk32 + gc];
+                        }
+                        const int u[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            int s1;
+                            const int s0 = subdot_halves(q[r], u, s1);
+                            const int sub = scale_int<T>(s0, s1, sc[r]);
+                            const float wd = vmx_f16_to_f32((uint16_t)raw[r][gi].d);
+                            if (live) acc[r][mi] += (wd * dav) * (float)sub;
+                        }
                     }
                 }
             }
