@@ -123,6 +123,26 @@ int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *packed, const
  * tile stream -> dense bf16 [K, N] (prefill path and parity aid). */
 int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K, int N, int group, void *stream);
 
+/* ----------------------------------------------------------------- FP8 weights */
+
+/* Replaces fp8_gemm_bf16_{naive,tiled,with_bias} (crates/core/kernels/fp8_gemm.cu:38-218; launcher
+ * fp8_cuda.rs:519-727) for small M: y[m,n] = bf16(sum_k x[m,k] * (e4m3(W[n,k]) * scale) + bias[n]);
+ * W u8 [N, K] OCP e4m3fn, scale f32 [1] or [N] (per_channel_scale), 1 <= M <= 16, K % 16 == 0. */
+int vmx_fp8_gemm_bf16(uint16_t *y, const uint16_t *x, const void *weight, const float *scale, const uint16_t *bias,
+                      int M, int N, int K, int per_channel_scale, void *stream);
+
+/* Replaces fp8_dequant_weights_bf16 / fp8_dequant_bf16 (fp8_gemm.cu:222-243, fp8_quant.cu:239-262):
+ * out[r,c] = bf16(e4m3(in[r,c]) * scale[r or 0]). */
+int vmx_fp8_dequant_bf16(uint16_t *out, const void *in, const float *scale, int64_t rows, int64_t cols,
+                         int per_row_scale, void *stream);
+
+/* Replaces fp8_static_quant_bf16, fp8_dynamic_per_token_quant_bf16 and fp8_quantize_input_bf16
+ * (fp8_quant.cu:89-112,190-237; fp8_gemm.cu:246-330): out = e4m3(x / scale), round-to-nearest-even,
+ * saturating at +-448.  dynamic_per_token: scale = max(absmax/448, 1e-12) per row, written to
+ * scales_out; otherwise scale_in[token] (per_token_scale) or scale_in[0]. */
+int vmx_fp8_quant_bf16(void *out, float *scales_out, const uint16_t *in, const float *scale_in, int tokens, int hidden,
+                       int dynamic_per_token, int per_token_scale, void *stream);
+
 /* ----------------------------------------------------------- glue operators */
 
 /* Replaces rms_norm_bf16 / fused_add_rms_norm_bf16 (crates/core/kernels/layernorm.cu:59-129,232-270;

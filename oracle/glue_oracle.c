@@ -303,3 +303,49 @@ void orc_q6k_dequant(const uint8_t *data, int64_t n_blocks, float *out) {
         }
     }
 }
+
+/* ---- FP8 weight path (crates/core/kernels/fp8_gemm.cu:38-70, fp8_quant.cu:89-112,190-262) ---- */
+
+/* y[m,n] = bf16(sum_k x[m,k] * (e4m3(W[n,k]) * scale_n) + bias[n]), f32 sequential accumulate. */
+void orc_fp8_gemm_bf16(const uint16_t *x, const uint8_t *W, const float *scale, const uint16_t *bias, int64_t M,
+                       int64_t N, int64_t K, int per_channel, uint16_t *y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; n++) {
+        float ws = per_channel ? scale[n] : scale[0];
+        for (int64_t m = 0; m < M; m++) {
+            float acc = 0.0f;
+            for (int64_t k = 0; k < K; k++) acc += orc_bf16_to_f32(x[m * K + k]) * (orc_fp8_e4m3_decode(W[n * K + k]) * ws);
+            if (bias) acc += orc_bf16_to_f32(bias[n]);
+            y[m * N + n] = orc_f32_to_bf16(acc);
+        }
+    }
+}
+
+/* dynamic per-token: scale = max(absmax/448, 1e-12); out = e4m3_satfinite_rne(x * (1/scale)).
+ * static: scale given (per token or single). */
+void orc_fp8_quant_bf16(const uint16_t *in, const float *scale_in, int64_t tokens, int64_t hidden, int dynamic,
+                        int per_token, uint8_t *out, float *scales_out) {
+    for (int64_t t = 0; t < tokens; t++) {
+        float sc;
+        if (dynamic) {
+            float mx = 0.0f;
+            for (int64_t i = 0; i < hidden; i++) {
+                float v = fabsf(orc_bf16_to_f32(in[t * hidden + i]));
+                if (v > mx) mx = v;
+            }
+            sc = mx / 448.0f;
+            if (sc < 1e-12f) sc = 1e-12f;
+            scales_out[t] = sc;
+        } else {
+            sc = per_token ? scale_in[t] : scale_in[0];
+        }
+        float inv = 1.0f / sc;
+        for (int64_t i = 0; i < hidden; i++) out[t * hidden + i] = orc_fp8_e4m3_encode_rne(orc_bf16_to_f32(in[t * hidden + i]) * inv);
+    }
+}
+
+void orc_fp8_dequant_bf16(const uint8_t *in, const float *scale, int64_t rows, int64_t cols, int per_row, uint16_t *out) {
+    for (int64_t r = 0; r < rows; r++)
+        for (int64_t c = 0; c < cols; c++)
+            out[r * cols + c] = orc_f32_to_bf16(orc_fp8_e4m3_decode(in[r * cols + c]) * (per_row ? scale[r] : scale[0]));
+}

@@ -70,6 +70,9 @@ for _name, _res, _args in [
     ("orc_reshape_and_cache", None, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
     ("orc_paged_attention_v2", None, [C.c_void_p] * 5 + [C.c_float, C.c_int64] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
     ("orc_q6k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_fp8_gemm_bf16", None, [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_void_p]),
+    ("orc_fp8_quant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("orc_fp8_dequant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
 ]:
     _f = getattr(_lib, _name)
     _f.restype = _res
@@ -299,4 +302,31 @@ def q6k_dequant(data) -> np.ndarray:
     nb = data.size // 210
     out = np.empty(nb * 256, np.float32)
     _lib.orc_q6k_dequant(_p(data), nb, _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- FP8 weight path
+def fp8_gemm_bf16(x_bf16, W_u8, scale, bias_bf16, per_channel: bool) -> np.ndarray:
+    x = _c(x_bf16, np.uint16); W = _c(W_u8, np.uint8); sc = _c(scale, np.float32)
+    M, K = x.shape; N = W.shape[0]
+    b = _c(bias_bf16, np.uint16) if bias_bf16 is not None else None
+    y = np.empty((M, N), np.uint16)
+    _lib.orc_fp8_gemm_bf16(_p(x), _p(W), _p(sc), _p(b) if b is not None else None, M, N, K, int(per_channel), _p(y))
+    return y
+
+
+def fp8_quant_bf16(x_bf16, scale=None, dynamic: bool = True, per_token: bool = False):
+    x = _c(x_bf16, np.uint16)
+    T, H = x.shape
+    out = np.empty((T, H), np.uint8)
+    scales = np.zeros(T, np.float32)
+    sc = _c(scale, np.float32) if scale is not None else None
+    _lib.orc_fp8_quant_bf16(_p(x), _p(sc) if sc is not None else None, T, H, int(dynamic), int(per_token), _p(out), _p(scales))
+    return out, scales
+
+
+def fp8_dequant_bf16(q_u8, scale, per_row: bool) -> np.ndarray:
+    q = _c(q_u8, np.uint8); sc = _c(scale, np.float32)
+    out = np.empty(q.shape, np.uint16)
+    _lib.orc_fp8_dequant_bf16(_p(q), _p(sc), q.shape[0], q.shape[1], int(per_row), _p(out))
     return out

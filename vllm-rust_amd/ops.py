@@ -14,7 +14,7 @@ __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention", "dense_gemv",
-    "embedding_lookup",
+    "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant",
 ]
 
 
@@ -177,3 +177,29 @@ def embedding_lookup(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     out = torch.empty((ids.numel(), hidden), dtype=torch.bfloat16, device=table.device)
     check(lib.vmx_embedding_lookup_bf16(_ptr(out), _ptr(table), _ptr(ids), ids.numel(), hidden, vocab, _stream()))
     return out
+
+
+def fp8_gemm(x: torch.Tensor, W_u8: torch.Tensor, scale: torch.Tensor, bias=None) -> torch.Tensor:
+    """x bf16 [M, K], W e4m3 bytes [N, K], scale f32 [1] or [N] -> bf16 [M, N]."""
+    M, K = x.shape
+    N = W_u8.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(lib.vmx_fp8_gemm_bf16(_ptr(y), _ptr(x), _ptr(W_u8), _ptr(scale), _ptr(bias), M, N, K, int(scale.numel() > 1), _stream()))
+    return y
+
+
+def fp8_dequant(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    rows, cols = q_u8.shape
+    out = torch.empty((rows, cols), dtype=torch.bfloat16, device=q_u8.device)
+    check(lib.vmx_fp8_dequant_bf16(_ptr(out), _ptr(q_u8), _ptr(scale), rows, cols, int(scale.numel() > 1), _stream()))
+    return out
+
+
+def fp8_quant(x: torch.Tensor, scale=None):
+    """Dynamic per-token when scale is None, else static (scale f32 [1] or [tokens])."""
+    T, H = x.shape
+    out = torch.empty((T, H), dtype=torch.uint8, device=x.device)
+    scales = torch.empty(T, dtype=torch.float32, device=x.device)
+    check(lib.vmx_fp8_quant_bf16(_ptr(out), _ptr(scales), _ptr(x), _ptr(scale), T, H, int(scale is None),
+                                 int(scale is not None and scale.numel() > 1), _stream()))
+    return out, scales
