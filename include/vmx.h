@@ -197,6 +197,33 @@ int vmx_dense_gemv_bf16(uint16_t *y, const uint16_t *x, const uint16_t *W, const
 int vmx_embedding_lookup_bf16(uint16_t *out, const uint16_t *table, const int32_t *ids, int tokens, int hidden,
                               int vocab, void *stream);
 
+/* ---------------------------------------------------------- mixture of experts */
+
+/* Replaces topk_softmax_{f32,bf16}_warp / _generic (crates/core/kernels/topk_softmax.cu:63-311):
+ * softmax over experts (expf, max-subtracted), k rounds of argmax (ties -> smaller index), optional
+ * renormalisation by the selected sum.  round_probs_bf16 rounds the probabilities to bf16 before the
+ * selection, as the quantized Mixtral layer's bf16 softmax does (models/mixtral_quantized.rs:150-170).
+ * logits f32 or bf16 [tokens, num_experts<=256]; weights f32 [tokens,k]; ids i32 [tokens,k]. */
+int vmx_topk_softmax(const void *logits, int logits_dtype, float *topk_weights, int32_t *topk_ids, int tokens,
+                     int num_experts, int k, int renormalize, int round_probs_bf16, void *stream);
+
+/* Replaces moe_align_block_size(_small)_kernel + moe_sort_tokens_kernel (crates/core/kernels/fused_moe_align.cu:34-240):
+ * group the flattened (token*k+slot) indices by expert, each group padded to a multiple of block_size with
+ * `numel`; expert_ids[block] names each block's expert; total_tokens_post_pad[0] = padded length.
+ * Within an expert the indices ascend (the reference's atomic order is unspecified). */
+int vmx_moe_align_block_size(const int32_t *topk_ids, int32_t *sorted_token_ids, int32_t *expert_ids,
+                             int32_t *total_tokens_post_pad, int numel, int num_experts, int block_size,
+                             int sorted_capacity, void *stream);
+
+/* Replaces QuantizedMoELayer::forward's expert loop (models/mixtral_quantized.rs:138-195) for int4 experts:
+ * out[t] = sum_j bf16(w2_e(silu(w1_e x_t) * w3_e x_t) * weight[t,j]), e = ids[t,j], accumulated in bf16 in slot
+ * order.  w13_packed / w2_packed: DEVICE arrays of num_experts pointers to tile streams (vmx_int4_pack) of the
+ * merged gate|up [hidden -> 2*inter] and the down [inter -> hidden] projections.  No host read of the routing. */
+size_t vmx_moe_int4_workspace_bytes(int tokens, int k, int hidden, int inter);
+int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
+                         const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
+                         int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------- whole-token decoder */
 
 /* Engine-facing surface of the quantized Qwen3-family decoder: the C form of

@@ -47,6 +47,10 @@ _SIGS = {
     "vmx_fp8_gemm_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vmx_fp8_dequant_bf16": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),
     "vmx_fp8_quant_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vmx_topk_softmax": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vmx_moe_align_block_size": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vmx_moe_int4_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "vmx_moe_int4_forward": (_i, [_p] * 6 + [_i] * 6 + [_p, _sz, _p]),
     "vmx_rms_norm_bf16": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _p]),
     "vmx_rope_neox_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vmx_silu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _p]),

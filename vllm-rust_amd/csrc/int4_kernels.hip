@@ -154,10 +154,10 @@ __device__ __forceinline__ float chunk_sum16(const uint4 v) {
 }
 
 template <int UPW, bool TAIL>
-__global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
-                                                         const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
-                                                         uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N, int K,
-                                                         int group, int splits) {
+__device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                               const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+                                               uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride, int M,
+                                               int N, int K, int group, int block) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int KS = 4 * UPW * KB;       // k-values per workgroup
     constexpr int XROW = KS + 8;           // bf16 per staged row (+16 B pad against bank conflicts)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = N / NT, kblocks = K / KB, G = K / group;
-    const int nt = blockIdx.x % n_tiles, ks = blockIdx.x / n_tiles;
+    const int nt = block % n_tiles, ks = block / n_tiles;
     const int kb_wg = ks * 4 * UPW;        // first k-block of this workgroup
     const int k0 = kb_wg * KB;
     const int nl = lane & 15, h = lane >> 4;
@@ -281,11 +281,38 @@ __global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict_
                     if (bias) v += vmx_bf16_to_f32(bias[n]);
                     y[(int64_t)mrow * N + n] = vmx_f32_to_bf16(v);
                 } else {
-                    partial[((int64_t)ks * M + mrow) * N + n] = out4[r];
+                    partial[(int64_t)ks * slice_stride + (int64_t)mrow * N + n] = out4[r];
                 }
             }
         }
     }
+}
+
+template <int UPW, bool TAIL>
+__global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                         const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+                                                         uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N, int K,
+                                                         int group, int splits) {
+    (void)splits;
+    int4_gemm_body<UPW, TAIL>(W, SZ, x, bias, y, partial, (int64_t)M * N, M, N, K, group, blockIdx.x);
+}
+
+// Grouped form for mixture-of-experts decode: blockIdx.y = p selects one (token, expert slot) pair;
+// its weights are packed_table[expert_ids[p]], its activation row is x[p / x_row_div] and it writes
+// row p of partial[splits][pairs][N].  M = 1 per pair.
+template <int UPW, bool TAIL>
+__global__ __launch_bounds__(256) void int4_gemm_grouped_kernel(const void *const *__restrict__ packed_table,
+                                                                 const int32_t *__restrict__ expert_ids, int num_experts,
+                                                                 const uint16_t *__restrict__ x, int x_row_div,
+                                                                 float *__restrict__ partial, int pairs, int N, int K, int group) {
+    const int p = blockIdx.y;
+    int e = expert_ids[p];
+    e = e < 0 ? 0 : (e >= num_experts ? num_experts - 1 : e);  // ids come from top-k over num_experts
+    const char *packed = static_cast<const char *>(packed_table[e]);
+    const uint4 *W = reinterpret_cast<const uint4 *>(packed);
+    const uint32_t *SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
+    int4_gemm_body<UPW, TAIL>(W, SZ, x + (int64_t)(p / x_row_div) * K, nullptr, nullptr, partial + (int64_t)p * N, (int64_t)pairs * N, 1,
+                              N, K, group, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void int4_reduce_kernel(const float *__restrict__ partial, const uint16_t *__restrict__ bias,
@@ -432,6 +459,26 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
     return launch_gemm(p, W, SZ, x, nullptr, nullptr, partial, M, N, K, group, st);
+}
+
+int vmx_int4_gemm_grouped(const void *const *packed_table, const int32_t *expert_ids, int num_experts, const uint16_t *x,
+                          int x_row_div, float *partial, int pairs, int N, int K, int group, hipStream_t st) {
+    const GemmPlan p = plan_gemm(N, K);
+    const size_t lds = gemm_lds_bytes(1, p.upw);
+    const dim3 grid((unsigned)((N / NT) * p.splits), (unsigned)pairs), block(256);
+    const bool tail = (K / KB) % (4 * p.upw) != 0;
+#define GL_T(U, T) hipLaunchKernelGGL((int4_gemm_grouped_kernel<U, T>), grid, block, lds, st, packed_table, expert_ids, num_experts, x, x_row_div, partial, pairs, N, K, group)
+#define GL(U) do { if (tail) GL_T(U, true); else GL_T(U, false); } while (0)
+    switch (p.upw) {
+        case 8: GL(8); break;
+        case 4: GL(4); break;
+        case 2: GL(2); break;
+        default: GL(1); break;
+    }
+#undef GL
+#undef GL_T
+    VMX_CHECK_LAUNCH("int4_gemm(grouped)");
+    return VMX_OK;
 }
 
 // AWQ checkpoint tensors -> columns [col0, col0+N) of merged GPTQ-sequential tensors with Ntot columns.

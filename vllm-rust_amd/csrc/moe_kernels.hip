@@ -1,0 +1,217 @@
+// Mixture-of-experts operators for gfx950: router top-k softmax, token->expert alignment, and a
+// device-side quantized MoE decode layer over int4 (AWQ/GPTQ) experts.
+// Semantics: crates/core/kernels/topk_softmax.cu:63-311 (softmax with expf, max-subtracted; k rounds
+// of argmax, ties -> smaller index; optional renormalisation by the selected sum),
+// crates/core/kernels/fused_moe_align.cu:34-278 (moe_align_block_size), and the reference's
+// quantized Mixtral layer, which has no fused kernel: a host loop over tokens and their top-k experts
+// (crates/core/src/models/mixtral_quantized.rs:92-99,138-195).  Here the whole layer stays on the
+// device: expert ids are read by a grouped int4 GEMV (blockIdx.y = (token, slot) pair), so there is no
+// host read of the router output per token.
+#include "vmx_kernels.h"
+#include <float.h>
+
+namespace {
+
+__device__ __forceinline__ float rb(float v) { return vmx_bf16_to_f32(vmx_f32_to_bf16(v)); }
+
+// One wave per token; lane l holds experts l, l+64, ... (up to 4 per lane: E <= 256).
+template <bool BF16_IN>
+__global__ __launch_bounds__(256) void topk_softmax_kernel(const void *__restrict__ logits, float *__restrict__ w_out,
+                                                            int32_t *__restrict__ id_out, int tokens, int E, int k, int renorm,
+                                                            int round_probs_bf16) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= tokens) return;
+    float v[4];
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int e = lane + 64 * j;
+        v[j] = -FLT_MAX;
+        if (e < E) v[j] = BF16_IN ? vmx_bf16_to_f32(((const uint16_t *)logits)[(int64_t)t * E + e]) : ((const float *)logits)[(int64_t)t * E + e];
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = vmx_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j] = (lane + 64 * j < E) ? expf(v[j] - mx) : 0.f;
+        sum += v[j];
+    }
+    sum = vmx_wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j] = (lane + 64 * j < E) ? v[j] / sum : -FLT_MAX;
+        if (round_probs_bf16 && lane + 64 * j < E) v[j] = rb(v[j]);
+    }
+    float selected = 0.f;
+    for (int ki = 0; ki < k; ki++) {
+        // key: larger value first, then smaller index
+        float bv = -FLT_MAX;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int e = lane + 64 * j;
+            if (e < E && (v[j] > bv)) { bv = v[j]; bi = e; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { w_out[(int64_t)t * k + ki] = bv; id_out[(int64_t)t * k + ki] = bi; }
+        selected += bv;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (lane + 64 * j == bi) v[j] = -FLT_MAX;
+    }
+    if (renorm && lane == 0) {
+        const float f = selected > 0.f ? 1.0f / selected : 1.0f;
+        for (int ki = 0; ki < k; ki++) w_out[(int64_t)t * k + ki] *= f;
+    }
+}
+
+// Single workgroup.  sorted_token_ids: per expert, the flattened (token*k + slot) indices routed to it in
+// ascending order, each expert's run padded to a multiple of block_size with `numel`; expert_ids: the
+// expert of each block; total_tokens_post_pad[0] = padded length.
+__global__ __launch_bounds__(256) void moe_align_kernel(const int32_t *__restrict__ topk_ids, int32_t *__restrict__ sorted,
+                                                         int32_t *__restrict__ expert_ids, int32_t *__restrict__ total_post_pad,
+                                                         int numel, int E, int block_size, int sorted_capacity) {
+    extern __shared__ int32_t sh[];  // counts[E] | offsets[E+1]
+    int32_t *counts = sh, *offs = sh + E;
+    for (int e = threadIdx.x; e < E; e += 256) counts[e] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < numel; i += 256) {
+        const int e = topk_ids[i];
+        if (e >= 0 && e < E) atomicAdd(&counts[e], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int e = 0; e < E; e++) {
+            offs[e] = acc;
+            acc += (counts[e] + block_size - 1) / block_size * block_size;
+        }
+        offs[E] = acc;
+        total_post_pad[0] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < sorted_capacity; i += 256) sorted[i] = numel;
+    for (int b = threadIdx.x; b < offs[E] / block_size; b += 256) {
+        int e = 0;
+        while (e + 1 < E && offs[e + 1] <= b * block_size) e++;
+        expert_ids[b] = e;
+    }
+    __syncthreads();
+    // stable placement: thread e walks the ids in order (numel is small on the decode path)
+    for (int e = threadIdx.x; e < E; e += 256) {
+        int pos = offs[e];
+        for (int i = 0; i < numel; i++)
+            if (topk_ids[i] == e) sorted[pos++] = i;
+    }
+}
+
+// out[t, :] = sum over slots j (in slot order) of bf16( bf16(expert_out[t*k+j, :]) * bf16(w[t,j]) ), each partial
+// sum rounded to bf16: the reference's `token_output + expert_out * weight` chain on bf16 tensors.
+__global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t *__restrict__ out, const float *__restrict__ partial, int splits,
+                                                           int pairs, const float *__restrict__ w, int k, int hidden) {
+    const int t = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hidden; i += gridDim.x * 256) {
+        float acc = 0.f;
+        for (int j = 0; j < k; j++) {
+            const int p = t * k + j;
+            float o = 0.f;
+            for (int s = 0; s < splits; s++) o += partial[((int64_t)s * pairs + p) * hidden + i];
+            acc = rb(acc + rb(rb(o) * rb(w[p])));
+        }
+        out[(int64_t)t * hidden + i] = vmx_f32_to_bf16(acc);
+    }
+}
+
+// act[p, i] = bf16(silu(bf16(gate)) * bf16(up)) from partial[splits][pairs][2*inter]
+__global__ __launch_bounds__(256) void moe_act_kernel(const float *__restrict__ partial, int splits, int pairs, uint16_t *__restrict__ act,
+                                                       int inter) {
+    const int64_t total = (int64_t)pairs * inter, slice = (int64_t)pairs * 2 * inter;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / inter, c = i % inter;
+        float g = 0.f, u = 0.f;
+        for (int s = 0; s < splits; s++) {
+            g += partial[s * slice + p * 2 * inter + c];
+            u += partial[s * slice + p * 2 * inter + inter + c];
+        }
+        g = rb(g);
+        act[i] = vmx_f32_to_bf16((g / (1.0f + expf(-g))) * rb(u));
+    }
+}
+
+}  // namespace
+
+extern "C" int vmx_topk_softmax(const void *logits, int logits_dtype, float *topk_weights, int32_t *topk_ids, int tokens,
+                                int num_experts, int k, int renormalize, int round_probs_bf16, void *stream) {
+    VMX_REQUIRE(logits && topk_weights && topk_ids, "topk_softmax: null pointer");
+    VMX_REQUIRE(logits_dtype == VMX_F32 || logits_dtype == VMX_BF16, "topk_softmax: logits dtype must be f32 or bf16");
+    VMX_REQUIRE(num_experts >= 1 && num_experts <= 256, "topk_softmax: num_experts (%d) must be in 1..256", num_experts);
+    VMX_REQUIRE(k >= 1 && k <= num_experts, "topk_softmax: k (%d) must be in 1..num_experts", k);
+    if (tokens <= 0) return VMX_OK;
+    const dim3 grid((tokens + 3) / 4), block(256);
+    if (logits_dtype == VMX_BF16)
+        hipLaunchKernelGGL(topk_softmax_kernel<true>, grid, block, 0, vmx_stream(stream), logits, topk_weights, topk_ids, tokens, num_experts,
+                           k, renormalize, round_probs_bf16);
+    else
+        hipLaunchKernelGGL(topk_softmax_kernel<false>, grid, block, 0, vmx_stream(stream), logits, topk_weights, topk_ids, tokens, num_experts,
+                           k, renormalize, round_probs_bf16);
+    VMX_CHECK_LAUNCH("topk_softmax");
+    return VMX_OK;
+}
+
+extern "C" int vmx_moe_align_block_size(const int32_t *topk_ids, int32_t *sorted_token_ids, int32_t *expert_ids,
+                                        int32_t *total_tokens_post_pad, int numel, int num_experts, int block_size,
+                                        int sorted_capacity, void *stream) {
+    VMX_REQUIRE(topk_ids && sorted_token_ids && expert_ids && total_tokens_post_pad, "moe_align_block_size: null pointer");
+    VMX_REQUIRE(numel >= 0 && num_experts >= 1 && num_experts <= 1024 && block_size >= 1, "moe_align_block_size: bad arguments");
+    VMX_REQUIRE(sorted_capacity >= numel + num_experts * (block_size - 1), "moe_align_block_size: sorted_token_ids capacity %d too small",
+                sorted_capacity);
+    hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(256), (2 * num_experts + 1) * sizeof(int32_t), vmx_stream(stream), topk_ids,
+                       sorted_token_ids, expert_ids, total_tokens_post_pad, numel, num_experts, block_size, sorted_capacity);
+    VMX_CHECK_LAUNCH("moe_align_block_size");
+    return VMX_OK;
+}
+
+extern "C" size_t vmx_moe_int4_workspace_bytes(int tokens, int k, int hidden, int inter) {
+    if (tokens <= 0 || k <= 0 || hidden <= 0 || inter <= 0) return 0;
+    const size_t pairs = (size_t)tokens * k;
+    const size_t s1 = (size_t)vmx_int4_splits(2 * inter, hidden), s2 = (size_t)vmx_int4_splits(hidden, inter);
+    size_t a = s1 * pairs * 2 * inter * 4, b = s2 * pairs * hidden * 4;
+    a = (a + 255) & ~(size_t)255;
+    b = (b + 255) & ~(size_t)255;
+    return a + b + ((pairs * inter * 2 + 255) & ~(size_t)255);
+}
+
+extern "C" int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
+                                    const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
+                                    int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(out && x && topk_weights && topk_ids && w13_packed && w2_packed && workspace, "moe_int4_forward: null pointer");
+    VMX_REQUIRE(tokens >= 1 && k >= 1 && num_experts >= 1, "moe_int4_forward: bad counts");
+    VMX_REQUIRE(hidden % 128 == 0 && inter % 128 == 0 && group > 0 && group % 128 == 0 && hidden % group == 0 && inter % group == 0,
+                "moe_int4_forward: hidden (%d), inter (%d) and group (%d) must be multiples of 128", hidden, inter, group);
+    VMX_REQUIRE(workspace_bytes >= vmx_moe_int4_workspace_bytes(tokens, k, hidden, inter), "moe_int4_forward: workspace too small");
+    hipStream_t st = vmx_stream(stream);
+    const int pairs = tokens * k;
+    const int s1 = vmx_int4_splits(2 * inter, hidden), s2 = vmx_int4_splits(hidden, inter);
+    char *ws = (char *)workspace;
+    float *p1 = (float *)ws;
+    ws += ((size_t)s1 * pairs * 2 * inter * 4 + 255) & ~(size_t)255;
+    float *p2 = (float *)ws;
+    ws += ((size_t)s2 * pairs * hidden * 4 + 255) & ~(size_t)255;
+    uint16_t *act = (uint16_t *)ws;
+    // gate|up of every (token, slot) pair with its expert's weights; x row = token
+    if (int rc = vmx_int4_gemm_grouped(w13_packed, topk_ids, num_experts, x, k, p1, pairs, 2 * inter, hidden, group, st)) return rc;
+    int64_t blocks = ((int64_t)pairs * inter + 255) / 256;
+    hipLaunchKernelGGL(moe_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p1, s1, pairs, act, inter);
+    VMX_CHECK_LAUNCH("moe_act");
+    // down projection; x row = pair
+    if (int rc = vmx_int4_gemm_grouped(w2_packed, topk_ids, num_experts, act, 1, p2, pairs, hidden, inter, group, st)) return rc;
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden + 255) / 256, tokens), dim3(256), 0, st, out, p2, s2, pairs, topk_weights, k, hidden);
+    VMX_CHECK_LAUNCH("moe_combine");
+    return VMX_OK;
+}

@@ -15,6 +15,7 @@ __all__ = [
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant",
+    "topk_softmax", "moe_align_block_size", "moe_int4_forward",
 ]
 
 
@@ -203,3 +204,33 @@ def fp8_quant(x: torch.Tensor, scale=None):
     check(lib.vmx_fp8_quant_bf16(_ptr(out), _ptr(scales), _ptr(x), _ptr(scale), T, H, int(scale is None),
                                  int(scale is not None and scale.numel() > 1), _stream()))
     return out, scales
+
+
+def topk_softmax(logits: torch.Tensor, k: int, renormalize: bool = True, round_probs_bf16: bool = False):
+    T, E = logits.shape
+    dt = 0 if logits.dtype == torch.float32 else 1
+    w = torch.empty((T, k), dtype=torch.float32, device=logits.device)
+    ids = torch.empty((T, k), dtype=torch.int32, device=logits.device)
+    check(lib.vmx_topk_softmax(_ptr(logits), dt, _ptr(w), _ptr(ids), T, E, k, int(renormalize), int(round_probs_bf16), _stream()))
+    return w, ids
+
+
+def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, block_size: int):
+    numel = topk_ids.numel()
+    cap = numel + num_experts * (block_size - 1)
+    sorted_ids = torch.empty(cap, dtype=torch.int32, device=topk_ids.device)
+    expert_ids = torch.full(((cap + block_size - 1) // block_size,), -1, dtype=torch.int32, device=topk_ids.device)
+    total = torch.zeros(1, dtype=torch.int32, device=topk_ids.device)
+    check(lib.vmx_moe_align_block_size(_ptr(topk_ids), _ptr(sorted_ids), _ptr(expert_ids), _ptr(total), numel, num_experts,
+                                       block_size, cap, _stream()))
+    return sorted_ids, expert_ids, total
+
+
+def moe_int4_forward(x, topk_weights, topk_ids, w13_table, w2_table, num_experts: int, hidden: int, inter: int, group: int):
+    """w13_table / w2_table: int64 CUDA tensors holding the experts' packed-buffer device pointers."""
+    T, k = topk_ids.shape
+    ws = torch.empty(lib.vmx_moe_int4_workspace_bytes(T, k, hidden, inter), dtype=torch.uint8, device=x.device)
+    out = torch.empty((T, hidden), dtype=torch.bfloat16, device=x.device)
+    check(lib.vmx_moe_int4_forward(_ptr(out), _ptr(x), _ptr(topk_weights), _ptr(topk_ids), _ptr(w13_table), _ptr(w2_table), T, k,
+                                   num_experts, hidden, inter, group, _ptr(ws), ws.numel(), _stream()))
+    return out
