@@ -9,8 +9,9 @@ timed steps are replayed from one hipGraph (decode step + device-side step bookk
 inputs resident in HBM.
 
 With --gpus N > 1 each rank (one process per GPU, launched by torch.distributed.run) runs an
-independent replica of the same job ("replicas only": data-parallel serving, no exchange step on
-the data path); value is the sum over ranks, time is the max over ranks.
+independent replica of the same job (data-parallel serving, no exchange step on the data path);
+value is the sum over ranks, time is the max over ranks.  --tp instead shards ONE model over the
+ranks (column/row-parallel int4 linears, RCCL all-reduce over xGMI, vocab-parallel lm_head).
 
 Prints one JSON line on rank 0 with `roofline` (the int4 linear kernel, timed with HIP events on
 its launch stream over back-to-back replays of the step's linear launches) and `cpu_baseline` (the CPU oracle's
@@ -83,6 +84,9 @@ def main():
     ap.add_argument("--prompt", type=int, default=256)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tp", action="store_true",
+                    help="with --gpus N > 1: ONE model tensor-parallel over the N ranks (RCCL all-reduce after every row-parallel "
+                         "linear, strong scaling) instead of N independent replicas")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,8 +111,16 @@ def main():
                               max_seq_len=total_tokens + 1)
     if args.layers:
         spec.num_layers = args.layers
+    use_tp = args.tp and dist_on
+    comm = None
+    if use_tp:
+        from vllm_rust_amd.parallel import Communicator, shard_spec
+        spec = shard_spec(spec, rank, world)   # this rank's heads / MLP columns / lm_head rows (random-init shards)
+        comm = Communicator(rank, world)
     model = QuantizedQwen3ForCausalLM(spec, device=local_rank)
     model.load_synthetic(seed=1234 + rank)
+    if comm is not None:
+        model.set_comm(comm)
 
     dev = model.device
     B = 1
@@ -184,15 +196,15 @@ def main():
                     "alg_bytes_per_launch": round(alg / launches)}
 
     if rank == 0:
-        tok_s = world * B * K_steps / elapsed
+        tok_s = (1 if use_tp else world) * B * K_steps / elapsed
         line = {
             "metric": "decode tok/s (greedy, batch=1 per GPU) + %HBM-peak of the int4 linear kernel, Qwen3-8B AWQ",
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": K_steps, "warmup": W_steps,
-            "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if use_tp else "weak", "vs_baseline": None,
             "dtype": "int4 weights x bf16 activations, f32 accumulate", "data": "synthetic",
             "config": {"workload": "Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, 256-token prompt then timed tokens, bf16 KV",
                        "layers": spec.num_layers, "hidden": spec.hidden_size, "vocab": spec.vocab_size,
-                       "parallelism": "tp1" if world == 1 else f"dp{world} replicas (tp1 each)",
+                       "parallelism": "tp1" if world == 1 else (f"tp{world} (RCCL all-reduce)" if use_tp else f"dp{world} replicas (tp1 each)"),
                        "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
                        "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
             "roofline": roofline,

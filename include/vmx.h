@@ -224,6 +224,22 @@ int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_wei
                          const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
                          int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------- tensor-parallel communicator */
+
+/* RCCL over xGMI, resolved with dlopen like the reference's NCCL binding (crates/core/src/distributed/nccl.rs:479-560;
+ * DeviceCommunicator, distributed/communicator.rs:29-98).  One process per GPU: rank 0 calls vmx_comm_unique_id, the
+ * 128 bytes travel to the other ranks out of band (the launcher's TCP exchange in the reference,
+ * torch.distributed in bench.py), then every rank calls vmx_comm_create.  Collectives run on the caller's stream. */
+typedef struct vmx_comm vmx_comm;
+int vmx_comm_unique_id(void *out128);
+int vmx_comm_create(const void *id128, int rank, int world, vmx_comm **out);
+void vmx_comm_destroy(vmx_comm *c);
+int vmx_comm_rank(const vmx_comm *c);
+int vmx_comm_world(const vmx_comm *c);
+/* all_reduce(Sum) of row-parallel linear outputs (parallel_layers.rs:296) and all_reduce(Max) of argmax keys. */
+int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t count, void *stream);
+int vmx_comm_all_reduce_max_u64(vmx_comm *c, unsigned long long *buf, size_t count, void *stream);
+
 /* ------------------------------------------------------- whole-token decoder */
 
 /* Engine-facing surface of the quantized Qwen3-family decoder: the C form of
@@ -242,6 +258,9 @@ typedef struct vmx_qwen3_config {
     int block_size, num_blocks; /* paged KV cache geometry, per layer */
     int max_batch;           /* 1..16 */
     int max_seq_len;         /* sizes the split-KV workspace */
+    int tp_size, tp_rank;    /* tensor parallelism: 0/1 = off.  With tp_size > 1 num_heads, num_kv_heads and
+                                intermediate_size are THIS RANK's shares, vocab_size stays global (the lm_head is
+                                split by rows, vocab_size / tp_size per rank) and a communicator must be attached */
 } vmx_qwen3_config;
 
 typedef struct vmx_qwen3 vmx_qwen3;
@@ -304,6 +323,9 @@ int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, double *alg_b
 /* Measurement aid: stream `bytes` from p with the int4 linear's access shape (upw 1 KiB units per wave,
  * all requested up front) and discard them; gives the HBM floor for a launch of that size. */
 int vmx_debug_stream_read(const void *p, size_t bytes, int upw, void *sink, void *stream);
+
+/* Attach the tensor-parallel group of a model created with tp_size > 1 (not owned by the model). */
+int vmx_qwen3_set_comm(vmx_qwen3 *m, vmx_comm *comm);
 
 /* Parity aid: read back an internal activation of the last step (0 = residual stream h,
  * 1 = final normed x, 2 = logits), bf16. */

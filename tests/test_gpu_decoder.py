@@ -149,3 +149,49 @@ def test_dense_gemv_and_embedding(gpu):
     out = vmx.embedding_lookup(table, ids)
     assert torch.equal(out[0], table[3]) and torch.equal(out[1], table[49]) and torch.equal(out[4], table[0])
     assert not out[2].any() and not out[3].any()
+
+
+def test_tp_collective_path_world1_matches_plain_decode(gpu):
+    """A 1-rank RCCL communicator drives the row-parallel all-reduce and the vocab-parallel argmax path;
+    its results must equal the plain path bit for bit, eagerly and from a captured graph."""
+    from vllm_rust_amd.parallel import Communicator
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
+    vmx, torch = gpu
+    spec = _tiny_spec()
+    B, MB = 2, 8
+    bt = torch.arange(B * MB, dtype=torch.int32, device="cuda").reshape(B, MB)
+    outs = []
+    for use_comm in (False, True):
+        model = QuantizedQwen3ForCausalLM(spec)
+        model.load_synthetic(seed=9)
+        comm = None
+        if use_comm:
+            comm = Communicator(0, 1)
+            model.set_comm(comm)
+        ids = torch.tensor([5, 77], dtype=torch.int32, device="cuda")
+        pos = torch.zeros(B, dtype=torch.int32, device="cuda")
+        slots = (bt[:, 0] * spec.block_size).contiguous()
+        sl = torch.ones(B, dtype=torch.int32, device="cuda")
+        out = torch.empty(B, dtype=torch.int32, device="cuda")
+        logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        seq = []
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            model.forward_decode_batch(ids, pos, slots, bt, sl, out_ids=out, logits=logits)
+            model.advance(ids, out, pos, slots, sl, bt)
+            torch.cuda.synchronize()
+            seq.append((out.clone(), logits.clone()))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                model.forward_decode_batch(ids, pos, slots, bt, sl, out_ids=out, logits=logits)
+                model.advance(ids, out, pos, slots, sl, bt)
+            for _ in range(3):
+                g.replay()
+                torch.cuda.synchronize()
+                seq.append((out.clone(), logits.clone()))
+        outs.append(seq)
+        model.close()
+        if comm:
+            comm.close()
+    for (o0, l0), (o1, l1) in zip(*outs):
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)

@@ -1,0 +1,82 @@
+"""World-size-2 gloo test (CPU) of the tensor-parallel sharding rules: column shards concatenate to the
+full linear, row shards sum (all_reduce) to it.  The arithmetic is the CPU oracle's."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _awq_case(rng, K, N, g):
+    qw = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32)
+    qz = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // g, N // 8), dtype=np.int64).astype(np.int32)
+    sc = ((rng.random((K // g, N)) * 0.5 + 0.75) / (6.5 * np.sqrt(K))).astype(np.float16)
+    return qw, qz, sc
+
+
+def _oracle_linear(orc, x_u16, qw, qz, sc, g):
+    K, N = qw.shape[0], qw.shape[1] * 8
+    gq = orc.awq_to_gptq_qweight(qw.view(np.uint32), K, N)
+    gz = orc.repack_awq_nibbles(qz.view(np.uint32))
+    sb = orc.f32_to_bf16(sc.astype(np.float32))
+    return orc.int4_gemv_bf16(x_u16, gq, sb, gz, None, K, N, g)
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from vllm_rust_amd.parallel import shard_awq_column, shard_awq_row, shard_spec
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    rng = np.random.default_rng(0)                      # same data on every rank
+    K, N, g = 512, 256, 128
+    qw, qz, sc = _awq_case(rng, K, N, g)
+    x = orc.f32_to_bf16(rng.standard_normal((2, K)).astype(np.float32))
+    full = orc.bf16_to_f32(_oracle_linear(orc, x, qw, qz, sc, g))
+    t = lambda a: torch.from_numpy(a)
+    # column parallel: all_gather of the shards' outputs == full output, bit for bit
+    cqw, cqz, csc = (a.numpy() for a in shard_awq_column(t(qw), t(qz), t(sc), rank, world))
+    part = torch.from_numpy(orc.bf16_to_f32(_oracle_linear(orc, x, cqw, cqz, csc, g)))
+    parts = [torch.empty_like(part) for _ in range(world)]
+    dist.all_gather(parts, part)
+    ok_col = np.array_equal(torch.cat(parts, 1).numpy(), full)
+    # row parallel: all_reduce(sum) of the bf16-rounded shard outputs == full output up to bf16 rounding of the partials
+    rqw, rqz, rsc = (a.numpy() for a in shard_awq_row(t(qw), t(qz), t(sc), rank, world, g))
+    xs = np.ascontiguousarray(x[:, rank * (K // world):(rank + 1) * (K // world)])
+    rpart = torch.from_numpy(orc.bf16_to_f32(_oracle_linear(orc, xs, rqw, rqz, rsc, g)))
+    dist.all_reduce(rpart)
+    err = float(np.abs(rpart.numpy() - full).max() / np.abs(full).max())
+    s = shard_spec(Qwen3Spec.qwen3_8b(), rank, world)
+    ok_spec = (s.num_heads, s.num_kv_heads, s.intermediate_size, s.vocab_size, s.tp_rank) == (16, 4, 6144, 151936, rank)
+    if rank == 0:
+        ret["col"], ret["row_err"], ret["spec"] = ok_col, err, ok_spec
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tp_sharding_world2_gloo():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["col"] is True
+    assert ret["row_err"] <= 2 ** -6                    # each rank rounds its partial to bf16 before the sum
+    assert ret["spec"] is True
+
+
+def test_shard_spec_rejects_bad_divisors():
+    sys.path.insert(0, str(ROOT))
+    from vllm_rust_amd.parallel import shard_spec
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    with pytest.raises(ValueError):
+        shard_spec(Qwen3Spec.qwen3_8b(), 0, 3)
+    with pytest.raises(ValueError):
+        shard_spec(Qwen3Spec.qwen3_8b(), 0, 16)         # 8 KV heads

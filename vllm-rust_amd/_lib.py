@@ -61,6 +61,14 @@ _SIGS = {
     "vmx_paged_attention_bf16": (_i, [_p] * 6 + [_f] + [_i] * 9 + [_p, _p, _p, _sz, _p]),
     "vmx_dense_gemv_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "vmx_embedding_lookup_bf16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "vmx_comm_unique_id": (_i, [_p]),
+    "vmx_comm_create": (_i, [_p, _i, _i, _p]),
+    "vmx_comm_destroy": (None, [_p]),
+    "vmx_comm_rank": (_i, [_p]),
+    "vmx_comm_world": (_i, [_p]),
+    "vmx_comm_all_reduce_sum_bf16": (_i, [_p, _p, _sz, _p]),
+    "vmx_comm_all_reduce_max_u64": (_i, [_p, _p, _sz, _p]),
+    "vmx_qwen3_set_comm": (_i, [_p, _p]),
     "vmx_qwen3_create": (_i, [_p, _p]),
     "vmx_qwen3_destroy": (None, [_p]),
     "vmx_qwen3_load_tensor": (_i, [_p, _i, _i, _p, _sz, _p]),
@@ -80,7 +88,7 @@ class Qwen3Config(C.Structure):
         ("hidden_size", _i), ("num_layers", _i), ("num_heads", _i), ("num_kv_heads", _i), ("head_dim", _i),
         ("intermediate_size", _i), ("vocab_size", _i), ("rms_norm_eps", _f), ("max_position", _i), ("group_size", _i),
         ("qk_norm", _i), ("tie_word_embeddings", _i), ("kv_cache_dtype", _i), ("block_size", _i), ("num_blocks", _i),
-        ("max_batch", _i), ("max_seq_len", _i),
+        ("max_batch", _i), ("max_seq_len", _i), ("tp_size", _i), ("tp_rank", _i),
     ]
 
 

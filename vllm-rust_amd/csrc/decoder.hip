@@ -70,7 +70,8 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float f[8]) {
 }
 
 // One workgroup per token.  h (bf16 residual stream, in/out), optional incoming linear output as
-// f32 partials [splits][tokens][hidden]:  o = bf16(sum partials); h = bf16(h + o);
+// f32 partials [splits][tokens][hidden] (splits < 0: `partial` is instead a bf16 [tokens][hidden] tensor,
+// the all-reduced output of a row-parallel linear):  o = bf16(sum partials); h = bf16(h + o);
 // x = bf16(h * rsqrt(mean(h^2) + eps) * w)   (add_bf16 then rms_norm_bf16: variance over the ROUNDED h).
 // Thread t owns the 8-element chunks t, t+256, ... (CH of them, hidden <= CH*2048) in registers.
 template <int CH>
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
             unpack_bf16x8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
             if (partial) {
                 float o[8];
-                sum_partials8(partial, splits, slice, row + 8 * ci, o);
+                if (splits < 0) unpack_bf16x8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(partial) + row + 8 * ci), o);
+                else sum_partials8(partial, splits, slice, row + 8 * ci, o);
 #pragma unroll
                 for (int j = 0; j < 8; j++) hv[c][j] = round_bf16(hv[c][j] + round_bf16(o[j]));
                 *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack_bf16x8(hv[c]);
@@ -190,6 +192,13 @@ __global__ __launch_bounds__(256) void gateup_act_kernel(const float *__restrict
     }
 }
 
+// y[i] = bf16(sum of split-K slices): the local output of a row-parallel linear before the all-reduce
+__global__ __launch_bounds__(256) void slices_to_bf16_kernel(const float *__restrict__ partial, int splits, int64_t n,
+                                                              uint16_t *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = vmx_f32_to_bf16(sum_partials(partial, splits, n, i));
+}
+
 __global__ __launch_bounds__(256) void f16_to_bf16_into_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int64_t n,
                                                                 int cols, int ldo) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -266,7 +275,9 @@ struct vmx_qwen3 {
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
-    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws;
+    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys;
+    vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
+    int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
 };
 
@@ -280,6 +291,16 @@ double int4_alg_bytes(const Int4Linear &l, int M) {
 
 int run_linear(vmx_qwen3 *, const Int4Linear &l, const uint16_t *xin, float *partial, int M, hipStream_t st) {
     return l.forward_partial(xin, partial, M, st);
+}
+
+// Row-parallel epilogue: red_bf16 = all_reduce_sum(bf16(sum of this rank's split-K slices)) — what composing the
+// reference's RowParallelLinear (distributed/parallel_layers.rs:275-305) with a quantized linear computes.
+int tp_reduce(vmx_qwen3 *m, const float *partial, int splits, int tokens, int hidden, hipStream_t st) {
+    const int64_t n = (int64_t)tokens * hidden;
+    hipLaunchKernelGGL(slices_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, splits, n,
+                       (uint16_t *)m->red_bf16.p);
+    VMX_CHECK_LAUNCH("slices_to_bf16");
+    return vmx_comm_all_reduce_sum_bf16(m->comm, (uint16_t *)m->red_bf16.p, (size_t)n, st);
 }
 
 int make_linear(Int4Linear &l, int K, int N, int group) {
@@ -343,6 +364,8 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     VMX_REQUIRE(c.block_size > 0 && c.num_blocks > 0 && c.max_seq_len > 0 && c.vocab_size > 0 && c.max_position > 0,
                 "qwen3_create: bad cache/vocab geometry");
     VMX_REQUIRE(c.kv_cache_dtype == VMX_KV_AUTO || c.kv_cache_dtype == VMX_KV_FP8_E4M3, "qwen3_create: unsupported kv dtype");
+    VMX_REQUIRE(c.tp_size >= 0 && c.tp_rank >= 0 && (c.tp_size <= 1 || (c.tp_rank < c.tp_size && c.vocab_size % c.tp_size == 0)),
+                "qwen3_create: tp_rank %d / tp_size %d invalid (vocab_size must divide by tp_size)", c.tp_rank, c.tp_size);
     vmx_qwen3 *m = new (std::nothrow) vmx_qwen3();
     VMX_REQUIRE(m, "qwen3_create: out of host memory");
     m->cfg = c;
@@ -353,7 +376,8 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
 #define TRY(e) do { if (!rc) rc = (e); } while (0)
     TRY(m->embed.alloc((size_t)c.vocab_size * H * 2));
     m->lm_head_tied = c.tie_word_embeddings != 0;
-    if (!m->lm_head_tied) TRY(m->lm_head.alloc((size_t)c.vocab_size * H * 2));
+    const int VL = m->vocab_local();  // lm_head rows held by this rank (vocab-parallel under TP)
+    if (!m->lm_head_tied) TRY(m->lm_head.alloc((size_t)VL * H * 2));
     TRY(m->final_norm.alloc((size_t)H * 2));
     TRY(m->cos_sin.alloc((size_t)c.max_position * hd * 4));
     const size_t kv_elem = c.kv_cache_dtype == VMX_KV_FP8_E4M3 ? 1 : 2;
@@ -393,9 +417,11 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     TRY(m->q.alloc((size_t)B * NO * 2));
     TRY(m->attn.alloc((size_t)B * NO * 2));
     TRY(m->act.alloc((size_t)B * I * 2));
-    TRY(m->logits.alloc((size_t)B * c.vocab_size * 2));
+    TRY(m->logits.alloc((size_t)B * VL * 2));
+    TRY(m->red_bf16.alloc((size_t)B * H * 2));
+    TRY(m->keys.alloc((size_t)B * 8));
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, hd, c.max_seq_len)));
-    TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
+    TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, VL)));
 #undef TRY
     if (rc) {
         vmx_qwen3_destroy(m);
@@ -415,7 +441,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.gu_stage);
     }
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
-                      &m->logits, &m->attn_ws, &m->argmax_ws})
+                      &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys})
         b->release();
     delete m;
 }
@@ -508,6 +534,8 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;  // ping-pong: each linear reads one, writes the other
     const float scale = 1.0f / sqrtf((float)hd);
     const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
+    const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
+    VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
 
     hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
     const float *pending = nullptr;  // down-projection output (f32 slices in PB) not yet folded into the residual stream
@@ -530,7 +558,14 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
         if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st)) return rc;
         if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
         // h += o; x = rms_norm(h);  gate|up = linear(x);  act = silu(gate) * up;  down = linear(act)
-        launch_resid_norm(st, h, x, PB, L.o.splits(), B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
+        const float *o_src = PB;
+        int o_splits = L.o.splits();
+        if (tp) {  // row-parallel: local bf16 output, summed over the ranks
+            if (int rc = tp_reduce(m, PB, o_splits, B, H, st)) return rc;
+            o_src = (const float *)m->red_bf16.p;
+            o_splits = -1;
+        }
+        launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
         if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
         int64_t blocks = ((int64_t)B * I + 255) / 256;
         hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA,
@@ -538,14 +573,40 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
         if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;
         pending = PB;
         pending_splits = L.down.splits();
+        if (tp) {
+            if (int rc = tp_reduce(m, PB, pending_splits, B, H, st)) return rc;
+            // the all-reduced bf16 vector is parked in the (now free) PA buffer so that red_bf16 can be reused
+            VMX_CHECK_HIP(hipMemcpyAsync(PA, m->red_bf16.p, (size_t)B * H * 2, hipMemcpyDeviceToDevice, st));
+            pending = PA;
+            pending_splits = -1;
+        }
     }
     launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H);
     VMX_CHECK_LAUNCH("qwen3_decode");
     uint16_t *logits = logits_out ? logits_out : (uint16_t *)m->logits.p;
-    const uint16_t *head = (const uint16_t *)(m->lm_head_tied ? m->embed.p : m->lm_head.p);
-    if (int rc = vmx_dense_gemv_launch(logits, x, head, nullptr, B, c.vocab_size, H, st)) return rc;
-    if (out_ids)
-        if (int rc = vmx_argmax_bf16(out_ids, logits, B, c.vocab_size, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
+    const int VL = m->vocab_local();
+    const int64_t v0 = tp ? (int64_t)c.tp_rank * VL : 0;  // first vocabulary row of this rank's lm_head slice
+    const uint16_t *head = m->lm_head_tied ? (const uint16_t *)m->embed.p + v0 * H : (const uint16_t *)m->lm_head.p;
+    if (int rc = vmx_dense_gemv_launch(logits, x, head, nullptr, B, VL, H, st)) return rc;
+    if (out_ids) {
+        if (!tp) {
+            if (int rc = vmx_argmax_bf16(out_ids, logits, B, VL, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
+        } else {  // vocab-parallel: best (value, global index) key per rank, max over ranks
+            unsigned long long *keys = (unsigned long long *)m->keys.p;
+            if (int rc = vmx_argmax_keys(keys, logits, B, VL, (uint32_t)v0, m->argmax_ws.p, st)) return rc;
+            if (int rc = vmx_comm_all_reduce_max_u64(m->comm, keys, B, stream)) return rc;
+            if (int rc = vmx_argmax_keys_to_ids(keys, out_ids, B, st)) return rc;
+        }
+    }
+    return VMX_OK;
+}
+
+// Attach the tensor-parallel communicator (not owned).  Required before decoding when tp_size > 1.
+extern "C" int vmx_qwen3_set_comm(vmx_qwen3 *m, vmx_comm *comm) {
+    VMX_REQUIRE(m, "qwen3_set_comm: null model");
+    VMX_REQUIRE(!comm || (vmx_comm_world(comm) == (m->cfg.tp_size > 1 ? m->cfg.tp_size : 1) && vmx_comm_rank(comm) == m->cfg.tp_rank),
+                "qwen3_set_comm: communicator rank/world do not match the model's tp_rank/tp_size");
+    m->comm = comm;
     return VMX_OK;
 }
 

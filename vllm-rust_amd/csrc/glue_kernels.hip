@@ -4,7 +4,7 @@
 // activations.cu:33-35,148-164, sampling.cu:47-94, cache_ops.cu:28-62} and the FP8 branch of
 // crates/core/src/kv_cache/cache_engine.rs:196-247.  All are HBM/launch-bound: 16-byte
 // vector accesses, one pass over the data, wave64 butterflies for the reductions.
-#include "vmx_internal.h"
+#include "vmx_kernels.h"
 #include <float.h>
 
 namespace {
@@ -121,7 +121,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 
 // grid (chunks, rows): each workgroup reduces one slice of a row to a key in part[row][chunk].
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t *__restrict__ logits, unsigned long long *__restrict__ part,
-                                                              int vocab) {
+                                                              int vocab, uint32_t index_offset) {
     __shared__ unsigned long long red[4];
     const int row = blockIdx.y, chunks = gridDim.x;
     const uint16_t *lg = logits + (int64_t)row * vocab;
@@ -135,14 +135,14 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t *__r
         unpack8(*reinterpret_cast<const uint4 *>(lg + i), f);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const unsigned long long k = argmax_key(f[j], (uint32_t)(i + j));
+            const unsigned long long k = argmax_key(f[j], index_offset + (uint32_t)(i + j));
             best = k > best ? k : best;
         }
     }
     if (!vec_ok) i = lo + threadIdx.x * 8;
     for (; i < hi; i += 256 * 8)  // tail (or unaligned row): scalar
         for (int j = i; j < min(i + 8, hi); j++) {
-            const unsigned long long k = argmax_key(vmx_bf16_to_f32(lg[j]), (uint32_t)j);
+            const unsigned long long k = argmax_key(vmx_bf16_to_f32(lg[j]), index_offset + (uint32_t)j);
             best = k > best ? k : best;
         }
     best = wave_max_u64(best);
@@ -155,8 +155,9 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t *__r
     }
 }
 
+// out != NULL: token id; keys_out != NULL: the winning key (for a cross-rank max)
 __global__ __launch_bounds__(64) void argmax_final_kernel(const unsigned long long *__restrict__ part, int32_t *__restrict__ out,
-                                                           int chunks) {
+                                                           unsigned long long *__restrict__ keys_out, int chunks) {
     const int row = blockIdx.x;
     unsigned long long best = 0;
     for (int c = threadIdx.x; c < chunks; c += 64) {
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const unsigned long lo
         best = k > best ? k : best;
     }
     best = wave_max_u64(best);
-    if (threadIdx.x == 0) out[row] = (int32_t)(~(uint32_t)(best & 0xFFFFFFFFull));
+    if (threadIdx.x == 0) {
+        if (out) out[row] = (int32_t)(~(uint32_t)(best & 0xFFFFFFFFull));
+        if (keys_out) keys_out[row] = best;
+    }
 }
 
 // e4m3fn, round-to-nearest-even, saturating (no inf): the OCP conversion gfx950 has in hardware.
@@ -257,10 +261,10 @@ extern "C" int vmx_argmax_bf16(int32_t *out_ids, const uint16_t *logits, int row
     if (rows == 0) return VMX_OK;
     const int chunks = argmax_chunks(vocab);
     hipLaunchKernelGGL(argmax_partial_kernel, dim3(chunks, rows), dim3(256), 0, vmx_stream(stream), logits,
-                       (unsigned long long *)workspace, vocab);
+                       (unsigned long long *)workspace, vocab, 0u);
     VMX_CHECK_LAUNCH("argmax(partial)");
     hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, vmx_stream(stream), (const unsigned long long *)workspace, out_ids,
-                       chunks);
+                       (unsigned long long *)nullptr, chunks);
     VMX_CHECK_LAUNCH("argmax(final)");
     return VMX_OK;
 }
@@ -275,5 +279,32 @@ extern "C" int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value,
     hipLaunchKernelGGL(reshape_and_cache_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), key, value, k_cache, v_cache,
                        slot_mapping, kv_heads * head_dim, kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0, k_scale, v_scale);
     VMX_CHECK_LAUNCH("reshape_and_cache");
+    return VMX_OK;
+}
+
+namespace {
+__global__ void argmax_keys_to_ids_kernel(const unsigned long long *__restrict__ keys, int32_t *__restrict__ out, int rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) out[r] = (int32_t)(~(uint32_t)(keys[r] & 0xFFFFFFFFull));
+}
+}  // namespace
+
+// Vocab-parallel argmax, step 1: per-row winning key over this rank's logits slice (global index =
+// index_offset + local index).  keys: u64 [rows]; workspace as vmx_argmax_bf16, plus the keys.
+int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,
+                    hipStream_t st) {
+    const int chunks = argmax_chunks(vocab);
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(chunks, rows), dim3(256), 0, st, logits, (unsigned long long *)workspace, vocab,
+                       index_offset);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, (const unsigned long long *)workspace, (int32_t *)nullptr, keys,
+                       chunks);
+    VMX_CHECK_LAUNCH("argmax(keys)");
+    return VMX_OK;
+}
+
+// step 2 (after the cross-rank max of the keys): keys -> token ids.
+int vmx_argmax_keys_to_ids(const unsigned long long *keys, int32_t *out_ids, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_keys_to_ids_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, keys, out_ids, rows);
+    VMX_CHECK_LAUNCH("argmax(keys_to_ids)");
     return VMX_OK;
 }

@@ -21,3 +21,8 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
                               const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st);
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
                               int head_dim, int window, hipStream_t st);
+
+// glue_kernels.hip
+int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,
+                    hipStream_t st);
+int vmx_argmax_keys_to_ids(const unsigned long long *keys, int32_t *out_ids, int rows, hipStream_t st);

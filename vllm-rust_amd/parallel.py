@@ -1,0 +1,84 @@
+"""Tensor-parallel plumbing: communicator set-up over torch.distributed and Megatron-style shard
+selection of AWQ checkpoint tensors.
+
+Sharding follows the reference's dense TP layers (crates/core/src/distributed/parallel_layers.rs:
+ColumnParallelLinear :36-175 shards the output dim, RowParallelLinear :181-325 shards the input dim
+and all-reduces; models/tp_layers.rs:113-226): q/k/v/gate/up column-parallel, o/down row-parallel,
+lm_head split by vocabulary rows.  The reference has no quantized TP path; the alignment rules are the
+int4 tile stream's: column shards multiples of 16 (and of 8 for the packed zeros), row shards
+multiples of the group size.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+
+import torch
+
+from ._lib import check, lib
+
+
+class Communicator:
+    """RCCL communicator of libvmx; the unique id is broadcast through torch.distributed."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        import torch.distributed as dist
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            check(lib.vmx_comm_unique_id(buf))
+            uid = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            if dist.get_backend(group) == "nccl":
+                dev = uid.cuda()
+                dist.broadcast(dev, src=0, group=group)
+                uid = dev.cpu()
+            else:
+                dist.broadcast(uid, src=0, group=group)
+        raw = (C.c_uint8 * 128)(*uid.tolist())
+        self.handle = C.c_void_p()
+        check(lib.vmx_comm_create(raw, rank, world, C.byref(self.handle)))
+        self.rank, self.world = rank, world
+
+    def all_reduce_sum_bf16(self, t: torch.Tensor) -> None:
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+        check(lib.vmx_comm_all_reduce_sum_bf16(self.handle, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
+
+    def close(self):
+        if self.handle:
+            lib.vmx_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def shard_spec(spec, tp_rank: int, tp_size: int):
+    """Per-rank model geometry: heads and MLP width divided, hidden and vocabulary global."""
+    if tp_size == 1:
+        return dataclasses.replace(spec, tp_size=1, tp_rank=0)
+    for name in ("num_heads", "num_kv_heads", "intermediate_size", "vocab_size"):
+        if getattr(spec, name) % tp_size:
+            raise ValueError(f"{name}={getattr(spec, name)} is not divisible by tp_size={tp_size}")
+    if (spec.intermediate_size // tp_size) % max(spec.group_size, 128):
+        raise ValueError("row-parallel shard of the down projection must be a multiple of the group size (and of 128)")
+    if (spec.num_heads // tp_size * spec.head_dim) % max(spec.group_size, 128):
+        raise ValueError("row-parallel shard of the o projection must be a multiple of the group size (and of 128)")
+    return dataclasses.replace(spec, num_heads=spec.num_heads // tp_size, num_kv_heads=spec.num_kv_heads // tp_size,
+                               intermediate_size=spec.intermediate_size // tp_size, tp_size=tp_size, tp_rank=tp_rank)
+
+
+def shard_awq_column(qweight, qzeros, scales, tp_rank: int, tp_size: int):
+    """Column-parallel shard (output features): AWQ qweight [K, N/8], qzeros [G, N/8], scales [G, N]."""
+    n8 = qweight.shape[1]
+    assert n8 % tp_size == 0 and (n8 // tp_size * 8) % 16 == 0, "column shard must be a multiple of 16 outputs"
+    w = n8 // tp_size
+    sl8 = slice(tp_rank * w, (tp_rank + 1) * w)
+    sl = slice(tp_rank * w * 8, (tp_rank + 1) * w * 8)
+    return qweight[:, sl8].contiguous(), qzeros[:, sl8].contiguous(), scales[:, sl].contiguous()
+
+
+def shard_awq_row(qweight, qzeros, scales, tp_rank: int, tp_size: int, group_size: int):
+    """Row-parallel shard (input features): rows of qweight, whole groups of qzeros/scales."""
+    K, G = qweight.shape[0], qzeros.shape[0]
+    assert K % tp_size == 0 and (K // tp_size) % group_size == 0, "row shard must be whole quantisation groups"
+    k, g = K // tp_size, G // tp_size
+    return (qweight[tp_rank * k:(tp_rank + 1) * k].contiguous(), qzeros[tp_rank * g:(tp_rank + 1) * g].contiguous(),
+            scales[tp_rank * g:(tp_rank + 1) * g].contiguous())

@@ -41,6 +41,8 @@ class Qwen3Spec:
     num_blocks: int = 64
     max_batch: int = 1
     max_seq_len: int = 1024
+    tp_size: int = 1      # with tp_size > 1 the head counts and intermediate_size below are this rank's shares
+    tp_rank: int = 0
 
     @staticmethod
     def qwen3_8b(**kw):
@@ -74,11 +76,16 @@ class QuantizedQwen3ForCausalLM:
         cfg = Qwen3Config(spec.hidden_size, spec.num_layers, spec.num_heads, spec.num_kv_heads, spec.head_dim,
                           spec.intermediate_size, spec.vocab_size, spec.rms_norm_eps, spec.max_position, spec.group_size,
                           int(spec.qk_norm), int(spec.tie_word_embeddings), spec.kv_cache_dtype, spec.block_size,
-                          spec.num_blocks, spec.max_batch, spec.max_seq_len)
+                          spec.num_blocks, spec.max_batch, spec.max_seq_len, spec.tp_size, spec.tp_rank)
         self._h = C.c_void_p()
         check(lib.vmx_qwen3_create(C.byref(cfg), C.byref(self._h)))
         cs = torch.from_numpy(rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta)).to(self.device)
         self.load_tensor(T_COS_SIN, 0, cs)
+
+    def set_comm(self, comm) -> None:
+        """Attach a vllm_rust_amd.parallel.Communicator (kept alive by the model)."""
+        self._comm = comm
+        check(lib.vmx_qwen3_set_comm(self._h, comm.handle if comm is not None else None))
 
     def close(self):
         if self._h:
@@ -128,7 +135,8 @@ class QuantizedQwen3ForCausalLM:
         emb = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.5).to(torch.bfloat16)
         self.load_tensor(T_EMBED, 0, emb); keep("embed", emb)
         if not s.tie_word_embeddings:
-            head = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.05).to(torch.bfloat16)
+            rows = s.vocab_size // s.tp_size if s.tp_size > 1 else s.vocab_size
+            head = (torch.randn((rows, s.hidden_size), device=self.device, generator=g) * 0.05).to(torch.bfloat16)
             self.load_tensor(T_LM_HEAD, 0, head); keep("lm_head", head)
             del head
         del emb
