@@ -156,6 +156,19 @@ int vmx_rms_norm_bf16(uint16_t *out, const uint16_t *x, uint16_t *residual, cons
 int vmx_rope_neox_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin_cache,
                        int tokens, int rot_dim, int head_size, int num_heads, int num_kv_heads, void *stream);
 
+/* Replaces fused_qknorm_rope_bf16 (crates/core/kernels/qknorm_rope.cu:139-196): per-head RMSNorm (eps 1e-6) then NeoX
+ * RoPE with ONE rounding at the store; q/k laid out [batch, heads, seq, head_dim]; cos/sin f32 [max_pos, head_dim/2];
+ * positions i32 [batch, seq]. */
+int vmx_fused_qknorm_rope_bf16(uint16_t *out_q, uint16_t *out_k, const uint16_t *in_q, const uint16_t *in_k,
+                               const uint16_t *q_weight, const uint16_t *k_weight, const float *cos_cache,
+                               const float *sin_cache, const int32_t *positions, int batch, int num_q_heads,
+                               int num_kv_heads, int seq_len, int head_dim, void *stream);
+
+/* Replace add_bf16 and gelu_and_mul_bf16 / gelu_tanh_and_mul_bf16 (crates/core/kernels/activations.cu:16-31,37-77,96-110);
+ * gate and up are separate tensors here (the reference's packed [2d] row is gate = in, up = in + d). */
+int vmx_add_bf16(uint16_t *out, const uint16_t *a, const uint16_t *b, int64_t n, void *stream);
+int vmx_gelu_and_mul_bf16(uint16_t *out, const uint16_t *gate, const uint16_t *up, int64_t n, int tanh_approx, void *stream);
+
 /* Replaces silu_and_mul_separate_bf16 (crates/core/kernels/activations.cu:148-164). */
 int vmx_silu_and_mul_bf16(uint16_t *out, const uint16_t *gate, const uint16_t *up, int64_t n, void *stream);
 

@@ -147,3 +147,43 @@ def test_paged_attention(gpu, H, KVH, D, kv_dtype):
             assert np.abs(g - r).max() <= (1e-3 + 2 ** -7) * np.abs(r).max(), (window, psize)
             rel = np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum())
             assert rel <= 1e-3 + 2 ** -8
+
+
+def test_fused_qknorm_rope_add_gelu(gpu):
+    from oracle import oracle as orc
+    from vllm_rust_amd._lib import lib, check
+    vmx, torch = gpu
+    rng = np.random.default_rng(11)
+    Bt, Hq, Hkv, S, D = 2, 4, 2, 3, 128
+    q = orc.f32_to_bf16(rng.standard_normal((Bt, Hq, S, D)).astype(np.float32))
+    k = orc.f32_to_bf16(rng.standard_normal((Bt, Hkv, S, D)).astype(np.float32))
+    qw = orc.f32_to_bf16(1 + 0.1 * rng.standard_normal(D).astype(np.float32)); kw = orc.f32_to_bf16(1 + 0.1 * rng.standard_normal(D).astype(np.float32))
+    pos = rng.integers(0, 100, size=(Bt, S)).astype(np.int32)
+    inv = 1.0 / (1e6 ** (np.arange(0, D, 2) / D)); ang = np.arange(128)[:, None] * inv[None, :]
+    cos, sin = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    oq = torch.empty((Bt, Hq, S, D), dtype=torch.bfloat16, device="cuda"); ok = torch.empty((Bt, Hkv, S, D), dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    d = lambda a: torch.from_numpy(a).cuda()
+    tq, tk, tqw, tkw, tc, ts, tp = _bf(torch, q), _bf(torch, k), _bf(torch, qw), _bf(torch, kw), d(cos), d(sin), d(pos)
+    check(lib.vmx_fused_qknorm_rope_bf16(oq.data_ptr(), ok.data_ptr(), tq.data_ptr(), tk.data_ptr(), tqw.data_ptr(), tkw.data_ptr(),
+                                         tc.data_ptr(), ts.data_ptr(), tp.data_ptr(), Bt, Hq, Hkv, S, D, st))
+    def ref(x, w):  # qknorm_rope.cu:47-136 in float64, one rounding
+        xf = orc.bf16_to_f32(x).astype(np.float64); wf = orc.bf16_to_f32(w).astype(np.float64)
+        n = xf / np.sqrt((xf ** 2).mean(-1, keepdims=True) + 1e-6) * wf
+        c = cos[pos][:, None, :, :]; s_ = sin[pos][:, None, :, :]
+        lo, hi = n[..., :D // 2], n[..., D // 2:]
+        return np.concatenate([lo * c - hi * s_, hi * c + lo * s_], -1)
+    for got, exp in ((oq, ref(q, qw)), (ok, ref(k, kw))):
+        g = orc.bf16_to_f32(_u16(torch, got))
+        assert np.abs(g - exp).max() <= 2 ** -7 * np.abs(exp).max()
+    a = orc.f32_to_bf16(rng.standard_normal(5000).astype(np.float32) * 3); b = orc.f32_to_bf16(rng.standard_normal(5000).astype(np.float32))
+    out = torch.empty(5000, dtype=torch.bfloat16, device="cuda"); ta, tb = _bf(torch, a), _bf(torch, b)
+    check(lib.vmx_add_bf16(out.data_ptr(), ta.data_ptr(), tb.data_ptr(), 5000, st))
+    assert np.array_equal(_u16(torch, out), orc.f32_to_bf16(orc.bf16_to_f32(a) + orc.bf16_to_f32(b)))
+    from math import erf
+    af, bf = orc.bf16_to_f32(a).astype(np.float64), orc.bf16_to_f32(b).astype(np.float64)
+    for tanh_mode, fn in ((0, lambda x: x * 0.5 * (1 + np.vectorize(erf)(x / np.sqrt(2)))),
+                          (1, lambda x: 0.5 * x * (1 + np.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3))))):
+        check(lib.vmx_gelu_and_mul_bf16(out.data_ptr(), ta.data_ptr(), tb.data_ptr(), 5000, tanh_mode, st))
+        g = orc.bf16_to_f32(_u16(torch, out)); exp = fn(af) * bf
+        assert np.abs(g - exp).max() <= 2 ** -7 * np.abs(exp).max() + 1e-6

@@ -51,6 +51,9 @@ _SIGS = {
     "vmx_moe_align_block_size": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vmx_moe_int4_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vmx_moe_int4_forward": (_i, [_p] * 6 + [_i] * 6 + [_p, _sz, _p]),
+    "vmx_fused_qknorm_rope_bf16": (_i, [_p] * 9 + [_i] * 5 + [_p]),
+    "vmx_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
+    "vmx_gelu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "vmx_rms_norm_bf16": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _p]),
     "vmx_rope_neox_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vmx_silu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _p]),

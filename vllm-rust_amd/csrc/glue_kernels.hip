@@ -308,3 +308,89 @@ int vmx_argmax_keys_to_ids(const unsigned long long *keys, int32_t *out_ids, int
     VMX_CHECK_LAUNCH("argmax(keys_to_ids)");
     return VMX_OK;
 }
+
+// ---------------------------------------------------------------- more elementwise / fused glue
+namespace {
+
+// grid = batch*(Hq+Hkv)*seq heads, block 64: per-head RMSNorm (eps 1e-6) and NeoX RoPE in one pass with a
+// single rounding at the store (crates/core/kernels/qknorm_rope.cu:47-136).  Layout [batch, heads, seq, hd].
+__global__ __launch_bounds__(64) void fused_qknorm_rope_kernel(uint16_t *__restrict__ out_q, uint16_t *__restrict__ out_k,
+                                                                const uint16_t *__restrict__ in_q, const uint16_t *__restrict__ in_k,
+                                                                const uint16_t *__restrict__ qw, const uint16_t *__restrict__ kw,
+                                                                const float *__restrict__ cos_cache, const float *__restrict__ sin_cache,
+                                                                const int32_t *__restrict__ positions, int batch, int Hq, int Hkv, int seq,
+                                                                int hd) {
+    const int total_q = batch * Hq * seq;
+    int id = blockIdx.x;
+    const bool is_q = id < total_q;
+    if (!is_q) id -= total_q;
+    const int H = is_q ? Hq : Hkv;
+    const int s = id % seq, b = id / (H * seq);
+    const int64_t off = (int64_t)id * hd;  // ((b*H + head)*seq + s)*hd == id*hd
+    const uint16_t *in = (is_q ? in_q : in_k) + off;
+    uint16_t *out = (is_q ? out_q : out_k) + off;
+    const uint16_t *w = is_q ? qw : kw;
+    const int half = hd >> 1, lane = threadIdx.x;
+    float ss = 0.f;
+    for (int i = lane; i < hd; i += 64) { const float v = vmx_bf16_to_f32(in[i]); ss += v * v; }
+    ss = vmx_wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)hd + 1e-6f);
+    const int pos = positions[b * seq + s];
+    const float *cr = cos_cache + (int64_t)pos * half, *sr = sin_cache + (int64_t)pos * half;
+    for (int i = lane; i < half; i += 64) {
+        const float lo = vmx_bf16_to_f32(in[i]) * inv * vmx_bf16_to_f32(w[i]);
+        const float hi = vmx_bf16_to_f32(in[i + half]) * inv * vmx_bf16_to_f32(w[i + half]);
+        const float c = cr[i], sn = sr[i];
+        out[i] = vmx_f32_to_bf16(lo * c - hi * sn);
+        out[i + half] = vmx_f32_to_bf16(hi * c + lo * sn);
+    }
+}
+
+// mode 0: out = a + b;  1: gelu_erf(a) * b;  2: gelu_tanh(a) * b   (activations.cu:16-31,37-77, add_bf16 :96-110)
+__global__ __launch_bounds__(256) void binary_bf16_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ a,
+                                                           const uint16_t *__restrict__ b, int64_t n, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float x = vmx_bf16_to_f32(a[i]), y = vmx_bf16_to_f32(b[i]);
+        float r;
+        if (mode == 0) r = x + y;
+        else if (mode == 1) r = (x * 0.5f * (1.0f + erff(x * 0.7071067811865476f))) * y;
+        else r = (0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)))) * y;
+        out[i] = vmx_f32_to_bf16(r);
+    }
+}
+
+}  // namespace
+
+extern "C" int vmx_fused_qknorm_rope_bf16(uint16_t *out_q, uint16_t *out_k, const uint16_t *in_q, const uint16_t *in_k,
+                                          const uint16_t *q_weight, const uint16_t *k_weight, const float *cos_cache,
+                                          const float *sin_cache, const int32_t *positions, int batch, int num_q_heads, int num_kv_heads,
+                                          int seq_len, int head_dim, void *stream) {
+    VMX_REQUIRE(out_q && out_k && in_q && in_k && q_weight && k_weight && cos_cache && sin_cache && positions,
+                "fused_qknorm_rope: null pointer");
+    VMX_REQUIRE(batch >= 0 && seq_len >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0 && head_dim % 2 == 0,
+                "fused_qknorm_rope: bad geometry");
+    const int total = batch * (num_q_heads + num_kv_heads) * seq_len;
+    if (total == 0) return VMX_OK;
+    hipLaunchKernelGGL(fused_qknorm_rope_kernel, dim3(total), dim3(64), 0, vmx_stream(stream), out_q, out_k, in_q, in_k, q_weight,
+                       k_weight, cos_cache, sin_cache, positions, batch, num_q_heads, num_kv_heads, seq_len, head_dim);
+    VMX_CHECK_LAUNCH("fused_qknorm_rope");
+    return VMX_OK;
+}
+
+static int launch_binary(uint16_t *out, const uint16_t *a, const uint16_t *b, int64_t n, int mode, void *stream, const char *who) {
+    VMX_REQUIRE(out && a && b && n >= 0, "%s: bad arguments", who);
+    if (n == 0) return VMX_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(binary_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, vmx_stream(stream), out, a, b, n, mode);
+    VMX_CHECK_LAUNCH(who);
+    return VMX_OK;
+}
+
+extern "C" int vmx_add_bf16(uint16_t *out, const uint16_t *a, const uint16_t *b, int64_t n, void *stream) {
+    return launch_binary(out, a, b, n, 0, stream, "add_bf16");
+}
+
+extern "C" int vmx_gelu_and_mul_bf16(uint16_t *out, const uint16_t *gate, const uint16_t *up, int64_t n, int tanh_approx, void *stream) {
+    return launch_binary(out, gate, up, n, tanh_approx ? 2 : 1, stream, "gelu_and_mul");
+}
