@@ -179,6 +179,17 @@ size_t vmx_argmax_workspace_bytes(int rows, int vocab);
 int vmx_argmax_bf16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace,
                     size_t workspace_bytes, void *stream);
 
+/* Replace temperature_scale_bf16, softmax_to_probs(_f32) and top_k_top_p_sample(_per_seq)
+ * (crates/core/kernels/sampling.cu:102-190,197-293,351-520; callers sampling/gpu.rs:834-1094).
+ * probs f32 [rows, vocab]; rand_vals f32 [rows] uniform in [0,1); top_k 0 = off, top_p 1.0 = off; the
+ * per-sequence arrays (device, may be NULL) override the scalars.  Same thresholds as the reference
+ * (k-th largest distinct value; distinct values accumulated from the top until top_p * sum); the draw is the
+ * first index in vocabulary order whose running filtered sum exceeds rand * sum. */
+int vmx_temperature_scale_bf16(uint16_t *logits, float inv_temperature, int rows, int vocab, void *stream);
+int vmx_softmax_to_probs(float *probs, const void *logits, int logits_dtype, int rows, int vocab, void *stream);
+int vmx_top_k_top_p_sample(int32_t *out_ids, const float *probs, const float *rand_vals, const int32_t *top_k_per_seq,
+                           const float *top_p_per_seq, int top_k, float top_p, int rows, int vocab, void *stream);
+
 /* Replaces reshape_and_cache_bf16 and the FP8 quantise branch of CacheEngine::write_batch
  * (crates/core/kernels/cache_ops.cu:28-62; kv_cache/cache_engine.rs:196-247):
  * caches [blocks, block_size, kv_heads, head_dim]; kv_dtype VMX_KV_AUTO (bf16 copy) or

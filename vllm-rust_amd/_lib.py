@@ -54,6 +54,9 @@ _SIGS = {
     "vmx_fused_qknorm_rope_bf16": (_i, [_p] * 9 + [_i] * 5 + [_p]),
     "vmx_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "vmx_gelu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "vmx_temperature_scale_bf16": (_i, [_p, _f, _i, _i, _p]),
+    "vmx_softmax_to_probs": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vmx_top_k_top_p_sample": (_i, [_p, _p, _p, _p, _p, _i, _f, _i, _i, _p]),
     "vmx_rms_norm_bf16": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _p]),
     "vmx_rope_neox_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vmx_silu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _p]),
