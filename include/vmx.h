@@ -89,6 +89,16 @@ int vmx_iq_subdots_i32(int ggml_type, const void *w, const int8_t *aq, int32_t *
 int vmx_gather_dequant_q6k_f32(const void *blocks, const int32_t *ids, float *out, int num_ids, int dim,
                                int num_embeddings, void *stream);
 
+/* GGML legacy / K-quant tensors (GgufLinear -> candle QMatMul, crates/core/src/quantization/gguf/mod.rs:114-258;
+ * the arithmetic is third-party (candle-kernels 0.10.2), so these follow the public ggml block specs and parity is
+ * tolerance-only).  Supported type ids: 2 Q4_0, 8 Q8_0, 11 Q3_K, 12 Q4_K, 14 Q6_K. */
+int vmx_ggml_type_size(int ggml_type);    /* bytes per block (I-quant ids included), -1 if unknown */
+int vmx_ggml_block_elems(int ggml_type);  /* 32 or 256 */
+/* qt.dequantize (gguf/mod.rs:284): n_blocks blocks -> f32. */
+int vmx_kquant_dequantize_f32(int ggml_type, const void *blocks, float *out, int64_t n_blocks, void *stream);
+/* qmm.forward for small m (gguf/mod.rs:197): y[m, n_out] = x[m, n_in] @ dequant(W)^T, f32 in/out, 1 <= m <= 8. */
+int vmx_kquant_gemv_f32(int ggml_type, const void *w, const float *x, float *y, int n_out, int n_in, int m, void *stream);
+
 /* ------------------------------------------------------- AWQ / GPTQ int4 */
 
 /* Replaces awq_to_gptq_qweight_int4 (crates/core/kernels/marlin_gemm.cu:491;

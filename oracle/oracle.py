@@ -70,6 +70,10 @@ for _name, _res, _args in [
     ("orc_reshape_and_cache", None, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
     ("orc_paged_attention_v2", None, [C.c_void_p] * 5 + [C.c_float, C.c_int64] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
     ("orc_q6k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q4_0_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q8_0_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q4_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q3_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_fp8_gemm_bf16", None, [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_void_p]),
     ("orc_fp8_quant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("orc_fp8_dequant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
@@ -329,4 +333,20 @@ def fp8_dequant_bf16(q_u8, scale, per_row: bool) -> np.ndarray:
     q = _c(q_u8, np.uint8); sc = _c(scale, np.float32)
     out = np.empty(q.shape, np.uint16)
     _lib.orc_fp8_dequant_bf16(_p(q), _p(sc), q.shape[0], q.shape[1], int(per_row), _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- GGML legacy / K-quants
+GGML_BLOCK = {2: (18, 32), 8: (34, 32), 11: (110, 256), 12: (144, 256), 14: (210, 256)}
+
+
+def ggml_dequant(ggml_type: int, data) -> np.ndarray:
+    ts, qk = GGML_BLOCK[ggml_type]
+    data = _c(data, np.uint8).reshape(-1)
+    assert data.size % ts == 0
+    nb = data.size // ts
+    out = np.empty(nb * qk, np.float32)
+    fn = {2: _lib.orc_q4_0_dequant, 8: _lib.orc_q8_0_dequant, 11: _lib.orc_q3_k_dequant, 12: _lib.orc_q4_k_dequant,
+          14: _lib.orc_q6k_dequant}[ggml_type]
+    fn(_p(data), nb, _p(out))
     return out

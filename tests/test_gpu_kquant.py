@@ -1,0 +1,71 @@
+"""K-quant / legacy GGML blocks: GPU dequant == CPU oracle (ggml loop restatement) bit for bit, GEMV vs float64
+product of the dequantised weight.  No golden vectors exist for these formats in the reference (third-party
+candle arithmetic): parity unpinned."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TYPES = {2: "Q4_0", 8: "Q8_0", 11: "Q3_K", 12: "Q4_K", 14: "Q6_K"}
+D_OFF = {2: 0, 8: 0, 11: 108, 12: 0, 14: 208}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import vllm_rust_amd as vmx
+    assert torch.cuda.is_available()
+    vmx.init(0)
+    return vmx, torch
+
+
+def _blocks(rng, t, n):
+    from oracle import oracle as orc
+    ts, _ = orc.GGML_BLOCK[t]
+    b = rng.integers(0, 256, size=(n, ts), dtype=np.uint8)
+    for off in ([D_OFF[t]] + ([2] if t == 12 else [])):       # finite, small f16 scales
+        b[:, off] = 0
+        b[:, off + 1] = rng.integers(0x24, 0x2C, size=n)
+    return b.reshape(-1)
+
+
+@pytest.mark.parametrize("t", sorted(TYPES))
+def test_dequant_bit_exact_and_gemv(gpu, t):
+    from oracle import oracle as orc
+    from vllm_rust_amd._lib import lib, check
+    vmx, torch = gpu
+    rng = np.random.default_rng(t)
+    ts, qk = orc.GGML_BLOCK[t]
+    assert lib.vmx_ggml_type_size(t) == ts and lib.vmx_ggml_block_elems(t) == qk
+    n_out, n_in = 77, 1024
+    raw = _blocks(rng, t, n_out * n_in // qk)
+    ref = orc.ggml_dequant(t, raw)
+    w = torch.from_numpy(raw).cuda()
+    out = torch.empty(ref.size, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.vmx_kquant_dequantize_f32(t, w.data_ptr(), out.data_ptr(), raw.size // ts, st))
+    assert np.array_equal(out.cpu().numpy(), ref)
+    for m in (1, 3, 8):
+        x = rng.standard_normal((m, n_in)).astype(np.float32)
+        y = torch.empty((m, n_out), dtype=torch.float32, device="cuda")
+        xd = torch.from_numpy(x).cuda()
+        check(lib.vmx_kquant_gemv_f32(t, w.data_ptr(), xd.data_ptr(), y.data_ptr(), n_out, n_in, m, st))
+        exp = x.astype(np.float64) @ ref.reshape(n_out, n_in).astype(np.float64).T
+        got = y.cpu().numpy()
+        assert np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum()) <= 1e-5
+
+
+def test_q6k_matches_reference_gather_kernel_path(gpu):
+    """The Q6_K formula is the one the reference restates in-tree (gather_dequant.cu): the generic dequant and the
+    gather entry point must agree exactly."""
+    from vllm_rust_amd._lib import lib, check
+    vmx, torch = gpu
+    rng = np.random.default_rng(3)
+    rows, dim = 10, 512
+    raw = _blocks(rng, 14, rows * dim // 256)
+    w = torch.from_numpy(raw).cuda()
+    full = torch.empty(rows * dim, dtype=torch.float32, device="cuda")
+    check(lib.vmx_kquant_dequantize_f32(14, w.data_ptr(), full.data_ptr(), rows * dim // 256, torch.cuda.current_stream().cuda_stream))
+    ids = torch.arange(rows, dtype=torch.int32, device="cuda")
+    g = vmx.gather_dequant_q6k(w, ids, dim, rows)
+    assert torch.equal(g.reshape(-1), full)

@@ -37,6 +37,10 @@ _SIGS = {
     "vmx_iq_matmul_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vmx_iq_subdots_i32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
     "vmx_gather_dequant_q6k_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "vmx_ggml_type_size": (_i, [_i]),
+    "vmx_ggml_block_elems": (_i, [_i]),
+    "vmx_kquant_dequantize_f32": (_i, [_i, _p, _p, _i64, _p]),
+    "vmx_kquant_gemv_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
     "vmx_awq_to_gptq_qweight": (_i, [_p, _p, _i, _i, _p]),
     "vmx_awq_repack_nibbles": (_i, [_p, _p, _i64, _p]),
     "vmx_int4_packed_bytes": (_sz, [_i, _i, _i]),

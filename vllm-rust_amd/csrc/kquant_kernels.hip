@@ -1,0 +1,183 @@
+// GGML K-quant / legacy block formats: dequantisation and a dequant-fused small-M GEMV.
+// In the reference these tensors go through Candle's QMatMul (crates/core/src/quantization/gguf/mod.rs:114-258),
+// whose kernels live in candle-kernels 0.10.2 and are not part of the reference tree; the block layouts and
+// decode formulas below are the public ggml ones (ggml-common.h / ggml-quants.c): Q4_0 18 B/32, Q8_0 34 B/32,
+// Q3_K 110 B/256, Q4_K 144 B/256, Q6_K 210 B/256 (Q6_K is also restated in crates/core/kernels/gather_dequant.cu:52-82).
+// The GEMV multiplies the f32 activations with the exactly dequantised weights in f32 (no q8_1/Q8_K
+// activation quantisation step as in ggml's mul_mat_vec_q): parity with the third-party kernel is
+// tolerance-only by construction (the reference's own gate is rel-RMS < 3 % against a dense product).
+#include "vmx_internal.h"
+
+namespace {
+
+struct __attribute__((packed, aligned(2))) u16a2 { uint16_t v; };
+__device__ __forceinline__ float ldh(const uint8_t *p) { return vmx_f16_to_f32(reinterpret_cast<const u16a2 *>(p)->v); }
+
+template <int T> struct KTraits;
+template <> struct KTraits<2> { static constexpr int TS = 18, QK = 32; };    // Q4_0
+template <> struct KTraits<8> { static constexpr int TS = 34, QK = 32; };    // Q8_0
+template <> struct KTraits<11> { static constexpr int TS = 110, QK = 256; }; // Q3_K
+template <> struct KTraits<12> { static constexpr int TS = 144, QK = 256; }; // Q4_K
+template <> struct KTraits<14> { static constexpr int TS = 210, QK = 256; }; // Q6_K
+
+// Decode the 32 weights of sub-block s (s < QK/32) of block b into f[32] (element order of the block).
+template <int T> __device__ __forceinline__ void kdecode32(const uint8_t *b, int s, float f[32]) {
+    if constexpr (T == 2) {
+        const float d = ldh(b);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int q = b[2 + j];
+            f[j] = (float)((q & 0xF) - 8) * d;
+            f[j + 16] = (float)((q >> 4) - 8) * d;
+        }
+    } else if constexpr (T == 8) {
+        const float d = ldh(b);
+#pragma unroll
+        for (int j = 0; j < 32; j++) f[j] = (float)(int8_t)b[2 + j] * d;
+    } else if constexpr (T == 12) {  // d f16 @0, dmin f16 @2, scales[12] @4, qs[128] @16
+        const float d = ldh(b), dmin = ldh(b + 2);
+        const uint8_t *sc = b + 4;
+        int scv, mv;
+        if (s < 4) { scv = sc[s] & 63; mv = sc[s + 4] & 63; }
+        else { scv = (sc[s + 4] & 0xF) | ((sc[s - 4] >> 6) << 4); mv = (sc[s + 4] >> 4) | ((sc[s] >> 6) << 4); }
+        const float dl = d * (float)scv, ml = dmin * (float)mv;
+        const uint8_t *q = b + 16 + 32 * (s >> 1);
+        const int sh = (s & 1) * 4;
+#pragma unroll
+        for (int l = 0; l < 32; l++) f[l] = dl * (float)((q[l] >> sh) & 0xF) - ml;
+    } else if constexpr (T == 14) {  // ql[128] @0, qh[64] @128, scales i8[16] @192, d f16 @208
+        const float d = ldh(b + 208);
+        const int half = s >> 2, quarter = s & 3;  // 128-weight half; 32-weight group inside it
+        const uint8_t *ql = b + 64 * half + 32 * (quarter & 1), *qh = b + 128 + 32 * half;
+        const int8_t *scs = reinterpret_cast<const int8_t *>(b + 192) + 8 * half + 2 * quarter;
+        const int lsh = (quarter >> 1) * 4, hsh = 2 * quarter;
+#pragma unroll
+        for (int l = 0; l < 32; l++) {
+            const int q = (int)(((ql[l] >> lsh) & 0xF) | (((qh[l] >> hsh) & 3) << 4)) - 32;
+            f[l] = d * (float)scs[l >> 4] * (float)q;
+        }
+    } else {  // Q3_K: hmask[32] @0, qs[64] @32, scales[12] @96, d f16 @108
+        const float d = ldh(b + 108);
+        uint32_t a0 = b[96] | (b[97] << 8) | (b[98] << 16) | ((uint32_t)b[99] << 24);
+        uint32_t a1 = b[100] | (b[101] << 8) | (b[102] << 16) | ((uint32_t)b[103] << 24);
+        const uint32_t tmp = b[104] | (b[105] << 8) | (b[106] << 16) | ((uint32_t)b[107] << 24);
+        uint32_t aux[4];
+        aux[2] = ((a0 >> 4) & 0x0f0f0f0fu) | (((tmp >> 4) & 0x03030303u) << 4);
+        aux[3] = ((a1 >> 4) & 0x0f0f0f0fu) | (((tmp >> 6) & 0x03030303u) << 4);
+        aux[0] = (a0 & 0x0f0f0f0fu) | (((tmp >> 0) & 0x03030303u) << 4);
+        aux[1] = (a1 & 0x0f0f0f0fu) | (((tmp >> 2) & 0x03030303u) << 4);
+        // sub-block s: 128-half n = s>>2, j = s&3 (shift 2j, mask bit 4n + j), 16-weight scales 2s and 2s+1
+        const int n = s >> 2, j = s & 3;
+        const uint8_t *q = b + 32 + 32 * n, *hm = b;
+        const int m = 1 << (4 * n + j);
+#pragma unroll
+        for (int l = 0; l < 32; l++) {
+            const int si = 2 * s + (l >> 4);
+            const int scale = (int)(int8_t)((aux[si >> 2] >> (8 * (si & 3))) & 0xFF) - 32;
+            const int v = ((q[l] >> (2 * j)) & 3) - ((hm[l] & m) ? 0 : 4);
+            f[l] = d * (float)scale * (float)v;
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void kdequant_kernel(const uint8_t *__restrict__ blocks, float *__restrict__ out, int64_t n_blocks) {
+    constexpr int SUB = KTraits<T>::QK / 32;
+    const int64_t total = n_blocks * SUB;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float f[32];
+        kdecode32<T>(blocks + (i / SUB) * KTraits<T>::TS, (int)(i % SUB), f);
+        float4 *y = reinterpret_cast<float4 *>(out + i * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+    }
+}
+
+// y[m, o] = sum_k x[m, k] * dequant(W)[o, k]; wave per output row, lane per 32-weight sub-block.
+template <int T, int MT>
+__global__ __launch_bounds__(256) void kgemv_kernel(const uint8_t *__restrict__ w, const float *__restrict__ x, float *__restrict__ y,
+                                                     int n_out, int n_in, int m) {
+    constexpr int SUB = KTraits<T>::QK / 32, TS = KTraits<T>::TS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nsub = n_in / 32, nblk = n_in / KTraits<T>::QK;
+    for (int row = blockIdx.x * 4 + wave; row < n_out; row += gridDim.x * 4) {
+        float acc[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) acc[mi] = 0.f;
+        for (int g = lane; g < nsub; g += 64) {
+            float f[32];
+            kdecode32<T>(w + ((int64_t)row * nblk + g / SUB) * TS, g % SUB, f);
+#pragma unroll
+            for (int mi = 0; mi < MT; mi++) {
+                if (mi < m) {
+                    const float4 *xp = reinterpret_cast<const float4 *>(x + (int64_t)mi * n_in + g * 32);
+                    float a = acc[mi];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const float4 v = xp[k];
+                        a = fmaf(f[4 * k], v.x, a); a = fmaf(f[4 * k + 1], v.y, a); a = fmaf(f[4 * k + 2], v.z, a); a = fmaf(f[4 * k + 3], v.w, a);
+                    }
+                    acc[mi] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; mi++) {
+            const float v = vmx_wave_sum(acc[mi]);
+            if (lane == 0 && mi < m) y[(int64_t)mi * n_out + row] = v;
+        }
+    }
+}
+
+}  // namespace
+
+#define K_DISPATCH(type, CALL)                                                                  \
+    switch (type) {                                                                             \
+        case 2: CALL(2); break;                                                                 \
+        case 8: CALL(8); break;                                                                 \
+        case 11: CALL(11); break;                                                               \
+        case 12: CALL(12); break;                                                               \
+        case 14: CALL(14); break;                                                               \
+        default:                                                                                \
+            vmx_set_error("unsupported ggml type id %d (supported: 2 Q4_0, 8 Q8_0, 11 Q3_K, 12 Q4_K, 14 Q6_K)", type); \
+            return VMX_EUNSUPPORTED;                                                            \
+    }
+
+extern "C" int vmx_ggml_type_size(int t) {
+    switch (t) { case 2: return 18; case 8: return 34; case 11: return 110; case 12: return 144; case 14: return 210; default: return vmx_iq_type_size(t); }
+}
+
+extern "C" int vmx_ggml_block_elems(int t) { return (t == 2 || t == 8) ? 32 : 256; }
+
+extern "C" int vmx_kquant_dequantize_f32(int ggml_type, const void *blocks, float *out, int64_t n_blocks, void *stream) {
+    VMX_REQUIRE(blocks && out && n_blocks >= 0, "kquant_dequantize: bad arguments");
+    if (n_blocks == 0) return VMX_OK;
+    int64_t g = (n_blocks * 8 + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+#define CALL(T) hipLaunchKernelGGL((kdequant_kernel<T>), dim3((unsigned)g), dim3(256), 0, vmx_stream(stream), (const uint8_t *)blocks, out, n_blocks)
+    K_DISPATCH(ggml_type, CALL)
+#undef CALL
+    VMX_CHECK_LAUNCH("kquant_dequantize");
+    return VMX_OK;
+}
+
+extern "C" int vmx_kquant_gemv_f32(int ggml_type, const void *w, const float *x, float *y, int n_out, int n_in, int m, void *stream) {
+    VMX_REQUIRE(w && x && y, "kquant_gemv: null pointer");
+    VMX_REQUIRE(m >= 1 && m <= 8, "kquant_gemv: m (%d) must be in 1..8 (larger m takes the dequant + GEMM path)", m);
+    VMX_REQUIRE(n_out > 0 && n_in > 0 && n_in % vmx_ggml_block_elems(ggml_type) == 0, "kquant_gemv: n_in (%d) not a multiple of the block size",
+                n_in);
+    int grid = (n_out + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipStream_t st = vmx_stream(stream);
+#define CALL(T)                                                                                                                  \
+    do {                                                                                                                         \
+        if (m == 1) hipLaunchKernelGGL((kgemv_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, n_in, m); \
+        else if (m <= 4) hipLaunchKernelGGL((kgemv_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, n_in, m); \
+        else hipLaunchKernelGGL((kgemv_kernel<T, 8>), dim3(grid), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, n_in, m);   \
+    } while (0)
+    K_DISPATCH(ggml_type, CALL)
+#undef CALL
+    VMX_CHECK_LAUNCH("kquant_gemv");
+    return VMX_OK;
+}
