@@ -333,6 +333,13 @@ int vmx_qwen3_load_tensor(vmx_qwen3 *m, int which, int layer, const void *src, s
 int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
                               const uint16_t *scales_f16, void *stream);
 
+/* Load one projection as a GGUF I-quant tensor (IqLinear, crates/core/src/quantization/gguf/mod.rs:262-377;
+ * GgufWeightLoader::load_linear :1612-1662): raw block bytes of the [out, in] weight, ggml_type one of the I-quant ids.
+ * A layer runs either on its int4 linears or, when all seven projections were loaded this way, on I-quant MMVQ
+ * (activations quantised to q8_1 per linear input). */
+int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int ggml_type, const void *blocks, size_t bytes,
+                             void *stream);
+
 /* One decode step: input_ids/positions/slot_mapping/seq_lens i32 [batch], block_tables i32
  * [batch, max_blocks_per_seq] (all device).  Writes greedy token ids to out_ids (device i32 [batch],
  * may be NULL) and, if logits_out != NULL, bf16 logits [batch, vocab] there. */

@@ -195,3 +195,38 @@ def test_tp_collective_path_world1_matches_plain_decode(gpu):
             comm.close()
     for (o0, l0), (o1, l1) in zip(*outs):
         assert torch.equal(o0, o1) and torch.equal(l0, l1)
+
+
+@pytest.mark.parametrize("kv_dtype", [0, 1])
+def test_iq_decoder_matches_oracle(gpu, kv_dtype):
+    """Every projection a GGUF I-quant (the Gemma-4-12B UD-IQ3_XXS type mix), optional FP8 KV cache."""
+    from oracle import oracle as orc
+    from tests.model_oracle import OracleQwen3
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache, T_KV_SCALES
+    vmx, torch = gpu
+    spec = _tiny_spec(hidden_size=256, intermediate_size=512, kv_cache_dtype=kv_dtype)
+    model = QuantizedQwen3ForCausalLM(spec)
+    types = {0: 18, 1: 22, 2: 18, 3: 21, 4: 18, 5: 17, 6: 23}     # q,k,v,o,gate,up,down
+    ck = model.load_synthetic_iq(types, seed=4, keep_host_copy=True)
+    ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta))
+    if kv_dtype == 1:
+        scales = torch.tensor([0.02, 0.03], dtype=torch.float32, device="cuda")
+        for li in range(spec.num_layers):
+            model.load_tensor(T_KV_SCALES, li, scales)
+        ref.kv_scales = (0.02, 0.03)
+    B, MB = 2, 8
+    bt = np.arange(B * MB, dtype=np.int32).reshape(B, MB)
+    ids = np.array([17, 900], np.int32)
+    for step in range(4):
+        pos = np.full(B, step, np.int32)
+        slots = (bt[:, 0] * spec.block_size + pos).astype(np.int32)
+        sl = pos + 1
+        logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        out = model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, pos, slots, bt, sl)), logits=logits)
+        torch.cuda.synchronize()
+        exp, exp_h, _ = ref.decode(ids, pos, slots, bt, sl)
+        got = orc.bf16_to_f32(_u16(torch, logits)); exp = orc.bf16_to_f32(exp)
+        rel = np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum())
+        assert rel <= (3e-2 if kv_dtype == 0 else 5e-2), (step, rel)
+        ids = out.cpu().numpy().astype(np.int32)
+    model.close()

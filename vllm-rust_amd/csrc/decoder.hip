@@ -255,6 +255,14 @@ struct Int4Linear {
 
 };
 
+// Mirrors IqLinear (crates/core/src/quantization/gguf/mod.rs:262-377): the raw GGUF block bytes of one I-quant
+// weight [out, in]; forward = q8_1-quantise the activations, then MMVQ (decode path, M <= 16).
+struct IqLinear {
+    int ggml_type = 0, in_features = 0, out_features = 0;
+    DevBuf raw;
+    bool loaded = false;
+};
+
 // Merged GPTQ-sequential staging of several AWQ linears that share the input (q|k|v, gate|up).
 struct MergeStage {
     DevBuf qweight, qzeros, scales;
@@ -263,6 +271,9 @@ struct MergeStage {
 
 struct Layer {
     Int4Linear qkv, o, gate_up, down;
+    IqLinear iq[7];  // q, k, v, o, gate, up, down as GGUF I-quants (alternative to the int4 linears)
+    bool iq_ready() const { for (const IqLinear &l : iq) if (!l.loaded) return false; return true; }
+    bool int4_ready() const { return qkv.loaded && o.loaded && gate_up.loaded && down.loaded; }
     MergeStage qkv_stage, gu_stage;
     DevBuf input_ln, post_ln, q_norm, k_norm;
     DevBuf k_cache, v_cache, kv_scales;  // kv_scales: f32[2] = {k_scale, v_scale}
@@ -275,7 +286,7 @@ struct vmx_qwen3 {
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
-    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys;
+    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8;
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
@@ -293,6 +304,20 @@ int run_linear(vmx_qwen3 *, const Int4Linear &l, const uint16_t *xin, float *par
     return l.forward_partial(xin, partial, M, st);
 }
 
+// IqLinear::forward_inner on the decode path (gguf/mod.rs:329-377): activations bf16 -> (exact) f32 -> q8_1 ...
+int iq_quantize(vmx_qwen3 *m, const uint16_t *x, int tokens, int k, hipStream_t st) {
+    int8_t *aq = (int8_t *)m->q8.p;
+    float *ad = (float *)((char *)m->q8.p + (((size_t)tokens * k + 255) & ~(size_t)255));
+    return vmx_quantize_q8_1_bf16(x, aq, ad, (int64_t)tokens * (k / 32), st);
+}
+
+// ... then MMVQ into row-stride ldy (f32; the consumer rounds to bf16, the cast back to the model dtype)
+int iq_forward(vmx_qwen3 *m, const IqLinear &l, float *y, int ldy, int tokens, hipStream_t st) {
+    const int8_t *aq = (const int8_t *)m->q8.p;
+    const float *ad = (const float *)((const char *)m->q8.p + (((size_t)tokens * l.in_features + 255) & ~(size_t)255));
+    return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq, ad, y, l.out_features, l.in_features, tokens, ldy, st);
+}
+
 // Row-parallel epilogue: red_bf16 = all_reduce_sum(bf16(sum of this rank's split-K slices)) — what composing the
 // reference's RowParallelLinear (distributed/parallel_layers.rs:275-305) with a quantized linear computes.
 int tp_reduce(vmx_qwen3 *m, const float *partial, int splits, int tokens, int hidden, hipStream_t st) {
@@ -307,7 +332,7 @@ int make_linear(Int4Linear &l, int K, int N, int group) {
     l.in_features = K;
     l.out_features = N;
     l.group = group;
-    return l.packed.alloc(vmx_int4_packed_bytes(K, N, group));
+    return VMX_OK;  // the tile stream is allocated when the weights arrive (stage_pack)
 }
 
 int stage_alloc(MergeStage &s, int K, int Ntot, int group) {
@@ -337,6 +362,8 @@ int stage_put(MergeStage &s, const uint32_t *qweight, const uint32_t *qzeros, co
 }
 
 int stage_pack(MergeStage &s, Int4Linear &l, hipStream_t st) {
+    if (!l.packed.p)
+        if (int rc0 = l.packed.alloc(vmx_int4_packed_bytes(l.in_features, l.out_features, l.group))) return rc0;
     int rc = vmx_int4_pack((const uint32_t *)s.qweight.p, (const uint16_t *)s.scales.p, (const uint32_t *)s.qzeros.p, l.packed.p,
                            l.in_features, l.out_features, l.group, st);
     if (rc) return rc;
@@ -419,6 +446,10 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     TRY(m->act.alloc((size_t)B * I * 2));
     TRY(m->logits.alloc((size_t)B * VL * 2));
     TRY(m->red_bf16.alloc((size_t)B * H * 2));
+    {   // q8_1 staging for I-quant linears: int8 [B][Kmax] + f32 [B][Kmax/32]
+        const size_t kmax = (size_t)(H > I ? (H > NO ? H : NO) : (I > NO ? I : NO));
+        TRY(m->q8.alloc(B * kmax + 256 + B * (kmax / 32) * 4));
+    }
     TRY(m->keys.alloc((size_t)B * 8));
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, hd, c.max_seq_len)));
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, VL)));
@@ -434,6 +465,7 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
 extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
     if (!m) return;
     for (auto &L : m->layers) {
+        for (IqLinear &l : L.iq) l.raw.release();
         for (DevBuf *b : {&L.qkv.packed, &L.o.packed, &L.gate_up.packed, &L.down.packed, &L.input_ln, &L.post_ln, &L.q_norm, &L.k_norm,
                           &L.k_cache, &L.v_cache, &L.kv_scales})
             b->release();
@@ -441,7 +473,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.gu_stage);
     }
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
-                      &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys})
+                      &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8})
         b->release();
     delete m;
 }
@@ -516,6 +548,31 @@ extern "C" int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, cons
     }
 }
 
+extern "C" int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int ggml_type, const void *blocks, size_t bytes,
+                                        void *stream) {
+    VMX_REQUIRE(m && blocks, "qwen3_load_iq_linear: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && slot >= VMX_L_Q && slot <= VMX_L_DOWN,
+                "qwen3_load_iq_linear: layer %d / slot %d out of range", layer, slot);
+    const int ts = vmx_iq_type_size(ggml_type);
+    VMX_REQUIRE(ts > 0, "qwen3_load_iq_linear: ggml type %d is not a supported I-quant", ggml_type);
+    const vmx_qwen3_config &c = m->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, NQ = c.num_heads * c.head_dim, NKV = c.num_kv_heads * c.head_dim;
+    const int in_f[7] = {H, H, H, NQ, H, H, I}, out_f[7] = {NQ, NKV, NKV, H, I, I, H};
+    const int K = in_f[slot], N = out_f[slot];
+    VMX_REQUIRE(K % 256 == 0, "qwen3_load_iq_linear: in_features %d not a multiple of 256", K);
+    const size_t need = (size_t)N * (K / 256) * ts;
+    VMX_REQUIRE(bytes == need, "qwen3_load_iq_linear: expected %zu bytes for [%d, %d] of type %d, got %zu", need, N, K, ggml_type, bytes);
+    IqLinear &l = m->layers[layer].iq[slot];
+    l.raw.release();
+    if (int rc = l.raw.alloc(need)) return rc;
+    VMX_CHECK_HIP(hipMemcpyAsync(l.raw.p, blocks, need, hipMemcpyDefault, vmx_stream(stream)));
+    l.ggml_type = ggml_type;
+    l.in_features = K;
+    l.out_features = N;
+    l.loaded = true;
+    return VMX_OK;
+}
+
 // One decode step for `batch` sequences (one new token each).  Pure launch sequence.
 extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
                                 const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq,
@@ -526,10 +583,10 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "qwen3_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
                 c.max_seq_len);
     for (const Layer &L : m->layers)
-        VMX_REQUIRE(L.qkv.loaded && L.o.loaded && L.gate_up.loaded && L.down.loaded, "qwen3_decode: weights not fully loaded");
+        VMX_REQUIRE(L.int4_ready() || L.iq_ready(), "qwen3_decode: weights not fully loaded");
     hipStream_t st = vmx_stream(stream);
     const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = batch;
-    const int Hq = c.num_heads, Hkv = c.num_kv_heads;
+    const int Hq = c.num_heads, Hkv = c.num_kv_heads, NQKV_ = m->qkv_n();
     uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p;
     float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;  // ping-pong: each linear reads one, writes the other
     const float scale = 1.0f / sqrtf((float)hd);
@@ -541,12 +598,21 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     const float *pending = nullptr;  // down-projection output (f32 slices in PB) not yet folded into the residual stream
     int pending_splits = 0;
     uint16_t *attn = (uint16_t *)m->attn.p, *act = (uint16_t *)m->act.p;
+    const int NQ = Hq * hd, NKV = Hkv * hd;
     for (const Layer &L : m->layers) {
+        const bool iq = !L.int4_ready();  // GGUF I-quant layer: every projection is an IqLinear
+        const int s_qkv = iq ? 1 : L.qkv.splits(), s_o = iq ? 1 : L.o.splits(), s_gu = iq ? 1 : L.gate_up.splits(),
+                  s_down = iq ? 1 : L.down.splits();
         // h += pending; x = rms_norm(h);  q|k|v = linear(x)
         launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
-        if (int rc = run_linear(m, L.qkv, x, PA, B, st)) return rc;
+        if (iq) {
+            if (int rc = iq_quantize(m, x, B, H, st)) return rc;
+            if (int rc = iq_forward(m, L.iq[VMX_L_Q], PA, NQKV_, B, st)) return rc;
+            if (int rc = iq_forward(m, L.iq[VMX_L_K], PA + NQ, NQKV_, B, st)) return rc;
+            if (int rc = iq_forward(m, L.iq[VMX_L_V], PA + NQ + NKV, NQKV_, B, st)) return rc;
+        } else if (int rc = run_linear(m, L.qkv, x, PA, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
-        hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, L.qkv.splits(), B, q, L.k_cache.p,
+        hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, s_qkv, B, q, L.k_cache.p,
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                            c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
                            slot_mapping, Hq, Hkv, hd, hd, fp8, ks, ks + 1);
@@ -556,23 +622,32 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
                                                m->attn_ws.p, &ap, st))
             return rc;
         if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st)) return rc;
-        if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
+        if (iq) {
+            if (int rc = iq_quantize(m, attn, B, NQ, st)) return rc;
+            if (int rc = iq_forward(m, L.iq[VMX_L_O], PB, H, B, st)) return rc;
+        } else if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
         // h += o; x = rms_norm(h);  gate|up = linear(x);  act = silu(gate) * up;  down = linear(act)
         const float *o_src = PB;
-        int o_splits = L.o.splits();
+        int o_splits = s_o;
         if (tp) {  // row-parallel: local bf16 output, summed over the ranks
             if (int rc = tp_reduce(m, PB, o_splits, B, H, st)) return rc;
             o_src = (const float *)m->red_bf16.p;
             o_splits = -1;
         }
         launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
-        if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
+        if (iq) {
+            if (int rc = iq_quantize(m, x, B, H, st)) return rc;
+            if (int rc = iq_forward(m, L.iq[VMX_L_GATE], PA, 2 * I, B, st)) return rc;
+            if (int rc = iq_forward(m, L.iq[VMX_L_UP], PA + I, 2 * I, B, st)) return rc;
+        } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
         int64_t blocks = ((int64_t)B * I + 255) / 256;
-        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA,
-                           L.gate_up.splits(), B, act, I);
-        if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;
+        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA, s_gu, B, act, I);
+        if (iq) {
+            if (int rc = iq_quantize(m, act, B, I, st)) return rc;
+            if (int rc = iq_forward(m, L.iq[VMX_L_DOWN], PB, H, B, st)) return rc;
+        } else if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;
         pending = PB;
-        pending_splits = L.down.splits();
+        pending_splits = s_down;
         if (tp) {
             if (int rc = tp_reduce(m, PB, pending_splits, B, H, st)) return rc;
             // the all-reduced bf16 vector is parked in the (now free) PA buffer so that red_bf16 can be reused
@@ -624,6 +699,7 @@ extern "C" int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t b
 // HIP events this gives the kernel's average launch duration on its own stream.
 extern "C" int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream) {
     VMX_REQUIRE(m && batch >= 1 && batch <= m->cfg.max_batch, "qwen3_linears_only: bad arguments");
+    for (const Layer &L : m->layers) VMX_REQUIRE(L.int4_ready(), "qwen3_linears_only: the model has no int4 linears loaded");
     hipStream_t st = vmx_stream(stream);
     const uint16_t *x = (const uint16_t *)m->x.p, *attn = (const uint16_t *)m->attn.p, *act = (const uint16_t *)m->act.p;
     float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;

@@ -8,7 +8,7 @@
 // for the integer dots, rows streamed straight into VGPRs with several rows in
 // flight per wave, signs applied with a carry-free xor/add (codebook bytes are
 // never 0, so two's-complement negation of a byte cannot carry into its neighbour).
-#include "vmx_internal.h"
+#include "vmx_kernels.h"
 
 #define IQ_TABLE_QUAL static __device__ const
 #include "_gen/iq_tables_gen.h"
@@ -249,6 +249,34 @@ __global__ __launch_bounds__(256) void quantize_q8_1_kernel(const float *__restr
     }
 }
 
+// Same quantiser fed with bf16 activations (the cast bf16 -> f32 in IqLinear::forward_inner is exact).
+__global__ __launch_bounds__(256) void quantize_q8_1_bf16_kernel(const uint16_t *__restrict__ x, int8_t *__restrict__ aq,
+                                                                  float *__restrict__ ad, int64_t total_blocks) {
+    const int64_t lane4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t blk = lane4 >> 3;
+    const bool live = blk < total_blocks;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        const uint2 p = reinterpret_cast<const uint2 *>(x)[lane4];
+        v = make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xFFFF0000u), __uint_as_float(p.y << 16),
+                        __uint_as_float(p.y & 0xFFFF0000u));
+    }
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d = amax / 127.0f;
+    uint32_t packed = 0;
+    if (amax != 0.0f) {
+        int q0 = (int)roundf(v.x / d), q1 = (int)roundf(v.y / d), q2 = (int)roundf(v.z / d), q3 = (int)roundf(v.w / d);
+        packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+    }
+    if (live) {
+        reinterpret_cast<uint32_t *>(aq)[lane4] = packed;
+        if ((lane4 & 7) == 0) ad[blk] = d;
+    }
+}
+
 // ------------------------------------------------------------------ MMVQ
 // One wave owns R consecutive output rows per step; lane g walks the row's 32-weight sub-blocks two
 // at a time (g, g+64).  Per step every global load is issued before anything is decoded, in the
@@ -259,7 +287,7 @@ __global__ __launch_bounds__(256) void quantize_q8_1_kernel(const float *__restr
 template <int T, int MT, int R>
 __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
                                                        const float *__restrict__ ad, float *__restrict__ y, int n_out,
-                                                       int n_in, int m) {
+                                                       int n_in, int m, int ldy) {
     __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
     load_codebook<T>(cb);
     constexpr int TS = IqTraits<T>::TS;
@@ -341,7 +369,7 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
 #pragma unroll
             for (int mi = 0; mi < MT; mi++) {
                 const float v = vmx_wave_sum(acc[r][mi]);
-                if (lane == 0 && mi < m && row0 + r < n_out) y[(int64_t)mi * n_out + row0 + r] = v;
+                if (lane == 0 && mi < m && row0 + r < n_out) y[(int64_t)mi * ldy + row0 + r] = v;
             }
     }
 }
@@ -410,23 +438,23 @@ inline int grid_for(int64_t work_items, int per_block, int cap) {
 }
 
 template <int T>
-int launch_mmvq(const uint8_t *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, hipStream_t st) {
+int launch_mmvq(const uint8_t *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy, hipStream_t st) {
     // rows per workgroup = 4 waves * R; cap the grid and stride the rest.
     if (m == 1) {
         constexpr int R = 2;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 1, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 1, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
     } else if (m == 2) {
         constexpr int R = 2;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 2, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 2, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
     } else if (m <= 4) {
         constexpr int R = 2;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 4, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 4, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
     } else if (m <= 8) {
         constexpr int R = 1;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 8, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 8, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
     } else {
         constexpr int R = 1;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 16, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m);
+        hipLaunchKernelGGL((iq_mmvq_kernel<T, 16, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
     }
     VMX_CHECK_LAUNCH("iq_mmvq");
     return VMX_OK;
@@ -486,7 +514,7 @@ extern "C" int vmx_iq_mmvq_f32(int ggml_type, const void *w, const int8_t *aq, c
     VMX_REQUIRE(m >= 1 && m <= 16, "iq_matmul: m %d exceeds IQ_GEMV_MAX_M (16)", m);
     VMX_REQUIRE(n_in > 0 && n_in % QK_K == 0, "iq_matmul: n_in %d not a multiple of 256", n_in);
     VMX_REQUIRE(n_out > 0, "iq_matmul: n_out %d", n_out);
-#define CALL(T) { int rc = launch_mmvq<T>((const uint8_t *)w, aq, ad, y, n_out, n_in, m, vmx_stream(stream)); if (rc) return rc; }
+#define CALL(T) { int rc = launch_mmvq<T>((const uint8_t *)w, aq, ad, y, n_out, n_in, m, n_out, vmx_stream(stream)); if (rc) return rc; }
     IQ_DISPATCH(ggml_type, CALL)
 #undef CALL
     return VMX_OK;
@@ -533,5 +561,22 @@ extern "C" int vmx_gather_dequant_q6k_f32(const void *blocks, const int32_t *ids
     hipLaunchKernelGGL(gather_q6k_kernel, dim3(num_ids * bpr), dim3(64), 0, vmx_stream(stream), (const uint8_t *)blocks, ids, out,
                        num_ids, bpr, num_embeddings);
     VMX_CHECK_LAUNCH("gather_dequant_q6k");
+    return VMX_OK;
+}
+
+// ---- internal (C++) entry points used by the decoder
+int vmx_quantize_q8_1_bf16(const uint16_t *x, int8_t *aq, float *ad, int64_t total_blocks, hipStream_t st) {
+    const int64_t groups = total_blocks * 8;
+    hipLaunchKernelGGL(quantize_q8_1_bf16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, x, aq, ad, total_blocks);
+    VMX_CHECK_LAUNCH("quantize_q8_1(bf16)");
+    return VMX_OK;
+}
+
+// y[mi*ldy + row]: lets several projections write into one merged activation row
+int vmx_iq_mmvq_ld(int ggml_type, const void *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy,
+                   hipStream_t st) {
+#define CALL(T) { int rc = launch_mmvq<T>((const uint8_t *)w, aq, ad, y, n_out, n_in, m, ldy, st); if (rc) return rc; }
+    IQ_DISPATCH(ggml_type, CALL)
+#undef CALL
     return VMX_OK;
 }

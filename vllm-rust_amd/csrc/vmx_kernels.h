@@ -26,3 +26,8 @@ int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const in
 int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,
                     hipStream_t st);
 int vmx_argmax_keys_to_ids(const unsigned long long *keys, int32_t *out_ids, int rows, hipStream_t st);
+
+// iq_kernels.hip
+int vmx_quantize_q8_1_bf16(const uint16_t *x, int8_t *aq, float *ad, int64_t total_blocks, hipStream_t st);
+int vmx_iq_mmvq_ld(int ggml_type, const void *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy,
+                   hipStream_t st);

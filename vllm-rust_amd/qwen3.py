@@ -113,6 +113,12 @@ class QuantizedQwen3ForCausalLM:
                                             self._stream()))
         torch.cuda.current_stream().synchronize()
 
+    def load_iq_linear(self, layer: int, slot: int, ggml_type: int, blocks: torch.Tensor) -> None:
+        """blocks: uint8 tensor (device or host) with the raw GGUF bytes of the [out, in] weight."""
+        blocks = blocks.contiguous()
+        check(lib.vmx_qwen3_load_iq_linear(self._h, layer, slot, ggml_type, blocks.data_ptr(), blocks.numel(), self._stream()))
+        torch.cuda.current_stream().synchronize()
+
     def linear_shapes(self):
         s = self.spec
         nq, nkv = s.num_heads * s.head_dim, s.num_kv_heads * s.head_dim
@@ -120,10 +126,59 @@ class QuantizedQwen3ForCausalLM:
                 L_GATE: (s.hidden_size, s.intermediate_size), L_UP: (s.hidden_size, s.intermediate_size),
                 L_DOWN: (s.intermediate_size, s.hidden_size)}
 
+    IQ_TYPE_SIZE = {17: 74, 22: 82, 18: 98, 21: 110, 23: 136}
+
+    def load_synthetic_iq(self, slot_types, seed: int = 0, keep_host_copy: bool = False):
+        """Random valid I-quant blocks for every projection (slot_types: ggml type id per slot, e.g. the
+        Gemma-4-12B UD-IQ3_XXS mix), bf16 norms/embeddings as load_synthetic.  Super-block scales are sized so
+        that activations stay O(1)."""
+        s = self.spec
+        ck = self._load_synthetic_dense(seed, keep_host_copy)
+        g = torch.Generator(device=self.device).manual_seed(seed + 1)
+        for li in range(s.num_layers):
+            for slot, (K, N) in self.linear_shapes().items():
+                t = slot_types[slot]
+                ts = self.IQ_TYPE_SIZE[t]
+                nb = N * (K // 256)
+                raw = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=self.device, generator=g)
+                # f16 super-scale d: grid magnitudes are O(10-40) times a sub-scale O(1-8): aim for ~1/sqrt(K) weights
+                d = (torch.rand(nb, device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (120.0 * math.sqrt(K)))
+                if t == 23:
+                    d = d * 6.0   # IQ4_XS: values +-127 times (ls - 32)
+                dbits = d.to(torch.float16).view(torch.int16)
+                raw[:, 0] = (dbits & 0xFF).to(torch.uint8)
+                raw[:, 1] = ((dbits >> 8) & 0xFF).to(torch.uint8)
+                self.load_iq_linear(li, slot, t, raw.reshape(-1))
+                if keep_host_copy:
+                    ck[f"{li}.{slot}.iq"] = (t, raw.reshape(-1).cpu())
+        return ck
+
     def load_synthetic(self, seed: int = 0, keep_host_copy: bool = False):
         """Random-init weights of the model's architecture in AWQ checkpoint form (seeded).
         Scales are sized so activations stay O(1) through the stack.  Returns the host copy of the
         checkpoint when keep_host_copy (tiny test models only)."""
+        s = self.spec
+        ck = self._load_synthetic_dense(seed, keep_host_copy)
+        g = torch.Generator(device=self.device).manual_seed(seed + 1)
+
+        def keep(name, t):
+            if keep_host_copy:
+                ck[name] = t.cpu()
+
+        for li in range(s.num_layers):
+            for slot, (K, N) in self.linear_shapes().items():
+                qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=self.device, generator=g)
+                qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // s.group_size, N // 8), dtype=torch.int32, device=self.device,
+                                   generator=g)
+                # uniform int4 minus zero point has std ~6.5; aim for unit-variance outputs
+                sc = (torch.rand((K // s.group_size, N), device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (6.5 * math.sqrt(K)))
+                sc = sc.to(torch.float16)
+                self.load_awq_linear(li, slot, qw, qz, sc)
+                keep(f"{li}.{slot}.qweight", qw); keep(f"{li}.{slot}.qzeros", qz); keep(f"{li}.{slot}.scales", sc)
+        return ck
+
+    def _load_synthetic_dense(self, seed: int, keep_host_copy: bool):
+        """Embedding, lm_head and norm weights (bf16)."""
         s = self.spec
         g = torch.Generator(device=self.device).manual_seed(seed)
         ck = {}
@@ -147,15 +202,6 @@ class QuantizedQwen3ForCausalLM:
                                    (T_Q_NORM, s.head_dim, "q_norm"), (T_K_NORM, s.head_dim, "k_norm")):
                 w = (1.0 + 0.1 * torch.randn(n, device=self.device, generator=g)).to(torch.bfloat16)
                 self.load_tensor(which, li, w); keep(f"{li}.{name}", w)
-            for slot, (K, N) in self.linear_shapes().items():
-                qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=self.device, generator=g)
-                qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // s.group_size, N // 8), dtype=torch.int32, device=self.device,
-                                   generator=g)
-                # uniform int4 minus zero point has std ~6.5; aim for unit-variance outputs
-                sc = (torch.rand((K // s.group_size, N), device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (6.5 * math.sqrt(K)))
-                sc = sc.to(torch.float16)
-                self.load_awq_linear(li, slot, qw, qz, sc)
-                keep(f"{li}.{slot}.qweight", qw); keep(f"{li}.{slot}.qzeros", qz); keep(f"{li}.{slot}.scales", sc)
         return ck
 
     def forward_decode_batch(self, input_ids, positions, slot_mapping, block_tables, seq_lens, max_seq_len=None,
