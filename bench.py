@@ -76,6 +76,55 @@ def cpu_baseline(spec, budget_s=12.0):
                       f"{spec.num_layers} layers + numpy f32 lm_head on 1/16 of the vocabulary ({t_head * 1e3:.1f} ms)"}
 
 
+def iq3_secondary(prompt, steps, warmup):
+    """Decode tok/s of a model with Gemma-4-12B's layer shapes and its UD-IQ3_XXS tensor-type mix (GGUF I-quant MMVQ
+    linears, FP8 e4m3 KV cache), run through this library's Qwen3-style executor: NOT Gemma's op order (no sandwich
+    norms / sliding window / PLE), bf16 lm_head (2.0 GB) instead of the file's Q3_K one (0.43 GB)."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    total = prompt + warmup + steps + 8
+    n_blocks = (total + 15) // 16 + 1
+    spec = Qwen3Spec(hidden_size=3840, num_layers=48, num_heads=16, num_kv_heads=8, head_dim=256, intermediate_size=15360,
+                     vocab_size=262144, tie_word_embeddings=True, kv_cache_dtype=1, max_position=max(4096, total + 1),
+                     num_blocks=n_blocks, max_batch=1, max_seq_len=total + 1)
+    model = QuantizedQwen3ForCausalLM(spec)
+    types = {0: 18, 1: 22, 2: 18, 3: 21, 4: 18, 5: 18, 6: 21}   # q,k,v,o,gate,up,down: IQ3_XXS / IQ2_S / IQ3_S
+    model.load_synthetic_iq(types, seed=99)
+    ts = model.IQ_TYPE_SIZE
+    wbytes = sum(N * (K // 256) * ts[types[slot]] for slot, (K, N) in model.linear_shapes().items()) * spec.num_layers
+    dev = model.device
+    bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(1, n_blocks).contiguous()
+    ids = torch.tensor([11], dtype=torch.int32, device=dev)
+    pos = torch.zeros(1, dtype=torch.int32, device=dev)
+    slots = (bt[:, 0] * 16).to(torch.int32).contiguous()
+    sl = torch.ones(1, dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.int32, device=dev)
+
+    def step():
+        model.forward_decode_batch(ids, pos, slots, bt, sl, max_seq_len=spec.max_seq_len, out_ids=out)
+        model.advance(ids, out, pos, slots, sl, bt)
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        step()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            step()
+        for _ in range(prompt - 1 + warmup):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    model.close()
+    return {"metric": "decode tok/s, Gemma-4-12B-shaped GGUF IQ3_XXS-mix + FP8 KV, batch=1", "value": round(steps / dt, 2), "unit": "tok/s",
+            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "iquant_weight_bytes_per_token": wbytes, "iquant_GBps_if_only_weights": round(wbytes / (dt / steps) / 1e9, 1),
+            "note": "layer shapes and tensor-type mix of gemma-4-12b-it-UD-IQ3_XXS; Qwen3-style op order; bf16 tied lm_head"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +133,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=256)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the GGUF I-quant (Gemma-4-12B-shaped) secondary measurement")
     ap.add_argument("--tp", action="store_true",
                     help="with --gpus N > 1: ONE model tensor-parallel over the N ranks (RCCL all-reduce after every row-parallel "
                          "linear, strong scaling) instead of N independent replicas")
@@ -195,6 +245,14 @@ def main():
                     "launches_per_step": launches, "avg_launch_us": round(us / launches, 3),
                     "alg_bytes_per_launch": round(alg / launches)}
 
+    # ---- secondary (rank 0, N = 1 only): BASELINE.json's other headline model, GGUF I-quant decode
+    secondary = None
+    if rank == 0 and not dist_on and not args.no_secondary and not args.layers:
+        model.close()
+        del model, graph
+        torch.cuda.empty_cache()
+        secondary = iq3_secondary(args.prompt, max(16, K_steps // 2), W_steps)
+
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed
         line = {
@@ -209,6 +267,7 @@ def main():
                        "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
             "roofline": roofline,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(spec),
+            "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

@@ -77,7 +77,8 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float f[8]) {
 template <int CH>
 __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x,
                                                           const float *__restrict__ partial, int splits, int tokens,
-                                                          const uint16_t *__restrict__ w, float eps, int hidden) {
+                                                          const uint16_t *__restrict__ w, float eps, int hidden,
+                                                          int8_t *__restrict__ aq, float *__restrict__ ad) {
     __shared__ float red[4];
     const int t = blockIdx.x;
     const int64_t row = (int64_t)t * hidden;
@@ -112,7 +113,13 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
             unpack_bf16x8(*reinterpret_cast<const uint4 *>(w + 8 * ci), wv);
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = hv[c][j] * inv * wv[j];
-            *reinterpret_cast<uint4 *>(x + row + 8 * ci) = pack_bf16x8(o);
+            const uint4 packed = pack_bf16x8(o);
+            *reinterpret_cast<uint4 *>(x + row + 8 * ci) = packed;
+            if (aq) {  // q8_1 of the (bf16-rounded) normed row for an I-quant consumer; hidden % 32 == 0
+                float xr[8];
+                unpack_bf16x8(packed, xr);
+                vmx_q8_1_emit8(xr, aq + row + 8 * ci, ad + (row >> 5) + (ci >> 2), (ci & 3) == 0);
+            }
         }
     }
 }
@@ -179,16 +186,34 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ 
 }
 
 // a[t, i] = bf16(silu(bf16(gate)) * bf16(up)) from the merged gate|up linear output (f32 partials
-// [splits][tokens][2*inter], gate columns first).
+// [splits][tokens][2*inter], gate columns first); 8 elements per thread.  Optionally also the q8_1 form of the
+// result for an I-quant down projection (inter % 32 == 0).
 __global__ __launch_bounds__(256) void gateup_act_kernel(const float *__restrict__ partial, int splits, int tokens,
-                                                          uint16_t *__restrict__ act, int inter) {
-    const int64_t total = (int64_t)tokens * inter;
+                                                          uint16_t *__restrict__ act, int inter, int8_t *__restrict__ aq,
+                                                          float *__restrict__ ad) {
+    const int64_t chunks = (int64_t)tokens * inter / 8;
     const int64_t slice = (int64_t)tokens * 2 * inter;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t t = i / inter, c = i % inter;
-        const float g = round_bf16(sum_partials(partial, splits, slice, t * 2 * inter + c));
-        const float u = round_bf16(sum_partials(partial, splits, slice, t * 2 * inter + inter + c));
-        act[i] = vmx_f32_to_bf16((g / (1.0f + expf(-g))) * u);
+    const int cpr = inter / 8;
+    for (int64_t c0 = (int64_t)blockIdx.x * 256; c0 < chunks; c0 += (int64_t)gridDim.x * 256) {
+        const int64_t c = c0 + threadIdx.x;
+        if (c < chunks) {  // chunks % 4 == 0, so 4-lane groups are all in or all out
+            const int64_t t = c / cpr, col = (c % cpr) * 8;
+            float g[8], u[8];
+            sum_partials8(partial, splits, slice, t * 2 * inter + col, g);
+            sum_partials8(partial, splits, slice, t * 2 * inter + inter + col, u);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float gg = round_bf16(g[j]);
+                g[j] = (gg / (1.0f + expf(-gg))) * round_bf16(u[j]);
+            }
+            const uint4 packed = pack_bf16x8(g);
+            *reinterpret_cast<uint4 *>(act + c * 8) = packed;
+            if (aq) {
+                float r[8];
+                unpack_bf16x8(packed, r);
+                vmx_q8_1_emit8(r, aq + c * 8, ad + (c >> 2), (c & 3) == 0);
+            }
+        }
     }
 }
 
@@ -217,11 +242,11 @@ __global__ __launch_bounds__(256) void embed_kernel(uint16_t *__restrict__ out, 
 }
 
 void launch_resid_norm(hipStream_t st, uint16_t *h, uint16_t *x, const float *partial, int splits, int tokens, const uint16_t *w,
-                       float eps, int hidden) {
-    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
-    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
-    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
-    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden);
+                       float eps, int hidden, int8_t *aq = nullptr, float *ad = nullptr) {
+    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
+    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
+    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
+    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
 }
 
 struct DevBuf {
@@ -303,6 +328,9 @@ double int4_alg_bytes(const Int4Linear &l, int M) {
 int run_linear(vmx_qwen3 *, const Int4Linear &l, const uint16_t *xin, float *partial, int M, hipStream_t st) {
     return l.forward_partial(xin, partial, M, st);
 }
+
+int8_t *q8_aq(vmx_qwen3 *m) { return (int8_t *)m->q8.p; }
+float *q8_ad(vmx_qwen3 *m, int tokens, int k) { return (float *)((char *)m->q8.p + (((size_t)tokens * k + 255) & ~(size_t)255)); }
 
 // IqLinear::forward_inner on the decode path (gguf/mod.rs:329-377): activations bf16 -> (exact) f32 -> q8_1 ...
 int iq_quantize(vmx_qwen3 *m, const uint16_t *x, int tokens, int k, hipStream_t st) {
@@ -604,9 +632,9 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
         const int s_qkv = iq ? 1 : L.qkv.splits(), s_o = iq ? 1 : L.o.splits(), s_gu = iq ? 1 : L.gate_up.splits(),
                   s_down = iq ? 1 : L.down.splits();
         // h += pending; x = rms_norm(h);  q|k|v = linear(x)
-        launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H);
+        launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
+                          iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr);
         if (iq) {
-            if (int rc = iq_quantize(m, x, B, H, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_Q], PA, NQKV_, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_K], PA + NQ, NQKV_, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_V], PA + NQ + NKV, NQKV_, B, st)) return rc;
@@ -634,16 +662,16 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
             o_src = (const float *)m->red_bf16.p;
             o_splits = -1;
         }
-        launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H);
+        launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, iq ? q8_aq(m) : nullptr,
+                          iq ? q8_ad(m, B, H) : nullptr);
         if (iq) {
-            if (int rc = iq_quantize(m, x, B, H, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_GATE], PA, 2 * I, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_UP], PA + I, 2 * I, B, st)) return rc;
         } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
-        int64_t blocks = ((int64_t)B * I + 255) / 256;
-        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA, s_gu, B, act, I);
+        int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
+        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA, s_gu, B, act, I,
+                           iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr);
         if (iq) {
-            if (int rc = iq_quantize(m, act, B, I, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_DOWN], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;
         pending = PB;

@@ -79,3 +79,22 @@ __device__ __forceinline__ float vmx_block_sum_256(float v, float *red) {
     __syncthreads();
     return r;
 }
+
+// q8_1 of 8 consecutive values held by one lane, where 4 consecutive lanes (aligned to 4) hold one 32-value
+// block: d = amax/127 (f32 division), q = roundf(v/d) (half away from zero), all-zero block -> d = 0, q = 0
+// (crates/core/kernels/iq_dequant.cu:253-267).  Every lane of the 4-lane group must call it.
+__device__ __forceinline__ void vmx_q8_1_emit8(const float v[8], int8_t *aq8, float *ad_block, bool first_lane_of_block) {
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) amax = fmaxf(amax, fabsf(v[j]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    const float d = amax / 127.0f;
+    uint32_t w[2] = {0u, 0u};
+    if (amax != 0.0f) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j >> 2] |= ((uint32_t)((int)roundf(v[j] / d) & 0xFF)) << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint2 *>(aq8) = make_uint2(w[0], w[1]);
+    if (first_lane_of_block) *ad_block = d;
+}
