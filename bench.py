@@ -240,8 +240,15 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
         achieved = alg / us / 1e3 if us > 0 else 0.0  # bytes/us -> GB/s
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 cannot run inside this process):
+        # committed summary of `rocprofv3 --pmc ... -- python3 tools/pmc_linears.py`, same kernel, same shapes.
+        traffic = None
+        try:
+            traffic = json.loads((ROOT / "profiles" / "r01_pmc_traffic_int4_gemm.json").read_text())["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": "int4_gemm_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches_per_step": launches, "avg_launch_us": round(us / launches, 3),
                     "alg_bytes_per_launch": round(alg / launches)}
 
