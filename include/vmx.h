@@ -123,8 +123,9 @@ int vmx_int4_pack(const uint32_t *qweight, const uint16_t *scales_bf16, const ui
 /* Replaces the awq_gemv_int4_*_bf16 family and marlin_gemm_int4(_zp)_bf16 for
  * small M (crates/core/kernels/awq_gemv.cu:46-665; dispatcher
  * marlin_cuda.rs:337-640): y[m,n] = bf16(sum_k x[m,k]*(nib-zp)*scale + bias),
- * f32 accumulation.  1 <= M <= 16.  workspace >= vmx_int4_gemm_workspace_bytes
- * (split-K partial sums); bias bf16 [N] or NULL. */
+ * f32 accumulation.  Any M >= 1: rows are processed 16 at a time (one MFMA row tile), so prefill-sized M re-streams
+ * the weights M/16 times with the same arithmetic as decode (the reference instead switches to dequant + cuBLAS for
+ * M > 8, marlin_cuda.rs:893).  workspace >= vmx_int4_gemm_workspace_bytes (split-K partial sums); bias bf16 [N] or NULL. */
 size_t vmx_int4_gemm_workspace_bytes(int M, int N, int K);
 int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *packed, const uint16_t *bias, int M, int N,
                        int K, int group, void *workspace, size_t workspace_bytes, void *stream);

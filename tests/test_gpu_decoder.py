@@ -230,3 +230,25 @@ def test_iq_decoder_matches_oracle(gpu, kv_dtype):
         assert rel <= (3e-2 if kv_dtype == 0 else 5e-2), (step, rel)
         ids = out.cpu().numpy().astype(np.int32)
     model.close()
+
+
+def test_prefill_forward_equals_token_by_token_decode(gpu):
+    """forward() over a prompt (chunks of max_batch pseudo-sequences) must give the logits of feeding the same
+    tokens one at a time: rows of the small-M linears and the per-sequence attention are independent."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
+    vmx, torch = gpu
+    spec = _tiny_spec(max_batch=4, num_blocks=16)
+    prompt = torch.tensor([3, 500, 42, 42, 7, 999, 1, 250, 13, 77, 600], dtype=torch.int32, device="cuda")
+    bt = torch.tensor([9, 2, 5, 11], dtype=torch.int32, device="cuda")
+    a = QuantizedQwen3ForCausalLM(spec); a.load_synthetic(seed=21)
+    ids_a, logits_a = a.forward(prompt, 0, bt)
+    torch.cuda.synchronize()
+    b = QuantizedQwen3ForCausalLM(spec); b.load_synthetic(seed=21)
+    for i in range(prompt.numel()):
+        pos = torch.tensor([i], dtype=torch.int32, device="cuda")
+        slot = (bt[i // spec.block_size] * spec.block_size + i % spec.block_size).reshape(1).to(torch.int32)
+        lg = torch.empty((1, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        o = b.forward_decode_batch(prompt[i:i + 1].contiguous(), pos, slot, bt.reshape(1, -1), pos + 1, logits=lg)
+        torch.cuda.synchronize()
+        assert torch.equal(lg[0], logits_a[i]) and int(o[0]) == int(ids_a[i]), i
+    a.close(); b.close()

@@ -498,28 +498,33 @@ int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros
 extern "C" size_t vmx_int4_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % KB || N % NT) return 0;
     const GemmPlan p = plan_gemm(N, K);
-    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+    return p.splits > 1 ? (size_t)p.splits * (M < 16 ? M : 16) * N * sizeof(float) : 0;
 }
 
 extern "C" int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *packed, const uint16_t *bias, int M, int N, int K,
                                   int group, void *workspace, size_t workspace_bytes, void *stream) {
     VMX_REQUIRE(y && x && packed, "int4_gemm: null pointer");
-    VMX_REQUIRE(M >= 1 && M <= 16, "int4_gemm: M (%d) must be in 1..16 (larger M takes the dequant + GEMM path)", M);
+    VMX_REQUIRE(M >= 1, "int4_gemm: M (%d) must be positive", M);
     if (int rc = check_int4_shape("int4_gemm", K, N, group)) return rc;
     const GemmPlan p = plan_gemm(N, K);
-    const size_t need = p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+    const int mc = M < 16 ? M : 16;  // rows per launch; larger M (prefill) walks the rows in chunks of 16
+    const size_t need = p.splits > 1 ? (size_t)p.splits * mc * N * sizeof(float) : 0;
     VMX_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), "int4_gemm: workspace %zu B < required %zu B", workspace_bytes,
                 need);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
     hipStream_t st = vmx_stream(stream);
     float *partial = (float *)workspace;
-    if (int rc = launch_gemm(p, W, SZ, x, bias, p.splits == 1 ? y : nullptr, partial, M, N, K, group, st)) return rc;
-    if (p.splits > 1) {
-        const int64_t total = (int64_t)M * N;
-        hipLaunchKernelGGL(int4_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, bias, y, M, N,
-                           p.splits);
-        VMX_CHECK_LAUNCH("int4_reduce");
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        const int mm = M - m0 < 16 ? M - m0 : 16;
+        uint16_t *yc = y + (int64_t)m0 * N;
+        if (int rc = launch_gemm(p, W, SZ, x + (int64_t)m0 * K, bias, p.splits == 1 ? yc : nullptr, partial, mm, N, K, group, st)) return rc;
+        if (p.splits > 1) {
+            const int64_t total = (int64_t)mm * N;
+            hipLaunchKernelGGL(int4_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, bias, yc, mm, N,
+                               p.splits);
+            VMX_CHECK_LAUNCH("int4_reduce");
+        }
     }
     return VMX_OK;
 }

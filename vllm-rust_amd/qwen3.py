@@ -216,6 +216,26 @@ class QuantizedQwen3ForCausalLM:
                                    out_ids.data_ptr(), None if logits is None else logits.data_ptr(), self._stream()))
         return out_ids
 
+    def forward(self, input_ids: torch.Tensor, seqlen_offset: int, block_table: torch.Tensor, return_logits: bool = True):
+        """ModelForward::forward for one sequence (engine/model_forward.rs:22-64): a prompt (chunk) of S tokens at
+        positions offset..offset+S-1.  Runs through the decode executor max_batch tokens at a time: token i is a
+        pseudo-sequence of length offset+i+1 over the same block table, its K/V row is written before the chunk's
+        attention runs, so the result is causal attention over everything up to and including itself.
+        Returns (greedy ids int32 [S], logits bf16 [S, vocab] or None)."""
+        s = self.spec
+        S = input_ids.numel()
+        bt1 = block_table.reshape(1, -1).to(torch.int32)
+        ids_out = torch.empty(S, dtype=torch.int32, device=self.device)
+        logits = torch.empty((S, s.vocab_size), dtype=torch.bfloat16, device=self.device) if return_logits else None
+        for c0 in range(0, S, s.max_batch):
+            n = min(s.max_batch, S - c0)
+            pos = torch.arange(seqlen_offset + c0, seqlen_offset + c0 + n, dtype=torch.int32, device=self.device)
+            slots = (bt1[0, (pos // s.block_size).long()] * s.block_size + pos % s.block_size).to(torch.int32)
+            bt = bt1.expand(n, -1).contiguous()
+            self.forward_decode_batch(input_ids[c0:c0 + n].contiguous(), pos, slots, bt, (pos + 1).contiguous(),
+                                      out_ids=ids_out[c0:c0 + n], logits=None if logits is None else logits[c0:c0 + n])
+        return ids_out, logits
+
     def debug_read(self, which: int, shape) -> torch.Tensor:
         t = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
         check(lib.vmx_qwen3_debug_read(self._h, which, t.data_ptr(), t.numel() * 2, self._stream()))
