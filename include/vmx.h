@@ -134,6 +134,25 @@ int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *packed, const
  * tile stream -> dense bf16 [K, N] (prefill path and parity aid). */
 int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K, int N, int group, void *stream);
 
+/* ------------------------------------------------------------------------ EXL3 */
+
+/* Replaces reconstruct_kernel<K,cb> (crates/core/kernels/exl3/reconstruct.cu; exl3_reconstruct, exl3_cuda.rs:940-1040):
+ * trellis i16 [K/16, N/16, 16*bits] -> dense fp16 [K, N].  codebook 0 default, 1 mcg, 2 mul1 (exl3.rs:90-152). */
+int vmx_exl3_reconstruct_f16(const void *trellis, uint16_t *dense, int K, int N, int bits, int codebook, void *stream);
+
+/* Replaces had_hf_r_128_kernel<pre,post> (crates/core/kernels/exl3/hadamard.cu; had_r_128_fp16, exl3_cuda.rs:1044-1230):
+ * per 128-column block y = H128 v / sqrt(128) in f32, rounded to fp16; mode 0 none, 1 pre-scale (fp16 multiply by
+ * scale[col] first), 2 post-scale (fp16 multiply after the rounding). */
+int vmx_exl3_had_r_128_f16(uint16_t *y, const uint16_t *x, const uint16_t *scale, int rows, int cols, int mode, void *stream);
+
+/* Replaces exl3_gemm / Exl3GemmInplaceOp (exl3_cuda.rs:271-416,645-887; kernels exl3_gemm_decode_kernel / exl3_gemm_kernel):
+ * y = had128(had128(x * suh) @ decode(trellis)) * svh, x/y fp16, suh fp16 [K] / svh fp16 [N] (NULL = ones).
+ * K % 128 == 0, N % 128 == 0, any M >= 1 (16 rows per pass).  f32 accumulation in a fixed order: unlike the
+ * reference's stream-K chain the result does not depend on the number of compute units. */
+size_t vmx_exl3_gemm_workspace_bytes(int M, int K, int N);
+int vmx_exl3_gemm_f16(uint16_t *y, const uint16_t *x, const void *trellis, const uint16_t *suh, const uint16_t *svh, int M,
+                      int K, int N, int bits, int codebook, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ----------------------------------------------------------------- FP8 weights */
 
 /* Replaces fp8_gemm_bf16_{naive,tiled,with_bias} (crates/core/kernels/fp8_gemm.cu:38-218; launcher

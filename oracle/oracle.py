@@ -74,6 +74,11 @@ for _name, _res, _args in [
     ("orc_q8_0_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_q4_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_q3_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_exl3_decode", C.c_uint16, [C.c_uint32, C.c_int]),
+    ("orc_exl3_reconstruct", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    ("orc_exl3_had_fp16", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    ("orc_exl3_had_f32_to_fp16", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_exl3_gemm", C.c_int, [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4),
     ("orc_fp8_gemm_bf16", None, [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_void_p]),
     ("orc_fp8_quant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("orc_fp8_dequant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
@@ -350,3 +355,39 @@ def ggml_dequant(ggml_type: int, data) -> np.ndarray:
           14: _lib.orc_q6k_dequant}[ggml_type]
     fn(_p(data), nb, _p(out))
     return out
+
+
+# ---------------------------------------------------------------- EXL3
+def exl3_decode(w: int, cb: int = 0) -> int:
+    return int(_lib.orc_exl3_decode(w & 0xFFFF, cb))
+
+
+def exl3_reconstruct(trellis_u16, K: int, N: int, bits: int, cb: int = 0) -> np.ndarray:
+    t = _c(trellis_u16, np.uint16)
+    assert t.size == (K // 16) * (N // 16) * 16 * bits
+    out = np.empty((K, N), np.uint16)
+    assert _lib.orc_exl3_reconstruct(_p(t), K, N, bits, cb, _p(out)) == 0
+    return out
+
+
+def exl3_had_fp16(x_f16, scale_f16=None, mode: int = 0) -> np.ndarray:
+    x = _c(x_f16, np.uint16)
+    rows, cols = x.shape
+    sc = _c(scale_f16, np.uint16) if scale_f16 is not None else None
+    y = np.empty_like(x)
+    assert _lib.orc_exl3_had_fp16(_p(x), _p(sc) if sc is not None else None, rows, cols, mode, _p(y)) == 0
+    return y
+
+
+def exl3_gemm(x_f16, trellis_u16, suh_f16, svh_f16, K: int, N: int, bits: int, cb: int = 0) -> np.ndarray:
+    x = _c(x_f16, np.uint16).reshape(-1, K)
+    M = x.shape[0]
+    t = _c(trellis_u16, np.uint16)
+    su = _c(suh_f16, np.uint16) if suh_f16 is not None else None
+    sv = _c(svh_f16, np.uint16) if svh_f16 is not None else None
+    y = np.empty((M, N), np.uint16)
+    w = np.empty((K, N), np.uint16); a = np.empty((M, K), np.uint16); c = np.empty((M, N), np.float32)
+    rc = _lib.orc_exl3_gemm(_p(x), _p(t), _p(su) if su is not None else None, _p(sv) if sv is not None else None, M, K, N, bits, cb,
+                            _p(y), _p(w), _p(a), _p(c))
+    assert rc == 0
+    return y

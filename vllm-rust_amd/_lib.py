@@ -48,6 +48,10 @@ _SIGS = {
     "vmx_int4_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "vmx_int4_gemm_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "vmx_int4_dequant_bf16": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vmx_exl3_reconstruct_f16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vmx_exl3_had_r_128_f16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "vmx_exl3_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "vmx_exl3_gemm_f16": (_i, [_p] * 5 + [_i] * 5 + [_p, _sz, _p]),
     "vmx_fp8_gemm_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vmx_fp8_dequant_bf16": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),
     "vmx_fp8_quant_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
