@@ -8,7 +8,7 @@ from vllm_rust_amd._lib import lib, check
 vmx.init(0)
 IQ = {"iq2_xs": (17, 74), "iq2_s": (22, 82), "iq3_xxs": (18, 98), "iq3_s": (21, 110), "iq4_xs": (23, 136)}
 names = os.environ.get("TYPES", "iq3_xxs").split(",")
-shapes = [(4096, 4096), (14336, 4096), (15360, 3840)]
+shapes = [(4096, 4096), (14336, 4096), (30720, 3840), (3840, 15360)]
 M = int(os.environ.get("M", "1"))
 s = torch.cuda.Stream()
 for name in names:

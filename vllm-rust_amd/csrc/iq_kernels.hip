@@ -30,42 +30,73 @@ template <> struct IqTraits<18> { static constexpr int TS = 98;  static constexp
 template <> struct IqTraits<21> { static constexpr int TS = 110; static constexpr int LDS_WORDS = 512; };
 template <> struct IqTraits<23> { static constexpr int TS = 136; static constexpr int LDS_WORDS = 4; };
 
-// Stage the type's codebook in LDS (as u32 words).  Ends with a barrier.
-template <int T> __device__ __forceinline__ void load_codebook(uint32_t *lds) {
+template <int T> __device__ __forceinline__ const uint32_t *codebook_src() {
+    if constexpr (T == 17) return reinterpret_cast<const uint32_t *>(iq2xs_grid);
+    else if constexpr (T == 22) return reinterpret_cast<const uint32_t *>(iq2s_grid);
+    else if constexpr (T == 18) return iq3xxs_grid;
+    else if constexpr (T == 21) return iq3s_grid;
+    else return reinterpret_cast<const uint32_t *>(kvalues_iq4nl);
+}
+
+// Sign-mask table entries a type needs: 128 for the 7-bit "ksigns" types (IQ2_XS, IQ3_XXS), 256 for the types with explicit
+// sign bytes (IQ2_S, IQ3_S), none for IQ4_XS.
+template <int T> struct SignLut { static constexpr int N = (T == 17 || T == 18) ? 128 : (T == 23 ? 1 : 256); };
+
+// Stage the type's codebook in LDS (as u32 words) and build the sign-mask table: sg[i] = 0xFF in byte j of the 8-byte entry
+// when weight j of the group of 8 is negative.  For the 7-bit types entry i is the mask of ggml's ksigns_iq2xs[i]
+// (= i | parity(i) << 7).  Two halves so that a kernel can request its weights between them: tables_fetch issues the
+// global loads of the codebook words (256 threads), tables_commit writes LDS and ends with a barrier.
+template <int T> struct TableRegs { uint32_t w[(IqTraits<T>::LDS_WORDS + 255) / 256]; };
+
+template <int T> __device__ __forceinline__ TableRegs<T> tables_fetch() {
     constexpr int W = IqTraits<T>::LDS_WORDS;
-    const uint32_t *src;
-    if constexpr (T == 17) src = reinterpret_cast<const uint32_t *>(iq2xs_grid);
-    else if constexpr (T == 22) src = reinterpret_cast<const uint32_t *>(iq2s_grid);
-    else if constexpr (T == 18) src = iq3xxs_grid;
-    else if constexpr (T == 21) src = iq3s_grid;
-    else src = reinterpret_cast<const uint32_t *>(kvalues_iq4nl);
-    for (int i = threadIdx.x; i < W; i += blockDim.x) lds[i] = src[i];
+    const uint32_t *src = codebook_src<T>();
+    TableRegs<T> t;
+#pragma unroll
+    for (int j = 0; j < (W + 255) / 256; j++) {
+        const int i = threadIdx.x + 256 * j;
+        t.w[j] = i < W ? src[i] : 0u;
+    }
+    return t;
+}
+
+template <int T> __device__ __forceinline__ void tables_commit(const TableRegs<T> &t, uint32_t *lds, uint2 *sg) {
+    constexpr int W = IqTraits<T>::LDS_WORDS;
+#pragma unroll
+    for (int j = 0; j < (W + 255) / 256; j++) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < W) lds[i] = t.w[j];
+    }
+    if constexpr (T != 23) {
+        const int i = threadIdx.x;
+        if (i < SignLut<T>::N) {
+            uint32_t s8 = (uint32_t)i;
+            if constexpr (SignLut<T>::N == 128) s8 |= (__popc(s8) & 1u) << 7;
+            const uint32_t l0 = __umul24(s8 & 0xFu, 0x00204081u) & 0x01010101u, l1 = __umul24(s8 >> 4, 0x00204081u) & 0x01010101u;
+            sg[i] = make_uint2((l0 << 8) - l0, (l1 << 8) - l1);
+        }
+    }
     __syncthreads();
 }
 
-// 4 sign bits -> 0x01 in each byte whose bit is set.
-__device__ __forceinline__ uint32_t spread4(uint32_t bits4) { return __umul24(bits4 & 0xFu, 0x00204081u) & 0x01010101u; }
-
-// Negate the bytes of g selected by the 4 sign bits.  g's bytes are in 1..127.
-__device__ __forceinline__ int sign4(uint32_t g, uint32_t bits4) {
-    uint32_t lsb = spread4(bits4);
-    uint32_t mask = (lsb << 8) - lsb;  // 0xFF per selected byte
-    return (int)((g ^ mask) + lsb);
+template <int T> __device__ __forceinline__ void load_tables(uint32_t *lds, uint2 *sg) {   // blockDim.x == 256
+    const TableRegs<T> t = tables_fetch<T>();
+    tables_commit<T>(t, lds, sg);
 }
 
-// ggml's ksigns_iq2xs[i] = i | (parity(i) << 7) for i in 0..127.
-__device__ __forceinline__ uint32_t ksign(uint32_t i7) { return i7 | ((__popc(i7) & 1u) << 7); }
+// Negate the bytes of g selected by mask (0xFF per selected byte).  g's bytes are in 1..127, so the two's-complement
+// negation (g ^ 0xFF) + 1 of a byte never carries into its neighbour.
+__device__ __forceinline__ int sign4(uint32_t g, uint32_t mask) { return (int)((g ^ mask) + (mask & 0x01010101u)); }
 
 // Eight 4-bit indices of `q4` through the 16-entry int8 table T[0..3] (as 4 words):
 // lo = entries of the low nibbles, hi = of the high nibbles.
 __device__ __forceinline__ void table16(uint32_t q4, const uint32_t T[4], int &lo, int &hi) {
     auto look = [&](uint32_t idx) -> int {  // idx: 4 bytes, each 0..15
-        uint32_t sel = idx & 0x07070707u;
-        uint32_t a = __builtin_amdgcn_perm(T[1], T[0], sel);
-        uint32_t b = __builtin_amdgcn_perm(T[3], T[2], sel);
-        uint32_t hb = (idx >> 3) & 0x01010101u;
-        uint32_t m = (hb << 8) - hb;
-        return (int)((b & m) | (a & ~m));
+        const uint32_t sel = idx & 0x07070707u;
+        const uint32_t a = __builtin_amdgcn_perm(T[1], T[0], sel);   // entries 0..7
+        const uint32_t b = __builtin_amdgcn_perm(T[3], T[2], sel);   // entries 8..15
+        const uint32_t pick = ((idx & 0x08080808u) >> 1) | 0x03020100u;   // byte j: j (from a) or 4 + j (from b)
+        return (int)__builtin_amdgcn_perm(b, a, pick);
     };
     lo = look(q4 & 0x0F0F0F0Fu);
     hi = look((q4 >> 4) & 0x0F0F0F0Fu);
@@ -104,48 +135,48 @@ template <int T> __device__ __forceinline__ RawSub load_raw(const uint8_t *b, in
 }
 
 // Decode a fetched sub-block into 8 words of 4 signed int8 (word k = weights 4k..4k+3) plus the
-// sub-block's integer scale fields.  cb = the type's codebook in LDS.
+// sub-block's integer scale fields.  cb = the type's codebook in LDS, sg = its sign-mask table.
 template <int T>
-__device__ __forceinline__ void decode_raw(const RawSub &r, int ib, const uint32_t *cb, int q[8], SubScale &sc) {
+__device__ __forceinline__ void decode_raw(const RawSub &r, int ib, const uint32_t *cb, const uint2 *sg, int q[8], SubScale &sc) {
     sc.ls0 = sc.ls1 = 0;
     if constexpr (T == 17) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t v = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
-            uint2 g = reinterpret_cast<const uint2 *>(cb)[v & 511u];
-            uint32_t s8 = ksign(v >> 9);
-            q[2 * l] = sign4(g.x, s8);
-            q[2 * l + 1] = sign4(g.y, s8 >> 4);
+            const uint32_t v = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
+            const uint2 g = reinterpret_cast<const uint2 *>(cb)[v & 511u];
+            const uint2 mk = sg[v >> 9];
+            q[2 * l] = sign4(g.x, mk.x);
+            q[2 * l + 1] = sign4(g.y, mk.y);
         }
         sc.ls0 = r.x & 0xF; sc.ls1 = r.x >> 4;
     } else if constexpr (T == 22) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t idx = ((r.a >> (8 * l)) & 0xFFu) | ((r.y << (8 - 2 * l)) & 0x300u);
-            uint2 g = reinterpret_cast<const uint2 *>(cb)[idx];
-            uint32_t s8 = (r.c >> (8 * l)) & 0xFFu;
-            q[2 * l] = sign4(g.x, s8);
-            q[2 * l + 1] = sign4(g.y, s8 >> 4);
+            const uint32_t idx = ((r.a >> (8 * l)) & 0xFFu) | ((r.y << (8 - 2 * l)) & 0x300u);
+            const uint2 g = reinterpret_cast<const uint2 *>(cb)[idx];
+            const uint2 mk = sg[(r.c >> (8 * l)) & 0xFFu];
+            q[2 * l] = sign4(g.x, mk.x);
+            q[2 * l + 1] = sign4(g.y, mk.y);
         }
         sc.ls0 = r.x & 0xF; sc.ls1 = r.x >> 4;
     } else if constexpr (T == 18) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t pair = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
-            uint32_t s8 = ksign((r.c >> (7 * l)) & 127u);
-            q[2 * l] = sign4(cb[pair & 0xFFu], s8);
-            q[2 * l + 1] = sign4(cb[pair >> 8], s8 >> 4);
+            const uint32_t pair = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
+            const uint2 mk = sg[(r.c >> (7 * l)) & 127u];
+            q[2 * l] = sign4(cb[pair & 0xFFu], mk.x);
+            q[2 * l + 1] = sign4(cb[pair >> 8], mk.y);
         }
         sc.ls0 = (int)(r.c >> 28);
     } else if constexpr (T == 21) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            uint32_t pair = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
-            uint32_t i1 = (pair & 0xFFu) | ((r.y << (8 - 2 * l)) & 256u);
-            uint32_t i2 = (pair >> 8) | ((r.y << (7 - 2 * l)) & 256u);
-            uint32_t s8 = (r.c >> (8 * l)) & 0xFFu;
-            q[2 * l] = sign4(cb[i1], s8);
-            q[2 * l + 1] = sign4(cb[i2], s8 >> 4);
+            const uint32_t pair = ((l < 2 ? r.a : r.b) >> (16 * (l & 1))) & 0xFFFFu;
+            const uint32_t i1 = (pair & 0xFFu) | ((r.y << (8 - 2 * l)) & 256u);
+            const uint32_t i2 = (pair >> 8) | ((r.y << (7 - 2 * l)) & 256u);
+            const uint2 mk = sg[(r.c >> (8 * l)) & 0xFFu];
+            q[2 * l] = sign4(cb[i1], mk.x);
+            q[2 * l + 1] = sign4(cb[i2], mk.y);
         }
         sc.ls0 = (r.x >> (4 * (ib & 1))) & 0xF;
     } else {
@@ -158,9 +189,9 @@ __device__ __forceinline__ void decode_raw(const RawSub &r, int ib, const uint32
 }
 
 template <int T>
-__device__ __forceinline__ void decode_sub(const uint8_t *b, int ib, const uint32_t *cb, int q[8], SubScale &sc) {
+__device__ __forceinline__ void decode_sub(const uint8_t *b, int ib, const uint32_t *cb, const uint2 *sg, int q[8], SubScale &sc) {
     const RawSub r = load_raw<T>(b, ib);
-    decode_raw<T>(r, ib, cb, q, sc);
+    decode_raw<T>(r, ib, cb, sg, q, sc);
 }
 
 // Integer scale step of vec_dot_iq*_q8_1 (C truncating division).
@@ -187,7 +218,8 @@ template <int T>
 __global__ __launch_bounds__(256) void iq_dequant_kernel(const uint8_t *__restrict__ blocks, float *__restrict__ out,
                                                           int64_t n_blocks) {
     __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
-    load_codebook<T>(cb);
+    __shared__ uint2 sg[SignLut<T>::N];
+    load_tables<T>(cb, sg);
     const int64_t total = n_blocks * 8;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
         const int64_t blk = s >> 3;
@@ -196,7 +228,7 @@ __global__ __launch_bounds__(256) void iq_dequant_kernel(const uint8_t *__restri
         const float d = vmx_f16_to_f32((uint16_t)ld16(b));
         int q[8];
         SubScale sc;
-        decode_sub<T>(b, ib, cb, q, sc);
+        decode_sub<T>(b, ib, cb, sg, q, sc);
         float db0, db1;
         if constexpr (T == 17 || T == 22) {
             db0 = d * (0.5f + (float)sc.ls0) * 0.25f;
@@ -278,68 +310,80 @@ __global__ __launch_bounds__(256) void quantize_q8_1_bf16_kernel(const uint16_t 
 }
 
 // ------------------------------------------------------------------ MMVQ
-// One wave owns R consecutive output rows per step; lane g walks the row's 32-weight sub-blocks two
-// at a time (g, g+64).  Per step every global load is issued before anything is decoded, in the
-// order the data will be needed back (vmcnt retires in issue order): first the q8_1 activations of
-// the lane's sub-blocks (L2-resident), then the raw weight fields of all R x 2 sub-blocks; only then
-// are the sub-blocks decoded (codebook gathers from LDS) and dotted.  Accumulation:
-// acc += (w_d * a_d) * (float)sub, lanes summed by a 64-wide butterfly.
-template <int T, int MT, int R>
+// One wave owns R consecutive output rows per step; lane l walks the row's 32-weight sub-blocks l, l+64, ... G at a
+// time.  A lane's position inside its super-block (ib = l & 7) never changes, so the field offsets are per-lane constants,
+// row bases are wave-uniform (scalar registers) and a load needs no per-load address arithmetic.  Per step every global
+// load is issued before anything is decoded, in the order the data is needed back (vmcnt retires in issue order): first
+// the q8_1 activations of the lane's sub-blocks (L2-resident), then the raw weight fields of all R x G sub-blocks; only
+// then are the sub-blocks decoded (codebook and sign-mask gathers from LDS) and dotted.  The decode is what bounds this
+// kernel (VALU, then LDS), so everything per sub-block is kept to ~60 vector instructions.
+// Accumulation: acc += (w_d * a_d) * (float)sub, lanes summed by a 64-wide butterfly.
+template <int T, int MT, int R, int G>
 __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
                                                        const float *__restrict__ ad, float *__restrict__ y, int n_out,
                                                        int n_in, int m, int ldy) {
     __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
-    load_codebook<T>(cb);
+    __shared__ uint2 sg[SignLut<T>::N];
+    const TableRegs<T> treg = tables_fetch<T>();   // committed to LDS after the first step's weight loads are issued
+    bool tables_pending = true;
     constexpr int TS = IqTraits<T>::TS;
-    constexpr int G = 2;                      // sub-blocks per lane per step
     constexpr bool ACT_FIRST = MT <= 2;       // activations of the step kept in registers
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ib = lane & 7;
     const int nb256 = n_in >> 8, nblk32 = n_in >> 5;
+    const int64_t row_bytes = (int64_t)nb256 * TS;
     const int waves_total = gridDim.x * 4;
     for (int row0 = (blockIdx.x * 4 + wave) * R; row0 < n_out; row0 += waves_total * R) {
+        const uint8_t *rb[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) rb[r] = w + (int64_t)min(row0 + r, n_out - 1) * row_bytes;
         float acc[R][MT];
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int mi = 0; mi < MT; mi++) acc[r][mi] = 0.0f;
 
-        for (int g0 = lane; g0 < nblk32; g0 += 64 * G) {
+        for (int gb = 0; gb < nblk32; gb += 64 * G) {   // wave-uniform
             int4 ua[G][ACT_FIRST ? MT : 1], ub[G][ACT_FIRST ? MT : 1];
             float da[G][ACT_FIRST ? MT : 1];
+            int gcl[G];      // the lane's sub-block index, clamped to the row
+            int boff[G];     // byte offset of its super-block inside the row
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) {
+                gcl[gi] = min(gb + lane + 64 * gi, nblk32 - 1);   // a clamped duplicate is discarded below
+                boff[gi] = (gcl[gi] >> 3) * TS;
+            }
             if constexpr (ACT_FIRST) {
 #pragma unroll
                 for (int gi = 0; gi < G; gi++) {
-                    const int g = min(g0 + 64 * gi, nblk32 - 1);
 #pragma unroll
                     for (int mi = 0; mi < MT; mi++) {
                         const int mm = min(mi, m - 1);
-                        const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)mm * n_in + g * 32);
+                        const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)mm * n_in + gcl[gi] * 32);
                         ua[gi][mi] = up[0];
                         ub[gi][mi] = up[1];
-                        da[gi][mi] = ad[(int64_t)mm * nblk32 + g];
+                        da[gi][mi] = ad[(int64_t)mm * nblk32 + gcl[gi]];
                     }
                 }
             }
             RawSub raw[R][G];
 #pragma unroll
-            for (int gi = 0; gi < G; gi++) {
-                const int g = min(g0 + 64 * gi, nblk32 - 1);  // a clamped duplicate is discarded below
+            for (int gi = 0; gi < G; gi++)
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int row = min(row0 + r, n_out - 1);
-                    raw[r][gi] = load_raw<T>(w + ((int64_t)row * nb256 + (g >> 3)) * TS, g & 7);
-                }
+                for (int r = 0; r < R; r++) raw[r][gi] = load_raw<T>(rb[r] + boff[gi], ib);
+            if (tables_pending) {
+                tables_commit<T>(treg, cb, sg);
+                tables_pending = false;
             }
 #pragma unroll
             for (int gi = 0; gi < G; gi++) {
-                const int g = g0 + 64 * gi;
-                const bool live = g < nblk32;
-                const int gc = min(g, nblk32 - 1);
+                const bool live = gb + lane + 64 * gi < nblk32;
+                const int gc = gcl[gi];
                 int q[R][8];
                 SubScale sc[R];
 #pragma unroll
-                for (int r = 0; r < R; r++) decode_raw<T>(raw[r][gi], gc & 7, cb, q[r], sc[r]);
+                for (int r = 0; r < R; r++) decode_raw<T>(raw[r][gi], ib, cb, sg, q[r], sc[r]);
 #pragma unroll
                 for (int mi = 0; mi < MT; mi++) {
                     if (mi < m) {
@@ -351,6 +395,7 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
                             const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)mi * n_in + gc * 32);
                             va = up[0]; vb = up[1]; dav = ad[(int64_t)mi * nblk32 + gc];
                         }
+                        if (!live) dav = 0.0f;
                         const int u[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -358,7 +403,7 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
                             const int s0 = subdot_halves(q[r], u, s1);
                             const int sub = scale_int<T>(s0, s1, sc[r]);
                             const float wd = vmx_f16_to_f32((uint16_t)raw[r][gi].d);
-                            if (live) acc[r][mi] += (wd * dav) * (float)sub;
+                            acc[r][mi] += (wd * dav) * (float)sub;
                         }
                     }
                 }
@@ -372,6 +417,125 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
                 if (lane == 0 && mi < m && row0 + r < n_out) y[(int64_t)mi * ldy + row0 + r] = v;
             }
     }
+    if (tables_pending) tables_commit<T>(treg, cb, sg);   // every wave of the workgroup reaches exactly one barrier
+}
+
+// ------------------------------------------------------------------ MMVQ, m == 1: pipelined
+// Sum of v over the wave, left in lane 63 (other lanes hold partial sums): four cross-lane adds inside each row of 16
+// lanes, then the two row broadcasts.  All DPP, no LDS traffic.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane holds its row's sum
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+
+// A wave owns one 4096-weight slice of the row (128 sub-blocks, two per lane: l and l + 64), so its q8_1 activations are
+// loaded ONCE and stay in registers for every row it processes (re-reading them per row costs three times the weight
+// bytes in L1 traffic).  Rows longer than 4096 weights are split over KW = 2 or 4 waves of the workgroup and combined
+// through LDS at the end.  Few waves per CU, each streaming many rows through a ring of D row slots: the loads of row
+// k + D are issued right after row k is decoded, so a wave's rows return in the order it decodes them and the decode
+// (VALU and LDS bound, as long as the weight stream itself) runs beside the stream instead of after it.  With every wave
+// requesting all its rows at once the memory pipeline serves all waves' first loads, then all second loads ..., each
+// wave's last bytes arrive at the end, and the decode time adds to the stream time (measured: 9.1 us = 6.4 + 3.9 - 1.2).
+constexpr int IQ_PIPE_MAX_STEPS = 64;
+
+template <int T, int KW, int D>
+__global__ __launch_bounds__(256) void iq_mmvq_pipe_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
+                                                            const float *__restrict__ ad, float *__restrict__ y, int n_out,
+                                                            int n_in, int steps) {
+    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
+    __shared__ uint2 sg[SignLut<T>::N];
+    __shared__ float part[KW > 1 ? IQ_PIPE_MAX_STEPS * 4 : 1];
+    const TableRegs<T> treg = tables_fetch<T>();
+    constexpr int TS = IqTraits<T>::TS;
+    constexpr int RPS = 4 / KW;            // rows per workgroup step
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = wave % KW, rsub = wave / KW;
+    const int ib = lane & 7;
+    const int nb256 = n_in >> 8, nblk32 = n_in >> 5;
+    const int64_t row_bytes = (int64_t)nb256 * TS;
+
+    // the lane's two sub-blocks and their activations
+    int boff[2];
+    int4 ua[2], ub[2];
+    float da[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; gi++) {
+        const int g = slice * 128 + lane + 64 * gi;
+        const int gc = min(g, nblk32 - 1);   // a clamped duplicate is weighted by zero
+        boff[gi] = (gc >> 3) * TS;
+        const int4 *up = reinterpret_cast<const int4 *>(aq + gc * 32);
+        ua[gi] = up[0];
+        ub[gi] = up[1];
+        da[gi] = g < nblk32 ? ad[gc] : 0.0f;
+    }
+
+    auto step_row = [&](int k) { return (k * (int)gridDim.x + (int)blockIdx.x) * RPS + rsub; };
+    auto load_step = [&](int k, RawSub (&raw)[2]) {
+        // Steps past the end still issue their loads (keeps the loop free of branches around loads, so every wait counts
+        // exactly the loads of the D - 1 younger slots) but all lanes then read the first super-block of the matrix:
+        // one cache line, nothing streamed.
+        const bool real = k < steps;
+        const uint8_t *rp = w + (real ? (int64_t)min(step_row(k), n_out - 1) * row_bytes : (int64_t)0);
+#pragma unroll
+        for (int gi = 0; gi < 2; gi++) raw[gi] = load_raw<T>(rp + (real ? boff[gi] : 0), ib);
+    };
+    auto compute_step = [&](int k, const RawSub (&raw)[2]) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int gi = 0; gi < 2; gi++) {
+            const int u[8] = {ua[gi].x, ua[gi].y, ua[gi].z, ua[gi].w, ub[gi].x, ub[gi].y, ub[gi].z, ub[gi].w};
+            int q[8];
+            SubScale sc;
+            decode_raw<T>(raw[gi], ib, cb, sg, q, sc);
+            int s1;
+            const int s0 = subdot_halves(q, u, s1);
+            const int sub = scale_int<T>(s0, s1, sc);
+            acc += (vmx_f16_to_f32((uint16_t)raw[gi].d) * da[gi]) * (float)sub;
+        }
+        const float v = wave_sum_lane63(acc);
+        if (lane == 63) {
+            if constexpr (KW == 1) {
+                const int row = step_row(k);
+                if (row < n_out) y[row] = v;
+            } else {
+                part[k * 4 + wave] = v;
+            }
+        }
+    };
+
+    RawSub ring[D][2];
+#pragma unroll
+    for (int j = 0; j < D; j++) load_step(j, ring[j]);
+    tables_commit<T>(treg, cb, sg);
+    for (int k0 = 0; k0 < steps; k0 += D) {   // wave-uniform; `steps` is the same for every wave of the grid
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            if (k0 + j < steps) compute_step(k0 + j, ring[j]);
+            load_step(k0 + j + D, ring[j]);
+        }
+    }
+    if constexpr (KW > 1) {
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < steps * RPS) {
+            const int k = t / RPS, rs = t % RPS;
+            const int row = (k * (int)gridDim.x + (int)blockIdx.x) * RPS + rs;
+            float v = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < KW; sl++) v += part[k * 4 + rs * KW + sl];
+            if (row < n_out) y[row] = v;
+        }
+    }
 }
 
 // Integer sub-dots only (parity aid): out[(o*m + mi)*nblk32 + g].
@@ -379,7 +543,8 @@ template <int T>
 __global__ __launch_bounds__(256) void iq_subdots_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
                                                           int32_t *__restrict__ out, int n_out, int n_in, int m) {
     __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
-    load_codebook<T>(cb);
+    __shared__ uint2 sg[SignLut<T>::N];
+    load_tables<T>(cb, sg);
     const int nb256 = n_in >> 8, nblk32 = n_in >> 5;
     const int64_t total = (int64_t)n_out * nblk32;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -387,7 +552,7 @@ __global__ __launch_bounds__(256) void iq_subdots_kernel(const uint8_t *__restri
         const uint8_t *b = w + ((int64_t)o * nb256 + (g >> 3)) * IqTraits<T>::TS;
         int q[8];
         SubScale sc;
-        decode_sub<T>(b, g & 7, cb, q, sc);
+        decode_sub<T>(b, g & 7, cb, sg, q, sc);
         for (int mi = 0; mi < m; mi++) {
             const int *up = reinterpret_cast<const int *>(aq + (int64_t)mi * n_in + g * 32);
             int u[8];
@@ -437,24 +602,39 @@ inline int grid_for(int64_t work_items, int per_block, int cap) {
     return (int)g;
 }
 
+template <int T, int MT, int R, int G>
+void launch_mmvq_cfg(const uint8_t *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy, hipStream_t st) {
+    // rows per workgroup = 4 waves * R; cap the grid and stride the rest.
+    hipLaunchKernelGGL((iq_mmvq_kernel<T, MT, R, G>), dim3(grid_for(n_out, 4 * R, 16384)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
+}
+
+template <int T, int KW>
+void launch_ring(const uint8_t *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, hipStream_t st) {
+    constexpr int RPS = 4 / KW;
+    const int step_rows = (n_out + RPS - 1) / RPS;                 // workgroup-steps of work
+    int grid = min(step_rows, vmx_num_cus() * 4);
+    int steps = (step_rows + grid - 1) / grid;
+    if (steps > IQ_PIPE_MAX_STEPS) steps = IQ_PIPE_MAX_STEPS;
+    grid = (step_rows + steps - 1) / steps;                        // even share: every workgroup runs `steps` steps
+    hipLaunchKernelGGL((iq_mmvq_pipe_kernel<T, KW, 2>), dim3(grid), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, steps);
+}
+
 template <int T>
 int launch_mmvq(const uint8_t *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy, hipStream_t st) {
-    // rows per workgroup = 4 waves * R; cap the grid and stride the rest.
-    if (m == 1) {
-        constexpr int R = 2;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 1, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
+    if (m == 1 && n_in > 4096 && n_in <= 16384 && ldy == n_out) {
+        // long rows: split over 2 or 4 waves, activations resident in registers (measured 9.3 vs 11.3 us on 3840 x 15360)
+        if (n_in <= 8192) launch_ring<T, 2>(w, aq, ad, y, n_out, n_in, st);
+        else launch_ring<T, 4>(w, aq, ad, y, n_out, n_in, st);
+    } else if (m == 1) {
+        launch_mmvq_cfg<T, 1, 2, 2>(w, aq, ad, y, n_out, n_in, m, ldy, st);
     } else if (m == 2) {
-        constexpr int R = 2;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 2, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
+        launch_mmvq_cfg<T, 2, 2, 2>(w, aq, ad, y, n_out, n_in, m, ldy, st);
     } else if (m <= 4) {
-        constexpr int R = 2;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 4, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
+        launch_mmvq_cfg<T, 4, 2, 2>(w, aq, ad, y, n_out, n_in, m, ldy, st);
     } else if (m <= 8) {
-        constexpr int R = 1;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 8, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
+        launch_mmvq_cfg<T, 8, 1, 2>(w, aq, ad, y, n_out, n_in, m, ldy, st);
     } else {
-        constexpr int R = 1;
-        hipLaunchKernelGGL((iq_mmvq_kernel<T, 16, R>), dim3(grid_for(n_out, 4 * R, 8192)), dim3(256), 0, st, w, aq, ad, y, n_out, n_in, m, ldy);
+        launch_mmvq_cfg<T, 16, 1, 2>(w, aq, ad, y, n_out, n_in, m, ldy, st);
     }
     VMX_CHECK_LAUNCH("iq_mmvq");
     return VMX_OK;

@@ -14,6 +14,17 @@ void vmx_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// Compute units of the current device (256 on MI355X); queried once per process, no device work.
+int vmx_num_cus(void) {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+        return cus;
+    }();
+    return n;
+}
+
 extern "C" const char *vmx_last_error(void) { return g_err; }
 
 extern "C" int vmx_abi_version(void) { return 1; }

@@ -11,6 +11,7 @@
 
 // ---------------------------------------------------------------- host side
 void vmx_set_error(const char *fmt, ...);
+int vmx_num_cus(void);
 
 #define VMX_REQUIRE(cond, ...)            \
     do {                                  \
