@@ -392,6 +392,68 @@ int vmx_qwen3_set_comm(vmx_qwen3 *m, vmx_comm *comm);
  * 1 = final normed x, 2 = logits), bf16. */
 int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t bytes, void *stream);
 
+
+/* ---------------------------------------------------- whole-token decoder, Gemma 4 (GGUF) */
+
+/* Engine-facing surface of the quantized Gemma 4 decoder: the C form of ModelForward::forward_decode_batch for
+ * QuantizedGemma4ForCausalLM on the paged-decode path (crates/core/src/models/gemma4_quantized.rs: attention
+ * :1311-1424, GeGLU MLP :1468-1473, sandwich-norm layer :1743-1774, embedding scale / final norm / soft-cap
+ * :2217-2279) with the honest per-layer KV geometry of KVCacheManager::new_heterogeneous
+ * (crates/server/src/main.rs:44-93): sliding layers kv_heads_sliding x head_dim_sliding with a window, full layers
+ * kv_heads_full x head_dim_full, full causal.  Every projection is a GGUF I-quant tensor (IqLinear); the token
+ * embedding (tied lm_head) is bf16 or a GGML K-quant table.  Not covered: KV-shared layers, PLE inputs, MoE blocks,
+ * attention-logit soft-capping (the reference leaves the paged path for those, :1282-1299). */
+typedef struct vmx_gemma4_config {
+    int hidden_size, num_layers, num_heads, intermediate_size, vocab_size;
+    float rms_norm_eps;
+    int head_dim_sliding, head_dim_full;      /* 256 / 512 on the 12B model */
+    int kv_heads_sliding, kv_heads_full;      /* 8 / 1 */
+    int sliding_window;                       /* tokens a sliding layer attends to */
+    int rot_dim_sliding, rot_dim_full;        /* rotated leading dims (full rotary / proportional partial rotary) */
+    int max_position;                         /* rows of the two cos/sin tables */
+    int kv_cache_dtype;                       /* VMX_KV_AUTO (bf16) or VMX_KV_FP8_E4M3 */
+    int block_size, num_blocks;               /* paged KV geometry, the same block ids in every layer's cache */
+    int max_batch, max_seq_len;
+    float final_logit_softcap;                /* 0 = off */
+    int embed_ggml_type;                      /* 0 = bf16 table, else the GGML type id of token_embd (11 Q3_K, 14 Q6_K, ...) */
+} vmx_gemma4_config;
+
+typedef struct vmx_gemma4 vmx_gemma4;
+
+/* layer_flags[i]: bit 0 = sliding-attention layer, bit 1 = V reuses the K projection (attention_k_eq_v, :863-870) */
+#define VMX_G4_SLIDING 1
+#define VMX_G4_K_EQ_V 2
+
+/* tensor ids for vmx_gemma4_load_tensor */
+#define VMX_G4T_EMBED 0          /* bf16 [vocab, hidden] or raw GGML blocks of token_embd */
+#define VMX_G4T_FINAL_NORM 1     /* bf16 [hidden] */
+#define VMX_G4T_COS_SIN_SLIDING 2 /* f32 [max_position, rot_dim_sliding]: cos | sin halves per row */
+#define VMX_G4T_COS_SIN_FULL 3   /* f32 [max_position, rot_dim_full] */
+#define VMX_G4T_INPUT_LN 4       /* per layer, bf16 [hidden] */
+#define VMX_G4T_POST_ATTN_LN 5
+#define VMX_G4T_PRE_FFN_LN 6
+#define VMX_G4T_POST_FFN_LN 7
+#define VMX_G4T_Q_NORM 8         /* bf16 [head_dim of the layer] */
+#define VMX_G4T_K_NORM 9
+#define VMX_G4T_LAYER_SCALAR 10  /* bf16 [1] */
+#define VMX_G4T_KV_SCALES 11     /* f32 [2] = {k_scale, v_scale} */
+
+int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_flags, vmx_gemma4 **out);
+void vmx_gemma4_destroy(vmx_gemma4 *m);
+int vmx_gemma4_load_tensor(vmx_gemma4 *m, int which, int layer, const void *src, size_t bytes, void *stream);
+/* slot: VMX_L_Q .. VMX_L_DOWN; raw I-quant blocks of the [out, in] weight (GgufWeightLoader::load_linear, gguf/mod.rs:1612-1662) */
+int vmx_gemma4_load_iq_linear(vmx_gemma4 *m, int layer, int slot, int ggml_type, const void *blocks, size_t bytes, void *stream);
+/* One decode step; arguments as vmx_qwen3_decode.  Fixed launch sequence, hipGraph-capturable. */
+int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+                      const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq, int max_seq_len,
+                      int32_t *out_ids, uint16_t *logits_out, void *stream);
+/* Measurement aid: launches and summed algorithmic bytes (weights + q8_1 activations + f32 outputs) of the MMVQ calls of one step,
+ * and a pass that runs only those launches on the model's own buffers. */
+int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_bytes);
+int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream);
+/* Parity aid: 0 = residual stream h, 1 = final normed x (bf16 [batch, hidden]). */
+int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

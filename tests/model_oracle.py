@@ -82,3 +82,80 @@ class OracleQwen3:
         head = self.ck["embed"] if s.tie_word_embeddings else self.ck["lm_head"]
         logits = orc.f32_to_bf16((orc.bf16_to_f32(x).astype(np.float64) @ orc.bf16_to_f32(head).astype(np.float64).T).astype(np.float32))
         return logits, h, x
+
+
+def mul_bf16(a_u16, b_u16):
+    return orc.f32_to_bf16(orc.bf16_to_f32(a_u16) * orc.bf16_to_f32(b_u16))
+
+
+def _rbf(x_f32):
+    return orc.bf16_to_f32(orc.f32_to_bf16(np.asarray(x_f32, np.float32)))
+
+
+class OracleGemma4:
+    """CPU restatement of the reference's quantized Gemma 4 decode step on its paged path, composed from the oracle's
+    operators in the reference's order (models/gemma4_quantized.rs: attention :1311-1424, MLP :1468-1473, layer
+    :1743-1774, embedding scale / final norm / tied lm_head / soft-cap :2217-2279)."""
+
+    def __init__(self, spec, ck, cos_sin_sliding, cos_sin_full):
+        self.s = spec
+        self.cs = (cos_sin_sliding, cos_sin_full)
+        self.ck = {k: (_np(v) if not isinstance(v, tuple) else v) for k, v in ck.items()}
+        s = spec
+        kv_np = np.uint8 if s.kv_cache_dtype == 1 else np.uint16
+        self.k_cache, self.v_cache = [], []
+        for li in range(s.num_layers):
+            hd, kvh, _, _, _ = s.layer_geom(li)
+            self.k_cache.append(np.zeros((s.num_blocks, s.block_size, kvh, hd), kv_np))
+            self.v_cache.append(np.zeros((s.num_blocks, s.block_size, kvh, hd), kv_np))
+        if s.embed_ggml_type == 0:
+            self.embed_f32 = orc.bf16_to_f32(self.ck["embed"])
+        else:   # dequantised table (QuantizedEmbedding / QMatMul over the same blocks)
+            self.embed_f32 = orc.ggml_dequant(s.embed_ggml_type, self.ck["embed"]).reshape(s.vocab_size, s.hidden_size)
+
+    def linear(self, li, slot, x_u16):
+        t, raw = self.ck[f"{li}.{slot}.iq"]
+        raw = raw.numpy() if hasattr(raw, "numpy") else raw
+        x = orc.bf16_to_f32(x_u16)
+        n_in = x.shape[1]
+        n_out = raw.size // (n_in // 256 * orc.IQ_TYPE_SIZE[t])
+        return orc.f32_to_bf16(orc.iq_matmul(t, raw, x, n_out, n_in))
+
+    def decode(self, ids, positions, slots, block_tables, seq_lens):
+        from scipy.special import erf
+        s = self.s
+        B = len(ids)
+        norm_bf16 = orc.f32_to_bf16(np.float32(np.sqrt(np.float32(s.hidden_size))))        # affine factor rounded to bf16
+        h = mul_bf16(orc.f32_to_bf16(self.embed_f32[ids]), np.broadcast_to(norm_bf16, (B, s.hidden_size)))
+        for li in range(s.num_layers):
+            hd, kvh, rot, window, keqv = s.layer_geom(li)
+            sliding = s.sliding(li)
+            x = orc.rms_norm_bf16(h, self.ck[f"{li}.input_ln"], s.rms_norm_eps)
+            q, k = self.linear(li, 0, x), self.linear(li, 1, x)
+            v = k if keqv else self.linear(li, 2, x)
+            ones = orc.f32_to_bf16(np.ones(hd, np.float32))
+            q = orc.rms_norm_bf16(q.reshape(B * s.num_heads, hd), self.ck[f"{li}.q_norm"], s.rms_norm_eps).reshape(B, -1)
+            v = orc.rms_norm_bf16(v.reshape(B * kvh, hd), ones, s.rms_norm_eps).reshape(B, -1)
+            k = orc.rms_norm_bf16(k.reshape(B * kvh, hd), self.ck[f"{li}.k_norm"], s.rms_norm_eps).reshape(B, -1)
+            q, k = orc.rope_neox_bf16(positions, q, k, self.cs[0 if sliding else 1], rot, hd, s.num_heads, kvh)
+            orc.reshape_and_cache(k, v, self.k_cache[li], self.v_cache[li], slots, kvh, hd, s.block_size, s.kv_cache_dtype, 1.0, 1.0)
+            psize = 64 if int(seq_lens.max()) <= 4096 else 256
+            attn = orc.paged_attention_v2(q, self.k_cache[li], self.v_cache[li], block_tables, seq_lens, 1.0, s.num_heads, kvh, hd,
+                                          s.block_size, psize, window, s.kv_cache_dtype, 1.0, 1.0)
+            o = self.linear(li, 3, attn)
+            h = add_bf16(orc.rms_norm_bf16(o, self.ck[f"{li}.post_attn_ln"], s.rms_norm_eps), h)
+            x = orc.rms_norm_bf16(h, self.ck[f"{li}.pre_ffn_ln"], s.rms_norm_eps)
+            g = orc.bf16_to_f32(self.linear(li, 4, x)).astype(np.float64)
+            ge = orc.f32_to_bf16((0.5 * g * (1.0 + erf(g / np.sqrt(2.0)))).astype(np.float32))      # gelu_erf, rounded to bf16
+            a = mul_bf16(ge, self.linear(li, 5, x))
+            d = self.linear(li, 6, a)
+            h = add_bf16(orc.rms_norm_bf16(d, self.ck[f"{li}.post_ffn_ln"], s.rms_norm_eps), h)
+            h = mul_bf16(h, np.broadcast_to(self.ck[f"{li}.scalar"].reshape(1, 1), h.shape))
+        x = orc.rms_norm_bf16(h, self.ck["final_norm"], s.rms_norm_eps)
+        logits = (orc.bf16_to_f32(x).astype(np.float64) @ self.embed_f32.astype(np.float64).T).astype(np.float32)
+        logits = _rbf(logits)
+        cap = s.final_logit_softcap
+        if cap > 0:
+            inv = _rbf(np.float32(1.0 / cap))
+            logits = _rbf(_rbf(np.tanh(_rbf(logits * inv))) * np.float32(cap))
+        return orc.f32_to_bf16(logits), h, x

@@ -1,0 +1,74 @@
+"""Quantized Gemma 4 decode executor against the composed CPU oracle (parity unpinned: the reference holds no golden
+vectors for the model level; the operators underneath are pinned individually)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(spec, steps, B, slot_types=None, seed=3):
+    import torch
+    import vllm_rust_amd as vmx
+    from oracle import oracle as orc
+    from tests.model_oracle import OracleGemma4
+    from vllm_rust_amd.gemma4 import QuantizedGemma4ForCausalLM
+    vmx.init(0)
+    model = QuantizedGemma4ForCausalLM(spec)
+    ck = model.load_synthetic(slot_types=slot_types, seed=seed, keep_host_copy=True)
+    ref = OracleGemma4(spec, ck, model.cos_sin_sliding, model.cos_sin_full)
+    nblk = spec.num_blocks // B
+    bt = np.arange(B * nblk, dtype=np.int32).reshape(B, nblk)
+    ids = np.array([7, 123, 55, 900][:B], np.int32)
+    worst = 0.0
+    for p in range(steps):
+        pos = np.full(B, p, np.int32)
+        slots = (bt[np.arange(B), p // spec.block_size] * spec.block_size + p % spec.block_size).astype(np.int32)
+        sl = pos + 1
+        logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        out = model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, pos, slots, bt, sl)), logits=logits)
+        torch.cuda.synchronize()
+        exp, h_exp, _ = ref.decode(ids, pos, slots, bt, sl)
+        got = orc.bf16_to_f32(logits.cpu().view(torch.int16).numpy().view(np.uint16))
+        expf = orc.bf16_to_f32(exp)
+        rel = float(np.sqrt(((got - expf) ** 2).sum() / (expf ** 2).sum()))
+        hg = orc.bf16_to_f32(model.debug_read(0, (B, spec.hidden_size)).cpu().view(torch.int16).numpy().view(np.uint16))
+        he = orc.bf16_to_f32(h_exp)
+        relh = float(np.sqrt(((hg - he) ** 2).sum() / (he ** 2).sum()))
+        assert np.isfinite(got).all()
+        assert relh <= 2e-2, f"step {p}: residual stream differs from the CPU oracle (rel L2 {relh})"
+        assert rel <= 2e-2, f"step {p}: logits differ from the CPU oracle (rel L2 {rel})"
+        worst = max(worst, rel)
+        # greedy id: the oracle's argmax, or a logit within one bf16 step of the oracle's maximum
+        o = out.cpu().numpy()
+        for b in range(B):
+            assert expf[b, o[b]] >= expf[b].max() - abs(expf[b].max()) * 2 ** -6
+        ids = o.astype(np.int32)
+    model.close()
+    return worst
+
+
+def test_gemma4_decode_matches_oracle_fp8_kv_window():
+    """3 layers (sliding, sliding, full), window 4 < steps so the sliding window is exercised, FP8 KV, soft-cap, bf16 embedding."""
+    from vllm_rust_amd.gemma4 import Gemma4Spec
+    spec = Gemma4Spec(256, 3, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=4, full_every=3, max_position=64, kv_cache_dtype=1, num_blocks=8, max_batch=2, max_seq_len=32)
+    _run(spec, steps=7, B=2)
+
+
+def test_gemma4_decode_k_eq_v_q3k_embedding_bf16_kv():
+    """Full layers reuse K as V; token embedding / tied lm_head is a Q3_K table; bf16 KV; all five I-quant types in use."""
+    from vllm_rust_amd.gemma4 import Gemma4Spec
+    spec = Gemma4Spec(256, 2, 4, 512, 512, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=16, full_every=2, k_eq_v_on_full=True, max_position=64, kv_cache_dtype=0, num_blocks=4,
+                      max_batch=1, max_seq_len=32, embed_ggml_type=11, final_logit_softcap=0.0)
+    _run(spec, steps=4, B=1, slot_types={0: 17, 1: 22, 2: 18, 3: 21, 4: 23, 5: 18, 6: 21})
+
+
+def test_gemma4_rejects_bad_config():
+    import ctypes as C
+    from vllm_rust_amd._lib import Gemma4Config, lib
+    cfg = Gemma4Config(250, 1, 4, 512, 100, 1e-6, 64, 128, 2, 1, 4, 64, 32, 64, 0, 16, 4, 1, 32, 0.0, 0)
+    h = C.c_void_p()
+    flags = (C.c_int * 1)(1)
+    assert lib.vmx_gemma4_create(C.byref(cfg), flags, C.byref(h)) == -1
+    assert b"hidden_size" in lib.vmx_last_error()

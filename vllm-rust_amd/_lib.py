@@ -94,6 +94,14 @@ _SIGS = {
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "vmx_qwen3_linears_only": (_i, [_p, _i, _p]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
+    "vmx_gemma4_create": (_i, [_p, _p, _p]),
+    "vmx_gemma4_destroy": (None, [_p]),
+    "vmx_gemma4_load_tensor": (_i, [_p, _i, _i, _p, _sz, _p]),
+    "vmx_gemma4_load_iq_linear": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
+    "vmx_gemma4_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "vmx_gemma4_mmvq_info": (_i, [_p, _i, _p, _p]),
+    "vmx_gemma4_mmvq_only": (_i, [_p, _i, _p]),
+    "vmx_gemma4_debug_read": (_i, [_p, _i, _p, _sz, _p]),
 }
 
 
@@ -104,6 +112,17 @@ class Qwen3Config(C.Structure):
         ("intermediate_size", _i), ("vocab_size", _i), ("rms_norm_eps", _f), ("max_position", _i), ("group_size", _i),
         ("qk_norm", _i), ("tie_word_embeddings", _i), ("kv_cache_dtype", _i), ("block_size", _i), ("num_blocks", _i),
         ("max_batch", _i), ("max_seq_len", _i), ("tp_size", _i), ("tp_rank", _i),
+    ]
+
+
+class Gemma4Config(C.Structure):
+    """struct vmx_gemma4_config (include/vmx.h)."""
+    _fields_ = [
+        ("hidden_size", _i), ("num_layers", _i), ("num_heads", _i), ("intermediate_size", _i), ("vocab_size", _i),
+        ("rms_norm_eps", _f), ("head_dim_sliding", _i), ("head_dim_full", _i), ("kv_heads_sliding", _i), ("kv_heads_full", _i),
+        ("sliding_window", _i), ("rot_dim_sliding", _i), ("rot_dim_full", _i), ("max_position", _i), ("kv_cache_dtype", _i),
+        ("block_size", _i), ("num_blocks", _i), ("max_batch", _i), ("max_seq_len", _i), ("final_logit_softcap", _f),
+        ("embed_ggml_type", _i),
     ]
 
 

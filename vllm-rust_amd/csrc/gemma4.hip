@@ -1,0 +1,616 @@
+// Whole-token decode executor for the quantized Gemma 4 decoder (GGUF I-quant linears, FP8 or bf16 paged KV cache
+// with per-layer geometry), mirroring the paged-decode path of the reference's QuantizedGemma4ForCausalLM
+// (crates/core/src/models/gemma4_quantized.rs: attention :1311-1424, MLP :1468-1473, layer :1743-1774,
+// model :2217-2279) behind a C ABI.
+//
+// Operator order and rounding points are the reference's: IqLinear returns f32 cast back to bf16; every norm output,
+// residual sum, layer-scalar product, rotated q/k, activation and product is rounded to bf16 where the reference's
+// separate tensor ops round it.  The launch structure is this library's own: one fused vector kernel folds
+// "bf16(linear out) -> post-norm -> + residual -> * layer_scalar -> next pre-norm -> q8_1" (the sandwich norms of
+// two consecutive sub-blocks), one kernel does per-head q/k/v norms + RoPE + KV write, one does GeGLU + q8_1.
+// A layer is 12 launches (6 MMVQ); the step is a fixed launch sequence (hipGraph-capturable).
+#include "vmx_kernels.h"
+
+#include <math.h>
+#include <new>
+#include <vector>
+
+namespace {
+
+__device__ __forceinline__ float rbf(float v) { return vmx_bf16_to_f32(vmx_f32_to_bf16(v)); }
+
+__device__ __forceinline__ void unpack8(const uint4 v, float f[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f[2 * j] = __uint_as_float(w[j] << 16);
+        f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+    }
+}
+
+__device__ __forceinline__ uint4 pack8(const float f[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = (uint32_t)vmx_f32_to_bf16(f[2 * j]) | ((uint32_t)vmx_f32_to_bf16(f[2 * j + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// h[t, :] = bf16(table[ids[t], :] * scale)   (embed_tokens.forward(ids) * sqrt(hidden), gemma4_quantized.rs:2217-2218)
+__global__ __launch_bounds__(256) void g4_embed_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ table,
+                                                        const int32_t *__restrict__ ids, int hidden, int vocab, float scale) {
+    const int t = blockIdx.x;
+    const int id = ids[t];
+    const bool ok = id >= 0 && id < vocab;
+    const uint4 *src = reinterpret_cast<const uint4 *>(table + (int64_t)(ok ? id : 0) * hidden);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (int64_t)t * hidden);
+    for (int i = threadIdx.x; i < (hidden >> 3); i += 256) {
+        float f[8];
+        unpack8(ok ? src[i] : make_uint4(0, 0, 0, 0), f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] *= scale;
+        dst[i] = pack8(f);
+    }
+}
+
+// One workgroup per token; thread t owns the 8-element chunks t, t+256, ... (CH of them) in registers.
+//   o given:  o_r = bf16(o);  n = bf16(o_r * rsqrt(mean(o_r^2) + eps) * w_post);  h = bf16(n + h);
+//             scalar given: h = bf16(h * scalar)                       (post-norm, residual add, layer_scalar)
+//   always:   x = bf16(h * rsqrt(mean(h^2) + eps) * w_next)  (+ its q8_1 form)   (the next sub-block's pre-norm)
+template <int CH>
+__global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x, const float *__restrict__ o,
+                                                       const uint16_t *__restrict__ w_post, const uint16_t *__restrict__ scalar,
+                                                       const uint16_t *__restrict__ w_next, float eps, int hidden,
+                                                       int8_t *__restrict__ aq, float *__restrict__ ad) {
+    __shared__ float red[4];
+    const int64_t row = (int64_t)blockIdx.x * hidden;
+    const int nchunk = hidden >> 3;
+    float hv[CH][8];
+    if (o) {
+        float ov[CH][8];
+        float v1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int ci = threadIdx.x + 256 * c;
+            if (ci < nchunk) {
+                const float4 a = *reinterpret_cast<const float4 *>(o + row + 8 * ci), b = *reinterpret_cast<const float4 *>(o + row + 8 * ci + 4);
+                const float t8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) { ov[c][j] = rbf(t8[j]); v1 += ov[c][j] * ov[c][j]; }
+            }
+        }
+        v1 = vmx_block_sum_256(v1, red);
+        const float inv1 = rsqrtf(v1 / (float)hidden + eps);
+        const float sc = scalar ? vmx_bf16_to_f32(scalar[0]) : 1.0f;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int ci = threadIdx.x + 256 * c;
+            if (ci < nchunk) {
+                float wv[8], hr[8];
+                unpack8(*reinterpret_cast<const uint4 *>(w_post + 8 * ci), wv);
+                unpack8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hr);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float v = rbf(rbf(ov[c][j] * inv1 * wv[j]) + hr[j]);
+                    if (scalar) v = rbf(v * sc);
+                    hv[c][j] = v;
+                }
+                *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack8(hv[c]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int ci = threadIdx.x + 256 * c;
+            if (ci < nchunk) unpack8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
+        }
+    }
+    float v2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int ci = threadIdx.x + 256 * c;
+        if (ci < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v2 += hv[c][j] * hv[c][j];
+        }
+    }
+    v2 = vmx_block_sum_256(v2, red);
+    const float inv2 = rsqrtf(v2 / (float)hidden + eps);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int ci = threadIdx.x + 256 * c;
+        if (ci < nchunk) {
+            float wv[8], out[8];
+            unpack8(*reinterpret_cast<const uint4 *>(w_next + 8 * ci), wv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) out[j] = hv[c][j] * inv2 * wv[j];
+            const uint4 packed = pack8(out);
+            *reinterpret_cast<uint4 *>(x + row + 8 * ci) = packed;
+            if (aq) {
+                float xr[8];
+                unpack8(packed, xr);
+                vmx_q8_1_emit8(xr, aq + row + 8 * ci, ad + (row >> 5) + (ci >> 2), (ci & 3) == 0);
+            }
+        }
+    }
+}
+
+// grid (Hq + 2*Hkv, tokens), block 64.  proj: f32 [tokens][ntot] = q | k | (v) projections.  Per head: bf16 round,
+// per-head RMSNorm (q, k weighted; v unweighted), NeoX RoPE on the first rot_dim dims of q and k, bf16 rounds after
+// each; q -> q_out, k and v -> the layer's paged cache (bf16 or FP8 e4m3).  v_from_k: V is the K projection
+// (before K's norm and rotation) put through the unweighted norm.
+__global__ __launch_bounds__(64) void g4_qkv_post_kernel(const float *__restrict__ proj, int ntot, uint16_t *__restrict__ q_out,
+                                                          void *__restrict__ k_cache, void *__restrict__ v_cache,
+                                                          const uint16_t *__restrict__ q_norm_w, const uint16_t *__restrict__ k_norm_w,
+                                                          float eps, const float *__restrict__ cos_sin,
+                                                          const int32_t *__restrict__ positions, const int32_t *__restrict__ slots, int Hq,
+                                                          int Hkv, int hd, int rot_dim, int v_from_k, int fp8,
+                                                          const float *__restrict__ k_scale, const float *__restrict__ v_scale) {
+    __shared__ float vals[512];
+    const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
+    int src_head = head;
+    if (!is_q && !is_k && v_from_k) src_head = head - Hkv;
+    const int64_t base = (int64_t)t * ntot + (int64_t)src_head * hd;
+    float ss = 0.f;
+    for (int i = lane; i < hd; i += 64) {
+        const float v = rbf(proj[base + i]);
+        vals[i] = v;
+        ss += v * v;
+    }
+    ss = vmx_wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)hd + eps);
+    const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
+    for (int i = lane; i < hd; i += 64) vals[i] = rbf(vals[i] * inv * (nw ? vmx_bf16_to_f32(nw[i]) : 1.0f));
+    __syncthreads();
+    if (is_q || is_k) {
+        const int half = rot_dim >> 1;
+        const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
+        for (int i = lane; i < half; i += 64) {
+            const float xv = vals[i], yv = vals[half + i], c = cs[i], s = cs[half + i];
+            vals[i] = rbf(xv * c - yv * s);
+            vals[half + i] = rbf(yv * c + xv * s);
+        }
+        __syncthreads();
+    }
+    if (is_q) {
+        for (int i = lane; i < hd; i += 64) q_out[((int64_t)t * Hq + head) * hd + i] = vmx_f32_to_bf16(vals[i]);
+        return;
+    }
+    const int slot = slots[t];
+    if (slot < 0) return;
+    const int kvh = is_k ? head - Hq : head - Hq - Hkv;
+    const int64_t dst = ((int64_t)slot * Hkv + kvh) * hd;
+    void *cache = is_k ? k_cache : v_cache;
+    if (!fp8) {
+        for (int i = lane; i < hd; i += 64) ((uint16_t *)cache)[dst + i] = vmx_f32_to_bf16(vals[i]);
+    } else {   // clamp(x / scale, +-448) -> bf16 -> e4m3 (kv_cache/cache_engine.rs:202-223)
+        const float sc = is_k ? *k_scale : *v_scale;
+        for (int i = lane; i < hd; i += 64) {
+            float a = vals[i] / sc;
+            a = rbf(fminf(fmaxf(a, -448.0f), 448.0f));
+            ((uint8_t *)cache)[dst + i] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, a, 0, false) & 0xFFu);
+        }
+    }
+}
+
+// act[t, i] = bf16(bf16(gelu_erf(bf16(gate))) * bf16(up)) from f32 [tokens][2*inter] (gate columns first), 8 elements per
+// thread, plus the q8_1 form of the result for the down projection.
+__global__ __launch_bounds__(256) void g4_geglu_kernel(const float *__restrict__ gu, int tokens, uint16_t *__restrict__ act, int inter,
+                                                        int8_t *__restrict__ aq, float *__restrict__ ad) {
+    const int64_t chunks = (int64_t)tokens * inter / 8;
+    const int cpr = inter / 8;
+    for (int64_t c0 = (int64_t)blockIdx.x * 256; c0 < chunks; c0 += (int64_t)gridDim.x * 256) {
+        const int64_t c = c0 + threadIdx.x;
+        if (c < chunks) {   // chunks % 4 == 0: 4-lane q8_1 groups are all in or all out
+            const int64_t t = c / cpr, col = (c % cpr) * 8;
+            const float *gp = gu + t * 2 * inter + col, *up = gp + inter;
+            const float4 g0 = *reinterpret_cast<const float4 *>(gp), g1 = *reinterpret_cast<const float4 *>(gp + 4);
+            const float4 u0 = *reinterpret_cast<const float4 *>(up), u1 = *reinterpret_cast<const float4 *>(up + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float gg = rbf(g[j]);
+                const float ge = rbf(0.5f * gg * (1.0f + erff(gg * 0.70710678118654752f)));
+                r[j] = ge * rbf(u[j]);
+            }
+            const uint4 packed = pack8(r);
+            *reinterpret_cast<uint4 *>(act + c * 8) = packed;
+            float rr[8];
+            unpack8(packed, rr);
+            vmx_q8_1_emit8(rr, aq + c * 8, ad + (c >> 2), (c & 3) == 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void g4_bf16_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = vmx_bf16_to_f32(in[i]);
+}
+
+// logits (bf16 in place, or from f32) -> optional soft-cap: bf16(bf16(tanh(bf16(l * bf16(1/cap)))) * cap)  (soft_cap, :61-67)
+__global__ __launch_bounds__(256) void g4_logits_kernel(uint16_t *__restrict__ logits, const float *__restrict__ src_f32, int64_t n,
+                                                         float inv_cap_bf16, float cap) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float l = src_f32 ? rbf(src_f32[i]) : vmx_bf16_to_f32(logits[i]);
+    if (cap > 0.f) l = rbf(rbf(tanhf(rbf(l * inv_cap_bf16))) * cap);
+    logits[i] = vmx_f32_to_bf16(l);
+}
+
+struct Buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        bytes = n;
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e != hipSuccess) {
+            vmx_set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+            return VMX_ENOMEM;
+        }
+        return VMX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+// IqLinear (crates/core/src/quantization/gguf/mod.rs:262-377): raw GGUF block bytes of one [out, in] weight.
+struct IqLin {
+    int ggml_type = 0, in_features = 0, out_features = 0;
+    Buf raw;
+    bool loaded = false;
+    double alg_bytes(int m) const {
+        return (double)out_features * (in_features / 256) * vmx_iq_type_size(ggml_type) + (double)m * in_features * (1.0 + 4.0 / 32.0) +
+               (double)m * out_features * 4.0;
+    }
+};
+
+struct G4Layer {
+    bool sliding = false, k_eq_v = false;
+    int hd = 0, kvh = 0, rot = 0, window = 0;
+    IqLin lin[7];
+    Buf input_ln, post_attn_ln, pre_ffn_ln, post_ffn_ln, q_norm, k_norm, scalar, k_cache, v_cache, kv_scales;
+    bool ready() const {
+        for (int s = 0; s < 7; s++)
+            if (!lin[s].loaded && !(s == VMX_L_V && k_eq_v)) return false;
+        return true;
+    }
+    int nq(int heads) const { return heads * hd; }
+    int nkv() const { return kvh * hd; }
+};
+
+}  // namespace
+
+struct vmx_gemma4 {
+    vmx_gemma4_config cfg;
+    std::vector<G4Layer> layers;
+    Buf embed, final_norm, cos_sin_s, cos_sin_f;
+    Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8;
+    float embed_scale = 1.f;
+};
+
+namespace {
+int8_t *aq_of(vmx_gemma4 *m) { return (int8_t *)m->q8.p; }
+float *ad_of(vmx_gemma4 *m, int tokens, int k) { return (float *)((char *)m->q8.p + (((size_t)tokens * k + 255) & ~(size_t)255)); }
+
+int mmvq(vmx_gemma4 *m, const IqLin &l, float *y, int ldy, int tokens, hipStream_t st) {
+    return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq_of(m), ad_of(m, tokens, l.in_features), y, l.out_features, l.in_features, tokens, ldy, st);
+}
+
+void launch_norm(hipStream_t st, int tokens, uint16_t *h, uint16_t *x, const float *o, const uint16_t *w_post, const uint16_t *scalar,
+                 const uint16_t *w_next, float eps, int hidden, int8_t *aq, float *ad) {
+    if (hidden <= 2048) hipLaunchKernelGGL(g4_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+    else if (hidden <= 4096) hipLaunchKernelGGL(g4_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+    else if (hidden <= 8192) hipLaunchKernelGGL(g4_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+    else hipLaunchKernelGGL(g4_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+}
+}  // namespace
+
+extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_flags, vmx_gemma4 **out) {
+    VMX_REQUIRE(cfg && layer_flags && out, "gemma4_create: null pointer");
+    const vmx_gemma4_config &c = *cfg;
+    VMX_REQUIRE(c.hidden_size > 0 && c.hidden_size % 256 == 0 && c.hidden_size <= 16384,
+                "gemma4_create: hidden_size (%d) must be a multiple of 256, at most 16384", c.hidden_size);
+    VMX_REQUIRE(c.intermediate_size > 0 && c.intermediate_size % 256 == 0, "gemma4_create: intermediate_size (%d) must be a multiple of 256",
+                c.intermediate_size);
+    VMX_REQUIRE(c.num_layers > 0 && c.num_heads > 0 && c.kv_heads_sliding > 0 && c.kv_heads_full > 0 &&
+                    c.num_heads % c.kv_heads_sliding == 0 && c.num_heads % c.kv_heads_full == 0,
+                "gemma4_create: bad head counts");
+    for (int hd : {c.head_dim_sliding, c.head_dim_full})
+        VMX_REQUIRE(hd == 64 || hd == 128 || hd == 256 || hd == 512, "gemma4_create: head_dim %d unsupported", hd);
+    VMX_REQUIRE(c.rot_dim_sliding > 0 && c.rot_dim_sliding % 2 == 0 && c.rot_dim_sliding <= c.head_dim_sliding && c.rot_dim_full > 0 &&
+                    c.rot_dim_full % 2 == 0 && c.rot_dim_full <= c.head_dim_full,
+                "gemma4_create: rotary dims (%d, %d) must be even and at most the head dims", c.rot_dim_sliding, c.rot_dim_full);
+    VMX_REQUIRE(c.max_batch >= 1 && c.max_batch <= 16, "gemma4_create: max_batch (%d) must be in 1..16", c.max_batch);
+    VMX_REQUIRE(c.block_size > 0 && c.num_blocks > 0 && c.max_seq_len > 0 && c.vocab_size > 0 && c.max_position > 0 && c.sliding_window > 0,
+                "gemma4_create: bad cache/vocab geometry");
+    VMX_REQUIRE(c.kv_cache_dtype == VMX_KV_AUTO || c.kv_cache_dtype == VMX_KV_FP8_E4M3, "gemma4_create: unsupported kv dtype");
+    VMX_REQUIRE(c.embed_ggml_type == 0 || (vmx_ggml_type_size(c.embed_ggml_type) > 0 && vmx_iq_type_size(c.embed_ggml_type) < 0),
+                "gemma4_create: token_embd type %d unsupported (bf16 or a GGML legacy/K-quant type)", c.embed_ggml_type);
+    VMX_REQUIRE(c.embed_ggml_type == 0 || c.hidden_size % vmx_ggml_block_elems(c.embed_ggml_type) == 0, "gemma4_create: hidden_size vs embed block");
+    vmx_gemma4 *m = new (std::nothrow) vmx_gemma4();
+    VMX_REQUIRE(m, "gemma4_create: out of host memory");
+    m->cfg = c;
+    m->layers.resize(c.num_layers);
+    // embed_tokens.forward(ids) * sqrt(hidden) is a bf16 affine: the factor is rounded to bf16 first
+    {
+        const float s = sqrtf((float)c.hidden_size);
+        uint32_t u;
+        memcpy(&u, &s, 4);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        memcpy(&m->embed_scale, &u, 4);
+    }
+    const int H = c.hidden_size, I = c.intermediate_size, B = c.max_batch;
+    const size_t kv_elem = c.kv_cache_dtype == VMX_KV_FP8_E4M3 ? 1 : 2;
+    int rc = VMX_OK;
+#define TRY(e) do { if (!rc) rc = (e); } while (0)
+    if (c.embed_ggml_type == 0) TRY(m->embed.alloc((size_t)c.vocab_size * H * 2));
+    else TRY(m->embed.alloc((size_t)c.vocab_size * (H / vmx_ggml_block_elems(c.embed_ggml_type)) * vmx_ggml_type_size(c.embed_ggml_type)));
+    TRY(m->final_norm.alloc((size_t)H * 2));
+    TRY(m->cos_sin_s.alloc((size_t)c.max_position * c.rot_dim_sliding * 4));
+    TRY(m->cos_sin_f.alloc((size_t)c.max_position * c.rot_dim_full * 4));
+    int max_nq = 0, max_proj = 2 * I, max_hd = 0;
+    for (int li = 0; li < c.num_layers; li++) {
+        G4Layer &L = m->layers[li];
+        L.sliding = (layer_flags[li] & VMX_G4_SLIDING) != 0;
+        L.k_eq_v = (layer_flags[li] & VMX_G4_K_EQ_V) != 0;
+        L.hd = L.sliding ? c.head_dim_sliding : c.head_dim_full;
+        L.kvh = L.sliding ? c.kv_heads_sliding : c.kv_heads_full;
+        L.rot = L.sliding ? c.rot_dim_sliding : c.rot_dim_full;
+        L.window = L.sliding ? c.sliding_window : 0;
+        const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd;
+        if (NQ % 256 != 0) {
+            vmx_set_error("gemma4_create: num_heads * head_dim (%d) must be a multiple of 256 (o_proj input)", NQ);
+            rc = rc ? rc : VMX_EINVAL;
+        }
+        const int in_f[7] = {H, H, H, NQ, H, H, I}, out_f[7] = {NQ, NKV, NKV, H, I, I, H};
+        for (int s = 0; s < 7; s++) { L.lin[s].in_features = in_f[s]; L.lin[s].out_features = out_f[s]; }
+        max_nq = NQ > max_nq ? NQ : max_nq;
+        max_proj = NQ + 2 * NKV > max_proj ? NQ + 2 * NKV : max_proj;
+        max_hd = L.hd > max_hd ? L.hd : max_hd;
+        TRY(L.input_ln.alloc((size_t)H * 2));
+        TRY(L.post_attn_ln.alloc((size_t)H * 2));
+        TRY(L.pre_ffn_ln.alloc((size_t)H * 2));
+        TRY(L.post_ffn_ln.alloc((size_t)H * 2));
+        TRY(L.q_norm.alloc((size_t)L.hd * 2));
+        TRY(L.k_norm.alloc((size_t)L.hd * 2));
+        TRY(L.scalar.alloc(2));
+        const size_t kvb = (size_t)c.num_blocks * c.block_size * L.kvh * L.hd * kv_elem;
+        TRY(L.k_cache.alloc(kvb));
+        TRY(L.v_cache.alloc(kvb));
+        TRY(L.kv_scales.alloc(8));
+        if (!rc) {
+            const float ones[2] = {1.0f, 1.0f};
+            const uint16_t one_bf16 = 0x3F80;
+            if (hipMemcpy(L.kv_scales.p, ones, 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(L.scalar.p, &one_bf16, 2, hipMemcpyHostToDevice) != hipSuccess)
+                rc = VMX_ELAUNCH;
+        }
+    }
+    TRY(m->h.alloc((size_t)B * H * 2));
+    TRY(m->x.alloc((size_t)B * H * 2));
+    TRY(m->q.alloc((size_t)B * max_nq * 2));
+    TRY(m->attn.alloc((size_t)B * max_nq * 2));
+    TRY(m->act.alloc((size_t)B * I * 2));
+    TRY(m->proj.alloc((size_t)B * max_proj * 4));
+    TRY(m->out.alloc((size_t)B * H * 4));
+    TRY(m->logits.alloc((size_t)B * c.vocab_size * 2));
+    if (c.embed_ggml_type != 0) {
+        TRY(m->logits_f32.alloc((size_t)B * c.vocab_size * 4));
+        TRY(m->x_f32.alloc((size_t)B * H * 4));
+    }
+    {
+        size_t kmax = (size_t)(H > I ? H : I);
+        kmax = (size_t)max_nq > kmax ? (size_t)max_nq : kmax;
+        TRY(m->q8.alloc(B * kmax + 256 + B * (kmax / 32) * 4));
+    }
+    TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, max_hd, c.max_seq_len)));
+    TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
+#undef TRY
+    if (rc) {
+        vmx_gemma4_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return VMX_OK;
+}
+
+extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
+    if (!m) return;
+    for (G4Layer &L : m->layers) {
+        for (IqLin &l : L.lin) l.raw.release();
+        for (Buf *b : {&L.input_ln, &L.post_attn_ln, &L.pre_ffn_ln, &L.post_ffn_ln, &L.q_norm, &L.k_norm, &L.scalar, &L.k_cache, &L.v_cache,
+                       &L.kv_scales})
+            b->release();
+    }
+    for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
+                   &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8})
+        b->release();
+    delete m;
+}
+
+extern "C" int vmx_gemma4_load_tensor(vmx_gemma4 *m, int which, int layer, const void *src, size_t bytes, void *stream) {
+    VMX_REQUIRE(m && src, "gemma4_load_tensor: null pointer");
+    Buf *dst = nullptr;
+    switch (which) {
+        case VMX_G4T_EMBED: dst = &m->embed; break;
+        case VMX_G4T_FINAL_NORM: dst = &m->final_norm; break;
+        case VMX_G4T_COS_SIN_SLIDING: dst = &m->cos_sin_s; break;
+        case VMX_G4T_COS_SIN_FULL: dst = &m->cos_sin_f; break;
+        default: break;
+    }
+    if (!dst && which >= VMX_G4T_INPUT_LN && which <= VMX_G4T_KV_SCALES) {
+        VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "gemma4_load_tensor: layer %d out of range", layer);
+        G4Layer &L = m->layers[layer];
+        Buf *tab[8] = {&L.input_ln, &L.post_attn_ln, &L.pre_ffn_ln, &L.post_ffn_ln, &L.q_norm, &L.k_norm, &L.scalar, &L.kv_scales};
+        dst = tab[which - VMX_G4T_INPUT_LN];
+    }
+    VMX_REQUIRE(dst, "gemma4_load_tensor: unknown tensor id %d", which);
+    VMX_REQUIRE(bytes == dst->bytes, "gemma4_load_tensor: tensor %d expects %zu bytes, got %zu", which, dst->bytes, bytes);
+    VMX_CHECK_HIP(hipMemcpyAsync(dst->p, src, bytes, hipMemcpyDefault, vmx_stream(stream)));
+    return VMX_OK;
+}
+
+extern "C" int vmx_gemma4_load_iq_linear(vmx_gemma4 *m, int layer, int slot, int ggml_type, const void *blocks, size_t bytes,
+                                         void *stream) {
+    VMX_REQUIRE(m && blocks, "gemma4_load_iq_linear: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && slot >= VMX_L_Q && slot <= VMX_L_DOWN,
+                "gemma4_load_iq_linear: layer %d / slot %d out of range", layer, slot);
+    const int ts = vmx_iq_type_size(ggml_type);
+    VMX_REQUIRE(ts > 0, "gemma4_load_iq_linear: ggml type %d is not a supported I-quant", ggml_type);
+    G4Layer &L = m->layers[layer];
+    VMX_REQUIRE(!(slot == VMX_L_V && L.k_eq_v), "gemma4_load_iq_linear: layer %d reuses K as V and has no v_proj", layer);
+    IqLin &l = L.lin[slot];
+    VMX_REQUIRE(l.in_features % 256 == 0, "gemma4_load_iq_linear: in_features %d not a multiple of 256", l.in_features);
+    const size_t need = (size_t)l.out_features * (l.in_features / 256) * ts;
+    VMX_REQUIRE(bytes == need, "gemma4_load_iq_linear: expected %zu bytes for [%d, %d] of type %d, got %zu", need, l.out_features,
+                l.in_features, ggml_type, bytes);
+    l.raw.release();
+    if (int rc = l.raw.alloc(need)) return rc;
+    VMX_CHECK_HIP(hipMemcpyAsync(l.raw.p, blocks, need, hipMemcpyDefault, vmx_stream(stream)));
+    l.ggml_type = ggml_type;
+    l.loaded = true;
+    return VMX_OK;
+}
+
+extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+                                 const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq, int max_seq_len,
+                                 int32_t *out_ids, uint16_t *logits_out, void *stream) {
+    VMX_REQUIRE(m && input_ids && positions && slot_mapping && block_tables && seq_lens, "gemma4_decode: null pointer");
+    const vmx_gemma4_config &c = m->cfg;
+    VMX_REQUIRE(batch >= 1 && batch <= c.max_batch, "gemma4_decode: batch %d exceeds max_batch %d", batch, c.max_batch);
+    VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "gemma4_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
+                c.max_seq_len);
+    for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_decode: weights not fully loaded");
+    hipStream_t st = vmx_stream(stream);
+    const int H = c.hidden_size, I = c.intermediate_size, B = batch, Hq = c.num_heads;
+    uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p, *attn = (uint16_t *)m->attn.p,
+             *act = (uint16_t *)m->act.p;
+    float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
+    const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
+
+    if (c.embed_ggml_type == 0) {
+        hipLaunchKernelGGL(g4_embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size,
+                           m->embed_scale);
+    } else if (int rc = vmx_kquant_gather_scaled_bf16(c.embed_ggml_type, m->embed.p, input_ids, h, B, H, c.vocab_size, m->embed_scale, st)) {
+        return rc;
+    }
+    // pending: the previous layer's MLP output still to be post-normed, added, scaled
+    const float *pending = nullptr;
+    const uint16_t *pending_w = nullptr, *pending_scalar = nullptr;
+    for (const G4Layer &L : m->layers) {
+        const int hd = L.hd, Hkv = L.kvh, NQ = Hq * hd, NKV = Hkv * hd;
+        const int ntot = NQ + (L.k_eq_v ? 1 : 2) * NKV;
+        // (previous layer's tail) + input_layernorm -> x, q8_1(x)
+        launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H, aq_of(m),
+                    ad_of(m, B, H));
+        if (int rc = mmvq(m, L.lin[VMX_L_Q], proj, ntot, B, st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_K], proj + NQ, ntot, B, st)) return rc;
+        if (!L.k_eq_v)
+            if (int rc = mmvq(m, L.lin[VMX_L_V], proj + NQ + NKV, ntot, B, st)) return rc;
+        const float *ks = (const float *)L.kv_scales.p;
+        hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, L.k_cache.p, L.v_cache.p,
+                           (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
+                           (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping, Hq, Hkv, hd, L.rot,
+                           L.k_eq_v ? 1 : 0, fp8, ks, ks + 1);
+        VmxAttnParts ap;
+        if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, 1.0f, B, Hq, Hkv, max_blocks_per_seq,
+                                               max_seq_len, hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, m->attn_ws.p, &ap, st))
+            return rc;
+        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st)) return rc;
+        if (int rc = vmx_quantize_q8_1_bf16(attn, aq_of(m), ad_of(m, B, NQ), (int64_t)B * (NQ / 32), st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, B, st)) return rc;
+        // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
+        launch_norm(st, B, h, x, out, (const uint16_t *)L.post_attn_ln.p, nullptr, (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, H,
+                    aq_of(m), ad_of(m, B, H));
+        if (int rc = mmvq(m, L.lin[VMX_L_GATE], proj, 2 * I, B, st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_UP], proj + I, 2 * I, B, st)) return rc;
+        int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
+        hipLaunchKernelGGL(g4_geglu_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, proj, B, act, I, aq_of(m),
+                           ad_of(m, B, I));
+        if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, B, st)) return rc;
+        pending = out;
+        pending_w = (const uint16_t *)L.post_ffn_ln.p;
+        pending_scalar = (const uint16_t *)L.scalar.p;
+    }
+    launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr);
+    VMX_CHECK_LAUNCH("gemma4_decode");
+    uint16_t *logits = logits_out ? logits_out : (uint16_t *)m->logits.p;
+    const int64_t nlog = (int64_t)B * c.vocab_size;
+    const float cap = c.final_logit_softcap;
+    float inv_cap = 0.f;
+    if (cap > 0.f) {   // xs / cap is a bf16 multiply by bf16(1 / cap)
+        const float ic = 1.0f / cap;
+        uint32_t u;
+        memcpy(&u, &ic, 4);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        memcpy(&inv_cap, &u, 4);
+    }
+    if (c.embed_ggml_type == 0) {
+        if (int rc = vmx_dense_gemv_launch(logits, x, (const uint16_t *)m->embed.p, nullptr, B, c.vocab_size, H, st)) return rc;
+        if (cap > 0.f)
+            hipLaunchKernelGGL(g4_logits_kernel, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, st, logits, (const float *)nullptr, nlog,
+                               inv_cap, cap);
+    } else {   // tied lm_head over the quantized table (QMatMul, :1849-1865): f32 activations, f32 result cast back to bf16
+        float *xf = (float *)m->x_f32.p, *lf = (float *)m->logits_f32.p;
+        hipLaunchKernelGGL(g4_bf16_to_f32_kernel, dim3((unsigned)(((int64_t)B * H + 255) / 256)), dim3(256), 0, st, x, xf, (int64_t)B * H);
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            const int mb = B - b0 < 8 ? B - b0 : 8;
+            if (int rc = vmx_kquant_gemv_f32(c.embed_ggml_type, m->embed.p, xf + (int64_t)b0 * H, lf + (int64_t)b0 * c.vocab_size,
+                                             c.vocab_size, H, mb, stream))
+                return rc;
+        }
+        hipLaunchKernelGGL(g4_logits_kernel, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, st, logits, (const float *)lf, nlog, inv_cap,
+                           cap);
+    }
+    VMX_CHECK_LAUNCH("gemma4_decode(lm_head)");
+    if (out_ids)
+        if (int rc = vmx_argmax_bf16(out_ids, logits, B, c.vocab_size, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
+    return VMX_OK;
+}
+
+extern "C" int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_bytes) {
+    VMX_REQUIRE(m && launches && alg_bytes, "gemma4_mmvq_info: null pointer");
+    double by = 0.0;
+    int n = 0;
+    for (const G4Layer &L : m->layers)
+        for (int s = 0; s < 7; s++) {
+            if (s == VMX_L_V && L.k_eq_v) continue;
+            by += L.lin[s].alg_bytes(batch);
+            n++;
+        }
+    *launches = n;
+    *alg_bytes = by;
+    return VMX_OK;
+}
+
+extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
+    VMX_REQUIRE(m && batch >= 1 && batch <= m->cfg.max_batch, "gemma4_mmvq_only: bad arguments");
+    for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_mmvq_only: weights not fully loaded");
+    hipStream_t st = vmx_stream(stream);
+    const vmx_gemma4_config &c = m->cfg;
+    float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
+    const int I = c.intermediate_size, H = c.hidden_size;
+    for (const G4Layer &L : m->layers) {
+        const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd, ntot = NQ + (L.k_eq_v ? 1 : 2) * NKV;
+        if (int rc = mmvq(m, L.lin[VMX_L_Q], proj, ntot, batch, st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_K], proj + NQ, ntot, batch, st)) return rc;
+        if (!L.k_eq_v)
+            if (int rc = mmvq(m, L.lin[VMX_L_V], proj + NQ + NKV, ntot, batch, st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_GATE], proj, 2 * I, batch, st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_UP], proj + I, 2 * I, batch, st)) return rc;
+        if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
+    }
+    return VMX_OK;
+}
+
+extern "C" int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, void *stream) {
+    VMX_REQUIRE(m && dst, "gemma4_debug_read: null pointer");
+    Buf *src = which == 0 ? &m->h : which == 1 ? &m->x : nullptr;
+    VMX_REQUIRE(src && bytes <= src->bytes, "gemma4_debug_read: bad request");
+    VMX_CHECK_HIP(hipMemcpyAsync(dst, src->p, bytes, hipMemcpyDefault, vmx_stream(stream)));
+    return VMX_OK;
+}

@@ -621,7 +621,7 @@ void launch_ring(const uint8_t *w, const int8_t *aq, const float *ad, float *y, 
 
 template <int T>
 int launch_mmvq(const uint8_t *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy, hipStream_t st) {
-    if (m == 1 && n_in > 4096 && n_in <= 16384 && ldy == n_out) {
+    if (m == 1 && n_in > 4096 && n_in <= 16384) {   // (with one activation row ldy is unused)
         // long rows: split over 2 or 4 waves, activations resident in registers (measured 9.3 vs 11.3 us on 3840 x 15360)
         if (n_in <= 8192) launch_ring<T, 2>(w, aq, ad, y, n_out, n_in, st);
         else launch_ring<T, 4>(w, aq, ad, y, n_out, n_in, st);

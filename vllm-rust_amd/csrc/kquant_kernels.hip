@@ -129,6 +129,30 @@ __global__ __launch_bounds__(256) void kgemv_kernel(const uint8_t *__restrict__ 
     }
 }
 
+// out[t, :] = bf16(bf16(dequant(table row ids[t])) * scale): QuantizedEmbedding::forward (gather the row's blocks,
+// dequantise, cast to the model dtype; crates/core/src/quantization/gguf/mod.rs:546-600) followed by the model's
+// embedding normaliser in bf16.  Out-of-range ids give a zero row.  One thread per 32-weight sub-block.
+template <int T>
+__global__ __launch_bounds__(256) void kgather_bf16_kernel(const uint8_t *__restrict__ table, const int32_t *__restrict__ ids,
+                                                            uint16_t *__restrict__ out, int tokens, int dim, int vocab, float scale) {
+    constexpr int SUB = KTraits<T>::QK / 32;
+    const int subs_per_row = dim / 32;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= tokens * subs_per_row) return;
+    const int t = i / subs_per_row, g = i % subs_per_row;
+    const int id = ids[t];
+    float f[32];
+    if (id >= 0 && id < vocab) {
+        kdecode32<T>(table + ((int64_t)id * (dim / KTraits<T>::QK) + g / SUB) * KTraits<T>::TS, g % SUB, f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; k++) f[k] = 0.f;
+    }
+    uint16_t *y = out + (int64_t)t * dim + g * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k++) y[k] = vmx_f32_to_bf16(vmx_bf16_to_f32(vmx_f32_to_bf16(f[k])) * scale);
+}
+
 }  // namespace
 
 #define K_DISPATCH(type, CALL)                                                                  \
@@ -179,5 +203,20 @@ extern "C" int vmx_kquant_gemv_f32(int ggml_type, const void *w, const float *x,
     K_DISPATCH(ggml_type, CALL)
 #undef CALL
     VMX_CHECK_LAUNCH("kquant_gemv");
+    return VMX_OK;
+}
+
+// ---- internal (C++) entry point used by the Gemma 4 decoder
+int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_t *ids, uint16_t *out, int tokens, int dim, int vocab,
+                                  float scale, hipStream_t st) {
+    if (dim <= 0 || dim % vmx_ggml_block_elems(ggml_type) != 0) {
+        vmx_set_error("kquant_gather: dim %d not a multiple of the block size", dim);
+        return VMX_EINVAL;
+    }
+    const int n = tokens * (dim / 32);
+#define CALL(T) hipLaunchKernelGGL((kgather_bf16_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t *)table, ids, out, tokens, dim, vocab, scale)
+    K_DISPATCH(ggml_type, CALL)
+#undef CALL
+    VMX_CHECK_LAUNCH("kquant_gather");
     return VMX_OK;
 }

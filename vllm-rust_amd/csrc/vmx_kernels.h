@@ -31,3 +31,10 @@ int vmx_argmax_keys_to_ids(const unsigned long long *keys, int32_t *out_ids, int
 int vmx_quantize_q8_1_bf16(const uint16_t *x, int8_t *aq, float *ad, int64_t total_blocks, hipStream_t st);
 int vmx_iq_mmvq_ld(int ggml_type, const void *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy,
                    hipStream_t st);
+
+// kquant_kernels.hip
+int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_t *ids, uint16_t *out, int tokens, int dim, int vocab,
+                                  float scale, hipStream_t st);
+
+// dense_kernels.hip
+int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st);

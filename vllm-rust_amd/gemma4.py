@@ -1,0 +1,239 @@
+"""Host-side driver of the quantized Gemma 4 decoder (libvmx `vmx_gemma4_*`).
+
+Mirrors the engine-facing surface of the reference's QuantizedGemma4ForCausalLM on its paged-decode path
+(crates/core/src/models/gemma4_quantized.rs:1311-1424, 1743-1774, 2217-2279): GGUF I-quant projections, per-layer
+KV geometry (sliding layers with a window, full-attention layers with one wide KV head), sandwich norms, GeGLU,
+layer scalars, final-logit soft-cap, tied (optionally K-quant) token embedding.  All arithmetic is in the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from ._lib import Gemma4Config, check, lib
+from .qwen3 import rope_cos_sin_cache
+
+(T_EMBED, T_FINAL_NORM, T_COS_SIN_SLIDING, T_COS_SIN_FULL, T_INPUT_LN, T_POST_ATTN_LN, T_PRE_FFN_LN, T_POST_FFN_LN, T_Q_NORM,
+ T_K_NORM, T_LAYER_SCALAR, T_KV_SCALES) = range(12)
+L_Q, L_K, L_V, L_O, L_GATE, L_UP, L_DOWN = range(7)
+G4_SLIDING, G4_K_EQ_V = 1, 2
+
+IQ_TYPE_SIZE = {17: 74, 22: 82, 18: 98, 21: 110, 23: 136}
+GGML_TYPE_SIZE = {2: (18, 32), 8: (34, 32), 11: (110, 256), 12: (144, 256), 14: (210, 256)}
+# projection types of gemma-4-12b-it-UD-IQ3_XXS (crates/core/src/quantization/gguf/header.rs:390-399): q, k, v, o, gate, up, down
+GEMMA4_12B_IQ3_MIX = {L_Q: 18, L_K: 22, L_V: 18, L_O: 21, L_GATE: 18, L_UP: 18, L_DOWN: 21}
+
+
+@dataclasses.dataclass
+class Gemma4Spec:
+    hidden_size: int
+    num_layers: int
+    num_heads: int
+    intermediate_size: int
+    vocab_size: int
+    head_dim_sliding: int = 256
+    head_dim_full: int = 512
+    kv_heads_sliding: int = 8
+    kv_heads_full: int = 1
+    sliding_window: int = 1024
+    full_every: int = 6                      # layer i is a full-attention layer when (i + 1) % full_every == 0
+    layer_is_sliding: Optional[List[bool]] = None
+    k_eq_v_on_full: bool = False
+    rope_theta_sliding: float = 10000.0
+    rope_theta_full: float = 1e6
+    partial_rotary_factor_full: float = 0.25
+    rms_norm_eps: float = 1e-6
+    max_position: int = 4096
+    kv_cache_dtype: int = 1                  # FP8 e4m3
+    block_size: int = 16
+    num_blocks: int = 64
+    max_batch: int = 1
+    max_seq_len: int = 1024
+    final_logit_softcap: float = 30.0
+    embed_ggml_type: int = 0                 # 0 bf16, 11 Q3_K (the 12B file), 14 Q6_K
+
+    @staticmethod
+    def gemma4_12b(**kw):
+        return Gemma4Spec(3840, 48, 16, 15360, 262144, **kw)
+
+    def sliding(self, i: int) -> bool:
+        if self.layer_is_sliding is not None:
+            return bool(self.layer_is_sliding[i])
+        return (i + 1) % self.full_every != 0
+
+    def layer_flags(self) -> List[int]:
+        return [(G4_SLIDING if self.sliding(i) else (G4_K_EQ_V if self.k_eq_v_on_full else 0)) for i in range(self.num_layers)]
+
+    def rot_dim_full(self) -> int:
+        r = int(self.head_dim_full * self.partial_rotary_factor_full)
+        return r - r % 2
+
+    def layer_geom(self, i: int):
+        """(head_dim, kv_heads, rot_dim, window, k_eq_v) of layer i."""
+        if self.sliding(i):
+            return self.head_dim_sliding, self.kv_heads_sliding, self.head_dim_sliding, self.sliding_window, False
+        return self.head_dim_full, self.kv_heads_full, self.rot_dim_full(), 0, self.k_eq_v_on_full
+
+    def linear_shapes(self, i: int):
+        hd, kvh, _, _, keqv = self.layer_geom(i)
+        H, I, nq, nkv = self.hidden_size, self.intermediate_size, self.num_heads * hd, kvh * hd
+        sh = {L_Q: (H, nq), L_K: (H, nkv), L_V: (H, nkv), L_O: (nq, H), L_GATE: (H, I), L_UP: (H, I), L_DOWN: (I, H)}
+        if keqv:
+            del sh[L_V]
+        return sh
+
+
+def proportional_cos_sin_cache(head_dim: int, rot_dim: int, max_position: int, theta: float) -> np.ndarray:
+    """cos|sin table of RotaryEmbedding::new_gemma4_proportional (crates/core/src/layers/rotary.rs:128-174): the exponent's
+    denominator is the full head_dim, only rot_dim leading dims rotate; values rounded to bf16 (model dtype)."""
+    i = np.arange(0, rot_dim, 2, dtype=np.float32)
+    inv_freq = (np.float32(1.0) / np.power(np.float32(theta), i / np.float32(head_dim))).astype(np.float32)
+    t = np.arange(max_position, dtype=np.float32)[:, None]
+    freqs = (t * inv_freq[None, :]).astype(np.float32)
+
+    def bf16_round(a):
+        u = a.astype(np.float32).view(np.uint32)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.view(np.float32)
+
+    return np.concatenate([bf16_round(np.cos(freqs)), bf16_round(np.sin(freqs))], axis=1).astype(np.float32)
+
+
+class QuantizedGemma4ForCausalLM:
+    def __init__(self, spec: Gemma4Spec, device: int = 0):
+        self.spec = spec
+        self.device = torch.device("cuda", device)
+        s = spec
+        cfg = Gemma4Config(s.hidden_size, s.num_layers, s.num_heads, s.intermediate_size, s.vocab_size, s.rms_norm_eps,
+                           s.head_dim_sliding, s.head_dim_full, s.kv_heads_sliding, s.kv_heads_full, s.sliding_window,
+                           s.head_dim_sliding, s.rot_dim_full(), s.max_position, s.kv_cache_dtype, s.block_size, s.num_blocks,
+                           s.max_batch, s.max_seq_len, s.final_logit_softcap, s.embed_ggml_type)
+        flags = (C.c_int * s.num_layers)(*s.layer_flags())
+        self._h = C.c_void_p()
+        check(lib.vmx_gemma4_create(C.byref(cfg), flags, C.byref(self._h)))
+        self.cos_sin_sliding = rope_cos_sin_cache(s.head_dim_sliding, s.max_position, s.rope_theta_sliding)
+        self.cos_sin_full = proportional_cos_sin_cache(s.head_dim_full, s.rot_dim_full(), s.max_position, s.rope_theta_full)
+        self.load_tensor(T_COS_SIN_SLIDING, 0, torch.from_numpy(self.cos_sin_sliding).to(self.device))
+        self.load_tensor(T_COS_SIN_FULL, 0, torch.from_numpy(self.cos_sin_full).to(self.device))
+
+    def close(self):
+        if self._h:
+            lib.vmx_gemma4_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def load_tensor(self, which: int, layer: int, t: torch.Tensor) -> None:
+        t = t.contiguous()
+        check(lib.vmx_gemma4_load_tensor(self._h, which, layer, t.data_ptr(), t.numel() * t.element_size(), self._stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def load_iq_linear(self, layer: int, slot: int, ggml_type: int, blocks: torch.Tensor) -> None:
+        blocks = blocks.contiguous()
+        check(lib.vmx_gemma4_load_iq_linear(self._h, layer, slot, ggml_type, blocks.data_ptr(), blocks.numel(), self._stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def load_synthetic(self, slot_types=None, seed: int = 0, keep_host_copy: bool = False):
+        """Seeded random-init weights of the architecture: valid random I-quant blocks per projection (slot_types: ggml type
+        per slot, default the 12B UD-IQ3_XXS mix), bf16 norms and layer scalars, bf16 or K-quant token embedding.
+        Super-block scales are sized so activations stay O(1).  Returns the host copy when keep_host_copy (tiny models)."""
+        s = self.spec
+        slot_types = slot_types or GEMMA4_12B_IQ3_MIX
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        ck = {}
+
+        def keep(name, t):
+            if keep_host_copy:
+                ck[name] = t.cpu() if isinstance(t, torch.Tensor) else t
+
+        if s.embed_ggml_type == 0:
+            emb = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.05).to(torch.bfloat16)
+        else:
+            ts, qk = GGML_TYPE_SIZE[s.embed_ggml_type]
+            nb = s.vocab_size * (s.hidden_size // qk)
+            emb = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=self.device, generator=g)
+            # valid small f16 super-scale(s): positions of the f16 fields per type (d; Q4_K also dmin)
+            dpos = {2: [0], 8: [0], 11: [108], 12: [0, 2], 14: [208]}[s.embed_ggml_type]
+            mag = {2: 0.01, 8: 0.0006, 11: 0.0008, 12: 0.0001, 14: 0.00004}[s.embed_ggml_type]
+            for pos in dpos:
+                d = ((torch.rand(nb, device=self.device, generator=g) * 0.5 + 0.75) * mag).to(torch.float16).view(torch.int16)
+                emb[:, pos] = (d & 0xFF).to(torch.uint8)
+                emb[:, pos + 1] = ((d >> 8) & 0xFF).to(torch.uint8)
+            emb = emb.reshape(-1)
+        self.load_tensor(T_EMBED, 0, emb); keep("embed", emb)
+        del emb
+        fn = (1.0 + 0.1 * torch.randn(s.hidden_size, device=self.device, generator=g)).to(torch.bfloat16)
+        self.load_tensor(T_FINAL_NORM, 0, fn); keep("final_norm", fn)
+        for li in range(s.num_layers):
+            hd = s.layer_geom(li)[0]
+            for which, n, name in ((T_INPUT_LN, s.hidden_size, "input_ln"), (T_POST_ATTN_LN, s.hidden_size, "post_attn_ln"),
+                                   (T_PRE_FFN_LN, s.hidden_size, "pre_ffn_ln"), (T_POST_FFN_LN, s.hidden_size, "post_ffn_ln"),
+                                   (T_Q_NORM, hd, "q_norm"), (T_K_NORM, hd, "k_norm")):
+                w = (1.0 + 0.1 * torch.randn(n, device=self.device, generator=g)).to(torch.bfloat16)
+                self.load_tensor(which, li, w); keep(f"{li}.{name}", w)
+            sc = (0.75 + 0.5 * torch.rand(1, device=self.device, generator=g)).to(torch.bfloat16)
+            self.load_tensor(T_LAYER_SCALAR, li, sc); keep(f"{li}.scalar", sc)
+            for slot, (K, N) in s.linear_shapes(li).items():
+                t = slot_types[slot]
+                ts = IQ_TYPE_SIZE[t]
+                nb = N * (K // 256)
+                raw = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=self.device, generator=g)
+                d = (torch.rand(nb, device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (120.0 * math.sqrt(K)))
+                if t == 23:
+                    d = d * 6.0
+                dbits = d.to(torch.float16).view(torch.int16)
+                raw[:, 0] = (dbits & 0xFF).to(torch.uint8)
+                raw[:, 1] = ((dbits >> 8) & 0xFF).to(torch.uint8)
+                self.load_iq_linear(li, slot, t, raw.reshape(-1))
+                keep(f"{li}.{slot}.iq", (t, raw.reshape(-1).cpu()) if keep_host_copy else None)
+        return ck
+
+    def iq_weight_bytes(self, slot_types=None) -> int:
+        slot_types = slot_types or GEMMA4_12B_IQ3_MIX
+        s = self.spec
+        return sum(N * (K // 256) * IQ_TYPE_SIZE[slot_types[slot]] for li in range(s.num_layers)
+                   for slot, (K, N) in s.linear_shapes(li).items())
+
+    def forward_decode_batch(self, input_ids, positions, slot_mapping, block_tables, seq_lens, max_seq_len=None, out_ids=None,
+                             logits=None):
+        """All arguments are int32 CUDA tensors; returns out_ids (int32 [B])."""
+        B = input_ids.numel()
+        if out_ids is None:
+            out_ids = torch.empty(B, dtype=torch.int32, device=self.device)
+        msl = int(max_seq_len if max_seq_len is not None else self.spec.max_seq_len)
+        check(lib.vmx_gemma4_decode(self._h, input_ids.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(),
+                                    block_tables.data_ptr(), seq_lens.data_ptr(), B, block_tables.shape[1], msl, out_ids.data_ptr(),
+                                    None if logits is None else logits.data_ptr(), self._stream()))
+        return out_ids
+
+    def advance(self, input_ids, next_ids, positions, slot_mapping, seq_lens, block_tables) -> None:
+        check(lib.vmx_decode_advance(input_ids.data_ptr(), next_ids.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(),
+                                     seq_lens.data_ptr(), block_tables.data_ptr(), input_ids.numel(), block_tables.shape[1],
+                                     self.spec.block_size, self._stream()))
+
+    def mmvq_only(self, batch: int = 1) -> None:
+        check(lib.vmx_gemma4_mmvq_only(self._h, batch, self._stream()))
+
+    def mmvq_info(self, batch: int = 1):
+        n, by = C.c_int(), C.c_double()
+        check(lib.vmx_gemma4_mmvq_info(self._h, batch, C.byref(n), C.byref(by)))
+        return n.value, by.value
+
+    def debug_read(self, which: int, shape) -> torch.Tensor:
+        t = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
+        check(lib.vmx_gemma4_debug_read(self._h, which, t.data_ptr(), t.numel() * 2, self._stream()))
+        torch.cuda.current_stream().synchronize()
+        return t
