@@ -76,21 +76,17 @@ def cpu_baseline(spec, budget_s=12.0):
                       f"{spec.num_layers} layers + numpy f32 lm_head on 1/16 of the vocabulary ({t_head * 1e3:.1f} ms)"}
 
 
-def iq3_secondary(prompt, steps, warmup):
-    """Decode tok/s of a model with Gemma-4-12B's layer shapes and its UD-IQ3_XXS tensor-type mix (GGUF I-quant MMVQ
-    linears, FP8 e4m3 KV cache), run through this library's Qwen3-style executor: NOT Gemma's op order (no sandwich
-    norms / sliding window / PLE), bf16 lm_head (2.0 GB) instead of the file's Q3_K one (0.43 GB)."""
-    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+def gemma4_secondary(prompt, steps, warmup):
+    """BASELINE.json configs[2]: decode tok/s of a Gemma-4-12B-shaped GGUF model (UD-IQ3_XXS tensor-type mix, Q3_K tied token
+    embedding, FP8 e4m3 KV cache with per-layer sliding/full geometry) through the Gemma 4 executor, plus the roofline of
+    its dominant kernel (the q8_1 MMVQ): the step's MMVQ launches alone replayed back to back between two HIP events."""
+    from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
     total = prompt + warmup + steps + 8
     n_blocks = (total + 15) // 16 + 1
-    spec = Qwen3Spec(hidden_size=3840, num_layers=48, num_heads=16, num_kv_heads=8, head_dim=256, intermediate_size=15360,
-                     vocab_size=262144, tie_word_embeddings=True, kv_cache_dtype=1, max_position=max(4096, total + 1),
-                     num_blocks=n_blocks, max_batch=1, max_seq_len=total + 1)
-    model = QuantizedQwen3ForCausalLM(spec)
-    types = {0: 18, 1: 22, 2: 18, 3: 21, 4: 18, 5: 18, 6: 21}   # q,k,v,o,gate,up,down: IQ3_XXS / IQ2_S / IQ3_S
-    model.load_synthetic_iq(types, seed=99)
-    ts = model.IQ_TYPE_SIZE
-    wbytes = sum(N * (K // 256) * ts[types[slot]] for slot, (K, N) in model.linear_shapes().items()) * spec.num_layers
+    spec = Gemma4Spec.gemma4_12b(sliding_window=1024, max_position=max(4096, total + 1), kv_cache_dtype=1, num_blocks=n_blocks,
+                                 max_batch=1, max_seq_len=total + 1, embed_ggml_type=11, final_logit_softcap=30.0)
+    model = QuantizedGemma4ForCausalLM(spec)
+    model.load_synthetic(seed=99)
     dev = model.device
     bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(1, n_blocks).contiguous()
     ids = torch.tensor([11], dtype=torch.int32, device=dev)
@@ -118,11 +114,35 @@ def iq3_secondary(prompt, steps, warmup):
             g.replay()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # roofline of the MMVQ kernel
+        launches, alg = model.mmvq_info(1)
+        model.mmvq_only(1)
+        lg = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(lg, stream=side):
+            model.mmvq_only(1)
+        reps = max(8, steps // 4)
+        lg.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(reps):
+            lg.replay()
+        e1.record(side)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    achieved = alg / us / 1e3
+    wbytes = model.iq_weight_bytes()
+    embed_bytes = spec.vocab_size * (spec.hidden_size // 256) * 110
     model.close()
-    return {"metric": "decode tok/s, Gemma-4-12B-shaped GGUF IQ3_XXS-mix + FP8 KV, batch=1", "value": round(steps / dt, 2), "unit": "tok/s",
+    return {"metric": "decode tok/s (greedy, batch=1), Gemma-4-12B GGUF UD-IQ3_XXS mix + FP8 KV", "value": round(steps / dt, 2), "unit": "tok/s",
             "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-            "iquant_weight_bytes_per_token": wbytes, "iquant_GBps_if_only_weights": round(wbytes / (dt / steps) / 1e9, 1),
-            "note": "layer shapes and tensor-type mix of gemma-4-12b-it-UD-IQ3_XXS; Qwen3-style op order; bf16 tied lm_head"}
+            "config": {"workload": "Gemma-4-12B-shaped GGUF (187 IQ3_XXS / IQ2_S / IQ3_S projections per the UD-IQ3_XXS mix, Q3_K tied "
+                                   "token embedding), 48 layers (40 sliding 8x256 window 1024, 8 full 1x512), FP8 e4m3 KV, soft-cap 30",
+                       "weights": "seeded random-init blocks of the architecture", "execution": "one hipGraph per step"},
+            "weight_bytes_per_token": wbytes + embed_bytes,
+            "roofline": {"bound": "hbm", "kernel": "iq_mmvq_kernel / iq_mmvq_pipe_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": launches,
+                         "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches)}}
 
 
 def main():
@@ -258,7 +278,7 @@ def main():
         model.close()
         del model, graph
         torch.cuda.empty_cache()
-        secondary = iq3_secondary(args.prompt, max(16, K_steps // 2), W_steps)
+        secondary = gemma4_secondary(args.prompt, max(16, K_steps // 2), W_steps)
 
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed

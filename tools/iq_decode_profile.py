@@ -6,4 +6,4 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import bench
 import vllm_rust_amd as vmx
 vmx.init(0)
-print(bench.iq3_secondary(64, 16, 2))
+print(bench.gemma4_secondary(64, 16, 2))

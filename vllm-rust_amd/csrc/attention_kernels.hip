@@ -227,7 +227,8 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
                                                                  const float *__restrict__ exp_sums,
                                                                  const float *__restrict__ max_logits,
                                                                  const int32_t *__restrict__ seq_lens, int num_heads, int head_dim,
-                                                                 int max_parts, int window, int part_tokens) {
+                                                                 int max_parts, int window, int part_tokens, int8_t *__restrict__ aq,
+                                                                 float *__restrict__ ad) {
     __shared__ float w_s[64];
     __shared__ float inv_s;
     const int head = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
@@ -237,27 +238,43 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
     const int np = (eff + part_tokens - 1) / part_tokens;
     const int64_t mo = ((int64_t)seq * num_heads + head) * max_parts;
     const float *tp = tmp_out + mo * head_dim;
-    uint16_t *o = out + ((int64_t)seq * num_heads + head) * head_dim;
-    if (np == 1) {
-        for (int d = tid; d < head_dim; d += 128) o[d] = vmx_f32_to_bf16(tp[d]);
-        return;
+    const int64_t obase = ((int64_t)seq * num_heads + head) * head_dim;
+    uint16_t *o = out + obase;
+    float inv = 1.0f;
+    if (np > 1) {
+        if (tid < 64) {
+            const float mx = tid < np ? max_logits[mo + tid] : -FLT_MAX;
+            const float sm = tid < np ? exp_sums[mo + tid] : 0.f;
+            const float gmax = vmx_wave_max(mx);
+            const float w = tid < np ? sm * __expf(mx - gmax) : 0.f;
+            const float gsum = vmx_wave_sum(w);
+            w_s[tid] = w;
+            if (tid == 0) inv_s = 1.0f / (gsum + 1e-6f);
+        }
+        __syncthreads();
+        inv = inv_s;
     }
-    if (tid < 64) {
-        const float mx = tid < np ? max_logits[mo + tid] : -FLT_MAX;
-        const float sm = tid < np ? exp_sums[mo + tid] : 0.f;
-        const float gmax = vmx_wave_max(mx);
-        const float w = tid < np ? sm * __expf(mx - gmax) : 0.f;
-        const float gsum = vmx_wave_sum(w);
-        w_s[tid] = w;
-        if (tid == 0) inv_s = 1.0f / (gsum + 1e-6f);
-    }
-    __syncthreads();
-    const float inv = inv_s;
-    for (int d = tid; d < head_dim; d += 128) {
-        float acc = 0.f;
+    for (int d = tid; d < head_dim; d += 128) {   // head_dim % 64 == 0: a wave is all in or all out
+        float val;
+        if (np == 1) {
+            val = tp[d];
+        } else {
+            float acc = 0.f;
 #pragma unroll 8
-        for (int p = 0; p < np; p++) acc += tp[(int64_t)p * head_dim + d] * w_s[p];
-        o[d] = vmx_f32_to_bf16(acc * inv);
+            for (int p = 0; p < np; p++) acc += tp[(int64_t)p * head_dim + d] * w_s[p];
+            val = acc * inv;
+        }
+        const uint16_t vb = vmx_f32_to_bf16(val);
+        o[d] = vb;
+        if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block (iq_dequant.cu:253-267)
+            const float v = vmx_bf16_to_f32(vb);
+            float amax = fabsf(v);
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            const float dq = amax / 127.0f;
+            aq[obase + d] = amax != 0.0f ? (int8_t)(int)roundf(v / dq) : (int8_t)0;
+            if ((d & 31) == 0) ad[(obase + d) >> 5] = dq;
+        }
     }
 }
 
@@ -336,9 +353,9 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
 }
 
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
-                              int head_dim, int window, hipStream_t st) {
+                              int head_dim, int window, hipStream_t st, int8_t *aq, float *ad) {
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,
-                       parts->max_logits, seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens);
+                       parts->max_logits, seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
 }
@@ -363,7 +380,8 @@ extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const 
                                            workspace, &parts, st))
         return rc;
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts.tmp_out, parts.exp_sums,
-                       parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window, parts.part_tokens);
+                       parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window, parts.part_tokens, (int8_t *)nullptr,
+                       (float *)nullptr);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
 }

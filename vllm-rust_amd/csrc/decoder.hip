@@ -649,9 +649,9 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
                                                max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
                                                m->attn_ws.p, &ap, st))
             return rc;
-        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st)) return rc;
+        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st, iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr))
+            return rc;
         if (iq) {
-            if (int rc = iq_quantize(m, attn, B, NQ, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_O], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
         // h += o; x = rms_norm(h);  gate|up = linear(x);  act = silu(gate) * up;  down = linear(act)

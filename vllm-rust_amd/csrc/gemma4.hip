@@ -8,7 +8,7 @@
 // separate tensor ops round it.  The launch structure is this library's own: one fused vector kernel folds
 // "bf16(linear out) -> post-norm -> + residual -> * layer_scalar -> next pre-norm -> q8_1" (the sandwich norms of
 // two consecutive sub-blocks), one kernel does per-head q/k/v norms + RoPE + KV write, one does GeGLU + q8_1.
-// A layer is 12 launches (6 MMVQ); the step is a fixed launch sequence (hipGraph-capturable).
+// A layer is 10 launches (4 MMVQ: q|k|v and gate|up each go out as one multi-tensor launch); the step is a fixed launch sequence (hipGraph-capturable).
 #include "vmx_kernels.h"
 
 #include <math.h>
@@ -506,10 +506,12 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
         // (previous layer's tail) + input_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H, aq_of(m),
                     ad_of(m, B, H));
-        if (int rc = mmvq(m, L.lin[VMX_L_Q], proj, ntot, B, st)) return rc;
-        if (int rc = mmvq(m, L.lin[VMX_L_K], proj + NQ, ntot, B, st)) return rc;
-        if (!L.k_eq_v)
-            if (int rc = mmvq(m, L.lin[VMX_L_V], proj + NQ + NKV, ntot, B, st)) return rc;
+        {
+            const VmxMmvqSeg segs[3] = {{L.lin[VMX_L_Q].raw.p, L.lin[VMX_L_Q].ggml_type, NQ, 0},
+                                        {L.lin[VMX_L_K].raw.p, L.lin[VMX_L_K].ggml_type, NKV, NQ},
+                                        {L.lin[VMX_L_V].raw.p, L.lin[VMX_L_V].ggml_type, NKV, NQ + NKV}};
+            if (int rc = vmx_iq_mmvq_multi(segs, L.k_eq_v ? 2 : 3, aq_of(m), ad_of(m, B, H), proj, H, B, ntot, st)) return rc;
+        }
         const float *ks = (const float *)L.kv_scales.p;
         hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, L.k_cache.p, L.v_cache.p,
                            (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
@@ -519,14 +521,16 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
         if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, 1.0f, B, Hq, Hkv, max_blocks_per_seq,
                                                max_seq_len, hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, m->attn_ws.p, &ap, st))
             return rc;
-        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st)) return rc;
-        if (int rc = vmx_quantize_q8_1_bf16(attn, aq_of(m), ad_of(m, B, NQ), (int64_t)B * (NQ / 32), st)) return rc;
+        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
         if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, B, st)) return rc;
         // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, out, (const uint16_t *)L.post_attn_ln.p, nullptr, (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, H,
                     aq_of(m), ad_of(m, B, H));
-        if (int rc = mmvq(m, L.lin[VMX_L_GATE], proj, 2 * I, B, st)) return rc;
-        if (int rc = mmvq(m, L.lin[VMX_L_UP], proj + I, 2 * I, B, st)) return rc;
+        {
+            const VmxMmvqSeg segs[2] = {{L.lin[VMX_L_GATE].raw.p, L.lin[VMX_L_GATE].ggml_type, I, 0},
+                                        {L.lin[VMX_L_UP].raw.p, L.lin[VMX_L_UP].ggml_type, I, I}};
+            if (int rc = vmx_iq_mmvq_multi(segs, 2, aq_of(m), ad_of(m, B, H), proj, H, B, 2 * I, st)) return rc;
+        }
         int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
         hipLaunchKernelGGL(g4_geglu_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, proj, B, act, I, aq_of(m),
                            ad_of(m, B, I));
@@ -575,12 +579,14 @@ extern "C" int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, dou
     VMX_REQUIRE(m && launches && alg_bytes, "gemma4_mmvq_info: null pointer");
     double by = 0.0;
     int n = 0;
-    for (const G4Layer &L : m->layers)
+    const bool multi = batch == 1 && m->cfg.hidden_size <= 4096;   // q|k|v and gate|up go out as one launch each
+    for (const G4Layer &L : m->layers) {
         for (int s = 0; s < 7; s++) {
             if (s == VMX_L_V && L.k_eq_v) continue;
             by += L.lin[s].alg_bytes(batch);
-            n++;
         }
+        n += multi ? 4 : (L.k_eq_v ? 6 : 7);
+    }
     *launches = n;
     *alg_bytes = by;
     return VMX_OK;
@@ -595,13 +601,14 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
     const int I = c.intermediate_size, H = c.hidden_size;
     for (const G4Layer &L : m->layers) {
         const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd, ntot = NQ + (L.k_eq_v ? 1 : 2) * NKV;
-        if (int rc = mmvq(m, L.lin[VMX_L_Q], proj, ntot, batch, st)) return rc;
-        if (int rc = mmvq(m, L.lin[VMX_L_K], proj + NQ, ntot, batch, st)) return rc;
-        if (!L.k_eq_v)
-            if (int rc = mmvq(m, L.lin[VMX_L_V], proj + NQ + NKV, ntot, batch, st)) return rc;
+        const VmxMmvqSeg qkv[3] = {{L.lin[VMX_L_Q].raw.p, L.lin[VMX_L_Q].ggml_type, NQ, 0},
+                                   {L.lin[VMX_L_K].raw.p, L.lin[VMX_L_K].ggml_type, NKV, NQ},
+                                   {L.lin[VMX_L_V].raw.p, L.lin[VMX_L_V].ggml_type, NKV, NQ + NKV}};
+        if (int rc = vmx_iq_mmvq_multi(qkv, L.k_eq_v ? 2 : 3, aq_of(m), ad_of(m, batch, H), proj, H, batch, ntot, st)) return rc;
         if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
-        if (int rc = mmvq(m, L.lin[VMX_L_GATE], proj, 2 * I, batch, st)) return rc;
-        if (int rc = mmvq(m, L.lin[VMX_L_UP], proj + I, 2 * I, batch, st)) return rc;
+        const VmxMmvqSeg gu[2] = {{L.lin[VMX_L_GATE].raw.p, L.lin[VMX_L_GATE].ggml_type, I, 0},
+                                  {L.lin[VMX_L_UP].raw.p, L.lin[VMX_L_UP].ggml_type, I, I}};
+        if (int rc = vmx_iq_mmvq_multi(gu, 2, aq_of(m), ad_of(m, batch, H), proj, H, batch, 2 * I, st)) return rc;
         if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
     }
     return VMX_OK;

@@ -319,11 +319,9 @@ __global__ __launch_bounds__(256) void quantize_q8_1_bf16_kernel(const uint16_t 
 // kernel (VALU, then LDS), so everything per sub-block is kept to ~60 vector instructions.
 // Accumulation: acc += (w_d * a_d) * (float)sub, lanes summed by a 64-wide butterfly.
 template <int T, int MT, int R, int G>
-__global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
-                                                       const float *__restrict__ ad, float *__restrict__ y, int n_out,
-                                                       int n_in, int m, int ldy) {
-    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
-    __shared__ uint2 sg[SignLut<T>::N];
+__device__ __forceinline__ void mmvq_body(uint32_t *cb, uint2 *sg, const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
+                                          const float *__restrict__ ad, float *__restrict__ y, int n_out, int n_in, int m, int ldy,
+                                          int block_index, int num_blocks) {
     const TableRegs<T> treg = tables_fetch<T>();   // committed to LDS after the first step's weight loads are issued
     bool tables_pending = true;
     constexpr int TS = IqTraits<T>::TS;
@@ -333,8 +331,8 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
     const int ib = lane & 7;
     const int nb256 = n_in >> 8, nblk32 = n_in >> 5;
     const int64_t row_bytes = (int64_t)nb256 * TS;
-    const int waves_total = gridDim.x * 4;
-    for (int row0 = (blockIdx.x * 4 + wave) * R; row0 < n_out; row0 += waves_total * R) {
+    const int waves_total = num_blocks * 4;
+    for (int row0 = (block_index * 4 + wave) * R; row0 < n_out; row0 += waves_total * R) {
         const uint8_t *rb[R];
 #pragma unroll
         for (int r = 0; r < R; r++) rb[r] = w + (int64_t)min(row0 + r, n_out - 1) * row_bytes;
@@ -418,6 +416,42 @@ __global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict_
             }
     }
     if (tables_pending) tables_commit<T>(treg, cb, sg);   // every wave of the workgroup reaches exactly one barrier
+}
+
+template <int T, int MT, int R, int G>
+__global__ __launch_bounds__(256) void iq_mmvq_kernel(const uint8_t *__restrict__ w, const int8_t *__restrict__ aq,
+                                                       const float *__restrict__ ad, float *__restrict__ y, int n_out,
+                                                       int n_in, int m, int ldy) {
+    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
+    __shared__ uint2 sg[SignLut<T>::N];
+    mmvq_body<T, MT, R, G>(cb, sg, w, aq, ad, y, n_out, n_in, m, ldy, blockIdx.x, gridDim.x);
+}
+
+// Up to three weights of possibly different I-quant types that share one activation row (q | k | v, gate | up), one
+// launch: workgroups [blk0[i], blk0[i+1]) work on segment i and write y + y_off[i].  One launch boundary instead of
+// three for projections that are each only a few microseconds long.
+struct MmvqSegs {
+    const uint8_t *w[3];
+    int type[3], n_out[3], y_off[3], blk0[4];
+};
+
+__global__ __launch_bounds__(256) void iq_mmvq_multi_kernel(MmvqSegs s, const int8_t *__restrict__ aq, const float *__restrict__ ad,
+                                                             float *__restrict__ y, int n_in) {
+    __shared__ uint32_t cb[2048];
+    __shared__ uint2 sg[256];
+    const int b = blockIdx.x;
+    const int seg = b >= s.blk0[2] ? 2 : (b >= s.blk0[1] ? 1 : 0);
+    const int bi = b - s.blk0[seg], nb = s.blk0[seg + 1] - s.blk0[seg];
+    const uint8_t *w = s.w[seg];
+    float *yo = y + s.y_off[seg];
+    const int n_out = s.n_out[seg];
+    switch (s.type[seg]) {
+        case 17: mmvq_body<17, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+        case 22: mmvq_body<22, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+        case 18: mmvq_body<18, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+        case 21: mmvq_body<21, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+        default: mmvq_body<23, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+    }
 }
 
 // ------------------------------------------------------------------ MMVQ, m == 1: pipelined
@@ -758,5 +792,44 @@ int vmx_iq_mmvq_ld(int ggml_type, const void *w, const int8_t *aq, const float *
 #define CALL(T) { int rc = launch_mmvq<T>((const uint8_t *)w, aq, ad, y, n_out, n_in, m, ldy, st); if (rc) return rc; }
     IQ_DISPATCH(ggml_type, CALL)
 #undef CALL
+    return VMX_OK;
+}
+
+// Several projections of one activation (m rows, q8_1 in aq/ad), outputs at y + y_off[i] with row stride ldy.  With one
+// activation row and short weight rows everything goes out as one launch; otherwise one launch per projection.
+int vmx_iq_mmvq_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int m, int ldy,
+                      hipStream_t st) {
+    if (nseg < 1 || nseg > 3) {
+        vmx_set_error("iq_mmvq_multi: %d segments (1..3)", nseg);
+        return VMX_EINVAL;
+    }
+    for (int i = 0; i < nseg; i++)
+        if (vmx_iq_type_size(segs[i].ggml_type) < 0) {
+            vmx_set_error("unsupported ggml type id %d", segs[i].ggml_type);
+            return VMX_EUNSUPPORTED;
+        }
+    if (m != 1 || n_in > 4096 || nseg == 1) {
+        for (int i = 0; i < nseg; i++)
+            if (int rc = vmx_iq_mmvq_ld(segs[i].ggml_type, segs[i].w, aq, ad, y + segs[i].y_off, segs[i].n_out, n_in, m, ldy, st)) return rc;
+        return VMX_OK;
+    }
+    MmvqSegs s = {};
+    int blk = 0;
+    for (int i = 0; i < 3; i++) {
+        s.blk0[i] = blk;
+        if (i < nseg) {
+            s.w[i] = (const uint8_t *)segs[i].w;
+            s.type[i] = segs[i].ggml_type;
+            s.n_out[i] = segs[i].n_out;
+            s.y_off[i] = segs[i].y_off;
+            blk += (segs[i].n_out + 7) / 8;   // 4 waves x 2 rows per workgroup
+        } else {
+            s.type[i] = 18;
+        }
+    }
+    s.blk0[3] = blk;
+    for (int i = nseg; i < 3; i++) s.blk0[i] = blk;
+    hipLaunchKernelGGL(iq_mmvq_multi_kernel, dim3(blk), dim3(256), 0, st, s, aq, ad, y, n_in);
+    VMX_CHECK_LAUNCH("iq_mmvq(multi)");
     return VMX_OK;
 }

@@ -19,8 +19,9 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
                               const int32_t *seq_lens, float scale, int num_seqs, int num_heads, int num_kv_heads,
                               int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window, int kv_dtype,
                               const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st);
+// aq/ad (optional): also emit the q8_1 form of the output rows [seqs][heads * head_dim] for an I-quant consumer
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
-                              int head_dim, int window, hipStream_t st);
+                              int head_dim, int window, hipStream_t st, int8_t *aq = nullptr, float *ad = nullptr);
 
 // glue_kernels.hip
 int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,
@@ -31,6 +32,12 @@ int vmx_argmax_keys_to_ids(const unsigned long long *keys, int32_t *out_ids, int
 int vmx_quantize_q8_1_bf16(const uint16_t *x, int8_t *aq, float *ad, int64_t total_blocks, hipStream_t st);
 int vmx_iq_mmvq_ld(int ggml_type, const void *w, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m, int ldy,
                    hipStream_t st);
+struct VmxMmvqSeg {
+    const void *w;      // raw I-quant blocks [n_out, n_in]
+    int ggml_type, n_out, y_off;
+};
+int vmx_iq_mmvq_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int m, int ldy,
+                      hipStream_t st);
 
 // kquant_kernels.hip
 int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_t *ids, uint16_t *out, int tokens, int dim, int vocab,
