@@ -69,3 +69,23 @@ def test_q6k_matches_reference_gather_kernel_path(gpu):
     ids = torch.arange(rows, dtype=torch.int32, device="cuda")
     g = vmx.gather_dequant_q6k(w, ids, dim, rows)
     assert torch.equal(g.reshape(-1), full)
+
+
+@pytest.mark.parametrize("n_out,n_in", [(1003, 3840), (37, 256), (4100, 2048), (9, 4096)])
+def test_q3k_lm_head_gemv(gpu, n_out, n_in):
+    """The one-row Q3_K kernel (tied lm_head shape: rows of 15 super-blocks, ragged row counts) against the float64
+    product of the oracle's dequantised table."""
+    from oracle import oracle as orc
+    from vllm_rust_amd._lib import lib, check
+    vmx, torch = gpu
+    rng = np.random.default_rng(n_out + n_in)
+    raw = _blocks(rng, 11, n_out * n_in // 256)
+    ref = orc.ggml_dequant(11, raw).reshape(n_out, n_in)
+    x = rng.standard_normal((1, n_in)).astype(np.float32)
+    w, xd = torch.from_numpy(raw).cuda(), torch.from_numpy(x).cuda()
+    y = torch.full((1, n_out + 8), 7.0, dtype=torch.float32, device="cuda")
+    check(lib.vmx_kquant_gemv_f32(11, w.data_ptr(), xd.data_ptr(), y.data_ptr(), n_out, n_in, 1, torch.cuda.current_stream().cuda_stream))
+    got = y.cpu().numpy()[0]
+    exp = (x.astype(np.float64) @ ref.astype(np.float64).T)[0]
+    assert np.all(got[n_out:] == 7.0)                      # nothing written past the last row
+    assert np.sqrt(((got[:n_out] - exp) ** 2).sum() / (exp ** 2).sum()) <= 1e-5

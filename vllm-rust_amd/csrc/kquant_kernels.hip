@@ -129,6 +129,91 @@ __global__ __launch_bounds__(256) void kgemv_kernel(const uint8_t *__restrict__ 
     }
 }
 
+// Q3_K x f32 vector, one activation row (the tied lm_head of a GGUF Gemma: 262144 x 3840, 432 MB): a lane owns 4
+// consecutive positions l0..l0+3 of one super-block's 32-wide pattern, i.e. the 32 weights {128n + 32j + l0 + i}: they
+// share one hmask dword and two qs dwords, so a block is fetched exactly once (8 lanes x 12 B + scales) and the lane's 32
+// activations (and their per-group sums, for the "- 4" offset) are loaded once and stay in registers for every row.
+// A wave covers 8 super-blocks per pass (P passes: rows of up to 8 P blocks) and streams its rows through a ring of D
+// row slots.  sum = d * sum_{n,j} scale[n,j,hi] * (sum_i t_i x_i - 4 sum_i x_i), t = q2 | hbit << 2.
+struct __attribute__((packed, aligned(2))) u32a2 { uint32_t v; };
+__device__ __forceinline__ uint32_t ldw(const uint8_t *p) { return reinterpret_cast<const u32a2 *>(p)->v; }
+
+struct Q3Raw { uint32_t hm, q0, q1, s0, s1, s2, d; };
+
+template <int P, int D>
+__global__ __launch_bounds__(256) void q3k_gemv_m1_kernel(const uint8_t *__restrict__ w, const float *__restrict__ x, float *__restrict__ y,
+                                                           int n_out, int nb, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lb = lane >> 3, l0 = (lane & 7) * 4, hi = l0 >> 4;
+    float xv[P][8][4], xs[P][8];
+    int boff[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int blk = lb + 8 * p;
+        const bool live = blk < nb;
+        boff[p] = min(blk, nb - 1) * 110;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {   // g = 4n + j
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = *reinterpret_cast<const float4 *>(x + blk * 256 + 32 * g + l0);
+            xv[p][g][0] = v.x; xv[p][g][1] = v.y; xv[p][g][2] = v.z; xv[p][g][3] = v.w;
+            xs[p][g] = 4.0f * (v.x + v.y + v.z + v.w);
+        }
+    }
+    const int row0 = gw * rows_per_wave;
+    const int64_t row_bytes = (int64_t)nb * 110;
+    auto load_row = [&](int k, Q3Raw (&r)[P]) {   // rows past the wave's range re-read its last row (cheap, never stored)
+        const uint8_t *rp = w + (int64_t)min(row0 + min(k, rows_per_wave - 1), n_out - 1) * row_bytes;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const uint8_t *b = rp + boff[p];
+            r[p].hm = ldw(b + l0); r[p].q0 = ldw(b + 32 + l0); r[p].q1 = ldw(b + 64 + l0);
+            r[p].s0 = ldw(b + 96); r[p].s1 = ldw(b + 100); r[p].s2 = ldw(b + 104);
+            r[p].d = reinterpret_cast<const u16a2 *>(b + 108)->v;
+        }
+    };
+    auto compute_row = [&](int k, const Q3Raw (&r)[P]) {
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            uint32_t aux[4];
+            aux[0] = (r[p].s0 & 0x0f0f0f0fu) | (((r[p].s2 >> 0) & 0x03030303u) << 4);
+            aux[1] = (r[p].s1 & 0x0f0f0f0fu) | (((r[p].s2 >> 2) & 0x03030303u) << 4);
+            aux[2] = ((r[p].s0 >> 4) & 0x0f0f0f0fu) | (((r[p].s2 >> 4) & 0x03030303u) << 4);
+            aux[3] = ((r[p].s1 >> 4) & 0x0f0f0f0fu) | (((r[p].s2 >> 6) & 0x03030303u) << 4);
+            float part = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                const int n = g >> 2, j = g & 3;
+                const uint32_t q = n ? r[p].q1 : r[p].q0;
+                const uint32_t t = ((q >> (2 * j)) & 0x03030303u) | (((r[p].hm >> g) & 0x01010101u) << 2);
+                // scale index 2g + hi -> word (2g + hi) >> 2 = g >> 1, byte ((2g & 3) + hi)
+                const int sc = (int)((aux[g >> 1] >> (8 * (((2 * g) & 3) + hi))) & 0xFFu) - 32;
+                float dot = (float)(t & 0xFFu) * xv[p][g][0];
+                dot = fmaf((float)((t >> 8) & 0xFFu), xv[p][g][1], dot);
+                dot = fmaf((float)((t >> 16) & 0xFFu), xv[p][g][2], dot);
+                dot = fmaf((float)(t >> 24), xv[p][g][3], dot);
+                part = fmaf((float)sc, dot - xs[p][g], part);
+            }
+            acc = fmaf(vmx_f16_to_f32((uint16_t)r[p].d), part, acc);
+        }
+        const float v = vmx_wave_sum(acc);
+        const int row = row0 + k;
+        if (lane == 0 && k < rows_per_wave && row < n_out) y[row] = v;
+    };
+    Q3Raw ring[D][P];
+#pragma unroll
+    for (int j = 0; j < D; j++) load_row(j, ring[j]);
+    for (int k0 = 0; k0 < rows_per_wave; k0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            compute_row(k0 + j, ring[j]);
+            load_row(k0 + j + D, ring[j]);
+        }
+    }
+}
+
 // out[t, :] = bf16(bf16(dequant(table row ids[t])) * scale): QuantizedEmbedding::forward (gather the row's blocks,
 // dequantise, cast to the model dtype; crates/core/src/quantization/gguf/mod.rs:546-600) followed by the model's
 // embedding normaliser in bf16.  Out-of-range ids give a zero row.  One thread per 32-weight sub-block.
@@ -191,9 +276,21 @@ extern "C" int vmx_kquant_gemv_f32(int ggml_type, const void *w, const float *x,
     VMX_REQUIRE(m >= 1 && m <= 8, "kquant_gemv: m (%d) must be in 1..8 (larger m takes the dequant + GEMM path)", m);
     VMX_REQUIRE(n_out > 0 && n_in > 0 && n_in % vmx_ggml_block_elems(ggml_type) == 0, "kquant_gemv: n_in (%d) not a multiple of the block size",
                 n_in);
+    hipStream_t st = vmx_stream(stream);
+    if (ggml_type == 11 && m == 1 && n_in <= 4096) {   // lm_head-sized Q3_K x vector
+        const int nb = n_in / 256;
+        int g = (n_out + 3) / 4;
+        const int cap = vmx_num_cus() * 3;
+        if (g > cap) g = cap;
+        const int rpw = (n_out + g * 4 - 1) / (g * 4);
+        g = (n_out + rpw * 4 - 1) / (rpw * 4);
+        if (nb <= 8) hipLaunchKernelGGL((q3k_gemv_m1_kernel<1, 3>), dim3(g), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, nb, rpw);
+        else hipLaunchKernelGGL((q3k_gemv_m1_kernel<2, 3>), dim3(g), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, nb, rpw);
+        VMX_CHECK_LAUNCH("kquant_gemv(q3_k)");
+        return VMX_OK;
+    }
     int grid = (n_out + 3) / 4;
     if (grid > 8192) grid = 8192;
-    hipStream_t st = vmx_stream(stream);
 #define CALL(T)                                                                                                                  \
     do {                                                                                                                         \
         if (m == 1) hipLaunchKernelGGL((kgemv_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, n_in, m); \
