@@ -64,30 +64,42 @@ __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, 
     __shared__ float red[4];
     const int64_t row = (int64_t)blockIdx.x * hidden;
     const int nchunk = hidden >> 3;
+    // every global load of the kernel is requested here, before the first reduction (the kernel is a chain of latencies)
+    float4 oa[CH], ob[CH];
+    uint4 hraw[CH], wp[CH], wn[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int ci = min(threadIdx.x + 256 * c, nchunk - 1);
+        if (o) {
+            oa[c] = *reinterpret_cast<const float4 *>(o + row + 8 * ci);
+            ob[c] = *reinterpret_cast<const float4 *>(o + row + 8 * ci + 4);
+            wp[c] = *reinterpret_cast<const uint4 *>(w_post + 8 * ci);
+        }
+        hraw[c] = *reinterpret_cast<const uint4 *>(h + row + 8 * ci);
+        wn[c] = *reinterpret_cast<const uint4 *>(w_next + 8 * ci);
+    }
+    const float sc = scalar ? vmx_bf16_to_f32(scalar[0]) : 1.0f;
     float hv[CH][8];
     if (o) {
         float ov[CH][8];
         float v1 = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; c++) {
-            const int ci = threadIdx.x + 256 * c;
-            if (ci < nchunk) {
-                const float4 a = *reinterpret_cast<const float4 *>(o + row + 8 * ci), b = *reinterpret_cast<const float4 *>(o + row + 8 * ci + 4);
-                const float t8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if ((int)threadIdx.x + 256 * c < nchunk) {
+                const float t8[8] = {oa[c].x, oa[c].y, oa[c].z, oa[c].w, ob[c].x, ob[c].y, ob[c].z, ob[c].w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) { ov[c][j] = rbf(t8[j]); v1 += ov[c][j] * ov[c][j]; }
             }
         }
         v1 = vmx_block_sum_256(v1, red);
         const float inv1 = rsqrtf(v1 / (float)hidden + eps);
-        const float sc = scalar ? vmx_bf16_to_f32(scalar[0]) : 1.0f;
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const int ci = threadIdx.x + 256 * c;
             if (ci < nchunk) {
                 float wv[8], hr[8];
-                unpack8(*reinterpret_cast<const uint4 *>(w_post + 8 * ci), wv);
-                unpack8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hr);
+                unpack8(wp[c], wv);
+                unpack8(hraw[c], hr);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     float v = rbf(rbf(ov[c][j] * inv1 * wv[j]) + hr[j]);
@@ -99,16 +111,12 @@ __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, 
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int ci = threadIdx.x + 256 * c;
-            if (ci < nchunk) unpack8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
-        }
+        for (int c = 0; c < CH; c++) unpack8(hraw[c], hv[c]);
     }
     float v2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; c++) {
-        const int ci = threadIdx.x + 256 * c;
-        if (ci < nchunk) {
+        if ((int)threadIdx.x + 256 * c < nchunk) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v2 += hv[c][j] * hv[c][j];
         }
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, 
         const int ci = threadIdx.x + 256 * c;
         if (ci < nchunk) {
             float wv[8], out[8];
-            unpack8(*reinterpret_cast<const uint4 *>(w_next + 8 * ci), wv);
+            unpack8(wn[c], wv);
 #pragma unroll
             for (int j = 0; j < 8; j++) out[j] = hv[c][j] * inv2 * wv[j];
             const uint4 packed = pack8(out);

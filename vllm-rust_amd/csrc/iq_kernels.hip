@@ -435,22 +435,29 @@ struct MmvqSegs {
     int type[3], n_out[3], y_off[3], blk0[4];
 };
 
+// TALL: 0 = the segments' types differ (sized for the largest tables and register need), else the type they all share.
+template <int TALL>
 __global__ __launch_bounds__(256) void iq_mmvq_multi_kernel(MmvqSegs s, const int8_t *__restrict__ aq, const float *__restrict__ ad,
                                                              float *__restrict__ y, int n_in) {
-    __shared__ uint32_t cb[2048];
-    __shared__ uint2 sg[256];
+    constexpr int TT = TALL ? TALL : 18;
+    __shared__ uint32_t cb[TALL ? IqTraits<TT>::LDS_WORDS : 2048];
+    __shared__ uint2 sg[TALL ? SignLut<TT>::N : 256];
     const int b = blockIdx.x;
     const int seg = b >= s.blk0[2] ? 2 : (b >= s.blk0[1] ? 1 : 0);
     const int bi = b - s.blk0[seg], nb = s.blk0[seg + 1] - s.blk0[seg];
     const uint8_t *w = s.w[seg];
     float *yo = y + s.y_off[seg];
     const int n_out = s.n_out[seg];
-    switch (s.type[seg]) {
-        case 17: mmvq_body<17, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
-        case 22: mmvq_body<22, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
-        case 18: mmvq_body<18, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
-        case 21: mmvq_body<21, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
-        default: mmvq_body<23, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+    if constexpr (TALL != 0) {
+        mmvq_body<TT, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb);
+    } else {
+        switch (s.type[seg]) {
+            case 17: mmvq_body<17, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+            case 22: mmvq_body<22, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+            case 18: mmvq_body<18, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+            case 21: mmvq_body<21, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+            default: mmvq_body<23, 1, 2, 2>(cb, sg, w, aq, ad, yo, n_out, n_in, 1, 0, bi, nb); break;
+        }
     }
 }
 
@@ -829,7 +836,15 @@ int vmx_iq_mmvq_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const 
     }
     s.blk0[3] = blk;
     for (int i = nseg; i < 3; i++) s.blk0[i] = blk;
-    hipLaunchKernelGGL(iq_mmvq_multi_kernel, dim3(blk), dim3(256), 0, st, s, aq, ad, y, n_in);
+    bool same = true;
+    for (int i = 1; i < nseg; i++) same = same && segs[i].ggml_type == segs[0].ggml_type;
+#define CALL(T) hipLaunchKernelGGL((iq_mmvq_multi_kernel<T>), dim3(blk), dim3(256), 0, st, s, aq, ad, y, n_in)
+    if (!same) {
+        CALL(0);
+    } else {
+        IQ_DISPATCH(segs[0].ggml_type, CALL)
+    }
+#undef CALL
     VMX_CHECK_LAUNCH("iq_mmvq(multi)");
     return VMX_OK;
 }
