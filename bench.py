@@ -131,6 +131,11 @@ def gemma4_secondary(prompt, steps, warmup):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     achieved = alg / us / 1e3
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC passes of the same kernels on the same shapes (tools/pmc_mmvq.py)
+        traffic = json.loads((ROOT / "profiles" / "r01_pmc_traffic_iq_mmvq.json").read_text())["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     wbytes = model.iq_weight_bytes()
     embed_bytes = spec.vocab_size * (spec.hidden_size // 256) * 110
     model.close()
@@ -140,8 +145,8 @@ def gemma4_secondary(prompt, steps, warmup):
                                    "token embedding), 48 layers (40 sliding 8x256 window 1024, 8 full 1x512), FP8 e4m3 KV, soft-cap 30",
                        "weights": "seeded random-init blocks of the architecture", "execution": "one hipGraph per step"},
             "weight_bytes_per_token": wbytes + embed_bytes,
-            "roofline": {"bound": "hbm", "kernel": "iq_mmvq_kernel / iq_mmvq_pipe_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": launches,
+            "roofline": {"bound": "hbm", "kernel": "iq_mmvq_kernel / iq_mmvq_multi_kernel / iq_mmvq_pipe_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": launches,
                          "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches)}}
 
 
