@@ -454,6 +454,43 @@ int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream);
 /* Parity aid: 0 = residual stream h, 1 = final normed x (bf16 [batch, hidden]). */
 int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, void *stream);
 
+
+/* ------------------------------------------------------------------ GGUF container (host only) */
+
+/* Replaces GgufHeader::read / read_tensor_bytes (crates/core/src/quantization/gguf/header.rs:221-321) and the HF ->
+ * llama.cpp name map of the GGUF weight loader (gguf/mod.rs:1416-1479).  GGUF v1-3; tensor shapes come back in the logical
+ * orientation (on-disk dims reversed: a 2-D weight is [out, in]); n_bytes = elements / block * type_size; tensor data
+ * starts at tensor_data_offset (aligned to general.alignment, default 32) + offset.  Unknown GGML type ids, a bad magic
+ * and truncated data are errors (VMX_EINVAL / VMX_EUNSUPPORTED with the reference's wording). */
+typedef struct vmx_gguf vmx_gguf;
+typedef struct vmx_gguf_tensor {
+    const char *name;    /* owned by the handle */
+    int n_dims;
+    uint64_t shape[8];
+    int ggml_type;
+    uint64_t offset, n_bytes;
+} vmx_gguf_tensor;
+
+int vmx_gguf_open(const char *path, vmx_gguf **out);
+int vmx_gguf_parse(const void *data, size_t bytes, vmx_gguf **out);   /* header bytes already in memory */
+void vmx_gguf_close(vmx_gguf *g);
+int vmx_gguf_version(const vmx_gguf *g);
+uint64_t vmx_gguf_tensor_data_offset(const vmx_gguf *g);
+int vmx_gguf_tensor_count(const vmx_gguf *g);
+int vmx_gguf_metadata_count(const vmx_gguf *g);
+int vmx_gguf_find_tensor(const vmx_gguf *g, const char *name);        /* index in file order, -1 if absent */
+int vmx_gguf_tensor_info(const vmx_gguf *g, int index, vmx_gguf_tensor *out);
+int vmx_gguf_read_tensor(const vmx_gguf *g, int index, void *dst_host, size_t dst_bytes);
+const char *vmx_gguf_metadata_key(const vmx_gguf *g, int index);
+/* value-type id 0..12 of a key (9 = array: *array_len, *elem_type filled), -1 if absent */
+int vmx_gguf_metadata_type(const vmx_gguf *g, const char *key, uint64_t *array_len, int *elem_type);
+/* array_index < 0: the value itself, else that element of an array value */
+int vmx_gguf_metadata_int(const vmx_gguf *g, const char *key, int array_index, int64_t *out);
+int vmx_gguf_metadata_float(const vmx_gguf *g, const char *key, int array_index, double *out);
+const char *vmx_gguf_metadata_string(const vmx_gguf *g, const char *key, int array_index);
+/* "model.layers.3.self_attn.q_proj" -> "blk.3.attn_q"; candidate `which` in priority order; returns the length, 0 if none */
+int vmx_gguf_llama_cpp_name(const char *hf_prefix, int which, char *out, size_t out_bytes);
+
 #ifdef __cplusplus
 }
 #endif

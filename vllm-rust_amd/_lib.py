@@ -94,6 +94,22 @@ _SIGS = {
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "vmx_qwen3_linears_only": (_i, [_p, _i, _p]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
+    "vmx_gguf_open": (_i, [C.c_char_p, _p]),
+    "vmx_gguf_parse": (_i, [_p, _sz, _p]),
+    "vmx_gguf_close": (None, [_p]),
+    "vmx_gguf_version": (_i, [_p]),
+    "vmx_gguf_tensor_data_offset": (C.c_uint64, [_p]),
+    "vmx_gguf_tensor_count": (_i, [_p]),
+    "vmx_gguf_metadata_count": (_i, [_p]),
+    "vmx_gguf_find_tensor": (_i, [_p, C.c_char_p]),
+    "vmx_gguf_tensor_info": (_i, [_p, _i, _p]),
+    "vmx_gguf_read_tensor": (_i, [_p, _i, _p, _sz]),
+    "vmx_gguf_metadata_key": (C.c_char_p, [_p, _i]),
+    "vmx_gguf_metadata_type": (_i, [_p, C.c_char_p, _p, _p]),
+    "vmx_gguf_metadata_int": (_i, [_p, C.c_char_p, _i, _p]),
+    "vmx_gguf_metadata_float": (_i, [_p, C.c_char_p, _i, _p]),
+    "vmx_gguf_metadata_string": (C.c_char_p, [_p, C.c_char_p, _i]),
+    "vmx_gguf_llama_cpp_name": (_i, [C.c_char_p, _i, C.c_char_p, _sz]),
     "vmx_gemma4_create": (_i, [_p, _p, _p]),
     "vmx_gemma4_destroy": (None, [_p]),
     "vmx_gemma4_load_tensor": (_i, [_p, _i, _i, _p, _sz, _p]),
@@ -113,6 +129,12 @@ class Qwen3Config(C.Structure):
         ("qk_norm", _i), ("tie_word_embeddings", _i), ("kv_cache_dtype", _i), ("block_size", _i), ("num_blocks", _i),
         ("max_batch", _i), ("max_seq_len", _i), ("tp_size", _i), ("tp_rank", _i),
     ]
+
+
+class GgufTensor(C.Structure):
+    """struct vmx_gguf_tensor (include/vmx.h)."""
+    _fields_ = [("name", C.c_char_p), ("n_dims", _i), ("shape", C.c_uint64 * 8), ("ggml_type", _i), ("offset", C.c_uint64),
+                ("n_bytes", C.c_uint64)]
 
 
 class Gemma4Config(C.Structure):
