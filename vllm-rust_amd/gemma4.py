@@ -201,6 +201,82 @@ class QuantizedGemma4ForCausalLM:
                 keep(f"{li}.{slot}.iq", (t, raw.reshape(-1).cpu()) if keep_host_copy else None)
         return ck
 
+    GGUF_SLOT_NAMES = {L_Q: "self_attn.q_proj", L_K: "self_attn.k_proj", L_V: "self_attn.v_proj", L_O: "self_attn.o_proj",
+                       L_GATE: "mlp.gate_proj", L_UP: "mlp.up_proj", L_DOWN: "mlp.down_proj"}
+    GGUF_NORM_NAMES = {T_INPUT_LN: "input_layernorm", T_POST_ATTN_LN: "post_attention_layernorm", T_PRE_FFN_LN: "pre_feedforward_layernorm",
+                       T_POST_FFN_LN: "post_feedforward_layernorm", T_Q_NORM: "self_attn.q_norm", T_K_NORM: "self_attn.k_norm",
+                       T_LAYER_SCALAR: "layer_scalar"}
+
+    def load_gguf(self, path: str) -> int:
+        """Load every weight of the model from a GGUF file through the library's container parser: projections as raw I-quant
+        blocks (GgufWeightLoader::load_linear, crates/core/src/quantization/gguf/mod.rs:1612-1662), F32/F16/BF16 norm vectors
+        and layer scalars cast to bf16, token_embd as bf16 or as its raw K-quant blocks.  Tensor names are resolved with the
+        HF -> llama.cpp map in priority order (gguf/mod.rs:1416-1479).  Returns the number of tensors loaded."""
+        from ._lib import GgufTensor
+        s = self.spec
+        h = C.c_void_p()
+        check(lib.vmx_gguf_open(str(path).encode(), C.byref(h)))
+        try:
+            def find(prefix):
+                for which in range(3):
+                    buf = C.create_string_buffer(128)
+                    if lib.vmx_gguf_llama_cpp_name(prefix.encode(), which, buf, 128) == 0:
+                        break
+                    idx = lib.vmx_gguf_find_tensor(h, buf.value + b".weight")
+                    if idx >= 0:
+                        return idx
+                return -1
+
+            def read(idx):
+                t = GgufTensor()
+                check(lib.vmx_gguf_tensor_info(h, idx, C.byref(t)))
+                raw = torch.empty(int(t.n_bytes), dtype=torch.uint8)
+                check(lib.vmx_gguf_read_tensor(h, idx, raw.data_ptr(), raw.numel()))
+                return t, raw
+
+            def dense_bf16(idx):
+                t, raw = read(idx)
+                if t.ggml_type == 0:
+                    return raw.view(torch.float32).to(torch.bfloat16)
+                if t.ggml_type == 1:
+                    return raw.view(torch.float16).to(torch.bfloat16)
+                if t.ggml_type == 30:
+                    return raw.view(torch.bfloat16)
+                raise ValueError(f"{t.name.decode()}: expected a dense tensor, got GGML type {t.ggml_type}")
+
+            n = 0
+            idx = find("model.embed_tokens")
+            if idx < 0:
+                raise KeyError("token_embd.weight not found")
+            t, raw = read(idx)
+            if s.embed_ggml_type == 0:
+                self.load_tensor(T_EMBED, 0, dense_bf16(idx).to(self.device))
+            else:
+                if t.ggml_type != s.embed_ggml_type:
+                    raise ValueError(f"token_embd is GGML type {t.ggml_type}, the model was created for {s.embed_ggml_type}")
+                self.load_tensor(T_EMBED, 0, raw.to(self.device))
+            n += 1
+            self.load_tensor(T_FINAL_NORM, 0, dense_bf16(find("model.norm")).to(self.device)); n += 1
+            for li in range(s.num_layers):
+                for which, name in self.GGUF_NORM_NAMES.items():
+                    idx = find(f"model.layers.{li}.{name}")
+                    if idx < 0:
+                        if which == T_LAYER_SCALAR:
+                            continue   # identity scalar stays
+                        raise KeyError(f"layer {li}: {name} not found")
+                    self.load_tensor(which, li, dense_bf16(idx).reshape(-1).to(self.device)); n += 1
+                for slot, (K, N) in s.linear_shapes(li).items():
+                    idx = find(f"model.layers.{li}.{self.GGUF_SLOT_NAMES[slot]}")
+                    if idx < 0:
+                        raise KeyError(f"layer {li}: {self.GGUF_SLOT_NAMES[slot]} not found")
+                    t, raw = read(idx)
+                    if list(t.shape[:t.n_dims]) != [N, K]:
+                        raise ValueError(f"{t.name.decode()}: shape {list(t.shape[:t.n_dims])}, expected {[N, K]}")
+                    self.load_iq_linear(li, slot, t.ggml_type, raw.to(self.device)); n += 1
+            return n
+        finally:
+            lib.vmx_gguf_close(h)
+
     def iq_weight_bytes(self, slot_types=None) -> int:
         slot_types = slot_types or GEMMA4_12B_IQ3_MIX
         s = self.spec
