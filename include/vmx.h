@@ -238,6 +238,17 @@ int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cac
                              int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
                              const float *v_scale, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Replaces AttentionBackend::prefill_attention (crates/core/src/layers/attention/backend.rs:60-71; semantics of the naive
+ * backend, naive.rs:38-83; the reference's GPU build goes through the third-party FlashInfer wrapper): causal attention of
+ * q_len new tokens at positions seqlen_offset .. seqlen_offset + q_len - 1 over the paged cache, which must already hold
+ * their K/V rows (vmx_reshape_and_cache first, as the reference writes before it reads).  q [q_len, heads, head_dim] bf16,
+ * out [q_len, heads * head_dim] bf16, block_table i32 [blocks of this sequence]; window = 0 means full causal, else each
+ * token sees the last `window` positions including its own.  No workspace; hipGraph-capturable. */
+int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                               const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
+                               int num_kv_heads, int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
+                               const float *v_scale, void *stream);
+
 
 /* Replaces the cuBLAS half_matmul_pooled used for the (tied) lm_head on the decode path
  * (crates/core/src/models/qwen3_quantized.rs:1258-1302; cuda_kernels.rs half_matmul_pooled):

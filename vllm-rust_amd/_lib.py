@@ -94,6 +94,7 @@ _SIGS = {
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "vmx_qwen3_linears_only": (_i, [_p, _i, _p]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
+    "vmx_prefill_attention_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vmx_gguf_open": (_i, [C.c_char_p, _p]),
     "vmx_gguf_parse": (_i, [_p, _sz, _p]),
     "vmx_gguf_close": (None, [_p]),

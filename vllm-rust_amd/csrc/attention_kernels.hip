@@ -298,6 +298,188 @@ static int parts_for_impl(int max_seq_len) {
     const int tiles = max_seq_len <= 0 ? 1 : (max_seq_len + 15) / 16, tpp = tiles_per_part_for(max_seq_len);
     return (tiles + tpp - 1) / tpp;
 }
+// ------------------------------------------------------------------ prefill over the paged cache
+// Causal (optionally windowed) attention of q_len new tokens at positions offset .. offset + q_len - 1 over everything the
+// paged cache holds for the sequence up to and including themselves (the caller wrote the new K/V rows first, as the
+// reference's naive backend does: write, read back, softmax(QK^T * scale + mask) V; layers/attention/naive.rs:38-83).
+// Flash-style on the matrix cores.  A workgroup = 4 waves = up to 4 query heads of one KV head x 16-token query tiles;
+// KV tiles of 16 tokens are staged through LDS once per workgroup (K row-major, V transposed), then per wave
+//   S^T = K Q^T      v_mfma_f32_16x16x32_bf16: A = K rows (row = token), B = the wave's q rows (column = query token);
+//                    the accumulator then holds, per lane, 4 consecutive tokens of ONE query row, which is
+//   O^T += V^T P^T   exactly the B fragment of v_mfma_f32_16x16x16_bf16 (k = token); A = V^T from LDS (row = head dim).
+// O^T keeps a query row in one accumulator column, so the online-softmax rescale is a per-lane multiply.
+typedef short vmx_s16x4 __attribute__((ext_vector_type(4)));
+
+template <int HD, int QPK, bool FP8>
+__global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ q,
+                                                            const void *__restrict__ k_cache, const void *__restrict__ v_cache,
+                                                            const int32_t *__restrict__ block_table, int q_len, int offset, float scale,
+                                                            int num_heads, int num_kv_heads, int block_size, int window,
+                                                            const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr) {
+    constexpr int HPW = QPK < 4 ? QPK : 4;   // query heads per workgroup
+    constexpr int TT = 4 / HPW;              // 16-token query tiles per workgroup
+    constexpr int KSTEPS = HD / 32, DT = HD / 16;
+    constexpr int KROW = HD + 8;             // bf16 per K row in LDS (16 B pad)
+    constexpr int VROW = 20;                 // bf16 per V^T row: 16 tokens + pad (rows stay 8-byte aligned)
+    __shared__ __align__(16) uint16_t Ks[16 * KROW];
+    __shared__ __align__(16) uint16_t Vt[HD * VROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int hh = wave % HPW, tt = wave / HPW;
+    constexpr int HGROUPS = QPK / HPW;
+    const int kvh = blockIdx.y / HGROUPS, hgrp = blockIdx.y % HGROUPS;
+    const int head = kvh * QPK + hgrp * HPW + hh;
+    const int wg_q0 = blockIdx.x * TT * 16, wg_q1 = min(q_len, wg_q0 + TT * 16);
+    const int qt0 = wg_q0 + tt * 16;                     // the wave's first query token
+    const int qi = qt0 + n;                              // this lane's query row
+    const bool q_valid = qi < q_len;
+    const int qpos = offset + min(qi, q_len - 1);
+    const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f, vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
+    const float lscale = scale * ksc;
+
+    uint4 qb[KSTEPS];
+#pragma unroll
+    for (int c = 0; c < KSTEPS; c++)
+        qb[c] = *reinterpret_cast<const uint4 *>(q + ((int64_t)min(qi, q_len - 1) * num_heads + head) * HD + 32 * c + 8 * g);
+
+    const int hi = offset + wg_q1;                                                    // tokens [lo, hi) are needed by the workgroup
+    int lo = window > 0 ? max(0, offset + wg_q0 - window + 1) : 0;
+    lo &= ~15;
+    const bool wave_live = qt0 < q_len;
+    const int wave_last_pos = offset + min(qt0 + 15, q_len - 1), wave_first_pos = offset + qt0;
+    const int64_t tok_stride = (int64_t)num_kv_heads * HD;
+
+    float m_run = -FLT_MAX, l_part = 0.f;
+    vmx_f32x4 acc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; d++) acc[d] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t0 = lo; t0 < hi; t0 += 16) {
+        __syncthreads();   // the previous tile is no longer read
+        for (int c = tid; c < 2 * HD; c += 256) {   // 16 tokens x HD / 8 chunks of 8 elements
+            const int tok = c / (HD / 8), dc = c % (HD / 8);
+            const int t = min(t0 + tok, hi - 1);    // rows past the end repeat the last valid row (their weights are 0)
+            const int blk = block_table[t / block_size];
+            const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD + dc * 8;
+            float kf[8], vf[8];
+            cvt8<FP8>(load8_raw<FP8>(k_cache, base), 1.0f, kf);
+            cvt8<FP8>(load8_raw<FP8>(v_cache, base), 1.0f, vf);
+            uint32_t kw[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) kw[j] = (__float_as_uint(kf[2 * j]) >> 16) | (__float_as_uint(kf[2 * j + 1]) & 0xFFFF0000u);
+            *reinterpret_cast<uint4 *>(&Ks[tok * KROW + dc * 8]) = make_uint4(kw[0], kw[1], kw[2], kw[3]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VROW + tok] = (uint16_t)(__float_as_uint(vf[e]) >> 16);
+        }
+        __syncthreads();
+        // wave-uniform: does this KV tile intersect the wave's causal / window range at all
+        const bool need = wave_live && t0 <= wave_last_pos && (window <= 0 || t0 + 15 > wave_first_pos - window);
+        if (need) {
+            vmx_f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KSTEPS; c++) {
+                const uint4 ka = *reinterpret_cast<const uint4 *>(&Ks[n * KROW + 32 * c + 8 * g]);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, ka), __builtin_bit_cast(vmx_bf16x8, qb[c]), sacc, 0, 0, 0);
+            }
+            float sv[4], tmax = -FLT_MAX;
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int tpos = t0 + 4 * g + i;
+                ok[i] = tpos <= qpos && (window <= 0 || tpos > qpos - window);
+                sv[i] = sacc[i] * lscale;
+                if (ok[i]) tmax = fmaxf(tmax, sv[i]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __expf(m_run - m_new);   // both -FLT_MAX (nothing seen yet): exp(0) = 1 on zero sums
+            m_run = m_new;
+            float p[4], psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                p[i] = ok[i] ? __expf(sv[i] - m_new) : 0.f;
+                psum += p[i];
+            }
+            l_part = l_part * alpha + psum;
+            vmx_s16x4 pb;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pb[i] = (short)vmx_f32_to_bf16(p[i]);
+#pragma unroll
+            for (int d = 0; d < DT; d++) {
+                acc[d] *= alpha;
+                const vmx_s16x4 va = *reinterpret_cast<const vmx_s16x4 *>(&Vt[(16 * d + n) * VROW + 4 * g]);
+                acc[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, acc[d], 0, 0, 0);
+            }
+        }
+    }
+    float l = l_part + __shfl_xor(l_part, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q_valid) {
+        const float inv = vsc / l;
+        uint16_t *o = out + ((int64_t)qi * num_heads + head) * HD;
+#pragma unroll
+        for (int d = 0; d < DT; d++) {   // acc[d][i] = O[query row n][dim 16 d + 4 g + i]
+            const uint32_t w0 = (uint32_t)vmx_f32_to_bf16(acc[d][0] * inv) | ((uint32_t)vmx_f32_to_bf16(acc[d][1] * inv) << 16);
+            const uint32_t w1 = (uint32_t)vmx_f32_to_bf16(acc[d][2] * inv) | ((uint32_t)vmx_f32_to_bf16(acc[d][3] * inv) << 16);
+            *reinterpret_cast<uint2 *>(o + 16 * d + 4 * g) = make_uint2(w0, w1);
+        }
+    }
+}
+
+template <int HD, int QPK, bool FP8>
+int launch_prefill(hipStream_t st, uint16_t *out, const uint16_t *q, const void *kc, const void *vc, const int32_t *bt, int q_len, int offset,
+                   float scale, int H, int KVH, int bs, int window, const float *ks, const float *vs) {
+    constexpr int HPW = QPK < 4 ? QPK : 4, TT = 4 / HPW;
+    const dim3 grid((q_len + 16 * TT - 1) / (16 * TT), KVH * (QPK / HPW));
+    hipLaunchKernelGGL((prefill_attn_kernel<HD, QPK, FP8>), grid, dim3(256), 0, st, out, q, kc, vc, bt, q_len, offset, scale, H, KVH, bs, window,
+                       ks, vs);
+    VMX_CHECK_LAUNCH("prefill_attention");
+    return VMX_OK;
+}
+}  // namespace
+
+extern "C" int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                          const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
+                                          int num_kv_heads, int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
+                                          const float *v_scale, void *stream) {
+    VMX_REQUIRE(out && q && k_cache && v_cache && block_table, "prefill_attention: null pointer");
+    VMX_REQUIRE(q_len >= 0 && seqlen_offset >= 0, "prefill_attention: q_len %d / seqlen_offset %d", q_len, seqlen_offset);
+    VMX_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+                "prefill_attention: num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
+    VMX_REQUIRE(block_size > 0 && window >= 0, "prefill_attention: bad cache geometry");
+    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3, "prefill_attention: unsupported kv dtype %d", kv_dtype);
+    if (q_len == 0) return VMX_OK;
+    hipStream_t st = vmx_stream(stream);
+    const int qpk = num_heads / num_kv_heads;
+    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
+    int rc = VMX_EUNSUPPORTED;
+#define ARGS st, out, q, k_cache, v_cache, block_table, q_len, seqlen_offset, scale, num_heads, num_kv_heads, block_size, window, k_scale, v_scale
+#define BY_QPK(HD)                                                                                                          \
+    switch (qpk) {                                                                                                          \
+        case 1: rc = fp8 ? launch_prefill<HD, 1, true>(ARGS) : launch_prefill<HD, 1, false>(ARGS); break;                   \
+        case 2: rc = fp8 ? launch_prefill<HD, 2, true>(ARGS) : launch_prefill<HD, 2, false>(ARGS); break;                   \
+        case 4: rc = fp8 ? launch_prefill<HD, 4, true>(ARGS) : launch_prefill<HD, 4, false>(ARGS); break;                   \
+        case 8: rc = fp8 ? launch_prefill<HD, 8, true>(ARGS) : launch_prefill<HD, 8, false>(ARGS); break;                   \
+        case 16: rc = fp8 ? launch_prefill<HD, 16, true>(ARGS) : launch_prefill<HD, 16, false>(ARGS); break;                \
+        default: vmx_set_error("prefill_attention: %d query heads per KV head unsupported (1,2,4,8,16)", qpk); return VMX_EUNSUPPORTED; \
+    }
+    switch (head_dim) {
+        case 64: BY_QPK(64) break;
+        case 128: BY_QPK(128) break;
+        case 256: BY_QPK(256) break;
+        case 512: BY_QPK(512) break;
+        default:
+            vmx_set_error("prefill_attention: head_dim %d unsupported (64, 128, 256, 512)", head_dim);
+            return VMX_EUNSUPPORTED;
+    }
+#undef BY_QPK
+#undef ARGS
+    return rc;
+}
+
+namespace {
+// (re-opened for the decode helpers below)
 }  // namespace
 
 
