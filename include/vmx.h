@@ -326,6 +326,7 @@ typedef struct vmx_qwen3_config {
     int tp_size, tp_rank;    /* tensor parallelism: 0/1 = off.  With tp_size > 1 num_heads, num_kv_heads and
                                 intermediate_size are THIS RANK's shares, vocab_size stays global (the lm_head is
                                 split by rows, vocab_size / tp_size per rank) and a communicator must be attached */
+    int max_prefill_tokens;  /* rows one vmx_qwen3_prefill call may carry (0 = no prefill entry point; at most 8192) */
 } vmx_qwen3_config;
 
 typedef struct vmx_qwen3 vmx_qwen3;
@@ -377,6 +378,14 @@ int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int ggml_type, c
 int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
                      const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq,
                      int max_seq_len, int32_t *out_ids, uint16_t *logits_out, void *stream);
+
+/* ModelForward::forward for one sequence (crates/core/src/engine/model_forward.rs:22-64; QuantizedQwen3ForCausalLM::forward,
+ * models/qwen3_quantized.rs:1090-1256): q_len <= max_prefill_tokens prompt tokens at positions seqlen_offset ..
+ * seqlen_offset + q_len - 1; slot_mapping i32 [q_len], block_table i32 [blocks of the sequence] (device).  K/V rows are
+ * written to the paged cache, attention is causal over the cache (vmx_prefill_attention_bf16).  Only the last row goes
+ * through the lm_head: out_id_last (device i32 [1], may be NULL) and logits_last (bf16 [vocab], may be NULL). */
+int vmx_qwen3_prefill(vmx_qwen3 *m, const int32_t *input_ids, int seqlen_offset, const int32_t *slot_mapping,
+                      const int32_t *block_table, int q_len, int32_t *out_id_last, uint16_t *logits_last, void *stream);
 
 /* Device-side step bookkeeping so consecutive steps replay from one graph: input_ids <- next_ids,
  * positions += 1, seq_lens = positions + 1, slot_mapping from block_tables (what the reference's

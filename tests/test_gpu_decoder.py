@@ -252,3 +252,47 @@ def test_prefill_forward_equals_token_by_token_decode(gpu):
         torch.cuda.synchronize()
         assert torch.equal(lg[0], logits_a[i]) and int(o[0]) == int(ids_a[i]), i
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("iq", [False, True])
+def test_native_prefill_matches_decode_path(gpu, iq):
+    """vmx_qwen3_prefill (all prompt rows through the linears at once, MFMA prefill attention) against the same prompt fed
+    through the decode path: identical KV-cache effect (the following decode step agrees) and last-row logits within the
+    attention kernels' tolerance; a second chunk with history (seqlen_offset > 0) continues the same sequence."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
+    vmx, torch = gpu
+    spec = _tiny_spec(max_batch=4, num_blocks=16)
+    spec.max_prefill_tokens = 40
+    prompt = torch.randint(0, spec.vocab_size, (37,), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    bt = torch.tensor([9, 2, 5, 11], dtype=torch.int32, device="cuda")
+    types = {0: 18, 1: 22, 2: 18, 3: 21, 4: 18, 5: 17, 6: 23}
+    a = QuantizedQwen3ForCausalLM(spec)
+    b = QuantizedQwen3ForCausalLM(spec)
+    for mdl in (a, b):
+        mdl.load_synthetic_iq(types, seed=21) if iq else mdl.load_synthetic(seed=21)
+    # reference: decode path, prompt in chunks of max_batch pseudo-sequences
+    _, logits_ref = a.forward(prompt, 0, bt)
+    # native: 25 tokens, then the remaining 12 with history
+    la = torch.empty(spec.vocab_size, dtype=torch.bfloat16, device="cuda")
+    b.prefill(prompt[:25], 0, bt)
+    nid = b.prefill(prompt[25:], 25, bt, logits_last=la)
+    torch.cuda.synchronize()
+    ref = logits_ref[-1].float(); got = la.float()
+    rel = float(((got - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+    assert rel <= 2e-2, rel
+    assert ref[int(nid[0])] >= ref.max() - abs(float(ref.max())) * 2 ** -6
+    # the caches must now serve a decode step equally well in both models
+    tok = torch.tensor([int(nid[0])], dtype=torch.int32, device="cuda")
+    pos = torch.tensor([37], dtype=torch.int32, device="cuda")
+    slot = (bt[37 // spec.block_size] * spec.block_size + 37 % spec.block_size).reshape(1).to(torch.int32)
+    l1 = torch.empty((1, spec.vocab_size), dtype=torch.bfloat16, device="cuda"); l2 = torch.empty_like(l1)
+    a.forward_decode_batch(tok, pos, slot, bt.reshape(1, -1), pos + 1, logits=l1)
+    b.forward_decode_batch(tok, pos, slot, bt.reshape(1, -1), pos + 1, logits=l2)
+    torch.cuda.synchronize()
+    rel = float(((l1.float() - l2.float()) ** 2).sum().sqrt() / (l1.float() ** 2).sum().sqrt())
+    assert rel <= 2e-2, rel
+    # preconditions
+    from vllm_rust_amd._lib import VmxError
+    with pytest.raises(VmxError, match="max_prefill_tokens"):
+        b.prefill(torch.zeros(41, dtype=torch.int32, device="cuda"), 0, bt)
+    a.close(); b.close()

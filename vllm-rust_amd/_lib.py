@@ -92,6 +92,7 @@ _SIGS = {
     "vmx_qwen3_debug_read": (_i, [_p, _i, _p, _sz, _p]),
     "vmx_debug_stream_read": (_i, [_p, _sz, _i, _p, _p]),
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
+    "vmx_qwen3_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "vmx_qwen3_linears_only": (_i, [_p, _i, _p]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
     "vmx_prefill_attention_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
@@ -128,7 +129,7 @@ class Qwen3Config(C.Structure):
         ("hidden_size", _i), ("num_layers", _i), ("num_heads", _i), ("num_kv_heads", _i), ("head_dim", _i),
         ("intermediate_size", _i), ("vocab_size", _i), ("rms_norm_eps", _f), ("max_position", _i), ("group_size", _i),
         ("qk_norm", _i), ("tie_word_embeddings", _i), ("kv_cache_dtype", _i), ("block_size", _i), ("num_blocks", _i),
-        ("max_batch", _i), ("max_seq_len", _i), ("tp_size", _i), ("tp_rank", _i),
+        ("max_batch", _i), ("max_seq_len", _i), ("tp_size", _i), ("tp_rank", _i), ("max_prefill_tokens", _i),
     ]
 
 

@@ -311,7 +311,7 @@ struct vmx_qwen3 {
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
-    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8;
+    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8, positions;
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
@@ -343,7 +343,13 @@ int iq_quantize(vmx_qwen3 *m, const uint16_t *x, int tokens, int k, hipStream_t 
 int iq_forward(vmx_qwen3 *m, const IqLinear &l, float *y, int ldy, int tokens, hipStream_t st) {
     const int8_t *aq = (const int8_t *)m->q8.p;
     const float *ad = (const float *)((const char *)m->q8.p + (((size_t)tokens * l.in_features + 255) & ~(size_t)255));
-    return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq, ad, y, l.out_features, l.in_features, tokens, ldy, st);
+    for (int r0 = 0; r0 < tokens; r0 += 16) {   // the MMVQ takes at most 16 activation rows (IQ_GEMV_MAX_M)
+        const int mr = tokens - r0 < 16 ? tokens - r0 : 16;
+        if (int rc = vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq + (size_t)r0 * l.in_features, ad + (size_t)r0 * (l.in_features / 32),
+                                    y + (size_t)r0 * ldy, l.out_features, l.in_features, mr, ldy, st))
+            return rc;
+    }
+    return VMX_OK;
 }
 
 // Row-parallel epilogue: red_bf16 = all_reduce_sum(bf16(sum of this rank's split-K slices)) — what composing the
@@ -425,7 +431,10 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     VMX_REQUIRE(m, "qwen3_create: out of host memory");
     m->cfg = c;
     m->layers.resize(c.num_layers);
-    const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = c.max_batch;
+    VMX_REQUIRE(c.max_prefill_tokens >= 0 && c.max_prefill_tokens <= 8192, "qwen3_create: max_prefill_tokens (%d) must be in 0..8192",
+                c.max_prefill_tokens);
+    // activation buffers hold max(decode batch, prefill chunk) token rows
+    const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = c.max_batch > c.max_prefill_tokens ? c.max_batch : c.max_prefill_tokens;
     const int NQKV = m->qkv_n(), NO = c.num_heads * hd;
     int rc = VMX_OK;
 #define TRY(e) do { if (!rc) rc = (e); } while (0)
@@ -472,15 +481,16 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     TRY(m->q.alloc((size_t)B * NO * 2));
     TRY(m->attn.alloc((size_t)B * NO * 2));
     TRY(m->act.alloc((size_t)B * I * 2));
-    TRY(m->logits.alloc((size_t)B * VL * 2));
+    TRY(m->logits.alloc((size_t)c.max_batch * VL * 2));
+    TRY(m->positions.alloc((size_t)B * 4));
     TRY(m->red_bf16.alloc((size_t)B * H * 2));
     {   // q8_1 staging for I-quant linears: int8 [B][Kmax] + f32 [B][Kmax/32]
         const size_t kmax = (size_t)(H > I ? (H > NO ? H : NO) : (I > NO ? I : NO));
         TRY(m->q8.alloc(B * kmax + 256 + B * (kmax / 32) * 4));
     }
-    TRY(m->keys.alloc((size_t)B * 8));
-    TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, hd, c.max_seq_len)));
-    TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, VL)));
+    TRY(m->keys.alloc((size_t)c.max_batch * 8));
+    TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(c.max_batch, c.num_heads, hd, c.max_seq_len)));
+    TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(c.max_batch, VL)));
 #undef TRY
     if (rc) {
         vmx_qwen3_destroy(m);
@@ -501,7 +511,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.gu_stage);
     }
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
-                      &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8})
+                      &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8, &m->positions})
         b->release();
     delete m;
 }
@@ -601,18 +611,19 @@ extern "C" int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int g
     return VMX_OK;
 }
 
-// One decode step for `batch` sequences (one new token each).  Pure launch sequence.
-extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
-                                const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq,
-                                int max_seq_len, int32_t *out_ids, uint16_t *logits_out, void *stream) {
-    VMX_REQUIRE(m && input_ids && positions && slot_mapping && block_tables && seq_lens, "qwen3_decode: null pointer");
+namespace {
+__global__ void iota_positions_kernel(int32_t *pos, int offset, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[i] = offset + i;
+}
+
+// The layer stack on `batch` token rows, up to and including the final norm (m->x).  prefill_offset < 0: every row is one
+// sequence's new token (paged decode attention over block_tables [batch, max_blocks_per_seq] / seq_lens); >= 0: the rows
+// are consecutive tokens of ONE sequence at positions prefill_offset + i (prefill attention over block_tables [max_blocks]).
+int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+               const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq, int max_seq_len,
+               int prefill_offset, hipStream_t st) {
     const vmx_qwen3_config &c = m->cfg;
-    VMX_REQUIRE(batch >= 1 && batch <= c.max_batch, "qwen3_decode: batch %d exceeds max_batch %d", batch, c.max_batch);
-    VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "qwen3_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
-                c.max_seq_len);
-    for (const Layer &L : m->layers)
-        VMX_REQUIRE(L.int4_ready() || L.iq_ready(), "qwen3_decode: weights not fully loaded");
-    hipStream_t st = vmx_stream(stream);
     const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = batch;
     const int Hq = c.num_heads, Hkv = c.num_kv_heads, NQKV_ = m->qkv_n();
     uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p;
@@ -644,13 +655,22 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                            c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
                            slot_mapping, Hq, Hkv, hd, hd, fp8, ks, ks + 1);
-        VmxAttnParts ap;
-        if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, scale, B, Hq, Hkv,
-                                               max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
-                                               m->attn_ws.p, &ap, st))
-            return rc;
-        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st, iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr))
-            return rc;
+        if (prefill_offset >= 0) {
+            if (int rc = vmx_prefill_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, scale, Hq, Hkv, hd,
+                                                    c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, st))
+                return rc;
+            if (iq)
+                if (int rc = iq_quantize(m, attn, B, NQ, st)) return rc;
+        } else {
+            VmxAttnParts ap;
+            if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, scale, B, Hq, Hkv,
+                                                   max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
+                                                   m->attn_ws.p, &ap, st))
+                return rc;
+            if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st, iq ? q8_aq(m) : nullptr,
+                                                   iq ? q8_ad(m, B, NQ) : nullptr))
+                return rc;
+        }
         if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_O], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
@@ -685,7 +705,16 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
         }
     }
     launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H);
-    VMX_CHECK_LAUNCH("qwen3_decode");
+    VMX_CHECK_LAUNCH("qwen3 layers");
+    return VMX_OK;
+}
+
+// lm_head (+ greedy ids) on `rows` rows of normed activations starting at x
+int run_head(vmx_qwen3 *m, const uint16_t *x, int rows, int32_t *out_ids, uint16_t *logits_out, void *stream) {
+    const vmx_qwen3_config &c = m->cfg;
+    hipStream_t st = vmx_stream(stream);
+    const int H = c.hidden_size, B = rows;
+    const bool tp = c.tp_size > 1 || m->comm != nullptr;
     uint16_t *logits = logits_out ? logits_out : (uint16_t *)m->logits.p;
     const int VL = m->vocab_local();
     const int64_t v0 = tp ? (int64_t)c.tp_rank * VL : 0;  // first vocabulary row of this rank's lm_head slice
@@ -702,6 +731,48 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
         }
     }
     return VMX_OK;
+}
+}  // namespace
+
+// One decode step for `batch` sequences (one new token each).  Pure launch sequence.
+extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+                                const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq,
+                                int max_seq_len, int32_t *out_ids, uint16_t *logits_out, void *stream) {
+    VMX_REQUIRE(m && input_ids && positions && slot_mapping && block_tables && seq_lens, "qwen3_decode: null pointer");
+    const vmx_qwen3_config &c = m->cfg;
+    VMX_REQUIRE(batch >= 1 && batch <= c.max_batch, "qwen3_decode: batch %d exceeds max_batch %d", batch, c.max_batch);
+    VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "qwen3_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
+                c.max_seq_len);
+    for (const Layer &L : m->layers)
+        VMX_REQUIRE(L.int4_ready() || L.iq_ready(), "qwen3_decode: weights not fully loaded");
+    const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
+    VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
+    if (int rc = run_layers(m, input_ids, positions, slot_mapping, block_tables, seq_lens, batch, max_blocks_per_seq, max_seq_len, -1,
+                            vmx_stream(stream)))
+        return rc;
+    return run_head(m, (const uint16_t *)m->x.p, batch, out_ids, logits_out, stream);
+}
+
+// ModelForward::forward for one sequence (crates/core/src/engine/model_forward.rs:22-64): q_len prompt tokens at positions
+// seqlen_offset .. seqlen_offset + q_len - 1.  The linears run on all rows (16 per MFMA pass), K/V rows are written to the
+// paged cache at slot_mapping, attention is the causal prefill kernel over the cache; only the LAST row goes through the
+// lm_head (greedy id and, if asked for, its logits) - the only row the engine samples from.  Pure launch sequence.
+extern "C" int vmx_qwen3_prefill(vmx_qwen3 *m, const int32_t *input_ids, int seqlen_offset, const int32_t *slot_mapping,
+                                 const int32_t *block_table, int q_len, int32_t *out_id_last, uint16_t *logits_last, void *stream) {
+    VMX_REQUIRE(m && input_ids && slot_mapping && block_table, "qwen3_prefill: null pointer");
+    const vmx_qwen3_config &c = m->cfg;
+    VMX_REQUIRE(q_len >= 1 && q_len <= c.max_prefill_tokens, "qwen3_prefill: q_len %d exceeds max_prefill_tokens %d", q_len, c.max_prefill_tokens);
+    VMX_REQUIRE(seqlen_offset >= 0 && seqlen_offset + q_len <= c.max_position, "qwen3_prefill: positions %d..%d exceed max_position %d",
+                seqlen_offset, seqlen_offset + q_len - 1, c.max_position);
+    for (const Layer &L : m->layers)
+        VMX_REQUIRE(L.int4_ready() || L.iq_ready(), "qwen3_prefill: weights not fully loaded");
+    const bool tp = c.tp_size > 1 || m->comm != nullptr;
+    VMX_REQUIRE(!tp || m->comm, "qwen3_prefill: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
+    hipStream_t st = vmx_stream(stream);
+    int32_t *pos = (int32_t *)m->positions.p;
+    hipLaunchKernelGGL(iota_positions_kernel, dim3((q_len + 255) / 256), dim3(256), 0, st, pos, seqlen_offset, q_len);
+    if (int rc = run_layers(m, input_ids, pos, slot_mapping, block_table, nullptr, q_len, 0, 0, seqlen_offset, st)) return rc;
+    return run_head(m, (const uint16_t *)m->x.p + (size_t)(q_len - 1) * c.hidden_size, 1, out_id_last, logits_last, stream);
 }
 
 // Attach the tensor-parallel communicator (not owned).  Required before decoding when tp_size > 1.

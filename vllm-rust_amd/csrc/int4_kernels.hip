@@ -292,9 +292,9 @@ template <int UPW, bool TAIL>
 __global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                          const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
                                                          uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N, int K,
-                                                         int group, int splits) {
-    (void)splits;
-    int4_gemm_body<UPW, TAIL>(W, SZ, x, bias, y, partial, (int64_t)M * N, M, N, K, group, blockIdx.x);
+                                                         int group, int slice_rows) {
+    // slice_rows: rows of one split-K slice of `partial` (>= M when this launch covers 16 of a larger call's rows)
+    int4_gemm_body<UPW, TAIL>(W, SZ, x, bias, y, partial, (int64_t)slice_rows * N, M, N, K, group, blockIdx.x);
 }
 
 // Grouped form for mixture-of-experts decode: blockIdx.y = p selects one (token, expert slot) pair;
@@ -355,7 +355,8 @@ inline size_t gemm_lds_bytes(int M, int upw) {
 }
 
 int launch_gemm(const GemmPlan &p, const uint4 *W, const uint32_t *SZ, const uint16_t *x, const uint16_t *bias, uint16_t *y,
-                float *partial, int M, int N, int K, int group, hipStream_t st) {
+                float *partial, int M, int N, int K, int group, hipStream_t st, int slice_rows = 0) {
+    if (slice_rows <= 0) slice_rows = M;
     const size_t lds = gemm_lds_bytes(M, p.upw);
     if (lds > 160 * 1024) {
         vmx_set_error("int4_gemm: LDS need %zu B exceeds 160 KiB", lds);
@@ -368,7 +369,7 @@ int launch_gemm(const GemmPlan &p, const uint4 *W, const uint32_t *SZ, const uin
         if (lds > 64 * 1024)                                                                                                   \
             VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_kernel<U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)lds));                                                                      \
-        hipLaunchKernelGGL((int4_gemm_kernel<U, T>), grid, block, lds, st, W, SZ, x, bias, y, partial, M, N, K, group, p.splits); \
+        hipLaunchKernelGGL((int4_gemm_kernel<U, T>), grid, block, lds, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows); \
     } while (0)
 #define LAUNCH(U)                    \
     do {                             \
@@ -458,7 +459,11 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
     const GemmPlan p = plan_gemm(N, K);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
-    return launch_gemm(p, W, SZ, x, nullptr, nullptr, partial, M, N, K, group, st);
+    for (int m0 = 0; m0 < M; m0 += 16) {   // 16 rows (one MFMA row tile) per launch; every launch re-streams the weights
+        const int mm = M - m0 < 16 ? M - m0 : 16;
+        if (int rc = launch_gemm(p, W, SZ, x + (int64_t)m0 * K, nullptr, nullptr, partial + (int64_t)m0 * N, mm, N, K, group, st, M)) return rc;
+    }
+    return VMX_OK;
 }
 
 int vmx_int4_gemm_grouped(const void *const *packed_table, const int32_t *expert_ids, int num_experts, const uint16_t *x,

@@ -43,6 +43,7 @@ class Qwen3Spec:
     max_seq_len: int = 1024
     tp_size: int = 1      # with tp_size > 1 the head counts and intermediate_size below are this rank's shares
     tp_rank: int = 0
+    max_prefill_tokens: int = 0   # rows per native prefill call (0: prompts go through the decode path in max_batch chunks)
 
     @staticmethod
     def qwen3_8b(**kw):
@@ -76,7 +77,7 @@ class QuantizedQwen3ForCausalLM:
         cfg = Qwen3Config(spec.hidden_size, spec.num_layers, spec.num_heads, spec.num_kv_heads, spec.head_dim,
                           spec.intermediate_size, spec.vocab_size, spec.rms_norm_eps, spec.max_position, spec.group_size,
                           int(spec.qk_norm), int(spec.tie_word_embeddings), spec.kv_cache_dtype, spec.block_size,
-                          spec.num_blocks, spec.max_batch, spec.max_seq_len, spec.tp_size, spec.tp_rank)
+                          spec.num_blocks, spec.max_batch, spec.max_seq_len, spec.tp_size, spec.tp_rank, spec.max_prefill_tokens)
         self._h = C.c_void_p()
         check(lib.vmx_qwen3_create(C.byref(cfg), C.byref(self._h)))
         cs = torch.from_numpy(rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta)).to(self.device)
@@ -215,6 +216,20 @@ class QuantizedQwen3ForCausalLM:
                                    block_tables.data_ptr(), seq_lens.data_ptr(), B, block_tables.shape[1], msl,
                                    out_ids.data_ptr(), None if logits is None else logits.data_ptr(), self._stream()))
         return out_ids
+
+    def prefill(self, input_ids: torch.Tensor, seqlen_offset: int, block_table: torch.Tensor, out_id=None, logits_last=None):
+        """Native prompt path (vmx_qwen3_prefill): all of input_ids (at most max_prefill_tokens) in one pass; returns the greedy
+        id after the last prompt token (int32 [1]); logits_last: optional bf16 [vocab] for that row."""
+        s = self.spec
+        S = input_ids.numel()
+        bt = block_table.reshape(-1).to(torch.int32).contiguous()
+        pos = torch.arange(seqlen_offset, seqlen_offset + S, dtype=torch.int64, device=self.device)
+        slots = (bt[(pos // s.block_size)].to(torch.int64) * s.block_size + pos % s.block_size).to(torch.int32).contiguous()
+        if out_id is None:
+            out_id = torch.empty(1, dtype=torch.int32, device=self.device)
+        check(lib.vmx_qwen3_prefill(self._h, input_ids.contiguous().data_ptr(), int(seqlen_offset), slots.data_ptr(), bt.data_ptr(), S,
+                                    out_id.data_ptr(), None if logits_last is None else logits_last.data_ptr(), self._stream()))
+        return out_id
 
     def forward(self, input_ids: torch.Tensor, seqlen_offset: int, block_table: torch.Tensor, return_logits: bool = True):
         """ModelForward::forward for one sequence (engine/model_forward.rs:22-64): a prompt (chunk) of S tokens at
