@@ -4,9 +4,9 @@
 A "step" is one decode token for the whole batch (batch = 1 per GPU: BASELINE.json configs[1],
 "Qwen3-8B AWQ int4 TP=1 on one MI355X, packed-int GEMM decode, batch=1 seq=1").  Weights are a
 seeded random-init AWQ checkpoint of the Qwen3-8B architecture (no network, no model files); a
-256-token prompt is first pushed through the same decode path (untimed), then W warm-up and K
-timed steps are replayed from one hipGraph (decode step + device-side step bookkeeping), with all
-inputs resident in HBM.
+256-token prompt first goes through the native prefill entry point (untimed for `value`, reported
+under `prefill`), then W warm-up and K timed steps are replayed from one hipGraph (decode step +
+device-side step bookkeeping), with all inputs resident in HBM.
 
 With --gpus N > 1 each rank (one process per GPU, launched by torch.distributed.run) runs an
 independent replica of the same job (data-parallel serving, no exchange step on the data path);
@@ -183,7 +183,7 @@ def main():
     block_size = 16
     n_blocks = (total_tokens + block_size - 1) // block_size + 1
     spec = Qwen3Spec.qwen3_8b(max_position=max(4096, total_tokens + 1), num_blocks=n_blocks, block_size=block_size, max_batch=1,
-                              max_seq_len=total_tokens + 1)
+                              max_seq_len=total_tokens + 1, max_prefill_tokens=args.prompt)
     if args.layers:
         spec.num_layers = args.layers
     use_tp = args.tp and dist_on
@@ -200,10 +200,13 @@ def main():
     dev = model.device
     B = 1
     bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(B, n_blocks).contiguous()
-    ids = torch.tensor([11], dtype=torch.int32, device=dev)
-    pos = torch.zeros(B, dtype=torch.int32, device=dev)
-    slots = (bt[:, 0] * block_size).to(torch.int32).contiguous()
-    seq_lens = torch.ones(B, dtype=torch.int32, device=dev)
+    prompt_ids = torch.randint(0, spec.vocab_size, (args.prompt,), dtype=torch.int32, device=dev,
+                               generator=torch.Generator(device=dev).manual_seed(7))
+    ids = torch.empty(B, dtype=torch.int32, device=dev)
+    P = args.prompt
+    pos = torch.full((B,), P, dtype=torch.int32, device=dev)
+    slots = (bt[:, P // block_size] * block_size + P % block_size).to(torch.int32).contiguous()
+    seq_lens = torch.full((B,), P + 1, dtype=torch.int32, device=dev)
     out = torch.empty(B, dtype=torch.int32, device=dev)
 
     def step():
@@ -212,14 +215,18 @@ def main():
 
     side = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(side):
-        step()  # first call outside capture (lazy module load)
+        # prompt: one native prefill pass (all rows through the linears, MFMA prefill attention); run twice, the second timed
+        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
+        torch.cuda.synchronize()
+        prefill_s = time.perf_counter() - tp0
+        step()  # first decode call outside capture (lazy module load); position P -> P + 1
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         with torch.cuda.graph(graph, stream=side):
             step()
-        # prompt: the remaining prompt tokens through the decode path (positions 1 .. prompt-1)
-        for _ in range(args.prompt - 1):
-            graph.replay()
         for _ in range(W_steps):
             graph.replay()
     torch.cuda.synchronize()
@@ -236,7 +243,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     pos_after = int(pos.item())
-    assert pos_after == args.prompt + W_steps + K_steps, (pos_after, args.prompt, W_steps, K_steps)
+    assert pos_after == args.prompt + 1 + W_steps + K_steps, (pos_after, args.prompt, W_steps, K_steps)
     if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -292,11 +299,13 @@ def main():
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": K_steps, "warmup": W_steps,
             "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if use_tp else "weak", "vs_baseline": None,
             "dtype": "int4 weights x bf16 activations, f32 accumulate", "data": "synthetic",
-            "config": {"workload": "Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, 256-token prompt then timed tokens, bf16 KV",
+            "config": {"workload": f"Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, {args.prompt}-token prompt (native prefill) then timed tokens, bf16 KV",
                        "layers": spec.num_layers, "hidden": spec.hidden_size, "vocab": spec.vocab_size,
                        "parallelism": "tp1" if world == 1 else (f"tp{world} (RCCL all-reduce)" if use_tp else f"dp{world} replicas (tp1 each)"),
                        "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
                        "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
+            "prefill": {"tokens": args.prompt, "ms": round(prefill_s * 1e3, 3), "tok_s": round(args.prompt / prefill_s, 1),
+                        "note": "one vmx_qwen3_prefill call (int4 GEMM 16 rows per pass, MFMA prefill attention); untimed part of the job"},
             "roofline": roofline,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(spec),
             "secondary": secondary,
