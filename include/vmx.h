@@ -91,7 +91,7 @@ int vmx_gather_dequant_q6k_f32(const void *blocks, const int32_t *ids, float *ou
 
 /* GGML legacy / K-quant tensors (GgufLinear -> candle QMatMul, crates/core/src/quantization/gguf/mod.rs:114-258;
  * the arithmetic is third-party (candle-kernels 0.10.2), so these follow the public ggml block specs and parity is
- * tolerance-only).  Supported type ids: 2 Q4_0, 8 Q8_0, 11 Q3_K, 12 Q4_K, 14 Q6_K. */
+ * tolerance-only).  Supported type ids: 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 10 Q2_K, 11 Q3_K, 12 Q4_K, 13 Q5_K, 14 Q6_K. */
 int vmx_ggml_type_size(int ggml_type);    /* bytes per block (I-quant ids included), -1 if unknown */
 int vmx_ggml_block_elems(int ggml_type);  /* 32 or 256 */
 /* qt.dequantize (gguf/mod.rs:284): n_blocks blocks -> f32. */

@@ -74,6 +74,11 @@ for _name, _res, _args in [
     ("orc_q8_0_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_q4_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_q3_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q4_1_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q5_0_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q5_1_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q2_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    ("orc_q5_k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_exl3_decode", C.c_uint16, [C.c_uint32, C.c_int]),
     ("orc_exl3_reconstruct", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     ("orc_exl3_had_fp16", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
@@ -342,7 +347,8 @@ def fp8_dequant_bf16(q_u8, scale, per_row: bool) -> np.ndarray:
 
 
 # ---------------------------------------------------------------- GGML legacy / K-quants
-GGML_BLOCK = {2: (18, 32), 8: (34, 32), 11: (110, 256), 12: (144, 256), 14: (210, 256)}
+GGML_BLOCK = {2: (18, 32), 3: (20, 32), 6: (22, 32), 7: (24, 32), 8: (34, 32), 10: (84, 256), 11: (110, 256), 12: (144, 256),
+              13: (176, 256), 14: (210, 256)}
 
 
 def ggml_dequant(ggml_type: int, data) -> np.ndarray:
@@ -351,8 +357,9 @@ def ggml_dequant(ggml_type: int, data) -> np.ndarray:
     assert data.size % ts == 0
     nb = data.size // ts
     out = np.empty(nb * qk, np.float32)
-    fn = {2: _lib.orc_q4_0_dequant, 8: _lib.orc_q8_0_dequant, 11: _lib.orc_q3_k_dequant, 12: _lib.orc_q4_k_dequant,
-          14: _lib.orc_q6k_dequant}[ggml_type]
+    fn = {2: _lib.orc_q4_0_dequant, 3: _lib.orc_q4_1_dequant, 6: _lib.orc_q5_0_dequant, 7: _lib.orc_q5_1_dequant,
+          8: _lib.orc_q8_0_dequant, 10: _lib.orc_q2_k_dequant, 11: _lib.orc_q3_k_dequant, 12: _lib.orc_q4_k_dequant,
+          13: _lib.orc_q5_k_dequant, 14: _lib.orc_q6k_dequant}[ggml_type]
     fn(_p(data), nb, _p(out))
     return out
 

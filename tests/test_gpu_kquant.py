@@ -6,8 +6,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TYPES = {2: "Q4_0", 8: "Q8_0", 11: "Q3_K", 12: "Q4_K", 14: "Q6_K"}
-D_OFF = {2: 0, 8: 0, 11: 108, 12: 0, 14: 208}
+TYPES = {2: "Q4_0", 3: "Q4_1", 6: "Q5_0", 7: "Q5_1", 8: "Q8_0", 10: "Q2_K", 11: "Q3_K", 12: "Q4_K", 13: "Q5_K", 14: "Q6_K"}
+D_OFF = {2: [0], 3: [0, 2], 6: [0], 7: [0, 2], 8: [0], 10: [80, 82], 11: [108], 12: [0, 2], 13: [0, 2], 14: [208]}
 
 
 @pytest.fixture(scope="module")
@@ -23,7 +23,7 @@ def _blocks(rng, t, n):
     from oracle import oracle as orc
     ts, _ = orc.GGML_BLOCK[t]
     b = rng.integers(0, 256, size=(n, ts), dtype=np.uint8)
-    for off in ([D_OFF[t]] + ([2] if t == 12 else [])):       # finite, small f16 scales
+    for off in D_OFF[t]:       # finite, small f16 scales
         b[:, off] = 0
         b[:, off + 1] = rng.integers(0x24, 0x2C, size=n)
     return b.reshape(-1)

@@ -102,3 +102,31 @@ def test_q6k_dequant_structure():
     blk[0] = 0x21; blk[128] = 0b00_01_00_11
     out = orc.q6k_dequant(blk)
     assert out[0] == (1 | (3 << 4)) - 32 and out[64] == (2 | (1 << 4)) - 32
+
+
+def test_legacy_ggml_blocks_against_numpy_formulas():
+    """Q4_1 / Q5_0 / Q5_1 (public ggml block specs; parity unpinned): the C loops against vectorised numpy formulas."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    for t, (ts, _) in ((3, orc.GGML_BLOCK[3]), (6, orc.GGML_BLOCK[6]), (7, orc.GGML_BLOCK[7])):
+        nb = 50
+        b = rng.integers(0, 256, size=(nb, ts), dtype=np.uint8)
+        for off in ([0, 2] if t in (3, 7) else [0]):
+            b[:, off] = 0; b[:, off + 1] = rng.integers(0x24, 0x2C, size=nb)
+        d = b[:, 0:2].copy().view(np.float16).astype(np.float32)[:, 0]
+        m = b[:, 2:4].copy().view(np.float16).astype(np.float32)[:, 0] if t in (3, 7) else None
+        qoff = {3: 4, 6: 6, 7: 8}[t]
+        qs = b[:, qoff:qoff + 16].astype(np.int32)
+        lo, hi = qs & 0xF, qs >> 4
+        if t != 3:
+            hoff = 2 if t == 6 else 4
+            qh = b[:, hoff:hoff + 4].copy().view(np.uint32)[:, 0].astype(np.int64)
+            j = np.arange(16)
+            lo = lo | (((qh[:, None] >> j) & 1) << 4)
+            hi = hi | (((qh[:, None] >> (j + 16)) & 1) << 4)
+        if t == 6:
+            exp = np.concatenate([(lo - 16) * d[:, None], (hi - 16) * d[:, None]], axis=1)
+        else:
+            exp = np.concatenate([lo.astype(np.float32) * d[:, None] + m[:, None], hi.astype(np.float32) * d[:, None] + m[:, None]], axis=1)
+        got = orc.ggml_dequant(t, b.reshape(-1)).reshape(nb, 32)
+        assert np.array_equal(got, exp.astype(np.float32)), t

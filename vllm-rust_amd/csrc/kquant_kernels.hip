@@ -2,7 +2,7 @@
 // In the reference these tensors go through Candle's QMatMul (crates/core/src/quantization/gguf/mod.rs:114-258),
 // whose kernels live in candle-kernels 0.10.2 and are not part of the reference tree; the block layouts and
 // decode formulas below are the public ggml ones (ggml-common.h / ggml-quants.c): Q4_0 18 B/32, Q8_0 34 B/32,
-// Q3_K 110 B/256, Q4_K 144 B/256, Q6_K 210 B/256 (Q6_K is also restated in crates/core/kernels/gather_dequant.cu:52-82).
+// Q4_1 20 B/32, Q5_0 22 B/32, Q5_1 24 B/32, Q2_K 84 B/256, Q3_K 110 B/256, Q4_K 144 B/256, Q5_K 176 B/256, Q6_K 210 B/256 (Q6_K is also restated in crates/core/kernels/gather_dequant.cu:52-82).
 // The GEMV multiplies the f32 activations with the exactly dequantised weights in f32 (no q8_1/Q8_K
 // activation quantisation step as in ggml's mul_mat_vec_q): parity with the third-party kernel is
 // tolerance-only by construction (the reference's own gate is rel-RMS < 3 % against a dense product).
@@ -15,7 +15,12 @@ __device__ __forceinline__ float ldh(const uint8_t *p) { return vmx_f16_to_f32(r
 
 template <int T> struct KTraits;
 template <> struct KTraits<2> { static constexpr int TS = 18, QK = 32; };    // Q4_0
+template <> struct KTraits<3> { static constexpr int TS = 20, QK = 32; };    // Q4_1
+template <> struct KTraits<6> { static constexpr int TS = 22, QK = 32; };    // Q5_0
+template <> struct KTraits<7> { static constexpr int TS = 24, QK = 32; };    // Q5_1
 template <> struct KTraits<8> { static constexpr int TS = 34, QK = 32; };    // Q8_0
+template <> struct KTraits<10> { static constexpr int TS = 84, QK = 256; };  // Q2_K
+template <> struct KTraits<13> { static constexpr int TS = 176, QK = 256; }; // Q5_K
 template <> struct KTraits<11> { static constexpr int TS = 110, QK = 256; }; // Q3_K
 template <> struct KTraits<12> { static constexpr int TS = 144, QK = 256; }; // Q4_K
 template <> struct KTraits<14> { static constexpr int TS = 210, QK = 256; }; // Q6_K
@@ -30,10 +35,54 @@ template <int T> __device__ __forceinline__ void kdecode32(const uint8_t *b, int
             f[j] = (float)((q & 0xF) - 8) * d;
             f[j + 16] = (float)((q >> 4) - 8) * d;
         }
+    } else if constexpr (T == 3) {   // d f16 @0, m f16 @2, qs[16] @4
+        const float d = ldh(b), mn = ldh(b + 2);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int q = b[4 + j];
+            f[j] = __fadd_rn(__fmul_rn((float)(q & 0xF), d), mn);
+            f[j + 16] = __fadd_rn(__fmul_rn((float)(q >> 4), d), mn);
+        }
+    } else if constexpr (T == 6 || T == 7) {   // Q5_0: d, qh u32 @2, qs[16] @6;  Q5_1: d, m, qh u32 @4, qs[16] @8
+        const float d = ldh(b), mn = T == 7 ? ldh(b + 2) : 0.f;
+        const uint8_t *hp = b + (T == 7 ? 4 : 2), *qs = b + (T == 7 ? 8 : 6);
+        const uint32_t qh = hp[0] | (hp[1] << 8) | (hp[2] << 16) | ((uint32_t)hp[3] << 24);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int x0 = (qs[j] & 0xF) | (((qh >> j) << 4) & 0x10), x1 = (qs[j] >> 4) | ((qh >> (j + 12)) & 0x10);
+            if constexpr (T == 6) {
+                f[j] = (float)(x0 - 16) * d;
+                f[j + 16] = (float)(x1 - 16) * d;
+            } else {
+                f[j] = __fadd_rn(__fmul_rn((float)x0, d), mn);
+                f[j + 16] = __fadd_rn(__fmul_rn((float)x1, d), mn);
+            }
+        }
     } else if constexpr (T == 8) {
         const float d = ldh(b);
 #pragma unroll
         for (int j = 0; j < 32; j++) f[j] = (float)(int8_t)b[2 + j] * d;
+    } else if constexpr (T == 10) {  // scales[16] @0, qs[64] @16, d f16 @80, dmin f16 @82
+        const float d = ldh(b + 80), dmin = ldh(b + 82);
+        const int n = s >> 2, j = s & 3;
+        const uint8_t *q = b + 16 + 32 * n;
+#pragma unroll
+        for (int l = 0; l < 32; l++) {
+            const int sc = b[8 * n + 2 * j + (l >> 4)];
+            const float dl = d * (float)(sc & 0xF), ml = dmin * (float)(sc >> 4);
+            f[l] = __fsub_rn(__fmul_rn(dl, (float)((q[l] >> (2 * j)) & 3)), ml);
+        }
+    } else if constexpr (T == 13) {  // d @0, dmin @2, scales[12] @4, qh[32] @16, qs[128] @48
+        const float d = ldh(b), dmin = ldh(b + 2);
+        const uint8_t *sc = b + 4;
+        int scv, mv;
+        if (s < 4) { scv = sc[s] & 63; mv = sc[s + 4] & 63; }
+        else { scv = (sc[s + 4] & 0xF) | ((sc[s - 4] >> 6) << 4); mv = (sc[s + 4] >> 4) | ((sc[s] >> 6) << 4); }
+        const float dl = d * (float)scv, ml = dmin * (float)mv;
+        const uint8_t *ql = b + 48 + 32 * (s >> 1), *qh = b + 16;
+        const int sh = (s & 1) * 4;
+#pragma unroll
+        for (int l = 0; l < 32; l++) f[l] = __fsub_rn(__fmul_rn(dl, (float)(((ql[l] >> sh) & 0xF) + (((qh[l] >> s) & 1) << 4))), ml);
     } else if constexpr (T == 12) {  // d f16 @0, dmin f16 @2, scales[12] @4, qs[128] @16
         const float d = ldh(b), dmin = ldh(b + 2);
         const uint8_t *sc = b + 4;
@@ -243,20 +292,29 @@ __global__ __launch_bounds__(256) void kgather_bf16_kernel(const uint8_t *__rest
 #define K_DISPATCH(type, CALL)                                                                  \
     switch (type) {                                                                             \
         case 2: CALL(2); break;                                                                 \
+        case 3: CALL(3); break;                                                                 \
+        case 6: CALL(6); break;                                                                 \
+        case 7: CALL(7); break;                                                                 \
         case 8: CALL(8); break;                                                                 \
+        case 10: CALL(10); break;                                                               \
         case 11: CALL(11); break;                                                               \
         case 12: CALL(12); break;                                                               \
+        case 13: CALL(13); break;                                                               \
         case 14: CALL(14); break;                                                               \
         default:                                                                                \
-            vmx_set_error("unsupported ggml type id %d (supported: 2 Q4_0, 8 Q8_0, 11 Q3_K, 12 Q4_K, 14 Q6_K)", type); \
+            vmx_set_error("unsupported ggml type id %d (supported: 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 10 Q2_K, 11 Q3_K, 12 Q4_K, 13 Q5_K, 14 Q6_K)", type); \
             return VMX_EUNSUPPORTED;                                                            \
     }
 
 extern "C" int vmx_ggml_type_size(int t) {
-    switch (t) { case 2: return 18; case 8: return 34; case 11: return 110; case 12: return 144; case 14: return 210; default: return vmx_iq_type_size(t); }
+    switch (t) {
+        case 2: return 18; case 3: return 20; case 6: return 22; case 7: return 24; case 8: return 34;
+        case 10: return 84; case 11: return 110; case 12: return 144; case 13: return 176; case 14: return 210;
+        default: return vmx_iq_type_size(t);
+    }
 }
 
-extern "C" int vmx_ggml_block_elems(int t) { return (t == 2 || t == 8) ? 32 : 256; }
+extern "C" int vmx_ggml_block_elems(int t) { return (t == 2 || t == 3 || t == 6 || t == 7 || t == 8) ? 32 : 256; }
 
 extern "C" int vmx_kquant_dequantize_f32(int ggml_type, const void *blocks, float *out, int64_t n_blocks, void *stream) {
     VMX_REQUIRE(blocks && out && n_blocks >= 0, "kquant_dequantize: bad arguments");

@@ -24,7 +24,7 @@ L_Q, L_K, L_V, L_O, L_GATE, L_UP, L_DOWN = range(7)
 G4_SLIDING, G4_K_EQ_V = 1, 2
 
 IQ_TYPE_SIZE = {17: 74, 22: 82, 18: 98, 21: 110, 23: 136}
-GGML_TYPE_SIZE = {2: (18, 32), 8: (34, 32), 11: (110, 256), 12: (144, 256), 14: (210, 256)}
+GGML_TYPE_SIZE = {2: (18, 32), 3: (20, 32), 6: (22, 32), 7: (24, 32), 8: (34, 32), 10: (84, 256), 11: (110, 256), 12: (144, 256), 13: (176, 256), 14: (210, 256)}
 # projection types of gemma-4-12b-it-UD-IQ3_XXS (crates/core/src/quantization/gguf/header.rs:390-399): q, k, v, o, gate, up, down
 GEMMA4_12B_IQ3_MIX = {L_Q: 18, L_K: 22, L_V: 18, L_O: 21, L_GATE: 18, L_UP: 18, L_DOWN: 21}
 
