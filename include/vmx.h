@@ -327,6 +327,8 @@ typedef struct vmx_qwen3_config {
                                 intermediate_size are THIS RANK's shares, vocab_size stays global (the lm_head is
                                 split by rows, vocab_size / tp_size per rank) and a communicator must be attached */
     int max_prefill_tokens;  /* rows one vmx_qwen3_prefill call may carry (0 = no prefill entry point; at most 8192) */
+    int num_experts, experts_per_tok; /* > 0: the MLP of every layer is a mixture of int4 experts (Mixtral: 8 / 2); intermediate_size
+                                         is then the expert width.  0 = dense MLP */
 } vmx_qwen3_config;
 
 typedef struct vmx_qwen3 vmx_qwen3;
@@ -341,6 +343,7 @@ typedef struct vmx_qwen3 vmx_qwen3;
 #define VMX_T_Q_NORM 6      /* bf16 [head_dim] */
 #define VMX_T_K_NORM 7
 #define VMX_T_KV_SCALES 8   /* f32 [2] = {k_scale, v_scale} (FP8 KV cache) */
+#define VMX_T_ROUTER 9      /* per layer, MoE models: bf16 [num_experts, hidden] (the dense `gate`, mixtral_quantized.rs:118-119) */
 
 /* linear slots for vmx_qwen3_load_awq_linear */
 #define VMX_L_Q 0
@@ -364,6 +367,14 @@ int vmx_qwen3_load_tensor(vmx_qwen3 *m, int which, int layer, const void *src, s
  * merged into one linear each once all their parts have arrived. */
 int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
                               const uint16_t *scales_f16, void *stream);
+
+/* Load one expert of a mixture-of-experts layer in GPTQ form (QuantizedMoELayer / MarlinLinear, models/mixtral_quantized.rs:92-130;
+ * w = (nib - 8) * scale as marlin_gemm.cu:43-48): w1 = gate, w3 = up (qweight u32 [hidden/8, inter], scales f16 [hidden/g, inter]),
+ * w2 = down (qweight u32 [inter/8, hidden], scales f16 [inter/g, hidden]); device or host pointers.  Attention projections of such
+ * a model are loaded with vmx_qwen3_load_awq_linear (slots Q, K, V, O). */
+int vmx_qwen3_load_gptq_expert(vmx_qwen3 *m, int layer, int expert, const uint32_t *w1_qweight, const uint16_t *w1_scales_f16,
+                               const uint32_t *w3_qweight, const uint16_t *w3_scales_f16, const uint32_t *w2_qweight,
+                               const uint16_t *w2_scales_f16, void *stream);
 
 /* Load one projection as a GGUF I-quant tensor (IqLinear, crates/core/src/quantization/gguf/mod.rs:262-377;
  * GgufWeightLoader::load_linear :1612-1662): raw block bytes of the [out, in] weight, ggml_type one of the I-quant ids.

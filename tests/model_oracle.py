@@ -35,6 +35,8 @@ class OracleQwen3:
                     t, raw = ck[f"{li}.{slot}.iq"]
                     self.iq[(li, slot)] = (t, raw.numpy())
                     continue
+                if f"{li}.{slot}.qweight" not in self.ck:
+                    continue   # mixture-of-experts model: no dense gate / up / down
                 qw, qz, sc = (self.ck[f"{li}.{slot}.{n}"] for n in ("qweight", "qzeros", "scales"))
                 K, N = qw.shape[0], qw.shape[1] * 8
                 gq = orc.awq_to_gptq_qweight(qw, K, N)                       # awq_marlin.rs:622
@@ -57,6 +59,35 @@ class OracleQwen3:
         gq, gz, sb, K, N = self.lin[(li, slot)]
         return orc.int4_gemv_bf16(x_u16, gq, sb, gz, None, K, N, self.s.group_size)
 
+    def moe(self, li, x_u16):
+        """QuantizedMoELayer::forward (models/mixtral_quantized.rs:138-195): dense router in bf16, softmax rounded to bf16,
+        top-k (ties -> smaller index), renormalise, out = sum_j bf16(expert_j(x) * bf16(w_j)) accumulated in bf16."""
+        s = self.s
+        T, H, I, g = x_u16.shape[0], s.hidden_size, s.intermediate_size, s.group_size
+        xf = orc.bf16_to_f32(x_u16).astype(np.float64)
+        logits = orc.bf16_to_f32(orc.f32_to_bf16((xf @ orc.bf16_to_f32(self.ck[f"{li}.router"]).astype(np.float64).T).astype(np.float32)))
+        e = np.exp(logits - logits.max(-1, keepdims=True)).astype(np.float32)
+        p = orc.bf16_to_f32(orc.f32_to_bf16((e / e.sum(-1, keepdims=True, dtype=np.float32)).astype(np.float32)))
+        ids = np.argsort(-p, axis=-1, kind="stable")[:, :s.experts_per_tok]
+        w = np.take_along_axis(p, ids, -1)
+        w = (w / w.sum(-1, keepdims=True)).astype(np.float32)
+        out = np.zeros((T, H), np.uint16)
+
+        def ex(e, nm):
+            return self.ck[f"{li}.e{e}.{nm}.qweight"], orc.f32_to_bf16(orc.f16_to_f32(self.ck[f"{li}.e{e}.{nm}.scales"]))
+        for t in range(T):
+            acc = np.zeros(H, np.float32)
+            for j in range(s.experts_per_tok):
+                w1, w3, w2 = ex(ids[t, j], "w1"), ex(ids[t, j], "w3"), ex(ids[t, j], "w2")
+                gate = orc.int4_gemv_bf16(x_u16[t:t + 1], w1[0], w1[1], None, None, H, I, g)
+                up = orc.int4_gemv_bf16(x_u16[t:t + 1], w3[0], w3[1], None, None, H, I, g)
+                hid = orc.silu_and_mul_bf16(gate, up)
+                eo = orc.bf16_to_f32(orc.int4_gemv_bf16(hid, w2[0], w2[1], None, None, I, H, g))[0]
+                ws = orc.bf16_to_f32(orc.f32_to_bf16(np.float32(w[t, j])))
+                acc = orc.bf16_to_f32(orc.f32_to_bf16(acc + orc.bf16_to_f32(orc.f32_to_bf16(eo * ws))))
+            out[t] = orc.f32_to_bf16(acc)
+        return out
+
     def decode(self, ids, positions, slots, block_tables, seq_lens):
         s = self.s
         B = len(ids)
@@ -76,6 +107,9 @@ class OracleQwen3:
                                           s.block_size, psize, 0, s.kv_cache_dtype, self.kv_scales[0], self.kv_scales[1])
             h = add_bf16(self.linear(li, 3, attn), h)
             x = orc.rms_norm_bf16(h, self.ck[f"{li}.post_ln"], s.rms_norm_eps)
+            if getattr(s, "num_experts", 0) > 0:
+                h = add_bf16(h, self.moe(li, x))
+                continue
             a = orc.silu_and_mul_bf16(self.linear(li, 4, x), self.linear(li, 5, x))
             h = add_bf16(h, self.linear(li, 6, a))
         x = orc.rms_norm_bf16(h, self.ck["final_norm"], s.rms_norm_eps)

@@ -296,3 +296,42 @@ def test_native_prefill_matches_decode_path(gpu, iq):
     with pytest.raises(VmxError, match="max_prefill_tokens"):
         b.prefill(torch.zeros(41, dtype=torch.int32, device="cuda"), 0, bt)
     a.close(); b.close()
+
+
+def test_mixtral_style_moe_decoder_matches_oracle(gpu):
+    """Mixtral-shaped layers (attention without q/k norms, 4 GPTQ experts top-2 behind a dense router) through the executor
+    against the composed CPU oracle; a prompt through the native prefill path must leave an equivalent cache."""
+    from oracle import oracle as orc
+    from tests.model_oracle import OracleQwen3
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache
+    vmx, torch = gpu
+    spec = _tiny_spec(qk_norm=False, num_experts=4, experts_per_tok=2, max_batch=3, max_prefill_tokens=20, rope_theta=1e6)
+    model = QuantizedQwen3ForCausalLM(spec)
+    ck = model.load_synthetic_moe(seed=11, keep_host_copy=True)
+    ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta))
+    B = 3
+    bt = np.arange(B * 4, dtype=np.int32).reshape(B, 4)
+    ids = np.array([7, 123, 999], np.int32)
+    for p in range(3):
+        pos = np.full(B, p, np.int32)
+        slots = (bt[:, 0] * spec.block_size + p).astype(np.int32)
+        sl = pos + 1
+        logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        out = model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, pos, slots, bt, sl)), logits=logits)
+        torch.cuda.synchronize()
+        exp, _, _ = ref.decode(ids, pos, slots, bt, sl)
+        got = orc.bf16_to_f32(_u16(torch, logits)); exp = orc.bf16_to_f32(exp)
+        rel = np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum())
+        assert rel <= 3e-2, (p, rel)
+        ids = out.cpu().numpy().astype(np.int32)
+    # native prefill of a 17-token prompt on a fresh block table, then one decode step, against the decode path
+    prompt = torch.randint(0, spec.vocab_size, (17,), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    bt2 = torch.tensor([20, 21], dtype=torch.int32, device="cuda"); bt3 = torch.tensor([24, 25], dtype=torch.int32, device="cuda")
+    la = torch.empty(spec.vocab_size, dtype=torch.bfloat16, device="cuda")
+    model.prefill(prompt, 0, bt2, logits_last=la)
+    spec_chunk = spec.max_batch
+    _, lref = model.forward(prompt, 0, bt3)
+    torch.cuda.synchronize()
+    a, b = la.float(), lref[-1].float()
+    assert float(((a - b) ** 2).sum().sqrt() / (b ** 2).sum().sqrt()) <= 3e-2
+    model.close()

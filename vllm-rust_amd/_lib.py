@@ -92,6 +92,7 @@ _SIGS = {
     "vmx_qwen3_debug_read": (_i, [_p, _i, _p, _sz, _p]),
     "vmx_debug_stream_read": (_i, [_p, _sz, _i, _p, _p]),
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
+    "vmx_qwen3_load_gptq_expert": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "vmx_qwen3_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "vmx_qwen3_linears_only": (_i, [_p, _i, _p]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
@@ -130,6 +131,7 @@ class Qwen3Config(C.Structure):
         ("intermediate_size", _i), ("vocab_size", _i), ("rms_norm_eps", _f), ("max_position", _i), ("group_size", _i),
         ("qk_norm", _i), ("tie_word_embeddings", _i), ("kv_cache_dtype", _i), ("block_size", _i), ("num_blocks", _i),
         ("max_batch", _i), ("max_seq_len", _i), ("tp_size", _i), ("tp_rank", _i), ("max_prefill_tokens", _i),
+        ("num_experts", _i), ("experts_per_tok", _i),
     ]
 
 

@@ -299,9 +299,15 @@ struct Layer {
     IqLinear iq[7];  // q, k, v, o, gate, up, down as GGUF I-quants (alternative to the int4 linears)
     bool iq_ready() const { for (const IqLinear &l : iq) if (!l.loaded) return false; return true; }
     bool int4_ready() const { return qkv.loaded && o.loaded && gate_up.loaded && down.loaded; }
+    bool int4_attn_ready() const { return qkv.loaded && o.loaded; }
     MergeStage qkv_stage, gu_stage;
     DevBuf input_ln, post_ln, q_norm, k_norm;
     DevBuf k_cache, v_cache, kv_scales;  // kv_scales: f32[2] = {k_scale, v_scale}
+    // mixture-of-experts MLP (num_experts > 0): dense router [E, hidden] and per-expert int4 tile streams
+    DevBuf router, w13_table, w2_table;   // tables: device arrays of E pointers (what vmx_moe_int4_forward takes)
+    std::vector<DevBuf> w13, w2;
+    int experts_loaded = 0;
+    bool moe_ready(int E) const { return E > 0 && experts_loaded == E; }
 };
 
 }  // namespace
@@ -312,6 +318,7 @@ struct vmx_qwen3 {
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
     DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8, positions;
+    DevBuf router_logits, topk_w, topk_ids, moe_ws, moe_out;   // MoE models only
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
@@ -427,6 +434,9 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     VMX_REQUIRE(c.kv_cache_dtype == VMX_KV_AUTO || c.kv_cache_dtype == VMX_KV_FP8_E4M3, "qwen3_create: unsupported kv dtype");
     VMX_REQUIRE(c.tp_size >= 0 && c.tp_rank >= 0 && (c.tp_size <= 1 || (c.tp_rank < c.tp_size && c.vocab_size % c.tp_size == 0)),
                 "qwen3_create: tp_rank %d / tp_size %d invalid (vocab_size must divide by tp_size)", c.tp_rank, c.tp_size);
+    VMX_REQUIRE(c.num_experts >= 0 && c.num_experts <= 256 && (c.num_experts == 0 || (c.experts_per_tok >= 1 && c.experts_per_tok <= c.num_experts)),
+                "qwen3_create: num_experts %d / experts_per_tok %d invalid", c.num_experts, c.experts_per_tok);
+    VMX_REQUIRE(c.num_experts == 0 || c.tp_size <= 1, "qwen3_create: mixture-of-experts layers are not tensor-parallel here");
     vmx_qwen3 *m = new (std::nothrow) vmx_qwen3();
     VMX_REQUIRE(m, "qwen3_create: out of host memory");
     m->cfg = c;
@@ -459,6 +469,13 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
         TRY(L.k_cache.alloc(kv_bytes));
         TRY(L.v_cache.alloc(kv_bytes));
         TRY(L.kv_scales.alloc(8));
+        if (c.num_experts > 0) {
+            TRY(L.router.alloc((size_t)c.num_experts * H * 2));
+            TRY(L.w13_table.alloc((size_t)c.num_experts * sizeof(void *)));
+            TRY(L.w2_table.alloc((size_t)c.num_experts * sizeof(void *)));
+            L.w13.resize(c.num_experts);
+            L.w2.resize(c.num_experts);
+        }
         if (!rc) {
             const float ones[2] = {1.0f, 1.0f};
             if (hipMemcpy(L.kv_scales.p, ones, 8, hipMemcpyHostToDevice) != hipSuccess) rc = VMX_ELAUNCH;
@@ -488,6 +505,13 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
         const size_t kmax = (size_t)(H > I ? (H > NO ? H : NO) : (I > NO ? I : NO));
         TRY(m->q8.alloc(B * kmax + 256 + B * (kmax / 32) * 4));
     }
+    if (c.num_experts > 0) {
+        TRY(m->router_logits.alloc((size_t)B * c.num_experts * 2));
+        TRY(m->topk_w.alloc((size_t)B * c.experts_per_tok * 4));
+        TRY(m->topk_ids.alloc((size_t)B * c.experts_per_tok * 4));
+        TRY(m->moe_ws.alloc(vmx_moe_int4_workspace_bytes(B, c.experts_per_tok, H, I)));
+        TRY(m->moe_out.alloc((size_t)B * H * 2));
+    }
     TRY(m->keys.alloc((size_t)c.max_batch * 8));
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(c.max_batch, c.num_heads, hd, c.max_seq_len)));
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(c.max_batch, VL)));
@@ -504,6 +528,9 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
     if (!m) return;
     for (auto &L : m->layers) {
         for (IqLinear &l : L.iq) l.raw.release();
+        for (DevBuf &b : L.w13) b.release();
+        for (DevBuf &b : L.w2) b.release();
+        for (DevBuf *b : {&L.router, &L.w13_table, &L.w2_table}) b->release();
         for (DevBuf *b : {&L.qkv.packed, &L.o.packed, &L.gate_up.packed, &L.down.packed, &L.input_ln, &L.post_ln, &L.q_norm, &L.k_norm,
                           &L.k_cache, &L.v_cache, &L.kv_scales})
             b->release();
@@ -511,7 +538,8 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         stage_free(L.gu_stage);
     }
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
-                      &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8, &m->positions})
+                      &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8, &m->positions, &m->router_logits, &m->topk_w, &m->topk_ids,
+                      &m->moe_ws, &m->moe_out})
         b->release();
     delete m;
 }
@@ -525,6 +553,11 @@ extern "C" int vmx_qwen3_load_tensor(vmx_qwen3 *m, int which, int layer, const v
         case VMX_T_FINAL_NORM: dst = &m->final_norm; break;
         case VMX_T_COS_SIN: dst = &m->cos_sin; break;
         default: break;
+    }
+    if (!dst && which == VMX_T_ROUTER) {
+        VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && m->cfg.num_experts > 0, "qwen3_load_tensor: no router on this model / layer %d",
+                    layer);
+        dst = &m->layers[layer].router;
     }
     if (!dst && which >= VMX_T_INPUT_LN && which <= VMX_T_KV_SCALES) {
         VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "qwen3_load_tensor: layer %d out of range", layer);
@@ -586,6 +619,56 @@ extern "C" int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, cons
     }
 }
 
+// One GPTQ expert of a mixture-of-experts layer (MarlinLinear semantics, w = (nib - 8) * scale, qzeros / g_idx ignored:
+// crates/core/kernels/marlin_gemm.cu:43-48): w1 (gate) and w3 (up) [hidden -> inter] are merged into one tile stream,
+// w2 (down) [inter -> hidden] is the second.  qweight u32 [K/8, N] GPTQ-sequential, scales f16 [K/group, N].
+extern "C" int vmx_qwen3_load_gptq_expert(vmx_qwen3 *m, int layer, int expert, const uint32_t *w1_qweight, const uint16_t *w1_scales_f16,
+                                          const uint32_t *w3_qweight, const uint16_t *w3_scales_f16, const uint32_t *w2_qweight,
+                                          const uint16_t *w2_scales_f16, void *stream) {
+    VMX_REQUIRE(m && w1_qweight && w1_scales_f16 && w3_qweight && w3_scales_f16 && w2_qweight && w2_scales_f16,
+                "qwen3_load_gptq_expert: null pointer");
+    const vmx_qwen3_config &c = m->cfg;
+    VMX_REQUIRE(c.num_experts > 0, "qwen3_load_gptq_expert: the model has no experts");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && expert >= 0 && expert < c.num_experts,
+                "qwen3_load_gptq_expert: layer %d / expert %d out of range", layer, expert);
+    hipStream_t st = vmx_stream(stream);
+    Layer &L = m->layers[layer];
+    const int H = c.hidden_size, I = c.intermediate_size, g = c.group_size;
+    DevBuf qw13, sc13, sc2;
+    int rc = qw13.alloc((size_t)(H / 8) * 2 * I * 4);
+    if (!rc) rc = sc13.alloc((size_t)(H / g) * 2 * I * 2);
+    if (!rc) rc = sc2.alloc((size_t)(I / g) * H * 2);
+    const bool fresh = L.w13[expert].p == nullptr;
+    if (!rc && fresh) rc = L.w13[expert].alloc(vmx_int4_packed_bytes(H, 2 * I, g));
+    if (!rc && !L.w2[expert].p) rc = L.w2[expert].alloc(vmx_int4_packed_bytes(I, H, g));
+    auto fail = [&](int code) { qw13.release(); sc13.release(); sc2.release(); return code; };
+    if (rc) return fail(rc);
+    // gate | up side by side: columns [0, I) and [I, 2I)
+    const size_t row = (size_t)I * 4;
+    if (hipMemcpy2DAsync(qw13.p, 2 * row, w1_qweight, row, row, H / 8, hipMemcpyDefault, st) != hipSuccess ||
+        hipMemcpy2DAsync((char *)qw13.p + row, 2 * row, w3_qweight, row, row, H / 8, hipMemcpyDefault, st) != hipSuccess) {
+        vmx_set_error("qwen3_load_gptq_expert: copying qweight failed");
+        return fail(VMX_ELAUNCH);
+    }
+    const int64_t n13 = (int64_t)(H / g) * I, n2 = (int64_t)(I / g) * H;
+    hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n13 + 255) / 256)), dim3(256), 0, st, w1_scales_f16, (uint16_t *)sc13.p, n13, I, 2 * I);
+    hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n13 + 255) / 256)), dim3(256), 0, st, w3_scales_f16, (uint16_t *)sc13.p + I, n13, I, 2 * I);
+    hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w2_scales_f16, (uint16_t *)sc2.p, n2, H, H);
+    if (hipGetLastError() != hipSuccess) { vmx_set_error("qwen3_load_gptq_expert: scale conversion launch failed"); return fail(VMX_ELAUNCH); }
+    rc = vmx_int4_pack((const uint32_t *)qw13.p, (const uint16_t *)sc13.p, nullptr, L.w13[expert].p, H, 2 * I, g, st);
+    if (!rc) rc = vmx_int4_pack(w2_qweight, (const uint16_t *)sc2.p, nullptr, L.w2[expert].p, I, H, g, st);
+    if (rc) return fail(rc);
+    void *p13 = L.w13[expert].p, *p2 = L.w2[expert].p;
+    if (hipMemcpyAsync((char *)L.w13_table.p + expert * sizeof(void *), &p13, sizeof(void *), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync((char *)L.w2_table.p + expert * sizeof(void *), &p2, sizeof(void *), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {   // load time: the staging buffers are freed right after
+        vmx_set_error("qwen3_load_gptq_expert: table update failed");
+        return fail(VMX_ELAUNCH);
+    }
+    if (fresh) L.experts_loaded++;
+    return fail(VMX_OK);
+}
+
 extern "C" int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int ggml_type, const void *blocks, size_t bytes,
                                         void *stream) {
     VMX_REQUIRE(m && blocks, "qwen3_load_iq_linear: null pointer");
@@ -639,7 +722,8 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     uint16_t *attn = (uint16_t *)m->attn.p, *act = (uint16_t *)m->act.p;
     const int NQ = Hq * hd, NKV = Hkv * hd;
     for (const Layer &L : m->layers) {
-        const bool iq = !L.int4_ready();  // GGUF I-quant layer: every projection is an IqLinear
+        const bool moe = c.num_experts > 0;  // int4 attention projections + mixture-of-experts MLP
+        const bool iq = !moe && !L.int4_ready();  // GGUF I-quant layer: every projection is an IqLinear
         const int s_qkv = iq ? 1 : L.qkv.splits(), s_o = iq ? 1 : L.o.splits(), s_gu = iq ? 1 : L.gate_up.splits(),
                   s_down = iq ? 1 : L.down.splits();
         // h += pending; x = rms_norm(h);  q|k|v = linear(x)
@@ -684,6 +768,26 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         }
         launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, iq ? q8_aq(m) : nullptr,
                           iq ? q8_ad(m, B, H) : nullptr);
+        if (moe) {
+            // QuantizedMoELayer::forward (models/mixtral_quantized.rs:138-195): dense router, softmax (bf16) -> top-k -> renormalise,
+            // out = sum_j bf16(expert_j(x) * w_j), experts = down(silu(gate x) * up x); no host read of the routing
+            uint16_t *rl = (uint16_t *)m->router_logits.p;
+            for (int r0 = 0; r0 < B; r0 += 16) {
+                const int mr = B - r0 < 16 ? B - r0 : 16;
+                if (int rc = vmx_dense_gemv_launch(rl + (size_t)r0 * c.num_experts, x + (size_t)r0 * H, (const uint16_t *)L.router.p, nullptr, mr,
+                                                   c.num_experts, H, st))
+                    return rc;
+            }
+            if (int rc = vmx_topk_softmax(rl, VMX_BF16, (float *)m->topk_w.p, (int32_t *)m->topk_ids.p, B, c.num_experts, c.experts_per_tok, 1, 1, st))
+                return rc;
+            if (int rc = vmx_moe_int4_forward((uint16_t *)m->moe_out.p, x, (const float *)m->topk_w.p, (const int32_t *)m->topk_ids.p,
+                                              (const void *const *)L.w13_table.p, (const void *const *)L.w2_table.p, B, c.experts_per_tok,
+                                              c.num_experts, H, I, c.group_size, m->moe_ws.p, m->moe_ws.bytes, st))
+                return rc;
+            pending = (const float *)m->moe_out.p;
+            pending_splits = -1;
+            continue;
+        }
         if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_GATE], PA, 2 * I, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_UP], PA + I, 2 * I, B, st)) return rc;
@@ -744,7 +848,7 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "qwen3_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
                 c.max_seq_len);
     for (const Layer &L : m->layers)
-        VMX_REQUIRE(L.int4_ready() || L.iq_ready(), "qwen3_decode: weights not fully loaded");
+        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_decode: weights not fully loaded");
     const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
     VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
     if (int rc = run_layers(m, input_ids, positions, slot_mapping, block_tables, seq_lens, batch, max_blocks_per_seq, max_seq_len, -1,
@@ -765,7 +869,7 @@ extern "C" int vmx_qwen3_prefill(vmx_qwen3 *m, const int32_t *input_ids, int seq
     VMX_REQUIRE(seqlen_offset >= 0 && seqlen_offset + q_len <= c.max_position, "qwen3_prefill: positions %d..%d exceed max_position %d",
                 seqlen_offset, seqlen_offset + q_len - 1, c.max_position);
     for (const Layer &L : m->layers)
-        VMX_REQUIRE(L.int4_ready() || L.iq_ready(), "qwen3_prefill: weights not fully loaded");
+        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_prefill: weights not fully loaded");
     const bool tp = c.tp_size > 1 || m->comm != nullptr;
     VMX_REQUIRE(!tp || m->comm, "qwen3_prefill: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
     hipStream_t st = vmx_stream(stream);

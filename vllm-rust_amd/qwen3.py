@@ -17,7 +17,7 @@ import torch
 
 from ._lib import Qwen3Config, check, lib
 
-T_EMBED, T_LM_HEAD, T_FINAL_NORM, T_COS_SIN, T_INPUT_LN, T_POST_LN, T_Q_NORM, T_K_NORM, T_KV_SCALES = range(9)
+T_EMBED, T_LM_HEAD, T_FINAL_NORM, T_COS_SIN, T_INPUT_LN, T_POST_LN, T_Q_NORM, T_K_NORM, T_KV_SCALES, T_ROUTER = range(10)
 L_Q, L_K, L_V, L_O, L_GATE, L_UP, L_DOWN = range(7)
 
 
@@ -44,10 +44,18 @@ class Qwen3Spec:
     tp_size: int = 1      # with tp_size > 1 the head counts and intermediate_size below are this rank's shares
     tp_rank: int = 0
     max_prefill_tokens: int = 0   # rows per native prefill call (0: prompts go through the decode path in max_batch chunks)
+    num_experts: int = 0          # > 0: mixture-of-experts MLP (Mixtral: 8 experts, 2 per token); intermediate_size = expert width
+    experts_per_tok: int = 0
 
     @staticmethod
     def qwen3_8b(**kw):
         return Qwen3Spec(4096, 36, 32, 8, 128, 12288, 151936, **kw)
+
+    @staticmethod
+    def mixtral_8x7b(**kw):
+        """Mixtral-8x7B geometry (models/mixtral_quantized.rs): Llama-style attention without q/k norms, 8 experts top-2."""
+        return Qwen3Spec(4096, 32, 32, 8, 128, 14336, 32000, rms_norm_eps=1e-5, rope_theta=1e6, qk_norm=False, num_experts=8,
+                         experts_per_tok=2, **kw)
 
     @staticmethod
     def qwen3_0_6b(**kw):
@@ -77,7 +85,8 @@ class QuantizedQwen3ForCausalLM:
         cfg = Qwen3Config(spec.hidden_size, spec.num_layers, spec.num_heads, spec.num_kv_heads, spec.head_dim,
                           spec.intermediate_size, spec.vocab_size, spec.rms_norm_eps, spec.max_position, spec.group_size,
                           int(spec.qk_norm), int(spec.tie_word_embeddings), spec.kv_cache_dtype, spec.block_size,
-                          spec.num_blocks, spec.max_batch, spec.max_seq_len, spec.tp_size, spec.tp_rank, spec.max_prefill_tokens)
+                          spec.num_blocks, spec.max_batch, spec.max_seq_len, spec.tp_size, spec.tp_rank, spec.max_prefill_tokens,
+                          spec.num_experts, spec.experts_per_tok)
         self._h = C.c_void_p()
         check(lib.vmx_qwen3_create(C.byref(cfg), C.byref(self._h)))
         cs = torch.from_numpy(rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta)).to(self.device)
@@ -119,6 +128,47 @@ class QuantizedQwen3ForCausalLM:
         blocks = blocks.contiguous()
         check(lib.vmx_qwen3_load_iq_linear(self._h, layer, slot, ggml_type, blocks.data_ptr(), blocks.numel(), self._stream()))
         torch.cuda.current_stream().synchronize()
+
+    def load_gptq_expert(self, layer: int, expert: int, w1, w3, w2) -> None:
+        """w1 / w3 / w2: (qweight int32 [K/8, N], scales f16 [K/g, N]) of the gate, up and down projections of one expert."""
+        for qw, sc in (w1, w3, w2):
+            assert qw.dtype == torch.int32 and sc.dtype == torch.float16 and qw.is_contiguous() and sc.is_contiguous()
+        check(lib.vmx_qwen3_load_gptq_expert(self._h, layer, expert, w1[0].data_ptr(), w1[1].data_ptr(), w3[0].data_ptr(), w3[1].data_ptr(),
+                                             w2[0].data_ptr(), w2[1].data_ptr(), self._stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def load_synthetic_moe(self, seed: int = 0, keep_host_copy: bool = False):
+        """Random-init Mixtral-style checkpoint: AWQ attention projections, bf16 router, GPTQ (symmetric) experts."""
+        s = self.spec
+        ck = self._load_synthetic_dense(seed, keep_host_copy)
+        g = torch.Generator(device=self.device).manual_seed(seed + 1)
+
+        def keep(name, t):
+            if keep_host_copy:
+                ck[name] = t.cpu()
+
+        H, I = s.hidden_size, s.intermediate_size
+        for li in range(s.num_layers):
+            for slot, (K, N) in self.linear_shapes().items():
+                if slot not in (L_Q, L_K, L_V, L_O):
+                    continue
+                qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=self.device, generator=g)
+                qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // s.group_size, N // 8), dtype=torch.int32, device=self.device, generator=g)
+                sc = ((torch.rand((K // s.group_size, N), device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (6.5 * math.sqrt(K)))).to(torch.float16)
+                self.load_awq_linear(li, slot, qw, qz, sc)
+                keep(f"{li}.{slot}.qweight", qw); keep(f"{li}.{slot}.qzeros", qz); keep(f"{li}.{slot}.scales", sc)
+            router = (torch.randn((s.num_experts, H), device=self.device, generator=g) * 0.3).to(torch.bfloat16)
+            self.load_tensor(T_ROUTER, li, router); keep(f"{li}.router", router)
+            for e in range(s.num_experts):
+                def mk(K, N):
+                    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), dtype=torch.int32, device=self.device, generator=g)
+                    sc = ((torch.rand((K // s.group_size, N), device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (4.6 * math.sqrt(K)))).to(torch.float16)
+                    return qw, sc
+                w1, w3, w2 = mk(H, I), mk(H, I), mk(I, H)
+                self.load_gptq_expert(li, e, w1, w3, w2)
+                for nm, (qw, sc) in (("w1", w1), ("w3", w3), ("w2", w2)):
+                    keep(f"{li}.e{e}.{nm}.qweight", qw); keep(f"{li}.e{e}.{nm}.scales", sc)
+        return ck
 
     def linear_shapes(self):
         s = self.spec
