@@ -150,6 +150,57 @@ def gemma4_secondary(prompt, steps, warmup):
                          "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches)}}
 
 
+def mixtral_secondary(prompt, steps, warmup):
+    """BASELINE.json configs[4] on one GPU: decode tok/s of a Mixtral-8x7B-shaped model (AWQ attention projections, 8 GPTQ
+    int4 experts top-2 per layer behind a dense router) through the executor's device-side fused MoE path."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    total = prompt + warmup + steps + 8
+    n_blocks = (total + 15) // 16 + 1
+    spec = Qwen3Spec.mixtral_8x7b(max_position=max(4096, total + 1), num_blocks=n_blocks, max_batch=1, max_seq_len=total + 1,
+                                  max_prefill_tokens=prompt)
+    model = QuantizedQwen3ForCausalLM(spec)
+    model.load_synthetic_moe(seed=5)
+    dev = model.device
+    bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(1, n_blocks).contiguous()
+    prompt_ids = torch.randint(0, spec.vocab_size, (prompt,), dtype=torch.int32, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    ids = torch.empty(1, dtype=torch.int32, device=dev)
+    pos = torch.full((1,), prompt, dtype=torch.int32, device=dev)
+    slots = (bt[:, prompt // 16] * 16 + prompt % 16).to(torch.int32).contiguous()
+    sl = torch.full((1,), prompt + 1, dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.int32, device=dev)
+
+    def step():
+        model.forward_decode_batch(ids, pos, slots, bt, sl, max_seq_len=spec.max_seq_len, out_ids=out)
+        model.advance(ids, out, pos, slots, sl, bt)
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
+        step()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            step()
+        for _ in range(warmup):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    H, I, E, k = spec.hidden_size, spec.intermediate_size, spec.num_experts, spec.experts_per_tok
+    nq, nkv = spec.num_heads * spec.head_dim, spec.num_kv_heads * spec.head_dim
+    int4 = lambda K, N: K * N / 2 + (K / 128) * N * 2.5
+    per_tok = spec.num_layers * (int4(H, nq + 2 * nkv) + int4(nq, H) + k * (int4(H, 2 * I) + int4(I, H)) + E * H * 2) + spec.vocab_size * H * 2
+    model.close()
+    return {"metric": "decode tok/s (greedy, batch=1), Mixtral-8x7B GPTQ int4 fused MoE, TP=1", "value": round(steps / dt, 2), "unit": "tok/s",
+            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "config": {"workload": "Mixtral-8x7B-shaped: 32 layers, hidden 4096, 8 experts x 14336 top-2 (GPTQ int4 g128), AWQ attention, bf16 KV",
+                       "weights": "seeded random-init checkpoint of the architecture", "execution": "one hipGraph per step; routing stays on the device"},
+            "weight_bytes_per_token": int(per_tok), "GBps_weights_only": round(per_tok / (dt / steps) / 1e9, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +210,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (invalidates the number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the GGUF I-quant (Gemma-4-12B-shaped) secondary measurement")
+    ap.add_argument("--no-moe", action="store_true", help="skip the Mixtral-8x7B-shaped fused-MoE secondary measurement")
     ap.add_argument("--tp", action="store_true",
                     help="with --gpus N > 1: ONE model tensor-parallel over the N ranks (RCCL all-reduce after every row-parallel "
                          "linear, strong scaling) instead of N independent replicas")
@@ -286,11 +338,15 @@ def main():
 
     # ---- secondary (rank 0, N = 1 only): BASELINE.json's other headline model, GGUF I-quant decode
     secondary = None
+    secondary_moe = None
     if rank == 0 and not dist_on and not args.no_secondary and not args.layers:
         model.close()
         del model, graph
         torch.cuda.empty_cache()
         secondary = gemma4_secondary(args.prompt, max(16, K_steps // 2), W_steps)
+        torch.cuda.empty_cache()
+        if not args.no_moe:
+            secondary_moe = mixtral_secondary(args.prompt, max(16, K_steps // 2), W_steps)
 
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed
@@ -309,6 +365,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(spec),
             "secondary": secondary,
+            "secondary_moe": secondary_moe,
         }
         print(json.dumps(line), flush=True)
     if dist_on:
