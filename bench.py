@@ -150,6 +150,56 @@ def gemma4_secondary(prompt, steps, warmup):
                          "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches)}}
 
 
+def exl3_secondary(reps=8):
+    """BASELINE.json configs[3] at TP=1, kernel level: the seven EXL3 4.0 bpw projections of every Qwen3-8B layer (random trellis,
+    +-1 sign vectors), M = 1, replayed from one hipGraph: Hadamard -> trellis-decode MFMA GEMM -> Hadamard per projection.
+    Reports the weight-stream rate of the EXL3 linear path; the f16 model around it is not built yet."""
+    import vllm_rust_amd as vmx
+    from vllm_rust_amd._lib import check, lib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    H, I, nq, nkv, L, bits = 4096, 12288, 4096, 1024, 36, 4
+    shapes = [(H, nq), (H, nkv), (H, nkv), (nq, H), (H, I), (H, I), (I, H)]
+    g = torch.Generator(device=dev).manual_seed(3)
+    layers = []
+    for _ in range(L):
+        lay = []
+        for K, N in shapes:
+            tr = torch.randint(-32768, 32767, ((K // 16) * (N // 16) * 16 * bits,), dtype=torch.int16, device=dev, generator=g)
+            suh = (torch.randint(0, 2, (K,), device=dev, generator=g) * 2 - 1).to(torch.float16)
+            svh = (torch.randint(0, 2, (N,), device=dev, generator=g) * 2 - 1).to(torch.float16)
+            lay.append((K, N, tr, suh, svh))
+        layers.append(lay)
+    x = {K: (torch.randn((1, K), device=dev, generator=g) * 0.05).to(torch.float16) for K in (H, I)}
+    y = {N: torch.empty((1, N), dtype=torch.float16, device=dev) for N in (H, nkv, I)}
+    ws = torch.empty(max(lib.vmx_exl3_gemm_workspace_bytes(1, K, N) for K, N in shapes), dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+
+    def chain():
+        st = side.cuda_stream
+        for lay in layers:
+            for K, N, tr, suh, svh in lay:
+                check(lib.vmx_exl3_gemm_f16(y[N].data_ptr(), x[K].data_ptr(), tr.data_ptr(), suh.data_ptr(), svh.data_ptr(), 1, K, N, bits, 0,
+                                            ws.data_ptr(), ws.numel(), st))
+    with torch.cuda.stream(side):
+        chain()
+        gph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gph, stream=side):
+            chain()
+        gph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(reps):
+            gph.replay()
+        e1.record(side)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = L * sum(K * N * bits / 8 + 2 * K + 2 * N + 2 * K + 2 * N for K, N in shapes)
+    return {"metric": "EXL3 4.0 bpw linear path, Qwen3-8B shapes, M=1, TP=1 (252 projections per token)", "ms_per_token_linears": round(ms, 4),
+            "tok_s_bound_from_linears": round(1e3 / ms, 1), "alg_bytes_per_token": int(alg), "GBps": round(alg / ms / 1e6, 1),
+            "frac_of_8TBs": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+
 def mixtral_secondary(prompt, steps, warmup):
     """BASELINE.json configs[4] on one GPU: decode tok/s of a Mixtral-8x7B-shaped model (AWQ attention projections, 8 GPTQ
     int4 experts top-2 per layer behind a dense router) through the executor's device-side fused MoE path."""
@@ -339,6 +389,7 @@ def main():
     # ---- secondary (rank 0, N = 1 only): BASELINE.json's other headline model, GGUF I-quant decode
     secondary = None
     secondary_moe = None
+    secondary_exl3 = None
     if rank == 0 and not dist_on and not args.no_secondary and not args.layers:
         model.close()
         del model, graph
@@ -347,6 +398,8 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_moe:
             secondary_moe = mixtral_secondary(args.prompt, max(16, K_steps // 2), W_steps)
+        torch.cuda.empty_cache()
+        secondary_exl3 = exl3_secondary()
 
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed
@@ -366,6 +419,7 @@ def main():
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(spec),
             "secondary": secondary,
             "secondary_moe": secondary_moe,
+            "secondary_exl3": secondary_exl3,
         }
         print(json.dumps(line), flush=True)
     if dist_on:
