@@ -416,6 +416,10 @@ int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, double *alg_b
  * all requested up front) and discard them; gives the HBM floor for a launch of that size. */
 int vmx_debug_stream_read(const void *p, size_t bytes, int upw, void *sink, void *stream);
 
+/* Measurement aid: out[i] = XCD id that workgroup i of an n_wgs-workgroup launch ran on (how the dispatcher
+ * spreads consecutive workgroup ids over the 8 dies, each with its own L2). */
+int vmx_debug_xcc_ids(int *out, int n_wgs, int wg_threads, void *stream);
+
 /* Attach the tensor-parallel group of a model created with tp_size > 1 (not owned by the model). */
 int vmx_qwen3_set_comm(vmx_qwen3 *m, vmx_comm *comm);
 

@@ -91,6 +91,7 @@ _SIGS = {
     "vmx_qwen3_decode": (_i, [_p] * 6 + [_i, _i, _i, _p, _p, _p]),
     "vmx_qwen3_debug_read": (_i, [_p, _i, _p, _sz, _p]),
     "vmx_debug_stream_read": (_i, [_p, _sz, _i, _p, _p]),
+    "vmx_debug_xcc_ids": (_i, [_p, _i, _i, _p]),
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "vmx_qwen3_load_gptq_expert": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "vmx_qwen3_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),

@@ -15,7 +15,20 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restric
     for (int u = 0; u < UPW; u++) acc ^= r[u].x ^ r[u].y ^ r[u].z ^ r[u].w;
     if (acc == 0x12345678u) sink[0] = acc;  // practically never taken; keeps the loads alive
 }
+// out[blockIdx.x] = id of the XCD (accelerator complex die) the workgroup runs on
+__global__ void xcc_id_kernel(int *__restrict__ out) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(v & 0xF);
+}
 }  // namespace
+
+extern "C" int vmx_debug_xcc_ids(int *out, int n_wgs, int wg_threads, void *stream) {
+    VMX_REQUIRE(out && n_wgs > 0 && wg_threads > 0 && wg_threads <= 1024, "debug_xcc_ids: bad arguments");
+    hipLaunchKernelGGL(xcc_id_kernel, dim3(n_wgs), dim3(wg_threads), 0, vmx_stream(stream), out);
+    VMX_CHECK_LAUNCH("debug_xcc_ids");
+    return VMX_OK;
+}
 
 extern "C" int vmx_debug_stream_read(const void *p, size_t bytes, int upw, void *sink, void *stream) {
     VMX_REQUIRE(p && sink && bytes >= 1024, "debug_stream_read: bad arguments");
