@@ -273,9 +273,13 @@ struct Int4Linear {
     int in_features = 0, out_features = 0, group = 128;
     DevBuf packed;
     bool loaded = false;
+    bool glu = false;  // merged gate|up packed for the fused activation epilogue (forward_glu instead of forward_partial)
     int splits() const { return vmx_int4_splits(out_features, in_features); }
     int forward_partial(const uint16_t *x, float *partial, int M, hipStream_t st) const {
         return vmx_int4_gemm_partial(packed.p, x, partial, M, out_features, in_features, group, st);
+    }
+    int forward_glu(const uint16_t *x, uint16_t *act, int M, hipStream_t st) const {
+        return vmx_int4_gemm_glu(packed.p, x, act, M, out_features, in_features, group, st);
     }
 
 };
@@ -402,11 +406,12 @@ int stage_put(MergeStage &s, const uint32_t *qweight, const uint32_t *qzeros, co
     return VMX_OK;
 }
 
-int stage_pack(MergeStage &s, Int4Linear &l, hipStream_t st) {
+int stage_pack(MergeStage &s, Int4Linear &l, hipStream_t st, bool gate_up = false) {
     if (!l.packed.p)
         if (int rc0 = l.packed.alloc(vmx_int4_packed_bytes(l.in_features, l.out_features, l.group))) return rc0;
-    int rc = vmx_int4_pack((const uint32_t *)s.qweight.p, (const uint16_t *)s.scales.p, (const uint32_t *)s.qzeros.p, l.packed.p,
-                           l.in_features, l.out_features, l.group, st);
+    l.glu = gate_up && vmx_int4_glu_fusable(l.out_features, l.in_features);
+    int rc = vmx_int4_pack_cols((const uint32_t *)s.qweight.p, (const uint16_t *)s.scales.p, (const uint32_t *)s.qzeros.p, l.packed.p,
+                                l.in_features, l.out_features, l.group, l.glu ? 1 : 0, st);
     if (rc) return rc;
     VMX_CHECK_HIP(hipStreamSynchronize(st));  // load time: staging is freed right after
     stage_free(s);
@@ -596,7 +601,7 @@ extern "C" int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, cons
             if (int rc = stage_alloc(L.gu_stage, H, 2 * I, g)) return rc;
             if (int rc = stage_put(L.gu_stage, qweight, qzeros, scales_f16, H, I, g, 2 * I, slot == VMX_L_GATE ? 0 : I, st)) return rc;
             L.gu_stage.filled |= slot == VMX_L_GATE ? 1 : 2;
-            if (L.gu_stage.filled == 3) return stage_pack(L.gu_stage, L.gate_up, st);
+            if (L.gu_stage.filled == 3) return stage_pack(L.gu_stage, L.gate_up, st, true);
             return VMX_OK;
         }
         case VMX_L_O: {
@@ -791,10 +796,14 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_GATE], PA, 2 * I, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_UP], PA + I, 2 * I, B, st)) return rc;
+        } else if (L.gate_up.glu) {  // act comes out of the GEMM epilogue
+            if (int rc = L.gate_up.forward_glu(x, act, B, st)) return rc;
         } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
-        int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
-        hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA, s_gu, B, act, I,
-                           iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr);
+        if (iq || !L.gate_up.glu) {
+            int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
+            hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA, s_gu, B, act, I,
+                               iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr);
+        }
         if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_DOWN], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;
@@ -909,7 +918,7 @@ extern "C" int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream) {
     for (const Layer &L : m->layers) {
         if (int rc = L.qkv.forward_partial(x, PA, batch, st)) return rc;
         if (int rc = L.o.forward_partial(attn, PB, batch, st)) return rc;
-        if (int rc = L.gate_up.forward_partial(x, PA, batch, st)) return rc;
+        if (int rc = L.gate_up.glu ? L.gate_up.forward_glu(x, (uint16_t *)m->act.p, batch, st) : L.gate_up.forward_partial(x, PA, batch, st)) return rc;
         if (int rc = L.down.forward_partial(act, PB, batch, st)) return rc;
     }
     return VMX_OK;

@@ -60,15 +60,23 @@ __global__ __launch_bounds__(256) void awq_nibble_reorder_kernel(const uint32_t 
     out[(i / cols) * ldo + (i % cols)] = r;
 }
 
+// Source column of packed column (nt, nl).  glu_half == 0: identity.  glu_half = N/2 (merged gate|up linear whose GEMM
+// epilogue applies the gated activation): tile nt holds gate columns 8nt..8nt+7 in its lanes 0..7 and the matching up
+// columns in lanes 8..15, so both operands of act[j] = silu(gate[j]) * up[j] end in one wave.
+__device__ __forceinline__ int pack_src_col(int nt, int nl, int glu_half) {
+    if (glu_half == 0) return nt * NT + nl;
+    return (nl < 8 ? 0 : glu_half) + nt * 8 + (nl & 7);
+}
+
 __global__ __launch_bounds__(256) void int4_pack_w_kernel(const uint32_t *__restrict__ qweight, uint32_t *__restrict__ W, int K,
-                                                           int N) {
+                                                           int N, int glu_half) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over K*N/8 output words
     if (idx >= (int64_t)K * N / 8) return;
     const int i = (int)(idx & 3), l = (int)((idx >> 2) & 63);
     const int64_t unit = idx >> 8;
     const int kblocks = K / KB;
     const int kb = (int)(unit % kblocks), nt = (int)(unit / kblocks);
-    const int n = nt * NT + (l & 15);
+    const int n = pack_src_col(nt, l & 15, glu_half);
     const int c = 4 * i + (l >> 4);  // 8-wide k chunk inside the unit
     const uint32_t src = qweight[(int64_t)(kb * 16 + c) * N + n];
     uint32_t r = 0;
@@ -81,12 +89,12 @@ __global__ __launch_bounds__(256) void int4_pack_w_kernel(const uint32_t *__rest
 }
 
 __global__ __launch_bounds__(256) void int4_pack_sz_kernel(const uint16_t *__restrict__ scales, const uint32_t *__restrict__ qzeros,
-                                                            uint32_t *__restrict__ SZ, int G, int N) {
+                                                            uint32_t *__restrict__ SZ, int G, int N, int glu_half) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [N/16][G][16]
     if (idx >= (int64_t)G * N) return;
     const int nl = (int)(idx & 15);
     const int g = (int)((idx >> 4) % G), nt = (int)((idx >> 4) / G);
-    const int n = nt * NT + nl;
+    const int n = pack_src_col(nt, nl, glu_half);
     uint32_t zp = 8;
     if (qzeros) zp = (qzeros[(int64_t)g * (N / 8) + (n >> 3)] >> (4 * (n & 7))) & 0xFu;
     SZ[idx] = (uint32_t)scales[(int64_t)g * N + n] | ((0x4300u | zp) << 16);
@@ -153,7 +161,9 @@ __device__ __forceinline__ float chunk_sum16(const uint4 v) {
     return s;
 }
 
-template <int UPW, bool TAIL>
+// GLU: the linear is a merged gate|up packed with glu_half = N/2 and runs unsplit; y is act[M][N/2] =
+// bf16(silu(bf16(gate)) * bf16(up)), the rounding points of silu_and_mul on the bf16 linear output (activations.cu:148-164).
+template <int UPW, bool TAIL, bool GLU = false>
 __device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
                                                uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride, int M,
@@ -275,7 +285,14 @@ __device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, cons
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int mrow = 4 * h + r;
-            if (mrow < M) {
+            if (GLU) {
+                const float up = __shfl_xor(out4[r], 8, 64);
+                if (mrow < M && nl < 8) {
+                    const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(out4[r]));
+                    const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
+                    y[(int64_t)mrow * (N >> 1) + nt * 8 + nl] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
+                }
+            } else if (mrow < M) {
                 if (y) {
                     float v = out4[r];
                     if (bias) v += vmx_bf16_to_f32(bias[n]);
@@ -295,6 +312,13 @@ __global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict_
                                                          int group, int slice_rows) {
     // slice_rows: rows of one split-K slice of `partial` (>= M when this launch covers 16 of a larger call's rows)
     int4_gemm_body<UPW, TAIL>(W, SZ, x, bias, y, partial, (int64_t)slice_rows * N, M, N, K, group, blockIdx.x);
+}
+
+template <int UPW, bool TAIL>
+__global__ __launch_bounds__(256) void int4_gemm_glu_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                             const uint16_t *__restrict__ x, uint16_t *__restrict__ act, int M, int N,
+                                                             int K, int group) {
+    int4_gemm_body<UPW, TAIL, true>(W, SZ, x, nullptr, act, nullptr, 0, M, N, K, group, blockIdx.x);
 }
 
 // Grouped form for mixture-of-experts decode: blockIdx.y = p selects one (token, expert slot) pair;
@@ -424,17 +448,24 @@ extern "C" size_t vmx_int4_packed_bytes(int K, int N, int group) {
 
 extern "C" int vmx_int4_pack(const uint32_t *qweight, const uint16_t *scales_bf16, const uint32_t *qzeros, void *packed, int K, int N,
                              int group, void *stream) {
+    return vmx_int4_pack_cols(qweight, scales_bf16, qzeros, packed, K, N, group, 0, stream);
+}
+
+int vmx_int4_pack_cols(const uint32_t *qweight, const uint16_t *scales_bf16, const uint32_t *qzeros, void *packed, int K, int N,
+                       int group, int glu, void *stream) {
     VMX_REQUIRE(qweight && scales_bf16 && packed, "int4_pack: null pointer");
     if (int rc = check_int4_shape("int4_pack", K, N, group)) return rc;
+    VMX_REQUIRE(!glu || N % 32 == 0, "int4_pack: a gate|up linear needs N (%d) divisible by 32", N);
+    const int glu_half = glu ? N / 2 : 0;
     uint32_t *W = (uint32_t *)packed;
     uint32_t *SZ = (uint32_t *)((char *)packed + sz_offset_bytes(K, N));
     const int64_t words = (int64_t)K * N / 8;
-    hipLaunchKernelGGL(int4_pack_w_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, vmx_stream(stream), qweight, W, K, N);
+    hipLaunchKernelGGL(int4_pack_w_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, vmx_stream(stream), qweight, W, K, N, glu_half);
     VMX_CHECK_LAUNCH("int4_pack(W)");
     const int G = K / group;
     const int64_t szn = (int64_t)G * N;
     hipLaunchKernelGGL(int4_pack_sz_kernel, dim3((unsigned)((szn + 255) / 256)), dim3(256), 0, vmx_stream(stream), scales_bf16, qzeros,
-                       SZ, G, N);
+                       SZ, G, N, glu_half);
     VMX_CHECK_LAUNCH("int4_pack(SZ)");
     return VMX_OK;
 }
@@ -463,6 +494,43 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
         const int mm = M - m0 < 16 ? M - m0 : 16;
         if (int rc = launch_gemm(p, W, SZ, x + (int64_t)m0 * K, nullptr, nullptr, partial + (int64_t)m0 * N, mm, N, K, group, st, M)) return rc;
     }
+    return VMX_OK;
+}
+
+// act[M][N/2] = silu(gate) * up straight from the GEMM epilogue; the linear must be GLU-packed and plan to one k slice.
+bool vmx_int4_glu_fusable(int N, int K) { return N % 32 == 0 && plan_gemm(N, K).splits == 1; }
+
+int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int M, int N, int K, int group, hipStream_t st) {
+    const GemmPlan p = plan_gemm(N, K);
+    VMX_REQUIRE(p.splits == 1, "int4_gemm_glu: linear [%d -> %d] is split over k", K, N);
+    const uint4 *W = (const uint4 *)packed;
+    const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    const bool tail = (K / KB) % (4 * p.upw) != 0;
+    const dim3 grid((unsigned)(N / NT)), block(256);
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        const int mm = M - m0 < 16 ? M - m0 : 16;
+        const size_t lds = gemm_lds_bytes(mm, p.upw);
+        VMX_REQUIRE(lds <= 160 * 1024, "int4_gemm_glu: LDS need %zu B exceeds 160 KiB", lds);
+        const uint16_t *xc = x + (int64_t)m0 * K;
+        uint16_t *ac = act + (int64_t)m0 * (N / 2);
+#define GLU_T(U, T)                                                                                                                \
+    do {                                                                                                                           \
+        if (lds > 64 * 1024)                                                                                                       \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_glu_kernel<U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              (int)lds));                                                                          \
+        hipLaunchKernelGGL((int4_gemm_glu_kernel<U, T>), grid, block, lds, st, W, SZ, xc, ac, mm, N, K, group);                    \
+    } while (0)
+#define GLU_L(U) do { if (tail) GLU_T(U, true); else GLU_T(U, false); } while (0)
+        switch (p.upw) {
+            case 8: GLU_L(8); break;
+            case 4: GLU_L(4); break;
+            case 2: GLU_L(2); break;
+            default: GLU_L(1); break;
+        }
+#undef GLU_L
+#undef GLU_T
+    }
+    VMX_CHECK_LAUNCH("int4_gemm(glu)");
     return VMX_OK;
 }
 

@@ -7,6 +7,11 @@ int vmx_int4_splits(int N, int K);
 int vmx_int4_gemm_grouped(const void *const *packed_table, const int32_t *expert_ids, int num_experts, const uint16_t *x,
                           int x_row_div, float *partial, int pairs, int N, int K, int group, hipStream_t st);
 int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial, int M, int N, int K, int group, hipStream_t st);
+// merged gate|up linear with the gated activation in the GEMM epilogue (pack with glu = 1; only when _glu_fusable)
+int vmx_int4_pack_cols(const uint32_t *qweight, const uint16_t *scales_bf16, const uint32_t *qzeros, void *packed, int K, int N,
+                       int group, int glu, void *stream);
+bool vmx_int4_glu_fusable(int N, int K);
+int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int M, int N, int K, int group, hipStream_t st);
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
                          int N, int group, int Ntot, int col0, hipStream_t st);
 
