@@ -102,8 +102,11 @@ __global__ __launch_bounds__(64) void exl3_had_f16_kernel(const uint16_t *__rest
 }
 
 // Output side: sum of f32 split-K slices -> Hadamard in f32 -> * 1/sqrt(128) -> fp16 -> * svh (fp16).  grid (N/128, M)
+// y32 != NULL: instead of fp16 into y, the value cast to bf16 (the model dtype of a bf16 model, exl3.rs:272-277) is written
+// as f32 at y32[row * ld32 + col] for consumers that take f32 linear outputs.
 __global__ __launch_bounds__(64) void exl3_out_had_kernel(const float *__restrict__ partial, int splits, int64_t slice,
-                                                           const uint16_t *__restrict__ svh, uint16_t *__restrict__ y, int N) {
+                                                           const uint16_t *__restrict__ svh, uint16_t *__restrict__ y, int N,
+                                                           float *__restrict__ y32, int ld32) {
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.y * N + blockIdx.x * 128 + 2 * lane;
     float e0 = 0.f, e1 = 0.f;
@@ -119,128 +122,240 @@ __global__ __launch_bounds__(64) void exl3_out_had_kernel(const float *__restric
         o0 = o0 * bits_to_half(sc & 0xffffu);
         o1 = o1 * bits_to_half(sc >> 16);
     }
-    *reinterpret_cast<uint32_t *>(y + base) = (uint32_t)half_to_bits(o0) | ((uint32_t)half_to_bits(o1) << 16);
+    if (y32) {
+        float *d = y32 + (int64_t)blockIdx.y * ld32 + blockIdx.x * 128 + 2 * lane;
+        *reinterpret_cast<float2 *>(d) = make_float2(vmx_bf16_to_f32(vmx_f32_to_bf16((float)o0)), vmx_bf16_to_f32(vmx_f32_to_bf16((float)o1)));
+    } else {
+        *reinterpret_cast<uint32_t *>(y + base) = (uint32_t)half_to_bits(o0) | ((uint32_t)half_to_bits(o1) << 16);
+    }
 }
 
 // ---------------------------------------------------------------- GEMM core: partial[ks][M][N] = A_had @ decode(trellis)
-// Workgroup = 4 waves = one 16-column tile x (4*U) k-steps of 32; wave w owns steps [w*U, (w+1)*U) of the slice.
-template <int BITS, int CB, int U>
+// Workgroup = 4 waves = 4 adjacent column tiles (one per wave) x KT k-tiles (one split-K slice).  A k-tile row of the four
+// tiles is contiguous in the checkpoint layout, so the slice is fetched with 16-byte loads, all requested before anything
+// else happens, and staged in LDS in four chunks (a chunk is decoded while the later ones are still in flight).
+// LDS holds each tile's bit stream word-reversed: stream word i at slot W-1-i, plus a copy of word W-1 at slot W, so that
+// the <= 24-bit window pair of weights (t, t+1) is always inside the two consecutive slots {s, s+1} = stream words
+// {i, i-1 (cyclic)}: one two-dword LDS read and one funnel shift per pair, with per-lane slot/shift constants computed
+// once.  (The first version moved words between lanes with 16 wave permutes per k-step.)
+template <int CB> __device__ __forceinline__ uint32_t exl3_hash(uint32_t w) {  // w < 2^16
+    // 32-bit products are quarter rate on CDNA: w * C (mod 2^32) comes from two full-rate 24-bit multiplies,
+    // w * (C & 0xFFFFFF) [+ ADD] + ((w * (C >> 24)) << 24).  Written as instructions because the optimiser folds the
+    // expression back into one v_mul_lo_u32.
+    constexpr uint32_t C = CB == 0 ? 89226354u : (CB == 1 ? 0xCBAC1FEDu : 0x83DCD12Du);
+    constexpr uint32_t ADD = CB == 0 ? 64248484u : 0u;
+    uint32_t lo, hi, x;
+    if constexpr (ADD != 0) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lo) : "v"(w), "s"(C & 0xFFFFFFu), "v"(ADD));
+    else asm("v_mul_u32_u24 %0, %1, %2" : "=v"(lo) : "s"(C & 0xFFFFFFu), "v"(w));
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(hi) : "s"(C >> 24), "v"(w));
+    asm("v_lshl_add_u32 %0, %1, 24, %2" : "=v"(x) : "v"(hi), "v"(lo));
+    return x;
+}
+
+// decoded weights of the windows w0, w1 as a packed fp16 pair (w0 low)
+template <int CB> __device__ __forceinline__ uint32_t exl3_decode_pair(uint32_t w0, uint32_t w1) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    if constexpr (CB == 0 || CB == 1) {
+        const uint32_t x0 = (exl3_hash<CB>(w0) & 0x8fff8fffu) ^ 0x3b603b60u, x1 = (exl3_hash<CB>(w1) & 0x8fff8fffu) ^ 0x3b603b60u;
+        const uint32_t lo = __builtin_amdgcn_perm(x1, x0, 0x05040100u), hi = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, lo) + __builtin_bit_cast(h2, hi));
+    } else {
+        return (uint32_t)half_to_bits(exl3_decode<2>(w0)) | ((uint32_t)half_to_bits(exl3_decode<2>(w1)) << 16);
+    }
+}
+
+// HAD: a_had is the raw activation row block x [M][K] (fp16, or bf16 when x_bf16) and suh its sign/scale vector; the
+// workgroup transforms the KT/8 128-blocks of its slice itself (fp16(x) * suh -> 128-point Hadamard in f32 -> * 1/sqrt(128)
+// -> fp16, the arithmetic of exl3_had_f16_kernel), after the weight requests are out.  Meant for M <= 4 (decode): the
+// transform is repeated by every column group.
+template <int BITS, int CB, int KT, bool HAD>
 __global__ __launch_bounds__(256) void exl3_gemm_kernel(const uint16_t *__restrict__ trellis, const uint16_t *__restrict__ a_had,
-                                                         float *__restrict__ partial, int M, int N, int K) {
+                                                         const uint16_t *__restrict__ suh, int x_bf16, float *__restrict__ partial,
+                                                         int M, int N, int K) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int W = 8 * BITS;            // u32 words per tile
-    constexpr int KS = 4 * U * 32;         // k-values per workgroup
+    constexpr int TS = W + 4;              // LDS words per staged tile (W + 1 used)
+    constexpr int CT = 4, NCH = 4, KTC = KT / NCH;   // column tiles per workgroup, chunks, k-tiles per chunk
+    constexpr int RP = 8 * BITS;           // 16-byte pieces per k-tile row of the workgroup (CT * W / 4)
+    constexpr int PPC = KTC * RP;          // pieces per chunk
+    constexpr int LPT = (PPC + 255) / 256; // loads per thread per chunk
+    constexpr int KS = KT * 16;            // k-values per workgroup
     constexpr int XROW = KS + 8;
-    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                       // [M][XROW] fp16
-    float *red = reinterpret_cast<float *>(smem + (size_t)M * XROW * 2);     // [4][64][4]
+    constexpr int XCH = 2;
+    uint32_t *tb = reinterpret_cast<uint32_t *>(smem);                              // [KT][CT][TS]
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem + (size_t)KT * CT * TS * 4);   // [M][XROW] fp16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tn = N / 16, steps = K / 32;
-    const int nt = blockIdx.x % tn, ks = blockIdx.x / tn;
-    const int step0 = ks * 4 * U;
-    const int k0 = step0 * 32;
+    const int tn = N / 16, ktiles = K / 16, ncg = tn / CT;
+    const int cg = blockIdx.x % ncg, ks = blockIdx.x / ncg;
+    const int kt0 = ks * KT, nt0 = cg * CT, k0 = kt0 * 16;
     const int n = lane & 15, g = lane >> 4;
 
-    // activations first (L2), then the tiles' words: lane = word index
+    // activations first (L2 hits), then every weight piece of the slice
     constexpr int CPR = KS / 8;
     const int total = M * CPR;
-    uint4 xv[4];
+    uint4 xv[XCH];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < XCH; j++) {
         const int c = tid + 256 * j;
         xv[j] = make_uint4(0, 0, 0, 0);
-        if (c < total) {
+        if (!HAD && c < total) {
             const int m = c / CPR, k = k0 + (c % CPR) * 8;
             if (k < K) xv[j] = *reinterpret_cast<const uint4 *>(a_had + (int64_t)m * K + k);
         }
     }
-    uint32_t wa[U], wb[U];
+    uint4 wr[NCH][LPT];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int st = step0 + wave * U + u;
-        wa[u] = wb[u] = 0;
-        if (st < steps && lane < W) {
-            wa[u] = reinterpret_cast<const uint32_t *>(trellis + ((int64_t)(2 * st) * tn + nt) * 16 * BITS)[lane];
-            wb[u] = reinterpret_cast<const uint32_t *>(trellis + ((int64_t)(2 * st + 1) * tn + nt) * 16 * BITS)[lane];
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int j = 0; j < LPT; j++) {
+            const int p = tid + 256 * j, kt = kt0 + c * KTC + p / RP;
+            wr[c][j] = make_uint4(0, 0, 0, 0);
+            if (p < PPC && kt < ktiles)
+                wr[c][j] = *reinterpret_cast<const uint4 *>(trellis + ((int64_t)kt * tn + nt0) * 16 * BITS + (p % RP) * 8);
+        }
+    if constexpr (HAD) {
+        constexpr int NB = KT / 8;   // 128-blocks of the slice
+        for (int it = wave; it < M * NB; it += 4) {
+            const int m = it / NB, kb = k0 + (it % NB) * 128;
+            uint32_t o = 0;
+            if (kb < K) {
+                const uint32_t in = *reinterpret_cast<const uint32_t *>(a_had + (int64_t)m * K + kb + 2 * lane);
+                const uint32_t sc = suh ? *reinterpret_cast<const uint32_t *>(suh + kb + 2 * lane) : 0x3c003c00u;
+                half_t a, b;
+                if (x_bf16) { a = (half_t)__uint_as_float(in << 16); b = (half_t)__uint_as_float(in & 0xffff0000u); }
+                else { a = bits_to_half(in & 0xffffu); b = bits_to_half(in >> 16); }
+                if (suh) { a = a * bits_to_half(sc & 0xffffu); b = b * bits_to_half(sc >> 16); }
+                float e0 = (float)a, e1 = (float)b;
+                had128_wave(e0, e1, lane);
+                o = (uint32_t)half_to_bits((half_t)(e0 * R_SCALE)) | ((uint32_t)half_to_bits((half_t)(e1 * R_SCALE)) << 16);
+            }
+            *reinterpret_cast<uint32_t *>(xs + m * XROW + (it % NB) * 128 + 2 * lane) = o;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < XCH; j++) {
+            const int c = tid + 256 * j;
+            if (c < total) *reinterpret_cast<uint4 *>(xs + (c / CPR) * XROW + (c % CPR) * 8) = xv[j];
+        }
+        for (int c = XCH * 256 + tid; c < total; c += 256) {
+            const int m = c / CPR, k = k0 + (c % CPR) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (k < K) v = *reinterpret_cast<const uint4 *>(a_had + (int64_t)m * K + k);
+            *reinterpret_cast<uint4 *>(xs + m * XROW + (c % CPR) * 8) = v;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int c = tid + 256 * j;
-        if (c < total) *reinterpret_cast<uint4 *>(xs + (c / CPR) * XROW + (c % CPR) * 8) = xv[j];
-    }
-    for (int c = 1024 + tid; c < total; c += 256) {
-        const int m = c / CPR, k = k0 + (c % CPR) * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (k < K) v = *reinterpret_cast<const uint4 *>(a_had + (int64_t)m * K + k);
-        *reinterpret_cast<uint4 *>(xs + m * XROW + (c % CPR) * 8) = v;
-    }
-    __syncthreads();
 
-    // this lane's weights: column n, rows 8*(g&1) .. +7 of tile (g>>1): t = t_base + 8q + {0,1}, q = 0..3
+    // this lane's weights: column n, rows 8*(g&1) .. +7 of k-tile (g>>1) of a step: t = t_base + 8q + {0,1}, q = 0..3.
+    // The pair's bits end at stream bit (t+258)*BITS (cyclic); slot = reversed index of the word holding the last bit.
     const int c2 = (n & 7) >> 1, h2 = n & 1, hb = g & 1;
     const int t_base = 64 * c2 + 32 * h2 + 4 * (n >> 3) + 2 * hb;
+    int slot[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b2 = (t_base + 8 * q + 258) * BITS;
+        const int em = (b2 - 1) % (256 * BITS) + 1;   // end of the pair's bits, in (0, 256*BITS]
+        const int i1 = (em - 1) >> 5;
+        slot[q] = W - 1 - i1;
+        sh[q] = (i1 + 1) * 32 - em;
+    }
     const uint16_t *xrow = xs + min(n, M - 1) * XROW + 8 * g;
     vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int st = step0 + wave * U + u;
-        if (st < steps) {  // wave-uniform
-            const uint32_t src = (g >> 1) ? wb[u] : wa[u];  // every lane evaluates both permutes' sources below
-            f16x8_t bf;
+    for (int c = 0; c < NCH; c++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int t = t_base + 8 * q;
-                // windows of t and t+1 share the words that hold stream bits [(t+257)*BITS - 16, (t+258)*BITS)
-                const int b2 = (t + 258) * BITS, b0 = (t + 257) * BITS - 16;
-                const int i0 = (b0 >> 5) % W, i2 = ((b2 - 1) >> 5) % W;
-                // words come from the lanes that loaded them; tile A's words live in wa, tile B's in wb
-                const uint32_t a_a = __shfl(wa[u], i0, 64), a_b = __shfl(wb[u], i0, 64);
-                const uint32_t b_a = __shfl(wa[u], i2, 64), b_b = __shfl(wb[u], i2, 64);
-                const uint32_t a = (g >> 1) ? a_b : a_a, b = (g >> 1) ? b_b : b_a;
-                const uint64_t merged = ((uint64_t)a << 32) | b;
-                const int s2 = (((b2 - 1) >> 5) + 1) * 32 - b2;
-                const uint32_t w1 = (uint32_t)(merged >> s2) & 0xffffu;
-                const uint32_t w0 = (uint32_t)(merged >> (s2 + BITS)) & 0xffffu;
-                bf[2 * q] = exl3_decode<CB>(w0);
-                bf[2 * q + 1] = exl3_decode<CB>(w1);
+        for (int j = 0; j < LPT; j++) {
+            const int p = tid + 256 * j;
+            if (p < PPC) {
+                const int r = p % RP, tile = r / (2 * BITS), i = (r % (2 * BITS)) * 4;   // stream words i..i+3 of the tile
+                uint32_t *dst = tb + ((c * KTC + p / RP) * CT + tile) * TS;
+                *reinterpret_cast<uint4 *>(dst + (W - 4 - i)) = make_uint4(wr[c][j].w, wr[c][j].z, wr[c][j].y, wr[c][j].x);
+                if (i == W - 4) dst[W] = wr[c][j].w;
             }
-            (void)src;
-            const uint4 au = *reinterpret_cast<const uint4 *>(xrow + (wave * U + u) * 32);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, au), bf, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        for (int s = 0; s < KTC / 2; s++) {
+            const int kt = c * KTC + 2 * s;   // first k-tile of the step inside the slice
+            if (kt0 + kt < ktiles) {          // wave-uniform; K % 32 == 0, so a step is all in or all out
+                const uint32_t *tile = tb + ((kt + (g >> 1)) * CT + wave) * TS;
+                uint4 bw;
+                uint32_t *bwp = reinterpret_cast<uint32_t *>(&bw);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t lo = tile[slot[q]], hi = tile[slot[q] + 1];
+                    const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, sh[q]);
+                    bwp[q] = exl3_decode_pair<CB>((v >> BITS) & 0xffffu, v & 0xffffu);
+                }
+                const uint4 au = *reinterpret_cast<const uint4 *>(xrow + kt * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, au), __builtin_bit_cast(f16x8_t, bw), acc, 0, 0, 0);
+            }
         }
     }
-    *reinterpret_cast<float4 *>(red + (wave * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    __syncthreads();
-    if (wave == 0) {
-        float4 s = *reinterpret_cast<const float4 *>(red + lane * 4);
 #pragma unroll
-        for (int wv = 1; wv < 4; wv++) {
-            const float4 b = *reinterpret_cast<const float4 *>(red + (wv * 64 + lane) * 4);
-            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-        }
-        const float o4[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int mrow = 4 * g + r;
-            if (mrow < M) partial[((int64_t)ks * M + mrow) * N + nt * 16 + n] = o4[r];
-        }
+    for (int r = 0; r < 4; r++) {
+        const int mrow = 4 * g + r;
+        if (mrow < M) partial[((int64_t)ks * M + mrow) * N + (nt0 + wave) * 16 + n] = acc[r];
     }
 }
 
-constexpr int EXL3_U = 4;
-inline int exl3_splits(int K) { return (K / 32 + 4 * EXL3_U - 1) / (4 * EXL3_U); }
+// k-tiles per workgroup: long slices (the whole matrix in ~32 KiB work items) when that still gives every CU a few
+// workgroups, short ones for narrow outputs.  Higher bit widths halve the slice to keep the staged bytes equal.
+struct Exl3Plan { int kt, splits; };
+inline Exl3Plan exl3_plan(int N, int K, int bits) {
+    const int ktiles = K / 16, kt_long = bits <= 4 ? 64 : 32;
+    Exl3Plan p;
+    p.kt = ((int64_t)(N / 64) * ((ktiles + kt_long - 1) / kt_long) >= 512) ? kt_long : 16;
+    p.splits = (ktiles + p.kt - 1) / p.kt;
+    return p;
+}
 
-template <int BITS>
-int launch_exl3_gemm(int cb, const uint16_t *trellis, const uint16_t *a_had, float *partial, int M, int N, int K, hipStream_t st) {
-    const size_t lds = (size_t)M * (4 * EXL3_U * 32 + 8) * 2 + 4 * 64 * 4 * 4;
-    const dim3 grid((unsigned)((N / 16) * exl3_splits(K))), block(256);
-    switch (cb) {
-        case 0: hipLaunchKernelGGL((exl3_gemm_kernel<BITS, 0, EXL3_U>), grid, block, lds, st, trellis, a_had, partial, M, N, K); break;
-        case 1: hipLaunchKernelGGL((exl3_gemm_kernel<BITS, 1, EXL3_U>), grid, block, lds, st, trellis, a_had, partial, M, N, K); break;
-        default: hipLaunchKernelGGL((exl3_gemm_kernel<BITS, 2, EXL3_U>), grid, block, lds, st, trellis, a_had, partial, M, N, K); break;
-    }
+template <int BITS, int CB, int KT>
+int launch_exl3_gemm_kt(const uint16_t *trellis, const uint16_t *a, const uint16_t *suh, int fuse_had, int x_bf16, float *partial, int M,
+                        int N, int K, int splits, hipStream_t st) {
+    const size_t lds = (size_t)KT * 4 * (8 * BITS + 4) * 4 + (size_t)M * (KT * 16 + 8) * 2;
+    const dim3 grid((unsigned)((N / 64) * splits));
+#define EXL3_GO(H)                                                                                                                       \
+    do {                                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                                             \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)exl3_gemm_kernel<BITS, CB, KT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              (int)lds));                                                                                \
+        hipLaunchKernelGGL((exl3_gemm_kernel<BITS, CB, KT, H>), grid, dim3(256), lds, st, trellis, a, suh, x_bf16, partial, M, N, K);     \
+    } while (0)
+    if (fuse_had) EXL3_GO(true);
+    else EXL3_GO(false);
+#undef EXL3_GO
     VMX_CHECK_LAUNCH("exl3_gemm");
     return VMX_OK;
+}
+
+// a: Hadamard-transformed fp16 activations (fuse_had == 0) or the raw activations (fuse_had != 0, M <= 4)
+template <int BITS>
+int launch_exl3_gemm(int cb, const uint16_t *trellis, const uint16_t *a, const uint16_t *suh, int fuse_had, int x_bf16, float *partial,
+                     int M, int N, int K, hipStream_t st) {
+    constexpr int KL = BITS <= 4 ? 64 : 32;
+    const Exl3Plan p = exl3_plan(N, K, BITS);
+#define EXL3_L(CBV)                                                                                                                \
+    return p.kt == 16 ? launch_exl3_gemm_kt<BITS, CBV, 16>(trellis, a, suh, fuse_had, x_bf16, partial, M, N, K, p.splits, st)      \
+                      : launch_exl3_gemm_kt<BITS, CBV, KL>(trellis, a, suh, fuse_had, x_bf16, partial, M, N, K, p.splits, st)
+    switch (cb) {
+        case 0: EXL3_L(0);
+        case 1: EXL3_L(1);
+        default: EXL3_L(2);
+    }
+#undef EXL3_L
+}
+
+int exl3_gemm_dispatch(int bits, int cb, const uint16_t *tr, const uint16_t *a, const uint16_t *suh, int fuse_had, int x_bf16,
+                       float *partial, int M, int N, int K, hipStream_t st) {
+    switch (bits) {
+        case 1: return launch_exl3_gemm<1>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+        case 2: return launch_exl3_gemm<2>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+        case 3: return launch_exl3_gemm<3>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+        case 4: return launch_exl3_gemm<4>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+        case 5: return launch_exl3_gemm<5>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+        case 6: return launch_exl3_gemm<6>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+        case 7: return launch_exl3_gemm<7>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+        default: return launch_exl3_gemm<8>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
+    }
 }
 
 }  // namespace
@@ -269,7 +384,8 @@ extern "C" int vmx_exl3_had_r_128_f16(uint16_t *y, const uint16_t *x, const uint
 extern "C" size_t vmx_exl3_gemm_workspace_bytes(int M, int K, int N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
     const size_t mc = M < 16 ? M : 16;
-    return ((mc * K * 2 + 255) & ~(size_t)255) + (size_t)exl3_splits(K) * mc * N * 4;
+    const size_t splits = (size_t)((K / 16 + 15) / 16);   // the plan depends on the bit width: sized for the shortest slice (16 k-tiles)
+    return ((mc * K * 2 + 255) & ~(size_t)255) + splits * mc * N * 4;
 }
 
 extern "C" int vmx_exl3_gemm_f16(uint16_t *y, const uint16_t *x, const void *trellis, const uint16_t *suh, const uint16_t *svh, int M,
@@ -284,26 +400,20 @@ extern "C" int vmx_exl3_gemm_f16(uint16_t *y, const uint16_t *x, const void *tre
     const int mc = M < 16 ? M : 16;
     uint16_t *a_had = (uint16_t *)workspace;
     float *partial = (float *)((char *)workspace + (((size_t)mc * K * 2 + 255) & ~(size_t)255));
-    const int splits = exl3_splits(K);
+    const int splits = exl3_plan(N, K, bits).splits;
+    const uint16_t *tr = (const uint16_t *)trellis;
     for (int m0 = 0; m0 < M; m0 += 16) {
         const int mm = M - m0 < 16 ? M - m0 : 16;
-        hipLaunchKernelGGL(exl3_had_f16_kernel, dim3(K / 128, mm), dim3(64), 0, st, x + (int64_t)m0 * K, suh, a_had, K, suh ? 1 : 0);
-        VMX_CHECK_LAUNCH("exl3_gemm(input hadamard)");
-        int rc;
-        const uint16_t *tr = (const uint16_t *)trellis;
-        switch (bits) {
-            case 1: rc = launch_exl3_gemm<1>(codebook, tr, a_had, partial, mm, N, K, st); break;
-            case 2: rc = launch_exl3_gemm<2>(codebook, tr, a_had, partial, mm, N, K, st); break;
-            case 3: rc = launch_exl3_gemm<3>(codebook, tr, a_had, partial, mm, N, K, st); break;
-            case 4: rc = launch_exl3_gemm<4>(codebook, tr, a_had, partial, mm, N, K, st); break;
-            case 5: rc = launch_exl3_gemm<5>(codebook, tr, a_had, partial, mm, N, K, st); break;
-            case 6: rc = launch_exl3_gemm<6>(codebook, tr, a_had, partial, mm, N, K, st); break;
-            case 7: rc = launch_exl3_gemm<7>(codebook, tr, a_had, partial, mm, N, K, st); break;
-            default: rc = launch_exl3_gemm<8>(codebook, tr, a_had, partial, mm, N, K, st); break;
+        const uint16_t *xc = x + (int64_t)m0 * K;
+        if (mm <= 4) {   // decode: the input transform runs inside the GEMM workgroups
+            if (int rc = exl3_gemm_dispatch(bits, codebook, tr, xc, suh, 1, 0, partial, mm, N, K, st)) return rc;
+        } else {
+            hipLaunchKernelGGL(exl3_had_f16_kernel, dim3(K / 128, mm), dim3(64), 0, st, xc, suh, a_had, K, suh ? 1 : 0);
+            VMX_CHECK_LAUNCH("exl3_gemm(input hadamard)");
+            if (int rc = exl3_gemm_dispatch(bits, codebook, tr, a_had, nullptr, 0, 0, partial, mm, N, K, st)) return rc;
         }
-        if (rc) return rc;
         hipLaunchKernelGGL(exl3_out_had_kernel, dim3(N / 128, mm), dim3(64), 0, st, partial, splits, (int64_t)mm * N, svh,
-                           y + (int64_t)m0 * N, N);
+                           y + (int64_t)m0 * N, N, (float *)nullptr, 0);
         VMX_CHECK_LAUNCH("exl3_gemm(output hadamard)");
     }
     return VMX_OK;
