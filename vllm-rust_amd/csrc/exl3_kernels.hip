@@ -203,33 +203,44 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(const uint16_t *__restri
             if (k < K) xv[j] = *reinterpret_cast<const uint4 *>(a_had + (int64_t)m * K + k);
         }
     }
+    // fused input transform: this wave's (row, 128-block) items, requested ahead of the weights (loads retire in issue order)
+    constexpr int NB = KT / 8;   // 128-blocks of the slice
+    uint32_t hin[NB], hsc[NB];   // M <= 4: at most NB items per wave
+    if constexpr (HAD) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int it = min(wave + 4 * i, M * NB - 1), m = it / NB, kb = min(k0 + (it % NB) * 128, K - 128);
+            hin[i] = *reinterpret_cast<const uint32_t *>(a_had + (int64_t)m * K + kb + 2 * lane);
+            hsc[i] = suh ? *reinterpret_cast<const uint32_t *>(suh + kb + 2 * lane) : 0x3c003c00u;
+        }
+    }
     uint4 wr[NCH][LPT];
 #pragma unroll
     for (int c = 0; c < NCH; c++)
 #pragma unroll
         for (int j = 0; j < LPT; j++) {
-            const int p = tid + 256 * j, kt = kt0 + c * KTC + p / RP;
-            wr[c][j] = make_uint4(0, 0, 0, 0);
-            if (p < PPC && kt < ktiles)
-                wr[c][j] = *reinterpret_cast<const uint4 *>(trellis + ((int64_t)kt * tn + nt0) * 16 * BITS + (p % RP) * 8);
+            // branch-free (a conditional load makes the compiler drain the queue at every join): out-of-range pieces re-read
+            // the last valid one and are never staged or decoded
+            const int p = min(tid + 256 * j, PPC - 1), kt = min(kt0 + c * KTC + p / RP, ktiles - 1);
+            wr[c][j] = *reinterpret_cast<const uint4 *>(trellis + ((int64_t)kt * tn + nt0) * 16 * BITS + (p % RP) * 8);
         }
     if constexpr (HAD) {
-        constexpr int NB = KT / 8;   // 128-blocks of the slice
-        for (int it = wave; it < M * NB; it += 4) {
-            const int m = it / NB, kb = k0 + (it % NB) * 128;
-            uint32_t o = 0;
-            if (kb < K) {
-                const uint32_t in = *reinterpret_cast<const uint32_t *>(a_had + (int64_t)m * K + kb + 2 * lane);
-                const uint32_t sc = suh ? *reinterpret_cast<const uint32_t *>(suh + kb + 2 * lane) : 0x3c003c00u;
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int it = wave + 4 * i;
+            if (it < M * NB) {   // wave-uniform
+                const int m = it / NB, kb = k0 + (it % NB) * 128;
+                const uint32_t in = hin[i], sc = hsc[i];
                 half_t a, b;
                 if (x_bf16) { a = (half_t)__uint_as_float(in << 16); b = (half_t)__uint_as_float(in & 0xffff0000u); }
                 else { a = bits_to_half(in & 0xffffu); b = bits_to_half(in >> 16); }
                 if (suh) { a = a * bits_to_half(sc & 0xffffu); b = b * bits_to_half(sc >> 16); }
                 float e0 = (float)a, e1 = (float)b;
                 had128_wave(e0, e1, lane);
-                o = (uint32_t)half_to_bits((half_t)(e0 * R_SCALE)) | ((uint32_t)half_to_bits((half_t)(e1 * R_SCALE)) << 16);
+                uint32_t o = (uint32_t)half_to_bits((half_t)(e0 * R_SCALE)) | ((uint32_t)half_to_bits((half_t)(e1 * R_SCALE)) << 16);
+                if (kb >= K) o = 0;
+                *reinterpret_cast<uint32_t *>(xs + m * XROW + (it % NB) * 128 + 2 * lane) = o;
             }
-            *reinterpret_cast<uint32_t *>(xs + m * XROW + (it % NB) * 128 + 2 * lane) = o;
         }
     } else {
 #pragma unroll
@@ -297,11 +308,11 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(const uint16_t *__restri
     }
 }
 
-// k-tiles per workgroup: long slices (the whole matrix in ~32 KiB work items) when that still gives every CU a few
-// workgroups, short ones for narrow outputs.  Higher bit widths halve the slice to keep the staged bytes equal.
+// k-tiles per workgroup: 32 when that still gives every CU a few workgroups, 16 for narrow outputs.
 struct Exl3Plan { int kt, splits; };
 inline Exl3Plan exl3_plan(int N, int K, int bits) {
-    const int ktiles = K / 16, kt_long = bits <= 4 ? 64 : 32;
+    (void)bits;
+    const int ktiles = K / 16, kt_long = 32;   // measured on 4096x12288 at 4 bpw: 32 k-tiles (16 KiB work items) beat 64 and 16
     Exl3Plan p;
     p.kt = ((int64_t)(N / 64) * ((ktiles + kt_long - 1) / kt_long) >= 512) ? kt_long : 16;
     p.splits = (ktiles + p.kt - 1) / p.kt;
@@ -331,11 +342,10 @@ int launch_exl3_gemm_kt(const uint16_t *trellis, const uint16_t *a, const uint16
 template <int BITS>
 int launch_exl3_gemm(int cb, const uint16_t *trellis, const uint16_t *a, const uint16_t *suh, int fuse_had, int x_bf16, float *partial,
                      int M, int N, int K, hipStream_t st) {
-    constexpr int KL = BITS <= 4 ? 64 : 32;
     const Exl3Plan p = exl3_plan(N, K, BITS);
 #define EXL3_L(CBV)                                                                                                                \
     return p.kt == 16 ? launch_exl3_gemm_kt<BITS, CBV, 16>(trellis, a, suh, fuse_had, x_bf16, partial, M, N, K, p.splits, st)      \
-                      : launch_exl3_gemm_kt<BITS, CBV, KL>(trellis, a, suh, fuse_had, x_bf16, partial, M, N, K, p.splits, st)
+                      : launch_exl3_gemm_kt<BITS, CBV, 32>(trellis, a, suh, fuse_had, x_bf16, partial, M, N, K, p.splits, st)
     switch (cb) {
         case 0: EXL3_L(0);
         case 1: EXL3_L(1);
