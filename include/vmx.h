@@ -383,6 +383,14 @@ int vmx_qwen3_load_gptq_expert(vmx_qwen3 *m, int layer, int expert, const uint32
 int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int ggml_type, const void *blocks, size_t bytes,
                              void *stream);
 
+/* Load one projection as an EXL3 trellis-coded tensor (Exl3Linear, crates/core/src/quantization/exl3.rs:204-286;
+ * Exl3WeightLoader::load_linear, weight_loader.rs:469-559): trellis i16 [in/16][out/16][16*bits] and the fp16 vectors
+ * suh [in], svh [out] as the checkpoint stores them; codebook 0 default, 1 mcg, 2 mul1.  When all seven projections of a
+ * layer were loaded this way the layer runs y = bf16(had(had(fp16(x) * suh) @ W) * svh) per projection (activations cast
+ * to fp16 for the linear and back, exl3.rs:222-228,272-277). */
+int vmx_qwen3_load_exl3_linear(vmx_qwen3 *m, int layer, int slot, const void *trellis, const uint16_t *suh, const uint16_t *svh,
+                               int in_features, int out_features, int bits, int codebook, void *stream);
+
 /* One decode step: input_ids/positions/slot_mapping/seq_lens i32 [batch], block_tables i32
  * [batch, max_blocks_per_seq] (all device).  Writes greedy token ids to out_ids (device i32 [batch],
  * may be NULL) and, if logits_out != NULL, bf16 logits [batch, vocab] there. */

@@ -29,8 +29,15 @@ class OracleQwen3:
         s = spec
         self.lin = {}
         self.iq = {}
+        self.ex = {}
         for li in range(s.num_layers):
             for slot in range(7):
+                if f"{li}.{slot}.exl3" in ck:
+                    import torch
+                    bits, cb, tr, suh, svh = ck[f"{li}.{slot}.exl3"]
+                    self.ex[(li, slot)] = (bits, cb, tr.numpy().view(np.uint16).reshape(-1), tr.shape[0] * 16, tr.shape[1] * 16,
+                                           suh.view(torch.int16).numpy().view(np.uint16), svh.view(torch.int16).numpy().view(np.uint16))
+                    continue
                 if f"{li}.{slot}.iq" in ck:
                     t, raw = ck[f"{li}.{slot}.iq"]
                     self.iq[(li, slot)] = (t, raw.numpy())
@@ -50,6 +57,10 @@ class OracleQwen3:
         self.kv_scales = (1.0, 1.0)
 
     def linear(self, li, slot, x_u16):
+        if (li, slot) in self.ex:   # Exl3Linear::forward (exl3.rs:216-286): cast to fp16, exl3_gemm, cast back to bf16
+            bits, cb, tr, K, N, suh, svh = self.ex[(li, slot)]
+            x16 = orc.f32_to_f16(orc.bf16_to_f32(x_u16))
+            return orc.f32_to_bf16(orc.f16_to_f32(orc.exl3_gemm(x16, tr, suh, svh, K, N, bits, cb)))
         if (li, slot) in self.iq:   # IqLinear::forward_inner (gguf/mod.rs:329-377): f32 cast, q8_1 MMVQ, cast back
             t, raw = self.iq[(li, slot)]
             x = orc.bf16_to_f32(x_u16)

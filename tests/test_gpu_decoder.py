@@ -232,6 +232,35 @@ def test_iq_decoder_matches_oracle(gpu, kv_dtype):
     model.close()
 
 
+@pytest.mark.parametrize("bits,cb", [(4, 0), (3, 1)])
+def test_exl3_decoder_matches_oracle(gpu, bits, cb):
+    """Every projection an EXL3 trellis-coded linear (bf16 model: activations cast to fp16 for the linear and back)."""
+    from oracle import oracle as orc
+    from tests.model_oracle import OracleQwen3
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache
+    vmx, torch = gpu
+    spec = _tiny_spec(hidden_size=256, intermediate_size=512)
+    model = QuantizedQwen3ForCausalLM(spec)
+    ck = model.load_synthetic_exl3(bits=bits, codebook=cb, seed=6, keep_host_copy=True)
+    ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta))
+    B, MB = 2, 8
+    bt = np.arange(B * MB, dtype=np.int32).reshape(B, MB)
+    ids = np.array([5, 731], np.int32)
+    for step in range(4):
+        pos = np.full(B, step, np.int32)
+        slots = (bt[:, 0] * spec.block_size + pos).astype(np.int32)
+        sl = pos + 1
+        logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        out = model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, pos, slots, bt, sl)), logits=logits)
+        torch.cuda.synchronize()
+        exp, exp_h, _ = ref.decode(ids, pos, slots, bt, sl)
+        got = orc.bf16_to_f32(_u16(torch, logits)); exp = orc.bf16_to_f32(exp)
+        rel = np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum())
+        assert rel <= 3e-2, (step, rel)
+        ids = out.cpu().numpy().astype(np.int32)
+    model.close()
+
+
 def test_prefill_forward_equals_token_by_token_decode(gpu):
     """forward() over a prompt (chunks of max_batch pseudo-sequences) must give the logits of feeding the same
     tokens one at a time: rows of the small-M linears and the per-sequence attention are independent."""

@@ -292,6 +292,14 @@ struct IqLinear {
     bool loaded = false;
 };
 
+// Mirrors Exl3Linear (crates/core/src/quantization/exl3.rs:204-286): trellis i16 [K/16][N/16][16*bits] as the checkpoint
+// stores it, fp16 sign/scale vectors suh [K] and svh [N], codebook 0 default / 1 mcg / 2 mul1.
+struct Exl3Lin {
+    int in_features = 0, out_features = 0, bits = 0, codebook = 0;
+    DevBuf trellis, suh, svh;
+    bool loaded = false;
+};
+
 // Merged GPTQ-sequential staging of several AWQ linears that share the input (q|k|v, gate|up).
 struct MergeStage {
     DevBuf qweight, qzeros, scales;
@@ -302,6 +310,8 @@ struct Layer {
     Int4Linear qkv, o, gate_up, down;
     IqLinear iq[7];  // q, k, v, o, gate, up, down as GGUF I-quants (alternative to the int4 linears)
     bool iq_ready() const { for (const IqLinear &l : iq) if (!l.loaded) return false; return true; }
+    Exl3Lin ex[7];   // ... or as EXL3 trellis-coded linears
+    bool exl3_ready() const { for (const Exl3Lin &l : ex) if (!l.loaded) return false; return true; }
     bool int4_ready() const { return qkv.loaded && o.loaded && gate_up.loaded && down.loaded; }
     bool int4_attn_ready() const { return qkv.loaded && o.loaded; }
     MergeStage qkv_stage, gu_stage;
@@ -323,6 +333,7 @@ struct vmx_qwen3 {
     bool lm_head_tied = false;
     DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8, positions;
     DevBuf router_logits, topk_w, topk_ids, moe_ws, moe_out;   // MoE models only
+    DevBuf exl3_ws;                                            // EXL3 models only: grown by the loader
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
@@ -361,6 +372,13 @@ int iq_forward(vmx_qwen3 *m, const IqLinear &l, float *y, int ldy, int tokens, h
             return rc;
     }
     return VMX_OK;
+}
+
+// Exl3Linear::forward on the rows of a bf16 activation tensor; the result (fp16 cast back to bf16, exl3.rs:272-277) lands
+// as f32 in y[row * ldy + col], the form the vector kernels take with splits == 1.
+int exl3_forward(vmx_qwen3 *m, const Exl3Lin &l, const uint16_t *x, float *y, int ldy, int tokens, hipStream_t st) {
+    return vmx_exl3_forward_f32(x, 1, l.trellis.p, (const uint16_t *)l.suh.p, (const uint16_t *)l.svh.p, y, ldy, tokens, l.in_features,
+                                l.out_features, l.bits, l.codebook, m->exl3_ws.p, m->exl3_ws.bytes, st);
 }
 
 // Row-parallel epilogue: red_bf16 = all_reduce_sum(bf16(sum of this rank's split-K slices)) — what composing the
@@ -536,6 +554,8 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         for (DevBuf &b : L.w13) b.release();
         for (DevBuf &b : L.w2) b.release();
         for (DevBuf *b : {&L.router, &L.w13_table, &L.w2_table}) b->release();
+        for (Exl3Lin &e : L.ex)
+            for (DevBuf *b : {&e.trellis, &e.suh, &e.svh}) b->release();
         for (DevBuf *b : {&L.qkv.packed, &L.o.packed, &L.gate_up.packed, &L.down.packed, &L.input_ln, &L.post_ln, &L.q_norm, &L.k_norm,
                           &L.k_cache, &L.v_cache, &L.kv_scales})
             b->release();
@@ -544,7 +564,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
     }
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
                       &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8, &m->positions, &m->router_logits, &m->topk_w, &m->topk_ids,
-                      &m->moe_ws, &m->moe_out})
+                      &m->moe_ws, &m->moe_out, &m->exl3_ws})
         b->release();
     delete m;
 }
@@ -699,6 +719,45 @@ extern "C" int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int g
     return VMX_OK;
 }
 
+extern "C" int vmx_qwen3_load_exl3_linear(vmx_qwen3 *m, int layer, int slot, const void *trellis, const uint16_t *suh,
+                                          const uint16_t *svh, int in_features, int out_features, int bits, int codebook, void *stream) {
+    VMX_REQUIRE(m && trellis && suh && svh, "qwen3_load_exl3_linear: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && slot >= VMX_L_Q && slot <= VMX_L_DOWN,
+                "qwen3_load_exl3_linear: layer %d / slot %d out of range", layer, slot);
+    VMX_REQUIRE(bits >= 1 && bits <= 8, "qwen3_load_exl3_linear: bits per weight (%d) must be in 1..8", bits);
+    VMX_REQUIRE(codebook >= 0 && codebook <= 2, "qwen3_load_exl3_linear: codebook %d unknown (0 default, 1 mcg, 2 mul1)", codebook);
+    const vmx_qwen3_config &c = m->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, NQ = c.num_heads * c.head_dim, NKV = c.num_kv_heads * c.head_dim;
+    const int in_f[7] = {H, H, H, NQ, H, H, I}, out_f[7] = {NQ, NKV, NKV, H, I, I, H};
+    const int K = in_f[slot], N = out_f[slot];
+    VMX_REQUIRE(in_features == K && out_features == N, "qwen3_load_exl3_linear: trellis is [%d -> %d], the model's projection is [%d -> %d]",
+                in_features, out_features, K, N);
+    VMX_REQUIRE(K % 128 == 0 && N % 128 == 0, "qwen3_load_exl3_linear: in_features (%d) and out_features (%d) must be multiples of 128", K, N);
+    hipStream_t st = vmx_stream(stream);
+    Exl3Lin &l = m->layers[layer].ex[slot];
+    for (DevBuf *b : {&l.trellis, &l.suh, &l.svh}) b->release();
+    const size_t tb = (size_t)(K / 16) * (N / 16) * 16 * bits * 2;
+    if (int rc = l.trellis.alloc(tb)) return rc;
+    if (int rc = l.suh.alloc((size_t)K * 2)) return rc;
+    if (int rc = l.svh.alloc((size_t)N * 2)) return rc;
+    VMX_CHECK_HIP(hipMemcpyAsync(l.trellis.p, trellis, tb, hipMemcpyDefault, st));
+    VMX_CHECK_HIP(hipMemcpyAsync(l.suh.p, suh, (size_t)K * 2, hipMemcpyDefault, st));
+    VMX_CHECK_HIP(hipMemcpyAsync(l.svh.p, svh, (size_t)N * 2, hipMemcpyDefault, st));
+    const int rows = c.max_batch > c.max_prefill_tokens ? c.max_batch : c.max_prefill_tokens;
+    const size_t need = vmx_exl3_gemm_workspace_bytes(rows, K, N);
+    if (need > m->exl3_ws.bytes) {   // load time: no step is in flight
+        VMX_CHECK_HIP(hipStreamSynchronize(st));
+        m->exl3_ws.release();
+        if (int rc = m->exl3_ws.alloc(need)) return rc;
+    }
+    l.in_features = K;
+    l.out_features = N;
+    l.bits = bits;
+    l.codebook = codebook;
+    l.loaded = true;
+    return VMX_OK;
+}
+
 namespace {
 __global__ void iota_positions_kernel(int32_t *pos, int offset, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -728,13 +787,19 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     const int NQ = Hq * hd, NKV = Hkv * hd;
     for (const Layer &L : m->layers) {
         const bool moe = c.num_experts > 0;  // int4 attention projections + mixture-of-experts MLP
-        const bool iq = !moe && !L.int4_ready();  // GGUF I-quant layer: every projection is an IqLinear
-        const int s_qkv = iq ? 1 : L.qkv.splits(), s_o = iq ? 1 : L.o.splits(), s_gu = iq ? 1 : L.gate_up.splits(),
-                  s_down = iq ? 1 : L.down.splits();
+        const bool ex = !moe && !L.int4_ready() && L.exl3_ready();   // EXL3 layer: every projection an Exl3Linear
+        const bool iq = !moe && !L.int4_ready() && !ex;              // GGUF I-quant layer: every projection is an IqLinear
+        const bool one = iq || ex;                                   // linear outputs arrive as one f32 slice
+        const int s_qkv = one ? 1 : L.qkv.splits(), s_o = one ? 1 : L.o.splits(), s_gu = one ? 1 : L.gate_up.splits(),
+                  s_down = one ? 1 : L.down.splits();
         // h += pending; x = rms_norm(h);  q|k|v = linear(x)
         launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
                           iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr);
-        if (iq) {
+        if (ex) {
+            if (int rc = exl3_forward(m, L.ex[VMX_L_Q], x, PA, NQKV_, B, st)) return rc;
+            if (int rc = exl3_forward(m, L.ex[VMX_L_K], x, PA + NQ, NQKV_, B, st)) return rc;
+            if (int rc = exl3_forward(m, L.ex[VMX_L_V], x, PA + NQ + NKV, NQKV_, B, st)) return rc;
+        } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_Q], PA, NQKV_, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_K], PA + NQ, NQKV_, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_V], PA + NQ + NKV, NQKV_, B, st)) return rc;
@@ -760,7 +825,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                                                    iq ? q8_ad(m, B, NQ) : nullptr))
                 return rc;
         }
-        if (iq) {
+        if (ex) {
+            if (int rc = exl3_forward(m, L.ex[VMX_L_O], attn, PB, H, B, st)) return rc;
+        } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_O], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
         // h += o; x = rms_norm(h);  gate|up = linear(x);  act = silu(gate) * up;  down = linear(act)
@@ -793,18 +860,23 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             pending_splits = -1;
             continue;
         }
-        if (iq) {
+        if (ex) {
+            if (int rc = exl3_forward(m, L.ex[VMX_L_GATE], x, PA, 2 * I, B, st)) return rc;
+            if (int rc = exl3_forward(m, L.ex[VMX_L_UP], x, PA + I, 2 * I, B, st)) return rc;
+        } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_GATE], PA, 2 * I, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_UP], PA + I, 2 * I, B, st)) return rc;
         } else if (L.gate_up.glu) {  // act comes out of the GEMM epilogue
             if (int rc = L.gate_up.forward_glu(x, act, B, st)) return rc;
         } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
-        if (iq || !L.gate_up.glu) {
+        if (one || !L.gate_up.glu) {
             int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
             hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA, s_gu, B, act, I,
                                iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr);
         }
-        if (iq) {
+        if (ex) {
+            if (int rc = exl3_forward(m, L.ex[VMX_L_DOWN], act, PB, H, B, st)) return rc;
+        } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_DOWN], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;
         pending = PB;
@@ -857,7 +929,7 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "qwen3_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
                 c.max_seq_len);
     for (const Layer &L : m->layers)
-        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_decode: weights not fully loaded");
+        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || L.exl3_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_decode: weights not fully loaded");
     const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
     VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
     if (int rc = run_layers(m, input_ids, positions, slot_mapping, block_tables, seq_lens, batch, max_blocks_per_seq, max_seq_len, -1,
@@ -878,7 +950,7 @@ extern "C" int vmx_qwen3_prefill(vmx_qwen3 *m, const int32_t *input_ids, int seq
     VMX_REQUIRE(seqlen_offset >= 0 && seqlen_offset + q_len <= c.max_position, "qwen3_prefill: positions %d..%d exceed max_position %d",
                 seqlen_offset, seqlen_offset + q_len - 1, c.max_position);
     for (const Layer &L : m->layers)
-        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_prefill: weights not fully loaded");
+        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || L.exl3_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_prefill: weights not fully loaded");
     const bool tp = c.tp_size > 1 || m->comm != nullptr;
     VMX_REQUIRE(!tp || m->comm, "qwen3_prefill: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
     hipStream_t st = vmx_stream(stream);

@@ -14,7 +14,7 @@
 // (lane (n, g) holds rows 8g..8g+7 of column n, i.e. four adjacent-t pairs), A = Hadamard-transformed activations
 // from LDS.  Accumulation is f32 and deterministic (the reference's stream-K chain rounds partial sums to fp16 in an
 // SM-count-dependent order); the output Hadamard runs on the f32 sums as in had_fh_r_128.
-#include "vmx_internal.h"
+#include "vmx_kernels.h"
 
 namespace {
 
@@ -85,12 +85,14 @@ __device__ __forceinline__ void had128_wave(float &e0, float &e1, int lane) {
 }
 
 // mode 0 none, 1 pre-scale (fp16 multiply before), 2 post-scale (fp16 multiply after rounding).  grid (cols/128, rows)
+// x_bf16: the input row is bf16 and is cast to fp16 first (Exl3Linear::forward on a bf16 model, exl3.rs:222-228)
 __global__ __launch_bounds__(64) void exl3_had_f16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ scale,
-                                                           uint16_t *__restrict__ y, int cols, int mode) {
+                                                           uint16_t *__restrict__ y, int cols, int mode, int x_bf16) {
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.y * cols + blockIdx.x * 128 + 2 * lane;
     const uint32_t in = *reinterpret_cast<const uint32_t *>(x + base);
     half_t a = bits_to_half(in & 0xffffu), b = bits_to_half(in >> 16);
+    if (x_bf16) { a = (half_t)__uint_as_float(in << 16); b = (half_t)__uint_as_float(in & 0xffff0000u); }
     uint32_t sc = 0;
     if (mode) sc = *reinterpret_cast<const uint32_t *>(scale + blockIdx.x * 128 + 2 * lane);
     if (mode == 1) { a = a * bits_to_half(sc & 0xffffu); b = b * bits_to_half(sc >> 16); }
@@ -386,7 +388,7 @@ extern "C" int vmx_exl3_had_r_128_f16(uint16_t *y, const uint16_t *x, const uint
     VMX_REQUIRE(cols > 0 && cols % 128 == 0, "had_r_128: cols (%d) must be a multiple of 128", cols);
     VMX_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || scale), "had_r_128: scaled modes need a scale vector");
     if (rows <= 0) return VMX_OK;
-    hipLaunchKernelGGL(exl3_had_f16_kernel, dim3(cols / 128, rows), dim3(64), 0, vmx_stream(stream), x, scale, y, cols, mode);
+    hipLaunchKernelGGL(exl3_had_f16_kernel, dim3(cols / 128, rows), dim3(64), 0, vmx_stream(stream), x, scale, y, cols, mode, 0);
     VMX_CHECK_LAUNCH("had_r_128");
     return VMX_OK;
 }
@@ -418,13 +420,40 @@ extern "C" int vmx_exl3_gemm_f16(uint16_t *y, const uint16_t *x, const void *tre
         if (mm <= 4) {   // decode: the input transform runs inside the GEMM workgroups
             if (int rc = exl3_gemm_dispatch(bits, codebook, tr, xc, suh, 1, 0, partial, mm, N, K, st)) return rc;
         } else {
-            hipLaunchKernelGGL(exl3_had_f16_kernel, dim3(K / 128, mm), dim3(64), 0, st, xc, suh, a_had, K, suh ? 1 : 0);
+            hipLaunchKernelGGL(exl3_had_f16_kernel, dim3(K / 128, mm), dim3(64), 0, st, xc, suh, a_had, K, suh ? 1 : 0, 0);
             VMX_CHECK_LAUNCH("exl3_gemm(input hadamard)");
             if (int rc = exl3_gemm_dispatch(bits, codebook, tr, a_had, nullptr, 0, 0, partial, mm, N, K, st)) return rc;
         }
         hipLaunchKernelGGL(exl3_out_had_kernel, dim3(N / 128, mm), dim3(64), 0, st, partial, splits, (int64_t)mm * N, svh,
                            y + (int64_t)m0 * N, N, (float *)nullptr, 0);
         VMX_CHECK_LAUNCH("exl3_gemm(output hadamard)");
+    }
+    return VMX_OK;
+}
+
+// ---- internal (C++) entry point used by the decoder: Exl3Linear::forward (exl3.rs:216-286) on `M` rows of a bf16 or fp16
+// activation tensor; the fp16 result cast back to the model dtype (bf16) is written as f32 at y32[row * ld + col].
+int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, const uint16_t *suh, const uint16_t *svh, float *y32,
+                         int ld, int M, int K, int N, int bits, int codebook, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    VMX_REQUIRE(workspace_bytes >= vmx_exl3_gemm_workspace_bytes(M, K, N), "exl3_forward: workspace too small");
+    const int mc = M < 16 ? M : 16;
+    uint16_t *a_had = (uint16_t *)workspace;
+    float *partial = (float *)((char *)workspace + (((size_t)mc * K * 2 + 255) & ~(size_t)255));
+    const int splits = exl3_plan(N, K, bits).splits;
+    const uint16_t *tr = (const uint16_t *)trellis;
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        const int mm = M - m0 < 16 ? M - m0 : 16;
+        const uint16_t *xc = x + (int64_t)m0 * K;
+        if (mm <= 4) {
+            if (int rc = exl3_gemm_dispatch(bits, codebook, tr, xc, suh, 1, x_bf16, partial, mm, N, K, st)) return rc;
+        } else {
+            hipLaunchKernelGGL(exl3_had_f16_kernel, dim3(K / 128, mm), dim3(64), 0, st, xc, suh, a_had, K, suh ? 1 : 0, x_bf16);
+            VMX_CHECK_LAUNCH("exl3_forward(input hadamard)");
+            if (int rc = exl3_gemm_dispatch(bits, codebook, tr, a_had, nullptr, 0, 0, partial, mm, N, K, st)) return rc;
+        }
+        hipLaunchKernelGGL(exl3_out_had_kernel, dim3(N / 128, mm), dim3(64), 0, st, partial, splits, (int64_t)mm * N, svh,
+                           (uint16_t *)nullptr, N, y32 + (int64_t)m0 * ld, ld);
+        VMX_CHECK_LAUNCH("exl3_forward(output hadamard)");
     }
     return VMX_OK;
 }

@@ -15,6 +15,10 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
                          int N, int group, int Ntot, int col0, hipStream_t st);
 
+// exl3_kernels.hip: Exl3Linear::forward for the whole-token executor; workspace = vmx_exl3_gemm_workspace_bytes(M, K, N)
+int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, const uint16_t *suh, const uint16_t *svh, float *y32,
+                         int ld, int M, int K, int N, int bits, int codebook, void *workspace, size_t workspace_bytes, hipStream_t st);
+
 // attention_kernels.hip
 struct VmxAttnParts {
     float *tmp_out, *exp_sums, *max_logits;  // [S][H][P][hd], [S][H][P], [S][H][P]

@@ -129,6 +129,15 @@ class QuantizedQwen3ForCausalLM:
         check(lib.vmx_qwen3_load_iq_linear(self._h, layer, slot, ggml_type, blocks.data_ptr(), blocks.numel(), self._stream()))
         torch.cuda.current_stream().synchronize()
 
+    def load_exl3_linear(self, layer: int, slot: int, trellis: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor, codebook: int = 0) -> None:
+        """trellis: int16 [in/16, out/16, 16 * bits]; suh f16 [in]; svh f16 [out]  (the tensors of an EXL3 checkpoint entry)."""
+        assert trellis.dtype == torch.int16 and trellis.dim() == 3 and suh.dtype == torch.float16 and svh.dtype == torch.float16
+        K, N, bits = trellis.shape[0] * 16, trellis.shape[1] * 16, trellis.shape[2] // 16
+        trellis, suh, svh = trellis.contiguous(), suh.contiguous(), svh.contiguous()
+        check(lib.vmx_qwen3_load_exl3_linear(self._h, layer, slot, trellis.data_ptr(), suh.data_ptr(), svh.data_ptr(), K, N, bits, codebook,
+                                             self._stream()))
+        torch.cuda.current_stream().synchronize()
+
     def load_gptq_expert(self, layer: int, expert: int, w1, w3, w2) -> None:
         """w1 / w3 / w2: (qweight int32 [K/8, N], scales f16 [K/g, N]) of the gate, up and down projections of one expert."""
         for qw, sc in (w1, w3, w2):
@@ -202,6 +211,23 @@ class QuantizedQwen3ForCausalLM:
                 self.load_iq_linear(li, slot, t, raw.reshape(-1))
                 if keep_host_copy:
                     ck[f"{li}.{slot}.iq"] = (t, raw.reshape(-1).cpu())
+        return ck
+
+    def load_synthetic_exl3(self, bits: int = 4, codebook: int = 0, seed: int = 0, keep_host_copy: bool = False):
+        """Random trellis words for every projection (EXL3 at `bits` bpw), random sign vectors; svh carries the scale that
+        keeps activations O(1) (decoded weights have unit-order magnitude).  bf16 norms/embeddings as load_synthetic."""
+        s = self.spec
+        ck = self._load_synthetic_dense(seed, keep_host_copy)
+        g = torch.Generator(device=self.device).manual_seed(seed + 1)
+        for li in range(s.num_layers):
+            for slot, (K, N) in self.linear_shapes().items():
+                tr = torch.randint(-32768, 32767, (K // 16, N // 16, 16 * bits), dtype=torch.int16, device=self.device, generator=g)
+                suh = (torch.randint(0, 2, (K,), device=self.device, generator=g) * 2 - 1).to(torch.float16)
+                svh = ((torch.randint(0, 2, (N,), device=self.device, generator=g) * 2 - 1).to(torch.float32)
+                       * (torch.rand(N, device=self.device, generator=g) * 0.5 + 0.75) / math.sqrt(K)).to(torch.float16)
+                self.load_exl3_linear(li, slot, tr, suh, svh, codebook)
+                if keep_host_copy:
+                    ck[f"{li}.{slot}.exl3"] = (bits, codebook, tr.cpu(), suh.cpu(), svh.cpu())
         return ck
 
     def load_synthetic(self, seed: int = 0, keep_host_copy: bool = False):
