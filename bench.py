@@ -200,6 +200,57 @@ def exl3_secondary(reps=8):
             "frac_of_8TBs": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
 
+def exl3_decode_secondary(prompt, steps, warmup):
+    """BASELINE.json configs[3] at TP=1: decode tok/s of a Qwen3-8B-shaped model whose 252 projections are EXL3 4.0 bpw
+    trellis-coded linears (bf16 model; each linear casts to fp16 and back as the reference's Exl3Linear does)."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    total = prompt + warmup + steps + 8
+    n_blocks = (total + 15) // 16 + 1
+    spec = Qwen3Spec.qwen3_8b(max_position=max(4096, total + 1), num_blocks=n_blocks, max_batch=1, max_seq_len=total + 1,
+                              max_prefill_tokens=prompt)
+    model = QuantizedQwen3ForCausalLM(spec)
+    model.load_synthetic_exl3(bits=4, codebook=0, seed=9)
+    dev = model.device
+    bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(1, n_blocks).contiguous()
+    prompt_ids = torch.randint(0, spec.vocab_size, (prompt,), dtype=torch.int32, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    ids = torch.empty(1, dtype=torch.int32, device=dev)
+    pos = torch.full((1,), prompt, dtype=torch.int32, device=dev)
+    slots = (bt[:, prompt // 16] * 16 + prompt % 16).to(torch.int32).contiguous()
+    sl = torch.full((1,), prompt + 1, dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.int32, device=dev)
+
+    def step():
+        model.forward_decode_batch(ids, pos, slots, bt, sl, max_seq_len=spec.max_seq_len, out_ids=out)
+        model.advance(ids, out, pos, slots, sl, bt)
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
+        step()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            step()
+        for _ in range(warmup):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    H, I = spec.hidden_size, spec.intermediate_size
+    nq, nkv = spec.num_heads * spec.head_dim, spec.num_kv_heads * spec.head_dim
+    ex = lambda K, N: K * N / 2 + 2 * K + 2 * N
+    per_tok = spec.num_layers * (ex(H, nq) + 2 * ex(H, nkv) + ex(nq, H) + 2 * ex(H, I) + ex(I, H)) + spec.vocab_size * H * 2
+    model.close()
+    return {"metric": "decode tok/s (greedy, batch=1), Qwen3-8B EXL3 4.0 bpw, TP=1", "value": round(steps / dt, 2), "unit": "tok/s",
+            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "config": {"workload": "Qwen3-8B-shaped: 36 layers, 252 EXL3 4.0 bpw projections (default codebook), bf16 lm_head and KV",
+                       "weights": "seeded random trellis words and sign/scale vectors", "execution": "one hipGraph per step"},
+            "weight_bytes_per_token": int(per_tok), "GBps_weights_only": round(per_tok / (dt / steps) / 1e9, 1)}
+
+
 def mixtral_secondary(prompt, steps, warmup):
     """BASELINE.json configs[4] on one GPU: decode tok/s of a Mixtral-8x7B-shaped model (AWQ attention projections, 8 GPTQ
     int4 experts top-2 per layer behind a dense router) through the executor's device-side fused MoE path."""
@@ -399,7 +450,8 @@ def main():
         if not args.no_moe:
             secondary_moe = mixtral_secondary(args.prompt, max(16, K_steps // 2), W_steps)
         torch.cuda.empty_cache()
-        secondary_exl3 = exl3_secondary()
+        secondary_exl3 = exl3_decode_secondary(args.prompt, min(args.steps, 64), args.warmup)
+        secondary_exl3["linears_only"] = exl3_secondary()
 
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed
