@@ -428,6 +428,11 @@ int vmx_debug_stream_read(const void *p, size_t bytes, int upw, void *sink, void
  * spreads consecutive workgroup ids over the 8 dies, each with its own L2). */
 int vmx_debug_xcc_ids(int *out, int n_wgs, int wg_threads, void *stream);
 
+/* Rows of a decode call normally are different sequences with disjoint cache blocks (execute_batched_decode,
+ * engine/helpers.rs:1076).  on != 0: the rows are consecutive tokens of one sequence over a shared block table (a prompt fed
+ * through the decode path); the executor then writes every row's K/V before any row's attention starts. */
+int vmx_qwen3_set_rows_share_cache(vmx_qwen3 *m, int on);
+
 /* Attach the tensor-parallel group of a model created with tp_size > 1 (not owned by the model). */
 int vmx_qwen3_set_comm(vmx_qwen3 *m, vmx_comm *comm);
 

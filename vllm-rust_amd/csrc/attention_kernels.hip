@@ -61,65 +61,29 @@ template <bool FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale
     }
 }
 
-// grid (kv_heads, seqs, partitions); block 64: ONE wave per (sequence, KV head, partition), serving
-// all QPK (<= 16) query heads of the KV head.  A partition is `tiles_per_part` tiles of 16 tokens,
-// walked with an online softmax (running max / sum / rescaled accumulator).  Per tile:
-//   QK^T  one v_mfma_f32_16x16x32_bf16 per 32 head dims: A = the q rows of the group (row = head),
-//         B = K^T (column = token); lane (token, dim group) feeds 16-byte pieces of its token's K row
-//         straight from the cache, so the 16x16 logit tile costs HD/32 matrix instructions and no
-//         cross-lane reduction.  bf16 products are exact in f32, as in the reference's FMA chain.
-//   softmax over the tile's 16 tokens with 4 butterfly steps inside each 16-lane row group;
-//   PV    dim per lane: a V row is one coalesced wave access; p[head][token] is broadcast from the
-//         lane that holds it with v_readlane (wave-uniform, no LDS).
-// Everything a tile needs from HBM (K pieces, V rows, q) is requested before its arithmetic starts;
-// with several tiles per partition the next tile's block-table entry is fetched one tile ahead.
+// Online-softmax walk over the tokens [p0, p1) of one sequence for the QPK query heads of one KV head (one wave).
+// qa: the q rows as MFMA A fragments (lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)); bt_row: the
+// sequence's block-table row.  Returns running max / sum per head row 4*dg + r and the un-normalised output accumulator.
 template <int HD, int QPK, bool FP8>
-__global__ __launch_bounds__(64) void paged_attn_partition_kernel(
-    float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
-    const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
-    const int32_t *__restrict__ seq_lens, float scale, int num_heads, int num_kv_heads, int max_blocks_per_seq, int block_size,
-    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part) {
-    constexpr int KSTEPS = HD / 32;                 // MFMA k-steps per tile
-    constexpr int NP = HD >= 128 ? HD / 128 : 1;    // V: pairs of dims per lane
-    constexpr int HG = (QPK + 3) / 4;               // 16-lane row groups that hold live heads
-    const int kvh = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
-    const int lane = threadIdx.x, tl = lane & 15, dg = lane >> 4;
-    const int seq_len = seq_lens[seq];
-    if (seq_len == 0) return;
-    const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
-    const int part_tokens = tiles_per_part * 16;
-    const int p0 = start + part * part_tokens;
-    if (p0 >= seq_len) return;
-    const int p1 = min(p0 + part_tokens, seq_len);
-    const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
-    const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
-    const float lscale = scale * ksc;
-    const int64_t tok_stride = (int64_t)num_kv_heads * HD;
-    const int head0 = kvh * QPK;
+__device__ __forceinline__ void attn_walk(const uint4 (&qa)[HD / 32], const void *__restrict__ k_cache, const void *__restrict__ v_cache,
+                                          const int32_t *__restrict__ bt_row, int p0, int p1, int block_size, int64_t tok_stride,
+                                          int kvh, float lscale, float vsc, int lane, float (&m_run)[4], float (&s_run)[4],
+                                          float (&o)[QPK][HD >= 128 ? HD / 128 : 1][2]) {
+    constexpr int KSTEPS = HD / 32;
+    constexpr int NP = HD >= 128 ? HD / 128 : 1;
+    const int tl = lane & 15, dg = lane >> 4;
     const bool lane_live = (HD >= 128) || (lane < 32);
-
-    // q rows as MFMA A fragments: lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)
-    uint4 qa[KSTEPS];
-#pragma unroll
-    for (int i = 0; i < KSTEPS; i++) {
-        qa[i] = make_uint4(0, 0, 0, 0);
-        if (tl < QPK) qa[i] = *reinterpret_cast<const uint4 *>(q + ((int64_t)seq * num_heads + head0 + tl) * HD + 32 * i + 8 * dg);
-    }
-
-    float m_run[4], s_run[4];  // per head row 4*dg + r (replicated over the 16 lanes of the group)
 #pragma unroll
     for (int r = 0; r < 4; r++) { m_run[r] = -FLT_MAX; s_run[r] = 0.f; }
-    float o[QPK][NP][2];
 #pragma unroll
     for (int h = 0; h < QPK; h++)
 #pragma unroll
         for (int p = 0; p < NP; p++) o[h][p][0] = o[h][p][1] = 0.f;
-
     for (int t0 = p0; t0 < p1; t0 += 16) {
         const int ntok = min(16, p1 - t0);
         // this lane's token (lanes past the end re-read the last valid row; their logits are masked)
         const int t = t0 + min(tl, ntok - 1);
-        const int blk = block_tables[(int64_t)seq * max_blocks_per_seq + t / block_size];
+        const int blk = bt_row[t / block_size];
         const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD;
         typename Raw8<FP8>::T kraw[KSTEPS];
 #pragma unroll
@@ -202,6 +166,58 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
         }
     }
 
+}
+
+// grid (kv_heads, seqs, partitions); block 64: ONE wave per (sequence, KV head, partition), serving
+// all QPK (<= 16) query heads of the KV head.  A partition is `tiles_per_part` tiles of 16 tokens,
+// walked with an online softmax (running max / sum / rescaled accumulator).  Per tile:
+//   QK^T  one v_mfma_f32_16x16x32_bf16 per 32 head dims: A = the q rows of the group (row = head),
+//         B = K^T (column = token); lane (token, dim group) feeds 16-byte pieces of its token's K row
+//         straight from the cache, so the 16x16 logit tile costs HD/32 matrix instructions and no
+//         cross-lane reduction.  bf16 products are exact in f32, as in the reference's FMA chain.
+//   softmax over the tile's 16 tokens with 4 butterfly steps inside each 16-lane row group;
+//   PV    dim per lane: a V row is one coalesced wave access; p[head][token] is broadcast from the
+//         lane that holds it with v_readlane (wave-uniform, no LDS).
+// Everything a tile needs from HBM (K pieces, V rows, q) is requested before its arithmetic starts;
+// with several tiles per partition the next tile's block-table entry is fetched one tile ahead.
+template <int HD, int QPK, bool FP8>
+__global__ __launch_bounds__(64) void paged_attn_partition_kernel(
+    float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
+    const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
+    const int32_t *__restrict__ seq_lens, float scale, int num_heads, int num_kv_heads, int max_blocks_per_seq, int block_size,
+    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part) {
+    constexpr int KSTEPS = HD / 32;                 // MFMA k-steps per tile
+    constexpr int NP = HD >= 128 ? HD / 128 : 1;    // V: pairs of dims per lane
+    constexpr int HG = (QPK + 3) / 4;               // 16-lane row groups that hold live heads
+    const int kvh = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
+    const int lane = threadIdx.x, tl = lane & 15, dg = lane >> 4;
+    const int seq_len = seq_lens[seq];
+    if (seq_len == 0) return;
+    const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
+    const int part_tokens = tiles_per_part * 16;
+    const int p0 = start + part * part_tokens;
+    if (p0 >= seq_len) return;
+    const int p1 = min(p0 + part_tokens, seq_len);
+    const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
+    const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
+    const float lscale = scale * ksc;
+    const int64_t tok_stride = (int64_t)num_kv_heads * HD;
+    const int head0 = kvh * QPK;
+    const bool lane_live = (HD >= 128) || (lane < 32);
+
+    // q rows as MFMA A fragments: lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)
+    uint4 qa[KSTEPS];
+#pragma unroll
+    for (int i = 0; i < KSTEPS; i++) {
+        qa[i] = make_uint4(0, 0, 0, 0);
+        if (tl < QPK) qa[i] = *reinterpret_cast<const uint4 *>(q + ((int64_t)seq * num_heads + head0 + tl) * HD + 32 * i + 8 * dg);
+    }
+
+    float m_run[4], s_run[4];  // per head row 4*dg + r (replicated over the 16 lanes of the group)
+    float o[QPK][NP][2];
+    attn_walk<HD, QPK, FP8>(qa, k_cache, v_cache, block_tables + (int64_t)seq * max_blocks_per_seq, p0, p1, block_size, tok_stride, kvh,
+                            lscale, vsc, lane, m_run, s_run, o);
+
     // ---- partition result: locally normalised output, max and sum per head
 #pragma unroll
     for (int h = 0; h < QPK; h++) {
@@ -276,6 +292,192 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
             if ((d & 31) == 0) ad[(obase + d) >> 5] = dq;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Short-context decode in ONE launch: grid (kv_heads, seqs), block = NW waves.  A decode step is a chain of dependent
+// launches and each link costs ~4-5 us whatever it computes, so for contexts of up to NW*64 tokens the three links
+// "q/k/v post-processing -> split-KV attention -> merge" become one:
+//   A  waves 0..QPK+1: one head each (QPK query heads, the k head, the v head) from the merged qkv linear output (f32
+//      split-K slices): bf16 round, optional per-head RMSNorm, NeoX RoPE (q, k) with the rounding points of the separate
+//      kernel; q stays in LDS, k and v go to the paged cache (bf16 or FP8 e4m3);
+//   B  after a workgroup barrier (stores of a workgroup are visible to its own waves: one CU, one vector L1) every wave
+//      walks its share of [start, seq_len) exactly like a partition of the split kernel;
+//   C  the partitions are merged through LDS with the same log-sum-exp rule (paged_attention.cu:840-953).
+template <int HD, int QPK, bool FP8, int NW>
+__global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
+    uint16_t *__restrict__ out, const float *__restrict__ partial, int splits, int tokens, void *__restrict__ k_cache,
+    void *__restrict__ v_cache, const uint16_t *__restrict__ q_norm_w, const uint16_t *__restrict__ k_norm_w, float eps,
+    const float *__restrict__ cos_sin, const int32_t *__restrict__ positions, const int32_t *__restrict__ slots,
+    const int32_t *__restrict__ block_tables, const int32_t *__restrict__ seq_lens, float scale, int Hq, int Hkv, int rot_dim,
+    int max_blocks_per_seq, int block_size, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr,
+    int8_t *__restrict__ aq, float *__restrict__ ad) {
+    constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1, EPL = HD / 64;   // EPL: elements per lane in phase A
+    extern __shared__ __align__(16) unsigned char smem_attn[];
+    uint16_t *qs = reinterpret_cast<uint16_t *>(smem_attn);                      // [QPK][HD] bf16
+    float *mo = reinterpret_cast<float *>(smem_attn + QPK * HD * 2);             // [NW][QPK][HD]
+    float *mm = mo + NW * QPK * HD;                                              // [NW][QPK] max
+    float *ms = mm + NW * QPK;                                                   // [NW][QPK] sum
+    const int kvh = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tl = lane & 15, dg = lane >> 4;
+    const int seq_len = seq_lens[seq];
+    const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
+    const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
+
+    // ---- A: this token's q / k / v heads
+    if (wave < QPK + 2) {
+        const bool is_q = wave < QPK, is_k = wave == QPK;
+        const int head = is_q ? kvh * QPK + wave : (is_k ? Hq + kvh : Hq + Hkv + kvh);
+        const int ntot = (Hq + 2 * Hkv) * HD;
+        const int64_t slice = (int64_t)tokens * ntot, base = (int64_t)seq * ntot + (int64_t)head * HD;
+        float v[EPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            float a = 0.f;
+            for (int sp = 0; sp < splits; sp++) a += partial[sp * slice + base + lane + 64 * j];
+            v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(a));
+            ss += v[j] * v[j];
+        }
+        const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
+        if (nw) {
+            ss = vmx_wave_sum(ss);
+            const float inv = rsqrtf(ss / (float)HD + eps);
+#pragma unroll
+            for (int j = 0; j < EPL; j++) v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j] * inv * vmx_bf16_to_f32(nw[lane + 64 * j])));
+        }
+        if (is_q || is_k) {   // NeoX rotation of the first rot_dim dims: pairs (i, i + rot_dim/2)
+            const int half = rot_dim >> 1;
+            const float *cs = cos_sin + (int64_t)positions[seq] * rot_dim;
+            if ((half & 63) == 0) {   // partner in the same lane: element j pairs with j + half/64
+                const int hj = half >> 6;
+#pragma unroll
+                for (int j = 0; j < EPL / 2; j++) {
+                    if (j < hj) {
+                        const int i = lane + 64 * j;
+                        const float xv = v[j], yv = v[j + hj], c = cs[i], sn = cs[half + i];
+                        v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(xv * c - yv * sn));
+                        v[j + hj] = vmx_bf16_to_f32(vmx_f32_to_bf16(yv * c + xv * sn));
+                    }
+                }
+            } else {                  // half == 32 (checked on the host): partner is lane ^ 32 of element 0
+                const float other = __shfl_xor(v[0], 32, 64);
+                const int i = lane & 31;
+                const float c = cs[i], sn = cs[32 + i];
+                v[0] = vmx_bf16_to_f32(vmx_f32_to_bf16(lane < 32 ? v[0] * c - other * sn : v[0] * c + other * sn));
+            }
+        }
+        if (is_q) {
+#pragma unroll
+            for (int j = 0; j < EPL; j++) qs[wave * HD + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+        } else {
+            const int slot = slots[seq];
+            if (slot >= 0) {
+                const int64_t dst = ((int64_t)slot * Hkv + kvh) * HD;
+                void *cache = is_k ? k_cache : v_cache;
+                if constexpr (!FP8) {
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) ((uint16_t *)cache)[dst + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+                } else {
+                    const float sc = is_k ? ksc : vsc;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) {
+                        float a = v[j] / sc;
+                        a = fminf(fmaxf(a, -448.0f), 448.0f);
+                        a = vmx_bf16_to_f32(vmx_f32_to_bf16(a));
+                        ((uint8_t *)cache)[dst + lane + 64 * j] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, a, 0, false) & 0xFFu);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (seq_len == 0) return;   // uniform over the workgroup
+
+    // ---- B: wave = partition
+    const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
+    const int tiles = (seq_len - start + 15) >> 4;
+    const int part_tokens = ((tiles + NW - 1) / NW) * 16;
+    const int p0 = start + wave * part_tokens, p1 = min(p0 + part_tokens, seq_len);
+    float m_run[4], s_run[4];
+    float o[QPK][NP][2];
+    if (p0 < seq_len) {   // wave-uniform
+        uint4 qa[KSTEPS];
+#pragma unroll
+        for (int i = 0; i < KSTEPS; i++) {
+            qa[i] = make_uint4(0, 0, 0, 0);
+            if (tl < QPK) qa[i] = *reinterpret_cast<const uint4 *>(qs + tl * HD + 32 * i + 8 * dg);
+        }
+        attn_walk<HD, QPK, FP8>(qa, k_cache, v_cache, block_tables + (int64_t)seq * max_blocks_per_seq, p0, p1, block_size,
+                                (int64_t)Hkv * HD, kvh, scale * ksc, vsc, lane, m_run, s_run, o);
+    }
+    const bool lane_live = (HD >= 128) || (lane < 32);
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        float sh = 0.f, mh = -FLT_MAX;
+        if (p0 < seq_len) {
+            sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_run[h & 3]), 16 * (h >> 2)));
+            mh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run[h & 3]), 16 * (h >> 2)));
+        }
+        if (lane == 0) { mm[wave * QPK + h] = mh; ms[wave * QPK + h] = sh; }
+        if (p0 < seq_len && lane_live) {
+            const float inv = 1.0f / (sh + 1e-6f);
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                *reinterpret_cast<float2 *>(mo + (wave * QPK + h) * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
+        }
+    }
+    __syncthreads();
+
+    // ---- C: merge the partitions (a partition that saw no token has sum 0 and contributes nothing)
+    const int np = min(NW, (seq_len - start + part_tokens - 1) / part_tokens);
+    for (int idx = tid; idx < QPK * HD; idx += 64 * NW) {   // QPK * HD is a multiple of 64: a wave is all in or all out
+        const int h = idx / HD, d = idx % HD;
+        float val;
+        if (np == 1) {
+            val = mo[h * HD + d];
+        } else {
+            float gmax = -FLT_MAX;
+            for (int p = 0; p < np; p++) gmax = fmaxf(gmax, mm[p * QPK + h]);
+            float gsum = 0.f, acc = 0.f;
+            for (int p = 0; p < np; p++) {
+                const float w = ms[p * QPK + h] * __expf(mm[p * QPK + h] - gmax);
+                gsum += w;
+                acc += mo[(p * QPK + h) * HD + d] * w;
+            }
+            val = acc * (1.0f / (gsum + 1e-6f));
+        }
+        const int64_t ob = ((int64_t)seq * Hq + kvh * QPK + h) * HD + d;
+        const uint16_t vb = vmx_f32_to_bf16(val);
+        out[ob] = vb;
+        if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block
+            const float vq = vmx_bf16_to_f32(vb);
+            float amax = fabsf(vq);
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            const float dq = amax / 127.0f;
+            aq[ob] = amax != 0.0f ? (int8_t)(int)roundf(vq / dq) : (int8_t)0;
+            if ((d & 31) == 0) ad[ob >> 5] = dq;
+        }
+    }
+}
+
+constexpr int FUSED_NW = 16;
+constexpr int FUSED_MAX_CTX = FUSED_NW * 64;   // <= 4 tiles per wave
+
+template <int HD, int QPK, bool FP8>
+int launch_fused(dim3 grid, hipStream_t st, uint16_t *out, const float *partial, int splits, int tokens, void *kc, void *vc,
+                 const uint16_t *qn, const uint16_t *kn, float eps, const float *cos_sin, const int32_t *positions, const int32_t *slots,
+                 const int32_t *bt, const int32_t *sl, float scale, int Hq, int Hkv, int rot_dim, int mbps, int bs, int window,
+                 const float *ks, const float *vs, int8_t *aq, float *ad) {
+    const size_t lds = (size_t)QPK * HD * 2 + (size_t)FUSED_NW * QPK * HD * 4 + (size_t)2 * FUSED_NW * QPK * 4;
+    if (lds > 64 * 1024)
+        VMX_CHECK_HIP(hipFuncSetAttribute((const void *)fused_decode_attn_kernel<HD, QPK, FP8, FUSED_NW>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((fused_decode_attn_kernel<HD, QPK, FP8, FUSED_NW>), grid, dim3(64 * FUSED_NW), lds, st, out, partial, splits, tokens,
+                       kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks, vs, aq, ad);
+    VMX_CHECK_LAUNCH("fused_decode_attention");
+    return VMX_OK;
 }
 
 template <int HD, int QPK, bool FP8>
@@ -540,6 +742,45 @@ int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const in
                        parts->max_logits, seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
+}
+
+// Whether the one-launch short-context path covers this geometry (otherwise: qkv post kernel + parts + merge).
+bool vmx_fused_decode_attention_ok(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
+    static const bool off = getenv("VMX_NO_FUSED_ATTN") && atoi(getenv("VMX_NO_FUSED_ATTN"));
+    if (off) return false;
+    if (head_dim != 64 && head_dim != 128) return false;
+    if (qpk != 1 && qpk != 2 && qpk != 4 && qpk != 8) return false;
+    const int half = rot_dim / 2;
+    if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return false;
+    const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
+    return ctx > 0 && ctx <= FUSED_MAX_CTX;
+}
+
+int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
+                               const uint16_t *q_norm_w, const uint16_t *k_norm_w, float eps, const float *cos_sin,
+                               const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
+                               float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
+                               int max_blocks_per_seq, int block_size, int window, int kv_dtype, const float *k_scale,
+                               const float *v_scale, int8_t *aq, float *ad, hipStream_t st) {
+    const int qpk = num_heads / num_kv_heads;
+    const dim3 grid(num_kv_heads, num_seqs);
+    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
+    int rc = VMX_EUNSUPPORTED;
+#define FARGS grid, st, out, qkv_partial, splits, num_seqs, k_cache, v_cache, q_norm_w, k_norm_w, eps, cos_sin, positions, slots, block_tables, \
+              seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size, window, k_scale, v_scale, aq, ad
+#define F_QPK(HD)                                                                                         \
+    switch (qpk) {                                                                                        \
+        case 1: rc = fp8 ? launch_fused<HD, 1, true>(FARGS) : launch_fused<HD, 1, false>(FARGS); break;   \
+        case 2: rc = fp8 ? launch_fused<HD, 2, true>(FARGS) : launch_fused<HD, 2, false>(FARGS); break;   \
+        case 4: rc = fp8 ? launch_fused<HD, 4, true>(FARGS) : launch_fused<HD, 4, false>(FARGS); break;   \
+        case 8: rc = fp8 ? launch_fused<HD, 8, true>(FARGS) : launch_fused<HD, 8, false>(FARGS); break;   \
+        default: break;                                                                                   \
+    }
+    if (head_dim == 64) { F_QPK(64) } else if (head_dim == 128) { F_QPK(128) }
+#undef F_QPK
+#undef FARGS
+    if (rc == VMX_EUNSUPPORTED) vmx_set_error("fused_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head)", head_dim, qpk);
+    return rc;
 }
 
 extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,

@@ -335,6 +335,7 @@ struct vmx_qwen3 {
     DevBuf router_logits, topk_w, topk_ids, moe_ws, moe_out;   // MoE models only
     DevBuf exl3_ws;                                            // EXL3 models only: grown by the loader
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
+    bool rows_share_cache = false;  // rows of a decode batch attend to K/V rows written by other rows of the same call
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
 };
@@ -805,11 +806,21 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             if (int rc = iq_forward(m, L.iq[VMX_L_V], PA + NQ + NKV, NQKV_, B, st)) return rc;
         } else if (int rc = run_linear(m, L.qkv, x, PA, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
+        const bool fused_attn = prefill_offset < 0 && !m->rows_share_cache && vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
+        if (fused_attn) {
+            if (int rc = vmx_fused_decode_attention(attn, PA, s_qkv, L.k_cache.p, L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
+                                                    c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
+                                                    (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
+                                                    Hkv, hd, hd, max_blocks_per_seq, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
+                                                    iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr, st))
+                return rc;
+        } else
         hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, s_qkv, B, q, L.k_cache.p,
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                            c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
                            slot_mapping, Hq, Hkv, hd, hd, fp8, ks, ks + 1);
-        if (prefill_offset >= 0) {
+        if (fused_attn) {
+        } else if (prefill_offset >= 0) {
             if (int rc = vmx_prefill_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, scale, Hq, Hkv, hd,
                                                     c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, st))
                 return rc;
@@ -958,6 +969,16 @@ extern "C" int vmx_qwen3_prefill(vmx_qwen3 *m, const int32_t *input_ids, int seq
     hipLaunchKernelGGL(iota_positions_kernel, dim3((q_len + 255) / 256), dim3(256), 0, st, pos, seqlen_offset, q_len);
     if (int rc = run_layers(m, input_ids, pos, slot_mapping, block_table, nullptr, q_len, 0, 0, seqlen_offset, st)) return rc;
     return run_head(m, (const uint16_t *)m->x.p + (size_t)(q_len - 1) * c.hidden_size, 1, out_id_last, logits_last, stream);
+}
+
+// Rows of one decode call normally belong to different sequences with disjoint cache blocks.  A caller that feeds
+// consecutive tokens of ONE sequence as rows of a decode call (each with its own seq_len over a shared block table) must
+// say so: every row's K/V must then be in the cache before any row's attention starts, which the one-launch short-context
+// attention does not provide across rows.
+extern "C" int vmx_qwen3_set_rows_share_cache(vmx_qwen3 *m, int on) {
+    VMX_REQUIRE(m, "qwen3_set_rows_share_cache: null model");
+    m->rows_share_cache = on != 0;
+    return VMX_OK;
 }
 
 // Attach the tensor-parallel communicator (not owned).  Required before decoding when tp_size > 1.

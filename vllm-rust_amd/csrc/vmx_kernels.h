@@ -15,6 +15,15 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
                          int N, int group, int Ntot, int col0, hipStream_t st);
 
+// attention_kernels.hip: q/k/v post-processing + short-context decode attention + merge in one launch
+bool vmx_fused_decode_attention_ok(int head_dim, int qpk, int rot_dim, int max_seq_len, int window);
+int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
+                               const uint16_t *q_norm_w, const uint16_t *k_norm_w, float eps, const float *cos_sin,
+                               const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
+                               float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
+                               int max_blocks_per_seq, int block_size, int window, int kv_dtype, const float *k_scale,
+                               const float *v_scale, int8_t *aq, float *ad, hipStream_t st);
+
 // exl3_kernels.hip: Exl3Linear::forward for the whole-token executor; workspace = vmx_exl3_gemm_workspace_bytes(M, K, N)
 int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, const uint16_t *suh, const uint16_t *svh, float *y32,
                          int ld, int M, int K, int N, int bits, int codebook, void *workspace, size_t workspace_bytes, hipStream_t st);

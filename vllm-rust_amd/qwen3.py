@@ -318,6 +318,16 @@ class QuantizedQwen3ForCausalLM:
         bt1 = block_table.reshape(1, -1).to(torch.int32)
         ids_out = torch.empty(S, dtype=torch.int32, device=self.device)
         logits = torch.empty((S, s.vocab_size), dtype=torch.bfloat16, device=self.device) if return_logits else None
+        check(lib.vmx_qwen3_set_rows_share_cache(self._h, 1))
+        try:
+            self._forward_chunks(input_ids, seqlen_offset, bt1, ids_out, logits)
+        finally:
+            check(lib.vmx_qwen3_set_rows_share_cache(self._h, 0))
+        return ids_out, logits
+
+    def _forward_chunks(self, input_ids, seqlen_offset, bt1, ids_out, logits):
+        s = self.spec
+        S = input_ids.numel()
         for c0 in range(0, S, s.max_batch):
             n = min(s.max_batch, S - c0)
             pos = torch.arange(seqlen_offset + c0, seqlen_offset + c0 + n, dtype=torch.int32, device=self.device)
@@ -325,7 +335,6 @@ class QuantizedQwen3ForCausalLM:
             bt = bt1.expand(n, -1).contiguous()
             self.forward_decode_batch(input_ids[c0:c0 + n].contiguous(), pos, slots, bt, (pos + 1).contiguous(),
                                       out_ids=ids_out[c0:c0 + n], logits=None if logits is None else logits[c0:c0 + n])
-        return ids_out, logits
 
     def debug_read(self, which: int, shape) -> torch.Tensor:
         t = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
