@@ -61,111 +61,133 @@ template <bool FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale
     }
 }
 
+// One 16-token tile of K and V as fetched from the cache (unconverted), waiting in registers.
+template <int HD, bool FP8> struct AttnTile {
+    typename Raw8<FP8>::T kraw[HD / 32];
+    uint32_t vraw[16][HD >= 128 ? HD / 128 : 1];
+};
+
+// Request tile [t0, min(t0 + 16, p1)): lane (token tl, dim group dg) takes 16-byte pieces of its token's K row, and every
+// V row of the tile is one coalesced wave access (row base broadcast from the lane that owns the token).  Lanes past the
+// end re-read the last valid row; their logits are masked later.
+template <int HD, bool FP8>
+__device__ __forceinline__ void attn_tile_load(AttnTile<HD, FP8> &t, const void *__restrict__ k_cache, const void *__restrict__ v_cache,
+                                               const int32_t *__restrict__ bt_row, int t0, int p1, int block_size, int64_t tok_stride,
+                                               int kvh, int lane) {
+    constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1;
+    const int tl = lane & 15, dg = lane >> 4;
+    const bool lane_live = (HD >= 128) || (lane < 32);
+    const int ntok = min(16, p1 - t0);
+    const int tok = t0 + min(tl, ntok - 1);
+    const int blk = bt_row[tok / block_size];
+    const int64_t base = ((int64_t)blk * block_size + tok % block_size) * tok_stride + (int64_t)kvh * HD;
+#pragma unroll
+    for (int i = 0; i < KSTEPS; i++) t.kraw[i] = load8_raw<FP8>(k_cache, base + 32 * i + 8 * dg);
+    const uint32_t base_lo = (uint32_t)base, base_hi = (uint32_t)(base >> 32);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int64_t rb = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)base_hi, j) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)base_lo, j));
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            t.vraw[j][p] = 0;
+            if (lane_live) t.vraw[j][p] = load2_raw<FP8>(v_cache, rb + 2 * lane + 128 * p);
+        }
+    }
+}
+
+// Fold one tile into the running softmax state.  QK^T: one v_mfma_f32_16x16x32_bf16 per 32 head dims (A = q rows, row =
+// head; B = K^T, column = token); softmax over the tile's tokens with 4 butterfly steps inside each 16-lane row group;
+// PV on the vector ALU, p[head][token] broadcast with v_readlane.
+template <int HD, int QPK, bool FP8>
+__device__ __forceinline__ void attn_tile_fold(const AttnTile<HD, FP8> &t, int ntok, const uint4 (&qa)[HD / 32], float lscale, float vsc,
+                                               int lane, float (&m_run)[4], float (&s_run)[4],
+                                               float (&o)[QPK][HD >= 128 ? HD / 128 : 1][2]) {
+    constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1;
+    const int tl = lane & 15;
+    vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KSTEPS; i++) {
+        uint4 kb;
+        if constexpr (!FP8) {
+            kb = t.kraw[i];
+        } else {  // e4m3 -> bf16 is exact
+            float f[8];
+            cvt8<FP8>(t.kraw[i], 1.0f, f);
+            kb.x = (uint32_t)vmx_f32_to_bf16(f[0]) | ((uint32_t)vmx_f32_to_bf16(f[1]) << 16);
+            kb.y = (uint32_t)vmx_f32_to_bf16(f[2]) | ((uint32_t)vmx_f32_to_bf16(f[3]) << 16);
+            kb.z = (uint32_t)vmx_f32_to_bf16(f[4]) | ((uint32_t)vmx_f32_to_bf16(f[5]) << 16);
+            kb.w = (uint32_t)vmx_f32_to_bf16(f[6]) | ((uint32_t)vmx_f32_to_bf16(f[7]) << 16);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, qa[i]), __builtin_bit_cast(vmx_bf16x8, kb), acc, 0, 0, 0);
+    }
+    float pw[4], corr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float l = tl < ntok ? acc[r] * lscale : -FLT_MAX;
+        float mx = l;
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+        const float m_new = fmaxf(m_run[r], mx);
+        const float e = tl < ntok ? __expf(l - m_new) : 0.f;
+        float sm = e;
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sm += __shfl_xor(sm, 4, 64);
+        sm += __shfl_xor(sm, 8, 64);
+        corr[r] = __expf(m_run[r] - m_new);  // 0 on the first tile (m_run = -FLT_MAX)
+        s_run[r] = s_run[r] * corr[r] + sm;
+        m_run[r] = m_new;
+        pw[r] = e;
+    }
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, corr[h & 3]), 16 * (h >> 2)));
+#pragma unroll
+        for (int p = 0; p < NP; p++) { o[h][p][0] *= c; o[h][p][1] *= c; }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j < ntok) {  // wave-uniform
+            float va[NP], vb[NP];
+#pragma unroll
+            for (int p = 0; p < NP; p++) cvt2<FP8>(t.vraw[j][p], vsc, va[p], vb[p]);
+#pragma unroll
+            for (int h = 0; h < QPK; h++) {
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pw[h & 3]), 16 * (h >> 2) + j));
+#pragma unroll
+                for (int p = 0; p < NP; p++) { o[h][p][0] += w * va[p]; o[h][p][1] += w * vb[p]; }
+            }
+        }
+    }
+}
+
 // Online-softmax walk over the tokens [p0, p1) of one sequence for the QPK query heads of one KV head (one wave).
 // qa: the q rows as MFMA A fragments (lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)); bt_row: the
-// sequence's block-table row.  Returns running max / sum per head row 4*dg + r and the un-normalised output accumulator.
+// sequence's block-table row.  `first` holds tile p0 when first_loaded (requested by the caller ahead of other work).
+// Returns running max / sum per head row 4*dg + r and the un-normalised output accumulator.
 template <int HD, int QPK, bool FP8>
 __device__ __forceinline__ void attn_walk(const uint4 (&qa)[HD / 32], const void *__restrict__ k_cache, const void *__restrict__ v_cache,
                                           const int32_t *__restrict__ bt_row, int p0, int p1, int block_size, int64_t tok_stride,
                                           int kvh, float lscale, float vsc, int lane, float (&m_run)[4], float (&s_run)[4],
-                                          float (&o)[QPK][HD >= 128 ? HD / 128 : 1][2]) {
-    constexpr int KSTEPS = HD / 32;
+                                          float (&o)[QPK][HD >= 128 ? HD / 128 : 1][2], AttnTile<HD, FP8> &first, bool first_loaded) {
     constexpr int NP = HD >= 128 ? HD / 128 : 1;
-    const int tl = lane & 15, dg = lane >> 4;
-    const bool lane_live = (HD >= 128) || (lane < 32);
 #pragma unroll
     for (int r = 0; r < 4; r++) { m_run[r] = -FLT_MAX; s_run[r] = 0.f; }
 #pragma unroll
     for (int h = 0; h < QPK; h++)
 #pragma unroll
         for (int p = 0; p < NP; p++) o[h][p][0] = o[h][p][1] = 0.f;
-    for (int t0 = p0; t0 < p1; t0 += 16) {
-        const int ntok = min(16, p1 - t0);
-        // this lane's token (lanes past the end re-read the last valid row; their logits are masked)
-        const int t = t0 + min(tl, ntok - 1);
-        const int blk = bt_row[t / block_size];
-        const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD;
-        typename Raw8<FP8>::T kraw[KSTEPS];
-#pragma unroll
-        for (int i = 0; i < KSTEPS; i++) kraw[i] = load8_raw<FP8>(k_cache, base + 32 * i + 8 * dg);
-        // V rows: row base of token j is wave-uniform (broadcast from lane j)
-        uint32_t vraw[16][NP];
-        const uint32_t base_lo = (uint32_t)base, base_hi = (uint32_t)(base >> 32);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int64_t rb = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)base_hi, j) << 32) |
-                                         (uint32_t)__builtin_amdgcn_readlane((int)base_lo, j));
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                vraw[j][p] = 0;
-                if (lane_live) vraw[j][p] = load2_raw<FP8>(v_cache, rb + 2 * lane + 128 * p);
-            }
-        }
-
-        // ---- logits tile: rows = heads, columns = tokens
-        vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < KSTEPS; i++) {
-            uint4 kb;
-            if constexpr (!FP8) {
-                kb = kraw[i];
-            } else {  // e4m3 -> bf16 is exact
-                float f[8];
-                cvt8<FP8>(kraw[i], 1.0f, f);
-                kb.x = (uint32_t)vmx_f32_to_bf16(f[0]) | ((uint32_t)vmx_f32_to_bf16(f[1]) << 16);
-                kb.y = (uint32_t)vmx_f32_to_bf16(f[2]) | ((uint32_t)vmx_f32_to_bf16(f[3]) << 16);
-                kb.z = (uint32_t)vmx_f32_to_bf16(f[4]) | ((uint32_t)vmx_f32_to_bf16(f[5]) << 16);
-                kb.w = (uint32_t)vmx_f32_to_bf16(f[6]) | ((uint32_t)vmx_f32_to_bf16(f[7]) << 16);
-            }
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, qa[i]), __builtin_bit_cast(vmx_bf16x8, kb), acc,
-                                                          0, 0, 0);
-        }
-        // ---- online softmax over the 16 tokens of the tile (lane = token tl, rows 4*dg + r)
-        float pw[4], corr[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float l = tl < ntok ? acc[r] * lscale : -FLT_MAX;
-            float mx = l;
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-            const float m_new = fmaxf(m_run[r], mx);
-            const float e = tl < ntok ? __expf(l - m_new) : 0.f;
-            float sm = e;
-            sm += __shfl_xor(sm, 1, 64);
-            sm += __shfl_xor(sm, 2, 64);
-            sm += __shfl_xor(sm, 4, 64);
-            sm += __shfl_xor(sm, 8, 64);
-            corr[r] = __expf(m_run[r] - m_new);  // 0 on the first tile (m_run = -FLT_MAX)
-            s_run[r] = s_run[r] * corr[r] + sm;
-            m_run[r] = m_new;
-            pw[r] = e;
-        }
-        // ---- PV: o[h] = o[h] * corr[h] + sum_t p[h][t] * V[t]
-#pragma unroll
-        for (int h = 0; h < QPK; h++) {
-            const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, corr[h & 3]), 16 * (h >> 2)));
-#pragma unroll
-            for (int p = 0; p < NP; p++) { o[h][p][0] *= c; o[h][p][1] *= c; }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (j < ntok) {  // wave-uniform
-                float va[NP], vb[NP];
-#pragma unroll
-                for (int p = 0; p < NP; p++) cvt2<FP8>(vraw[j][p], vsc, va[p], vb[p]);
-#pragma unroll
-                for (int h = 0; h < QPK; h++) {
-                    const float w =
-                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pw[h & 3]), 16 * (h >> 2) + j));
-#pragma unroll
-                    for (int p = 0; p < NP; p++) { o[h][p][0] += w * va[p]; o[h][p][1] += w * vb[p]; }
-                }
-            }
-        }
+    if (!first_loaded) attn_tile_load<HD, FP8>(first, k_cache, v_cache, bt_row, p0, p1, block_size, tok_stride, kvh, lane);
+    for (int t0 = p0; t0 < p1; t0 += 16) {   // the next tile is requested before the current one is folded
+        AttnTile<HD, FP8> next;
+        const bool more = t0 + 16 < p1;
+        if (more) attn_tile_load<HD, FP8>(next, k_cache, v_cache, bt_row, t0 + 16, p1, block_size, tok_stride, kvh, lane);
+        attn_tile_fold<HD, QPK, FP8>(first, min(16, p1 - t0), qa, lscale, vsc, lane, m_run, s_run, o);
+        if (more) first = next;
     }
-
 }
 
 // grid (kv_heads, seqs, partitions); block 64: ONE wave per (sequence, KV head, partition), serving
@@ -215,8 +237,9 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
 
     float m_run[4], s_run[4];  // per head row 4*dg + r (replicated over the 16 lanes of the group)
     float o[QPK][NP][2];
+    AttnTile<HD, FP8> tile;
     attn_walk<HD, QPK, FP8>(qa, k_cache, v_cache, block_tables + (int64_t)seq * max_blocks_per_seq, p0, p1, block_size, tok_stride, kvh,
-                            lscale, vsc, lane, m_run, s_run, o);
+                            lscale, vsc, lane, m_run, s_run, o, tile, false);
 
     // ---- partition result: locally normalised output, max and sum per head
 #pragma unroll
@@ -323,6 +346,18 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     const int seq_len = seq_lens[seq];
     const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
     const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
+    // Partitions are handed out from the last wave down, so that the waves busy with phase A get the trailing (often
+    // empty) ones; a wave without phase-A work whose first tile lies wholly before the new token requests it right away.
+    const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
+    const int tiles = (seq_len - start + 15) >> 4;
+    const int part_tokens = ((tiles + NW - 1) / NW) * 16;
+    const int part = NW - 1 - wave;
+    const int p0 = start + part * part_tokens, p1 = min(p0 + part_tokens, seq_len);
+    const bool active = seq_len > 0 && p0 < seq_len;
+    const int32_t *bt_row = block_tables + (int64_t)seq * max_blocks_per_seq;
+    AttnTile<HD, FP8> tile;
+    const bool pre = active && wave >= QPK + 2 && p0 + 16 < seq_len;
+    if (pre) attn_tile_load<HD, FP8>(tile, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, lane);
 
     // ---- A: this token's q / k / v heads
     if (wave < QPK + 2) {
@@ -395,36 +430,32 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     if (seq_len == 0) return;   // uniform over the workgroup
 
     // ---- B: wave = partition
-    const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
-    const int tiles = (seq_len - start + 15) >> 4;
-    const int part_tokens = ((tiles + NW - 1) / NW) * 16;
-    const int p0 = start + wave * part_tokens, p1 = min(p0 + part_tokens, seq_len);
     float m_run[4], s_run[4];
     float o[QPK][NP][2];
-    if (p0 < seq_len) {   // wave-uniform
+    if (active) {   // wave-uniform
         uint4 qa[KSTEPS];
 #pragma unroll
         for (int i = 0; i < KSTEPS; i++) {
             qa[i] = make_uint4(0, 0, 0, 0);
             if (tl < QPK) qa[i] = *reinterpret_cast<const uint4 *>(qs + tl * HD + 32 * i + 8 * dg);
         }
-        attn_walk<HD, QPK, FP8>(qa, k_cache, v_cache, block_tables + (int64_t)seq * max_blocks_per_seq, p0, p1, block_size,
-                                (int64_t)Hkv * HD, kvh, scale * ksc, vsc, lane, m_run, s_run, o);
+        attn_walk<HD, QPK, FP8>(qa, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, scale * ksc, vsc, lane, m_run,
+                                s_run, o, tile, pre);
     }
     const bool lane_live = (HD >= 128) || (lane < 32);
 #pragma unroll
     for (int h = 0; h < QPK; h++) {
         float sh = 0.f, mh = -FLT_MAX;
-        if (p0 < seq_len) {
+        if (active) {
             sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_run[h & 3]), 16 * (h >> 2)));
             mh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run[h & 3]), 16 * (h >> 2)));
         }
-        if (lane == 0) { mm[wave * QPK + h] = mh; ms[wave * QPK + h] = sh; }
-        if (p0 < seq_len && lane_live) {
+        if (lane == 0) { mm[part * QPK + h] = mh; ms[part * QPK + h] = sh; }
+        if (active && lane_live) {
             const float inv = 1.0f / (sh + 1e-6f);
 #pragma unroll
             for (int p = 0; p < NP; p++)
-                *reinterpret_cast<float2 *>(mo + (wave * QPK + h) * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
+                *reinterpret_cast<float2 *>(mo + (part * QPK + h) * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
         }
     }
     __syncthreads();
