@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
     const int nchunk = hidden >> 3;
     float hv[CH][8];
     float var = 0.f;
+    uint4 wraw[CH];   // norm weights requested with the first loads: the kernel is a chain of latencies
+#pragma unroll
+    for (int c = 0; c < CH; c++) wraw[c] = *reinterpret_cast<const uint4 *>(w + 8 * min((int)threadIdx.x + 256 * c, nchunk - 1));
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const int ci = threadIdx.x + 256 * c;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
         const int ci = threadIdx.x + 256 * c;
         if (ci < nchunk) {
             float wv[8], o[8];
-            unpack_bf16x8(*reinterpret_cast<const uint4 *>(w + 8 * ci), wv);
+            unpack_bf16x8(wraw[c], wv);
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = hv[c][j] * inv * wv[j];
             const uint4 packed = pack_bf16x8(o);
