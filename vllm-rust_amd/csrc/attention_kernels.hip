@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     const float *__restrict__ cos_sin, const int32_t *__restrict__ positions, const int32_t *__restrict__ slots,
     const int32_t *__restrict__ block_tables, const int32_t *__restrict__ seq_lens, float scale, int Hq, int Hkv, int rot_dim,
     int max_blocks_per_seq, int block_size, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr,
-    int8_t *__restrict__ aq, float *__restrict__ ad) {
+    int8_t *__restrict__ aq, float *__restrict__ ad, int v_norm) {
     constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1, EPL = HD / 64;   // EPL: elements per lane in phase A
     extern __shared__ __align__(16) unsigned char smem_attn[];
     uint16_t *qs = reinterpret_cast<uint16_t *>(smem_attn);                      // [QPK][HD] bf16
@@ -375,11 +375,12 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
             ss += v[j] * v[j];
         }
         const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
-        if (nw) {
+        if (nw || (!is_q && !is_k && v_norm)) {   // v_norm: RMSNorm without weight on the value head (gemma4_quantized.rs:1311-1424)
             ss = vmx_wave_sum(ss);
             const float inv = rsqrtf(ss / (float)HD + eps);
 #pragma unroll
-            for (int j = 0; j < EPL; j++) v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j] * inv * vmx_bf16_to_f32(nw[lane + 64 * j])));
+            for (int j = 0; j < EPL; j++)
+                v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j] * inv * (nw ? vmx_bf16_to_f32(nw[lane + 64 * j]) : 1.0f)));
         }
         if (is_q || is_k) {   // NeoX rotation of the first rot_dim dims: pairs (i, i + rot_dim/2)
             const int half = rot_dim >> 1;
@@ -493,20 +494,23 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     }
 }
 
-constexpr int FUSED_NW = 16;
-constexpr int FUSED_MAX_CTX = FUSED_NW * 64;   // <= 4 tiles per wave
+// waves per workgroup: 16 where a thread may hold 128 registers' worth of tiles, 8 for 256-wide heads; context bound = 4 tiles
+// per wave
+constexpr int fused_nw(int hd) { return hd <= 128 ? 16 : 8; }
+constexpr int fused_max_ctx(int hd) { return fused_nw(hd) * 64; }
 
 template <int HD, int QPK, bool FP8>
 int launch_fused(dim3 grid, hipStream_t st, uint16_t *out, const float *partial, int splits, int tokens, void *kc, void *vc,
                  const uint16_t *qn, const uint16_t *kn, float eps, const float *cos_sin, const int32_t *positions, const int32_t *slots,
                  const int32_t *bt, const int32_t *sl, float scale, int Hq, int Hkv, int rot_dim, int mbps, int bs, int window,
-                 const float *ks, const float *vs, int8_t *aq, float *ad) {
+                 const float *ks, const float *vs, int8_t *aq, float *ad, int v_norm) {
+    constexpr int FUSED_NW = fused_nw(HD);
     const size_t lds = (size_t)QPK * HD * 2 + (size_t)FUSED_NW * QPK * HD * 4 + (size_t)2 * FUSED_NW * QPK * 4;
     if (lds > 64 * 1024)
         VMX_CHECK_HIP(hipFuncSetAttribute((const void *)fused_decode_attn_kernel<HD, QPK, FP8, FUSED_NW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((fused_decode_attn_kernel<HD, QPK, FP8, FUSED_NW>), grid, dim3(64 * FUSED_NW), lds, st, out, partial, splits, tokens,
-                       kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks, vs, aq, ad);
+                       kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks, vs, aq, ad, v_norm);
     VMX_CHECK_LAUNCH("fused_decode_attention");
     return VMX_OK;
 }
@@ -779,12 +783,13 @@ int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const in
 bool vmx_fused_decode_attention_ok(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
     static const bool off = getenv("VMX_NO_FUSED_ATTN") && atoi(getenv("VMX_NO_FUSED_ATTN"));
     if (off) return false;
+    // 256-wide heads were measured slower here than the three-launch path (8 waves, 3+ tiles each): not covered
     if (head_dim != 64 && head_dim != 128) return false;
     if (qpk != 1 && qpk != 2 && qpk != 4 && qpk != 8) return false;
     const int half = rot_dim / 2;
     if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return false;
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
-    return ctx > 0 && ctx <= FUSED_MAX_CTX;
+    return ctx > 0 && ctx <= fused_max_ctx(head_dim);
 }
 
 int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
@@ -792,13 +797,13 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
                                const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
                                float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
                                int max_blocks_per_seq, int block_size, int window, int kv_dtype, const float *k_scale,
-                               const float *v_scale, int8_t *aq, float *ad, hipStream_t st) {
+                               const float *v_scale, int8_t *aq, float *ad, int v_norm, hipStream_t st) {
     const int qpk = num_heads / num_kv_heads;
     const dim3 grid(num_kv_heads, num_seqs);
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
     int rc = VMX_EUNSUPPORTED;
 #define FARGS grid, st, out, qkv_partial, splits, num_seqs, k_cache, v_cache, q_norm_w, k_norm_w, eps, cos_sin, positions, slots, block_tables, \
-              seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size, window, k_scale, v_scale, aq, ad
+              seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size, window, k_scale, v_scale, aq, ad, v_norm
 #define F_QPK(HD)                                                                                         \
     switch (qpk) {                                                                                        \
         case 1: rc = fp8 ? launch_fused<HD, 1, true>(FARGS) : launch_fused<HD, 1, false>(FARGS); break;   \

@@ -815,7 +815,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
                                                     Hkv, hd, hd, max_blocks_per_seq, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
-                                                    iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr, st))
+                                                    iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr, 0, st))
                 return rc;
         } else
         hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, s_qkv, B, q, L.k_cache.p,

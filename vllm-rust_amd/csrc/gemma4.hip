@@ -521,6 +521,16 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
             if (int rc = vmx_iq_mmvq_multi(segs, L.k_eq_v ? 2 : 3, aq_of(m), ad_of(m, B, H), proj, H, B, ntot, st)) return rc;
         }
         const float *ks = (const float *)L.kv_scales.p;
+        // short contexts: per-head norms + RoPE + KV write + attention + merge in one launch (not for K == V layers)
+        const bool fused_attn = !L.k_eq_v && vmx_fused_decode_attention_ok(hd, Hq / Hkv, L.rot, max_seq_len, L.window);
+        if (fused_attn) {
+            if (int rc = vmx_fused_decode_attention(attn, proj, 1, L.k_cache.p, L.v_cache.p, (const uint16_t *)L.q_norm.p,
+                                                    (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
+                                                    (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping,
+                                                    block_tables, seq_lens, 1.0f, B, Hq, Hkv, hd, L.rot, max_blocks_per_seq, c.block_size,
+                                                    L.window, c.kv_cache_dtype, ks, ks + 1, aq_of(m), ad_of(m, B, NQ), 1, st))
+                return rc;
+        } else {
         hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, L.k_cache.p, L.v_cache.p,
                            (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
                            (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping, Hq, Hkv, hd, L.rot,
@@ -530,6 +540,7 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
                                                max_seq_len, hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, m->attn_ws.p, &ap, st))
             return rc;
         if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
+        }
         if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, B, st)) return rc;
         // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, out, (const uint16_t *)L.post_attn_ln.p, nullptr, (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, H,
