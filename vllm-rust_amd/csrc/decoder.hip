@@ -314,6 +314,7 @@ struct Layer {
     IqLinear iq[7];  // q, k, v, o, gate, up, down as GGUF I-quants (alternative to the int4 linears)
     bool iq_ready() const { for (const IqLinear &l : iq) if (!l.loaded) return false; return true; }
     Exl3Lin ex[7];   // ... or as EXL3 trellis-coded linears
+    DevBuf ex_svh_qkv, ex_svh_gu;   // svh of q|k|v and of gate|up back to back, when the group can go out as one launch
     bool exl3_ready() const { for (const Exl3Lin &l : ex) if (!l.loaded) return false; return true; }
     bool int4_ready() const { return qkv.loaded && o.loaded && gate_up.loaded && down.loaded; }
     bool int4_attn_ready() const { return qkv.loaded && o.loaded; }
@@ -383,6 +384,22 @@ int iq_forward(vmx_qwen3 *m, const IqLinear &l, float *y, int ldy, int tokens, h
 int exl3_forward(vmx_qwen3 *m, const Exl3Lin &l, const uint16_t *x, float *y, int ldy, int tokens, hipStream_t st) {
     return vmx_exl3_forward_f32(x, 1, l.trellis.p, (const uint16_t *)l.suh.p, (const uint16_t *)l.svh.p, y, ldy, tokens, l.in_features,
                                 l.out_features, l.bits, l.codebook, m->exl3_ws.p, m->exl3_ws.bytes, st);
+}
+
+// Several EXL3 projections of one layer that share x, as one launch pair (M <= 4)
+int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> slots, const DevBuf &svh, const uint16_t *x, float *y, int ldy,
+                       int tokens, hipStream_t st) {
+    const void *tr[3];
+    const uint16_t *suh[3];
+    int n_out[3], n = 0;
+    for (int sl : slots) {
+        tr[n] = L.ex[sl].trellis.p;
+        suh[n] = (const uint16_t *)L.ex[sl].suh.p;
+        n_out[n++] = L.ex[sl].out_features;
+    }
+    const Exl3Lin &f = L.ex[*slots.begin()];
+    return vmx_exl3_forward_multi_f32(x, 1, n, tr, suh, n_out, (const uint16_t *)svh.p, y, ldy, tokens, f.in_features, f.bits, f.codebook,
+                                      m->exl3_ws.p, m->exl3_ws.bytes, st);
 }
 
 // Row-parallel epilogue: red_bf16 = all_reduce_sum(bf16(sum of this rank's split-K slices)) — what composing the
@@ -560,6 +577,8 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
         for (DevBuf *b : {&L.router, &L.w13_table, &L.w2_table}) b->release();
         for (Exl3Lin &e : L.ex)
             for (DevBuf *b : {&e.trellis, &e.suh, &e.svh}) b->release();
+        L.ex_svh_qkv.release();
+        L.ex_svh_gu.release();
         for (DevBuf *b : {&L.qkv.packed, &L.o.packed, &L.gate_up.packed, &L.down.packed, &L.input_ln, &L.post_ln, &L.q_norm, &L.k_norm,
                           &L.k_cache, &L.v_cache, &L.kv_scales})
             b->release();
@@ -759,6 +778,34 @@ extern "C" int vmx_qwen3_load_exl3_linear(vmx_qwen3 *m, int layer, int slot, con
     l.bits = bits;
     l.codebook = codebook;
     l.loaded = true;
+    // projections that share their input and agree in bit width and codebook are launched together: merged svh vectors
+    Layer &Lr = m->layers[layer];
+    auto merge = [&](DevBuf &dst, std::initializer_list<int> slots) -> int {
+        dst.release();
+        size_t total = 0;
+        const Exl3Lin &first = Lr.ex[*slots.begin()];
+        for (int sl : slots) {
+            const Exl3Lin &e = Lr.ex[sl];
+            if (!e.loaded || e.bits != first.bits || e.codebook != first.codebook) return VMX_OK;
+            total += (size_t)e.out_features * 2;
+        }
+        if (int rc = dst.alloc(total)) return rc;
+        size_t off = 0;
+        for (int sl : slots) {
+            const Exl3Lin &e = Lr.ex[sl];
+            VMX_CHECK_HIP(hipMemcpyAsync((char *)dst.p + off, e.svh.p, (size_t)e.out_features * 2, hipMemcpyDeviceToDevice, st));
+            off += (size_t)e.out_features * 2;
+        }
+        const size_t need_m = vmx_exl3_gemm_workspace_bytes(4, first.in_features, (int)(total / 2));
+        if (need_m > m->exl3_ws.bytes) {
+            VMX_CHECK_HIP(hipStreamSynchronize(st));
+            m->exl3_ws.release();
+            if (int rc = m->exl3_ws.alloc(need_m)) return rc;
+        }
+        return VMX_OK;
+    };
+    if (slot <= VMX_L_V) { if (int rc = merge(Lr.ex_svh_qkv, {VMX_L_Q, VMX_L_K, VMX_L_V})) return rc; }
+    else if (slot == VMX_L_GATE || slot == VMX_L_UP) { if (int rc = merge(Lr.ex_svh_gu, {VMX_L_GATE, VMX_L_UP})) return rc; }
     return VMX_OK;
 }
 
@@ -799,7 +846,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         // h += pending; x = rms_norm(h);  q|k|v = linear(x)
         launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
                           iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr);
-        if (ex) {
+        if (ex && B <= 4 && L.ex_svh_qkv.p) {
+            if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, PA, NQKV_, B, st)) return rc;
+        } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_Q], x, PA, NQKV_, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_K], x, PA + NQ, NQKV_, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_V], x, PA + NQ + NKV, NQKV_, B, st)) return rc;
@@ -874,7 +923,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             pending_splits = -1;
             continue;
         }
-        if (ex) {
+        if (ex && B <= 4 && L.ex_svh_gu.p) {
+            if (int rc = exl3_forward_group(m, L, {VMX_L_GATE, VMX_L_UP}, L.ex_svh_gu, x, PA, 2 * I, B, st)) return rc;
+        } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_GATE], x, PA, 2 * I, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_UP], x, PA + I, 2 * I, B, st)) return rc;
         } else if (iq) {

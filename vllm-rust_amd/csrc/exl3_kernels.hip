@@ -170,10 +170,17 @@ template <int CB> __device__ __forceinline__ uint32_t exl3_decode_pair(uint32_t 
 // workgroup transforms the KT/8 128-blocks of its slice itself (fp16(x) * suh -> 128-point Hadamard in f32 -> * 1/sqrt(128)
 // -> fp16, the arithmetic of exl3_had_f16_kernel), after the weight requests are out.  Meant for M <= 4 (decode): the
 // transform is repeated by every column group.
+// Up to three tensors that share the activation rows (q|k|v, gate|up) go out as ONE launch: the column groups (64 columns)
+// [cg_end[s-1], cg_end[s]) of the merged output belong to tensor s, which has its own trellis and input sign vector.
+struct Exl3Segs {
+    const uint16_t *tr[3];
+    const uint16_t *suh[3];
+    int cg_end[3];
+};
+
 template <int BITS, int CB, int KT, bool HAD>
-__global__ __launch_bounds__(256) void exl3_gemm_kernel(const uint16_t *__restrict__ trellis, const uint16_t *__restrict__ a_had,
-                                                         const uint16_t *__restrict__ suh, int x_bf16, float *__restrict__ partial,
-                                                         int M, int N, int K) {
+__global__ __launch_bounds__(256) void exl3_gemm_kernel(Exl3Segs segs, const uint16_t *__restrict__ a_had, int x_bf16,
+                                                         float *__restrict__ partial, int M, int N, int K) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int W = 8 * BITS;            // u32 words per tile
     constexpr int TS = W + 4;              // LDS words per staged tile (W + 1 used)
@@ -187,9 +194,15 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(const uint16_t *__restri
     uint32_t *tb = reinterpret_cast<uint32_t *>(smem);                              // [KT][CT][TS]
     uint16_t *xs = reinterpret_cast<uint16_t *>(smem + (size_t)KT * CT * TS * 4);   // [M][XROW] fp16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tn = N / 16, ktiles = K / 16, ncg = tn / CT;
+    const int ktiles = K / 16, ncg = N / (16 * CT);   // N: columns of the merged output
     const int cg = blockIdx.x % ncg, ks = blockIdx.x / ncg;
-    const int kt0 = ks * KT, nt0 = cg * CT, k0 = kt0 * 16;
+    int sgi = 0, cg0 = 0;
+    if (cg >= segs.cg_end[0]) { sgi = 1; cg0 = segs.cg_end[0]; }
+    if (cg >= segs.cg_end[1]) { sgi = 2; cg0 = segs.cg_end[1]; }
+    const uint16_t *__restrict__ trellis = segs.tr[sgi];
+    const uint16_t *__restrict__ suh = segs.suh[sgi];
+    const int tn = (segs.cg_end[sgi] - cg0) * CT;   // column tiles of this tensor
+    const int kt0 = ks * KT, nt0 = (cg - cg0) * CT, k0 = kt0 * 16;
     const int n = lane & 15, g = lane >> 4;
 
     // activations first (L2 hits), then every weight piece of the slice
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(const uint16_t *__restri
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int mrow = 4 * g + r;
-        if (mrow < M) partial[((int64_t)ks * M + mrow) * N + (nt0 + wave) * 16 + n] = acc[r];
+        if (mrow < M) partial[((int64_t)ks * M + mrow) * N + (cg * CT + wave) * 16 + n] = acc[r];
     }
 }
 
@@ -322,8 +335,8 @@ inline Exl3Plan exl3_plan(int N, int K, int bits) {
 }
 
 template <int BITS, int CB, int KT>
-int launch_exl3_gemm_kt(const uint16_t *trellis, const uint16_t *a, const uint16_t *suh, int fuse_had, int x_bf16, float *partial, int M,
-                        int N, int K, int splits, hipStream_t st) {
+int launch_exl3_gemm_kt(const Exl3Segs &segs, const uint16_t *a, int fuse_had, int x_bf16, float *partial, int M, int N, int K, int splits,
+                        hipStream_t st) {
     const size_t lds = (size_t)KT * 4 * (8 * BITS + 4) * 4 + (size_t)M * (KT * 16 + 8) * 2;
     const dim3 grid((unsigned)((N / 64) * splits));
 #define EXL3_GO(H)                                                                                                                       \
@@ -331,7 +344,7 @@ int launch_exl3_gemm_kt(const uint16_t *trellis, const uint16_t *a, const uint16
         if (lds > 64 * 1024)                                                                                                             \
             VMX_CHECK_HIP(hipFuncSetAttribute((const void *)exl3_gemm_kernel<BITS, CB, KT, H>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)lds));                                                                                \
-        hipLaunchKernelGGL((exl3_gemm_kernel<BITS, CB, KT, H>), grid, dim3(256), lds, st, trellis, a, suh, x_bf16, partial, M, N, K);     \
+        hipLaunchKernelGGL((exl3_gemm_kernel<BITS, CB, KT, H>), grid, dim3(256), lds, st, segs, a, x_bf16, partial, M, N, K);             \
     } while (0)
     if (fuse_had) EXL3_GO(true);
     else EXL3_GO(false);
@@ -342,12 +355,12 @@ int launch_exl3_gemm_kt(const uint16_t *trellis, const uint16_t *a, const uint16
 
 // a: Hadamard-transformed fp16 activations (fuse_had == 0) or the raw activations (fuse_had != 0, M <= 4)
 template <int BITS>
-int launch_exl3_gemm(int cb, const uint16_t *trellis, const uint16_t *a, const uint16_t *suh, int fuse_had, int x_bf16, float *partial,
-                     int M, int N, int K, hipStream_t st) {
+int launch_exl3_gemm(int cb, const Exl3Segs &segs, const uint16_t *a, int fuse_had, int x_bf16, float *partial, int M, int N, int K,
+                     hipStream_t st) {
     const Exl3Plan p = exl3_plan(N, K, BITS);
 #define EXL3_L(CBV)                                                                                                                \
-    return p.kt == 16 ? launch_exl3_gemm_kt<BITS, CBV, 16>(trellis, a, suh, fuse_had, x_bf16, partial, M, N, K, p.splits, st)      \
-                      : launch_exl3_gemm_kt<BITS, CBV, 32>(trellis, a, suh, fuse_had, x_bf16, partial, M, N, K, p.splits, st)
+    return p.kt == 16 ? launch_exl3_gemm_kt<BITS, CBV, 16>(segs, a, fuse_had, x_bf16, partial, M, N, K, p.splits, st)      \
+                      : launch_exl3_gemm_kt<BITS, CBV, 32>(segs, a, fuse_had, x_bf16, partial, M, N, K, p.splits, st)
     switch (cb) {
         case 0: EXL3_L(0);
         case 1: EXL3_L(1);
@@ -356,18 +369,25 @@ int launch_exl3_gemm(int cb, const uint16_t *trellis, const uint16_t *a, const u
 #undef EXL3_L
 }
 
+int exl3_gemm_dispatch_segs(int bits, int cb, const Exl3Segs &sg, const uint16_t *a, int fuse_had, int x_bf16, float *partial, int M, int N,
+                            int K, hipStream_t st) {
+    switch (bits) {
+        case 1: return launch_exl3_gemm<1>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+        case 2: return launch_exl3_gemm<2>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+        case 3: return launch_exl3_gemm<3>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+        case 4: return launch_exl3_gemm<4>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+        case 5: return launch_exl3_gemm<5>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+        case 6: return launch_exl3_gemm<6>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+        case 7: return launch_exl3_gemm<7>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+        default: return launch_exl3_gemm<8>(cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
+    }
+}
+
 int exl3_gemm_dispatch(int bits, int cb, const uint16_t *tr, const uint16_t *a, const uint16_t *suh, int fuse_had, int x_bf16,
                        float *partial, int M, int N, int K, hipStream_t st) {
-    switch (bits) {
-        case 1: return launch_exl3_gemm<1>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-        case 2: return launch_exl3_gemm<2>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-        case 3: return launch_exl3_gemm<3>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-        case 4: return launch_exl3_gemm<4>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-        case 5: return launch_exl3_gemm<5>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-        case 6: return launch_exl3_gemm<6>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-        case 7: return launch_exl3_gemm<7>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-        default: return launch_exl3_gemm<8>(cb, tr, a, suh, fuse_had, x_bf16, partial, M, N, K, st);
-    }
+    const int ncg = N / 64;
+    const Exl3Segs sg = {{tr, tr, tr}, {suh, suh, suh}, {ncg, ncg, ncg}};
+    return exl3_gemm_dispatch_segs(bits, cb, sg, a, fuse_had, x_bf16, partial, M, N, K, st);
 }
 
 }  // namespace
@@ -455,5 +475,34 @@ int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, con
                            (uint16_t *)nullptr, N, y32 + (int64_t)m0 * ld, ld);
         VMX_CHECK_LAUNCH("exl3_forward(output hadamard)");
     }
+    return VMX_OK;
+}
+
+// Up to three Exl3Linear tensors of equal bit width and codebook that share the input (q|k|v, gate|up), M <= 4 rows, in one
+// GEMM launch and one output-transform launch: column c of tensor s lands at y32[row * ld + (columns of tensors < s) + c].
+// svh_merged: the tensors' svh vectors back to back.  Workspace as for one linear of the summed width.
+int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const void *const *trellis, const uint16_t *const *suh,
+                               const int *n_out, const uint16_t *svh_merged, float *y32, int ld, int M, int K, int bits, int codebook,
+                               void *workspace, size_t workspace_bytes, hipStream_t st) {
+    VMX_REQUIRE(nseg >= 1 && nseg <= 3 && M >= 1 && M <= 4, "exl3_forward_multi: %d tensors / %d rows unsupported", nseg, M);
+    int N = 0;
+    Exl3Segs sg;
+    for (int i = 0; i < 3; i++) {
+        const int j = i < nseg ? i : nseg - 1;
+        if (i < nseg) {
+            VMX_REQUIRE(n_out[i] > 0 && n_out[i] % 128 == 0, "exl3_forward_multi: out_features (%d) must be a multiple of 128", n_out[i]);
+            N += n_out[i];
+        }
+        sg.tr[i] = (const uint16_t *)trellis[j];
+        sg.suh[i] = suh[j];
+        sg.cg_end[i] = N / 64;
+    }
+    VMX_REQUIRE(workspace_bytes >= vmx_exl3_gemm_workspace_bytes(M, K, N), "exl3_forward_multi: workspace too small");
+    float *partial = (float *)((char *)workspace + (((size_t)M * K * 2 + 255) & ~(size_t)255));
+    const int splits = exl3_plan(N, K, bits).splits;
+    if (int rc = exl3_gemm_dispatch_segs(bits, codebook, sg, x, 1, x_bf16, partial, M, N, K, st)) return rc;
+    hipLaunchKernelGGL(exl3_out_had_kernel, dim3(N / 128, M), dim3(64), 0, st, partial, splits, (int64_t)M * N, svh_merged, (uint16_t *)nullptr, N,
+                       y32, ld);
+    VMX_CHECK_LAUNCH("exl3_forward_multi(output hadamard)");
     return VMX_OK;
 }

@@ -15,6 +15,10 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
                          int N, int group, int Ntot, int col0, hipStream_t st);
 
+int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const void *const *trellis, const uint16_t *const *suh,
+                               const int *n_out, const uint16_t *svh_merged, float *y32, int ld, int M, int K, int bits, int codebook,
+                               void *workspace, size_t workspace_bytes, hipStream_t st);
+
 // attention_kernels.hip: q/k/v post-processing + short-context decode attention + merge in one launch
 bool vmx_fused_decode_attention_ok(int head_dim, int qpk, int rot_dim, int max_seq_len, int window);
 int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
