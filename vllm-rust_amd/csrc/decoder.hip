@@ -53,6 +53,52 @@ __device__ __forceinline__ void sum_partials8(const float *__restrict__ partial,
     }
 }
 
+// Output side of an EXL3 linear (exl3.rs:216-286; had_fh_r_128 of kernels/exl3/hadamard_inner.cuh) folded into the consumer
+// of its split-K sums: `o` holds 8 consecutive columns (the sums of all slices, taken in slice order); the 16 lanes that
+// hold one 128-column block apply the 128-point Hadamard in the stage order 1, 2, ..., 64 with v' = (bit ? -v : v) +
+// partner (three stages inside the thread, four across lanes), then * 1/sqrt(128) -> fp16 -> * svh (fp16) -> the value the
+// linear returns.  All 64 lanes of the wave must call it; col = first column of the thread's chunk.
+__device__ __forceinline__ void exl3_out_transform8(const float *__restrict__ partial, int splits, int64_t slice_stride, int64_t idx,
+                                                    const uint16_t *__restrict__ svh, int col, float o[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = 0.f;
+#pragma unroll 4
+    for (int sp = 0; sp < splits; sp++) {
+        const float4 a = *reinterpret_cast<const float4 *>(partial + sp * slice_stride + idx);
+        const float4 b = *reinterpret_cast<const float4 *>(partial + sp * slice_stride + idx + 4);
+        o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+        o[4] += b.x; o[5] += b.y; o[6] += b.z; o[7] += b.w;
+    }
+#pragma unroll
+    for (int st = 1; st < 8; st <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (!(j & st)) {
+                const float a = o[j], b = o[j | st];
+                o[j] = a + b;
+                o[j | st] = a - b;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const bool neg = (lane & m) != 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float p = __shfl_xor(o[j], m, 64);
+            o[j] = (neg ? -o[j] : o[j]) + p;
+        }
+    }
+    const uint4 sv = *reinterpret_cast<const uint4 *>(svh + col);
+    const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const _Float16 sc = __builtin_bit_cast(_Float16, (uint16_t)(j & 1 ? sw[j >> 1] >> 16 : sw[j >> 1] & 0xffffu));
+        o[j] = (float)((_Float16)(o[j] * 0.088388347648f) * sc);
+    }
+}
+
 __device__ __forceinline__ void unpack_bf16x8(const uint4 v, float f[8]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -78,7 +124,8 @@ template <int CH>
 __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x,
                                                           const float *__restrict__ partial, int splits, int tokens,
                                                           const uint16_t *__restrict__ w, float eps, int hidden,
-                                                          int8_t *__restrict__ aq, float *__restrict__ ad) {
+                                                          int8_t *__restrict__ aq, float *__restrict__ ad,
+                                                          const uint16_t *__restrict__ had_svh) {
     __shared__ float red[4];
     const int t = blockIdx.x;
     const int64_t row = (int64_t)t * hidden;
@@ -92,7 +139,18 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const int ci = threadIdx.x + 256 * c;
-        if (ci < nchunk) {
+        if (256 * c < nchunk && had_svh) {   // block-uniform; hidden % 128 == 0, so a 16-lane group is all in or all out: `partial` holds an EXL3 linear's raw split-K sums
+            float o[8];
+            exl3_out_transform8(partial, splits, slice, row + 8 * min(ci, nchunk - 1), had_svh, 8 * min(ci, nchunk - 1), o);
+            if (ci < nchunk) {
+                unpack_bf16x8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) hv[c][j] = round_bf16(hv[c][j] + round_bf16(o[j]));
+                *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack_bf16x8(hv[c]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) var += hv[c][j] * hv[c][j];
+            }
+        } else if (ci < nchunk) {
             unpack_bf16x8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
             if (partial) {
                 float o[8];
@@ -193,17 +251,24 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ 
 // result for an I-quant down projection (inter % 32 == 0).
 __global__ __launch_bounds__(256) void gateup_act_kernel(const float *__restrict__ partial, int splits, int tokens,
                                                           uint16_t *__restrict__ act, int inter, int8_t *__restrict__ aq,
-                                                          float *__restrict__ ad) {
+                                                          float *__restrict__ ad, const uint16_t *__restrict__ had_svh) {
     const int64_t chunks = (int64_t)tokens * inter / 8;
     const int64_t slice = (int64_t)tokens * 2 * inter;
     const int cpr = inter / 8;
     for (int64_t c0 = (int64_t)blockIdx.x * 256; c0 < chunks; c0 += (int64_t)gridDim.x * 256) {
         const int64_t c = c0 + threadIdx.x;
-        if (c < chunks) {  // chunks % 4 == 0, so 4-lane groups are all in or all out
-            const int64_t t = c / cpr, col = (c % cpr) * 8;
+        if (c < chunks || had_svh) {  // chunks % 4 == 0, so 4-lane groups are all in or all out; chunks % 16 == 0 with had_svh
+            const int64_t cc = c < chunks ? c : chunks - 1;
+            const int64_t t = cc / cpr, col = (cc % cpr) * 8;
             float g[8], u[8];
+            if (had_svh) {   // `partial` holds the raw split-K sums of an EXL3 gate|up launch (whole waves in or out: grid sized for it)
+                exl3_out_transform8(partial, splits, slice, t * 2 * inter + col, had_svh, (int)col, g);
+                exl3_out_transform8(partial, splits, slice, t * 2 * inter + inter + col, had_svh, inter + (int)col, u);
+                if (c >= chunks) continue;
+            } else {
             sum_partials8(partial, splits, slice, t * 2 * inter + col, g);
             sum_partials8(partial, splits, slice, t * 2 * inter + inter + col, u);
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float gg = round_bf16(g[j]);
@@ -245,11 +310,11 @@ __global__ __launch_bounds__(256) void embed_kernel(uint16_t *__restrict__ out, 
 }
 
 void launch_resid_norm(hipStream_t st, uint16_t *h, uint16_t *x, const float *partial, int splits, int tokens, const uint16_t *w,
-                       float eps, int hidden, int8_t *aq = nullptr, float *ad = nullptr) {
-    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
-    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
-    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
-    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad);
+                       float eps, int hidden, int8_t *aq = nullptr, float *ad = nullptr, const uint16_t *had_svh = nullptr) {
+    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
+    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
+    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
+    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
 }
 
 struct DevBuf {
@@ -388,7 +453,7 @@ int exl3_forward(vmx_qwen3 *m, const Exl3Lin &l, const uint16_t *x, float *y, in
 
 // Several EXL3 projections of one layer that share x, as one launch pair (M <= 4)
 int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> slots, const DevBuf &svh, const uint16_t *x, float *y, int ldy,
-                       int tokens, hipStream_t st) {
+                       int tokens, hipStream_t st, const float **partial_out = nullptr, int *splits_out = nullptr) {
     const void *tr[3];
     const uint16_t *suh[3];
     int n_out[3], n = 0;
@@ -399,7 +464,7 @@ int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> 
     }
     const Exl3Lin &f = L.ex[*slots.begin()];
     return vmx_exl3_forward_multi_f32(x, 1, n, tr, suh, n_out, (const uint16_t *)svh.p, y, ldy, tokens, f.in_features, f.bits, f.codebook,
-                                      m->exl3_ws.p, m->exl3_ws.bytes, st);
+                                      m->exl3_ws.p, m->exl3_ws.bytes, st, partial_out, splits_out);
 }
 
 // Row-parallel epilogue: red_bf16 = all_reduce_sum(bf16(sum of this rank's split-K slices)) — what composing the
@@ -834,6 +899,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
     const float *pending = nullptr;  // down-projection output (f32 slices in PB) not yet folded into the residual stream
     int pending_splits = 0;
+    const uint16_t *pending_svh = nullptr;  // EXL3: `pending` holds raw split-K sums whose output transform the norm kernel applies
     uint16_t *attn = (uint16_t *)m->attn.p, *act = (uint16_t *)m->act.p;
     const int NQ = Hq * hd, NKV = Hkv * hd;
     for (const Layer &L : m->layers) {
@@ -844,8 +910,11 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         const int s_qkv = one ? 1 : L.qkv.splits(), s_o = one ? 1 : L.o.splits(), s_gu = one ? 1 : L.gate_up.splits(),
                   s_down = one ? 1 : L.down.splits();
         // h += pending; x = rms_norm(h);  q|k|v = linear(x)
+        // EXL3 decode rows: the consumers of o, gate|up and down apply the output transform themselves (one launch less each)
+        const bool ex_fold = ex && B <= 4 && !tp && H % 128 == 0 && I % 128 == 0 && L.ex_svh_gu.p;
         launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
-                          iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr);
+                          iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh);
+        pending_svh = nullptr;
         if (ex && B <= 4 && L.ex_svh_qkv.p) {
             if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, PA, NQKV_, B, st)) return rc;
         } else if (ex) {
@@ -888,21 +957,25 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                                                    iq ? q8_ad(m, B, NQ) : nullptr))
                 return rc;
         }
-        if (ex) {
+        const float *o_src = PB;
+        int o_splits = s_o;
+        const uint16_t *o_svh = nullptr;
+        if (ex_fold) {
+            if (int rc = exl3_forward_group(m, L, {VMX_L_O}, L.ex[VMX_L_O].svh, attn, nullptr, H, B, st, &o_src, &o_splits)) return rc;
+            o_svh = (const uint16_t *)L.ex[VMX_L_O].svh.p;
+        } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_O], attn, PB, H, B, st)) return rc;
         } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_O], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
         // h += o; x = rms_norm(h);  gate|up = linear(x);  act = silu(gate) * up;  down = linear(act)
-        const float *o_src = PB;
-        int o_splits = s_o;
         if (tp) {  // row-parallel: local bf16 output, summed over the ranks
             if (int rc = tp_reduce(m, PB, o_splits, B, H, st)) return rc;
             o_src = (const float *)m->red_bf16.p;
             o_splits = -1;
         }
         launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, iq ? q8_aq(m) : nullptr,
-                          iq ? q8_ad(m, B, H) : nullptr);
+                          iq ? q8_ad(m, B, H) : nullptr, o_svh);
         if (moe) {
             // QuantizedMoELayer::forward (models/mixtral_quantized.rs:138-195): dense router, softmax (bf16) -> top-k -> renormalise,
             // out = sum_j bf16(expert_j(x) * w_j), experts = down(silu(gate x) * up x); no host read of the routing
@@ -923,7 +996,13 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             pending_splits = -1;
             continue;
         }
-        if (ex && B <= 4 && L.ex_svh_gu.p) {
+        const float *gu_src = PA;
+        int gu_splits = s_gu;
+        const uint16_t *gu_svh = nullptr;
+        if (ex_fold) {
+            if (int rc = exl3_forward_group(m, L, {VMX_L_GATE, VMX_L_UP}, L.ex_svh_gu, x, nullptr, 2 * I, B, st, &gu_src, &gu_splits)) return rc;
+            gu_svh = (const uint16_t *)L.ex_svh_gu.p;
+        } else if (ex && B <= 4 && L.ex_svh_gu.p) {
             if (int rc = exl3_forward_group(m, L, {VMX_L_GATE, VMX_L_UP}, L.ex_svh_gu, x, PA, 2 * I, B, st)) return rc;
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_GATE], x, PA, 2 * I, B, st)) return rc;
@@ -936,10 +1015,14 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
         if (one || !L.gate_up.glu) {
             int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
-            hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, PA, s_gu, B, act, I,
-                               iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr);
+            hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, gu_src, gu_splits, B, act, I,
+                               iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr, gu_svh);
         }
-        if (ex) {
+        if (ex_fold) {
+            if (int rc = exl3_forward_group(m, L, {VMX_L_DOWN}, L.ex[VMX_L_DOWN].svh, act, nullptr, H, B, st, &pending, &pending_splits)) return rc;
+            pending_svh = (const uint16_t *)L.ex[VMX_L_DOWN].svh.p;
+            continue;
+        } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_DOWN], act, PB, H, B, st)) return rc;
         } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_DOWN], PB, H, B, st)) return rc;
@@ -954,7 +1037,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             pending_splits = -1;
         }
     }
-    launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H);
+    launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr, pending_svh);
     VMX_CHECK_LAUNCH("qwen3 layers");
     return VMX_OK;
 }

@@ -481,9 +481,11 @@ int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, con
 // Up to three Exl3Linear tensors of equal bit width and codebook that share the input (q|k|v, gate|up), M <= 4 rows, in one
 // GEMM launch and one output-transform launch: column c of tensor s lands at y32[row * ld + (columns of tensors < s) + c].
 // svh_merged: the tensors' svh vectors back to back.  Workspace as for one linear of the summed width.
+// y32 == NULL: only the GEMM runs; *partial_out = its split-K sums f32 [*splits_out][M][N] (inside the workspace) for a
+// consumer that applies the output transform itself.
 int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const void *const *trellis, const uint16_t *const *suh,
                                const int *n_out, const uint16_t *svh_merged, float *y32, int ld, int M, int K, int bits, int codebook,
-                               void *workspace, size_t workspace_bytes, hipStream_t st) {
+                               void *workspace, size_t workspace_bytes, hipStream_t st, const float **partial_out, int *splits_out) {
     VMX_REQUIRE(nseg >= 1 && nseg <= 3 && M >= 1 && M <= 4, "exl3_forward_multi: %d tensors / %d rows unsupported", nseg, M);
     int N = 0;
     Exl3Segs sg;
@@ -501,6 +503,9 @@ int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const vo
     float *partial = (float *)((char *)workspace + (((size_t)M * K * 2 + 255) & ~(size_t)255));
     const int splits = exl3_plan(N, K, bits).splits;
     if (int rc = exl3_gemm_dispatch_segs(bits, codebook, sg, x, 1, x_bf16, partial, M, N, K, st)) return rc;
+    if (partial_out) *partial_out = partial;
+    if (splits_out) *splits_out = splits;
+    if (!y32) return VMX_OK;
     hipLaunchKernelGGL(exl3_out_had_kernel, dim3(N / 128, M), dim3(64), 0, st, partial, splits, (int64_t)M * N, svh_merged, (uint16_t *)nullptr, N,
                        y32, ld);
     VMX_CHECK_LAUNCH("exl3_forward_multi(output hadamard)");
