@@ -768,7 +768,8 @@ extern "C" int vmx_qwen3_load_gptq_expert(vmx_qwen3 *m, int layer, int expert, c
     hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n13 + 255) / 256)), dim3(256), 0, st, w3_scales_f16, (uint16_t *)sc13.p + I, n13, I, 2 * I);
     hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w2_scales_f16, (uint16_t *)sc2.p, n2, H, H);
     if (hipGetLastError() != hipSuccess) { vmx_set_error("qwen3_load_gptq_expert: scale conversion launch failed"); return fail(VMX_ELAUNCH); }
-    rc = vmx_int4_pack((const uint32_t *)qw13.p, (const uint16_t *)sc13.p, nullptr, L.w13[expert].p, H, 2 * I, g, st);
+    rc = vmx_int4_pack_cols((const uint32_t *)qw13.p, (const uint16_t *)sc13.p, nullptr, L.w13[expert].p, H, 2 * I, g,
+                            vmx_int4_glu_fusable(2 * I, H) ? 1 : 0, st);   // gate|up interleaved per tile for the fused activation
     if (!rc) rc = vmx_int4_pack(w2_qweight, (const uint16_t *)sc2.p, nullptr, L.w2[expert].p, I, H, g, st);
     if (rc) return fail(rc);
     void *p13 = L.w13[expert].p, *p2 = L.w2[expert].p;
@@ -988,9 +989,10 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             }
             if (int rc = vmx_topk_softmax(rl, VMX_BF16, (float *)m->topk_w.p, (int32_t *)m->topk_ids.p, B, c.num_experts, c.experts_per_tok, 1, 1, st))
                 return rc;
-            if (int rc = vmx_moe_int4_forward((uint16_t *)m->moe_out.p, x, (const float *)m->topk_w.p, (const int32_t *)m->topk_ids.p,
-                                              (const void *const *)L.w13_table.p, (const void *const *)L.w2_table.p, B, c.experts_per_tok,
-                                              c.num_experts, H, I, c.group_size, m->moe_ws.p, m->moe_ws.bytes, st))
+            if (int rc = vmx_moe_int4_forward_glu((uint16_t *)m->moe_out.p, x, (const float *)m->topk_w.p, (const int32_t *)m->topk_ids.p,
+                                                  (const void *const *)L.w13_table.p, (const void *const *)L.w2_table.p, B, c.experts_per_tok,
+                                                  c.num_experts, H, I, c.group_size, m->moe_ws.p, m->moe_ws.bytes,
+                                                  vmx_int4_glu_fusable(2 * I, H) ? 1 : 0, st))
                 return rc;
             pending = (const float *)m->moe_out.p;
             pending_splits = -1;

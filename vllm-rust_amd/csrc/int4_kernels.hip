@@ -339,6 +339,22 @@ __global__ __launch_bounds__(256) void int4_gemm_grouped_kernel(const void *cons
                               N, K, group, blockIdx.x);
 }
 
+// Grouped gate|up with the gated activation in the epilogue (experts packed with glu = 1, one k slice): act [pairs][N/2]
+template <int UPW, bool TAIL>
+__global__ __launch_bounds__(256) void int4_gemm_grouped_glu_kernel(const void *const *__restrict__ packed_table,
+                                                                     const int32_t *__restrict__ expert_ids, int num_experts,
+                                                                     const uint16_t *__restrict__ x, int x_row_div,
+                                                                     uint16_t *__restrict__ act, int N, int K, int group) {
+    const int p = blockIdx.y;
+    int e = expert_ids[p];
+    e = e < 0 ? 0 : (e >= num_experts ? num_experts - 1 : e);
+    const char *packed = static_cast<const char *>(packed_table[e]);
+    const uint4 *W = reinterpret_cast<const uint4 *>(packed);
+    const uint32_t *SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
+    int4_gemm_body<UPW, TAIL, true>(W, SZ, x + (int64_t)(p / x_row_div) * K, nullptr, act + (int64_t)p * (N / 2), nullptr, 0, 1, N, K, group,
+                                    blockIdx.x);
+}
+
 __global__ __launch_bounds__(256) void int4_reduce_kernel(const float *__restrict__ partial, const uint16_t *__restrict__ bias,
                                                            uint16_t *__restrict__ y, int M, int N, int splits) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,6 +567,27 @@ int vmx_int4_gemm_grouped(const void *const *packed_table, const int32_t *expert
 #undef GL
 #undef GL_T
     VMX_CHECK_LAUNCH("int4_gemm(grouped)");
+    return VMX_OK;
+}
+
+int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *expert_ids, int num_experts, const uint16_t *x,
+                              int x_row_div, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st) {
+    const GemmPlan p = plan_gemm(N, K);
+    VMX_REQUIRE(p.splits == 1, "int4_gemm_grouped_glu: linear [%d -> %d] is split over k", K, N);
+    const size_t lds = gemm_lds_bytes(1, p.upw);
+    const dim3 grid((unsigned)(N / NT), (unsigned)pairs), block(256);
+    const bool tail = (K / KB) % (4 * p.upw) != 0;
+#define GG_T(U, T) hipLaunchKernelGGL((int4_gemm_grouped_glu_kernel<U, T>), grid, block, lds, st, packed_table, expert_ids, num_experts, x, x_row_div, act, N, K, group)
+#define GG(U) do { if (tail) GG_T(U, true); else GG_T(U, false); } while (0)
+    switch (p.upw) {
+        case 8: GG(8); break;
+        case 4: GG(4); break;
+        case 2: GG(2); break;
+        default: GG(1); break;
+    }
+#undef GG
+#undef GG_T
+    VMX_CHECK_LAUNCH("int4_gemm(grouped glu)");
     return VMX_OK;
 }
 

@@ -190,12 +190,18 @@ extern "C" size_t vmx_moe_int4_workspace_bytes(int tokens, int k, int hidden, in
 extern "C" int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
                                     const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
                                     int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream) {
+    return vmx_moe_int4_forward_glu(out, x, topk_weights, topk_ids, w13_packed, w2_packed, tokens, k, num_experts, hidden, inter, group,
+                                    workspace, workspace_bytes, 0, vmx_stream(stream));
+}
+
+int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
+                             const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts, int hidden,
+                             int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st) {
     VMX_REQUIRE(out && x && topk_weights && topk_ids && w13_packed && w2_packed && workspace, "moe_int4_forward: null pointer");
     VMX_REQUIRE(tokens >= 1 && k >= 1 && num_experts >= 1, "moe_int4_forward: bad counts");
     VMX_REQUIRE(hidden % 128 == 0 && inter % 128 == 0 && group > 0 && group % 128 == 0 && hidden % group == 0 && inter % group == 0,
                 "moe_int4_forward: hidden (%d), inter (%d) and group (%d) must be multiples of 128", hidden, inter, group);
     VMX_REQUIRE(workspace_bytes >= vmx_moe_int4_workspace_bytes(tokens, k, hidden, inter), "moe_int4_forward: workspace too small");
-    hipStream_t st = vmx_stream(stream);
     const int pairs = tokens * k;
     const int s1 = vmx_int4_splits(2 * inter, hidden), s2 = vmx_int4_splits(hidden, inter);
     char *ws = (char *)workspace;
@@ -205,10 +211,14 @@ extern "C" int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const floa
     ws += ((size_t)s2 * pairs * hidden * 4 + 255) & ~(size_t)255;
     uint16_t *act = (uint16_t *)ws;
     // gate|up of every (token, slot) pair with its expert's weights; x row = token
-    if (int rc = vmx_int4_gemm_grouped(w13_packed, topk_ids, num_experts, x, k, p1, pairs, 2 * inter, hidden, group, st)) return rc;
-    int64_t blocks = ((int64_t)pairs * inter + 255) / 256;
-    hipLaunchKernelGGL(moe_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p1, s1, pairs, act, inter);
-    VMX_CHECK_LAUNCH("moe_act");
+    if (w13_glu) {   // act straight from the GEMM epilogue
+        if (int rc = vmx_int4_gemm_grouped_glu(w13_packed, topk_ids, num_experts, x, k, act, pairs, 2 * inter, hidden, group, st)) return rc;
+    } else {
+        if (int rc = vmx_int4_gemm_grouped(w13_packed, topk_ids, num_experts, x, k, p1, pairs, 2 * inter, hidden, group, st)) return rc;
+        int64_t blocks = ((int64_t)pairs * inter + 255) / 256;
+        hipLaunchKernelGGL(moe_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p1, s1, pairs, act, inter);
+        VMX_CHECK_LAUNCH("moe_act");
+    }
     // down projection; x row = pair
     if (int rc = vmx_int4_gemm_grouped(w2_packed, topk_ids, num_experts, act, 1, p2, pairs, hidden, inter, group, st)) return rc;
     hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden + 255) / 256, tokens), dim3(256), 0, st, out, p2, s2, pairs, topk_weights, k, hidden);

@@ -11,6 +11,12 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
 int vmx_int4_pack_cols(const uint32_t *qweight, const uint16_t *scales_bf16, const uint32_t *qzeros, void *packed, int K, int N,
                        int group, int glu, void *stream);
 bool vmx_int4_glu_fusable(int N, int K);
+int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *expert_ids, int num_experts, const uint16_t *x,
+                              int x_row_div, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st);
+// moe_kernels.hip: vmx_moe_int4_forward with the experts' gate|up tensors packed for the fused activation (w13_glu != 0)
+int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
+                             const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts, int hidden,
+                             int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st);
 int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int M, int N, int K, int group, hipStream_t st);
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
                          int N, int group, int Ntot, int col0, hipStream_t st);
