@@ -432,7 +432,7 @@ def main():
             traffic = json.loads((ROOT / "profiles" / "r01_pmc_traffic_int4_gemm.json").read_text())["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": "int4_gemm_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "int4_gemm_kernel / int4_gemm_glu_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches_per_step": launches, "avg_launch_us": round(us / launches, 3),
                     "alg_bytes_per_launch": round(alg / launches)}
