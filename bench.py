@@ -309,6 +309,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prompt", type=int, default=256)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (invalidates the number)")
+    ap.add_argument("--weights", choices=["awq", "exl3"], default="awq",
+                    help="exl3: the same Qwen3-8B geometry with EXL3 4.0 bpw projections (BASELINE.json configs[3]; with --tp: its TP curve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the GGUF I-quant (Gemma-4-12B-shaped) secondary measurement")
     ap.add_argument("--no-moe", action="store_true", help="skip the Mixtral-8x7B-shaped fused-MoE secondary measurement")
@@ -346,7 +348,11 @@ def main():
         spec = shard_spec(spec, rank, world)   # this rank's heads / MLP columns / lm_head rows (random-init shards)
         comm = Communicator(rank, world)
     model = QuantizedQwen3ForCausalLM(spec, device=local_rank)
-    model.load_synthetic(seed=1234 + rank)
+    exl3 = args.weights == "exl3"
+    if exl3:
+        model.load_synthetic_exl3(bits=4, codebook=0, seed=1234 + rank)
+    else:
+        model.load_synthetic(seed=1234 + rank)
     if comm is not None:
         model.set_comm(comm)
 
@@ -407,7 +413,7 @@ def main():
     # the stream the kernels run on; duration per launch = elapsed / launches (boundaries included, as in
     # rocprofv3's back-to-back kernel timestamps).
     roofline = None
-    if rank == 0:
+    if rank == 0 and not exl3:
         launches, alg = model.linears_info(B)
         with torch.cuda.stream(side):
             model.linears_only(B)
@@ -441,7 +447,7 @@ def main():
     secondary = None
     secondary_moe = None
     secondary_exl3 = None
-    if rank == 0 and not dist_on and not args.no_secondary and not args.layers:
+    if rank == 0 and not dist_on and not args.no_secondary and not args.layers and not exl3:
         model.close()
         del model, graph
         torch.cuda.empty_cache()
@@ -456,11 +462,14 @@ def main():
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed
         line = {
-            "metric": "decode tok/s (greedy, batch=1 per GPU) + %HBM-peak of the int4 linear kernel, Qwen3-8B AWQ",
+            "metric": "decode tok/s (greedy, batch=1 per GPU), Qwen3-8B EXL3 4.0 bpw" if exl3 else
+                      "decode tok/s (greedy, batch=1 per GPU) + %HBM-peak of the int4 linear kernel, Qwen3-8B AWQ",
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": K_steps, "warmup": W_steps,
             "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if use_tp else "weak", "vs_baseline": None,
-            "dtype": "int4 weights x bf16 activations, f32 accumulate", "data": "synthetic",
-            "config": {"workload": f"Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, {args.prompt}-token prompt (native prefill) then timed tokens, bf16 KV",
+            "dtype": "4-bit trellis weights x fp16 activations, f32 accumulate" if exl3 else "int4 weights x bf16 activations, f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": (f"Qwen3-8B EXL3 4.0 bpw greedy decode, batch=1, {args.prompt}-token prompt then timed tokens, bf16 KV" if exl3 else
+                                    f"Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, {args.prompt}-token prompt (native prefill) then timed tokens, bf16 KV"),
                        "layers": spec.num_layers, "hidden": spec.hidden_size, "vocab": spec.vocab_size,
                        "parallelism": "tp1" if world == 1 else (f"tp{world} (RCCL all-reduce)" if use_tp else f"dp{world} replicas (tp1 each)"),
                        "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
@@ -468,7 +477,7 @@ def main():
             "prefill": {"tokens": args.prompt, "ms": round(prefill_s * 1e3, 3), "tok_s": round(args.prompt / prefill_s, 1),
                         "note": "one vmx_qwen3_prefill call (int4 GEMM 16 rows per pass, MFMA prefill attention); untimed part of the job"},
             "roofline": roofline,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(spec),
+            "cpu_baseline": None if (args.no_cpu_baseline or exl3) else cpu_baseline(spec),
             "secondary": secondary,
             "secondary_moe": secondary_moe,
             "secondary_exl3": secondary_exl3,

@@ -151,9 +151,11 @@ def test_dense_gemv_and_embedding(gpu):
     assert not out[2].any() and not out[3].any()
 
 
-def test_tp_collective_path_world1_matches_plain_decode(gpu):
+@pytest.mark.parametrize("kind", ["awq", "exl3"])
+def test_tp_collective_path_world1_matches_plain_decode(gpu, kind):
     """A 1-rank RCCL communicator drives the row-parallel all-reduce and the vocab-parallel argmax path;
-    its results must equal the plain path bit for bit, eagerly and from a captured graph."""
+    its results must equal the plain path bit for bit, eagerly and from a captured graph.  (EXL3: the plain path lets the
+    consumers of o / gate|up / down apply the output transform, the collective path runs it as a launch of its own.)"""
     from vllm_rust_amd.parallel import Communicator
     from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
     vmx, torch = gpu
@@ -163,7 +165,7 @@ def test_tp_collective_path_world1_matches_plain_decode(gpu):
     outs = []
     for use_comm in (False, True):
         model = QuantizedQwen3ForCausalLM(spec)
-        model.load_synthetic(seed=9)
+        model.load_synthetic(seed=9) if kind == "awq" else model.load_synthetic_exl3(bits=4, seed=9)
         comm = None
         if use_comm:
             comm = Communicator(0, 1)

@@ -54,10 +54,32 @@ def _worker(rank, world, port, ret):
     rpart = torch.from_numpy(orc.bf16_to_f32(_oracle_linear(orc, xs, rqw, rqz, rsc, g)))
     dist.all_reduce(rpart)
     err = float(np.abs(rpart.numpy() - full).max() / np.abs(full).max())
+    # EXL3 linear: column shards (whole 128-column blocks) concatenate bit for bit; row shards sum to the full output up to
+    # the fp16 rounding of each rank's output
+    from vllm_rust_amd.parallel import shard_exl3_column, shard_exl3_row
+    Ke, Ne, bits = 512, 256, 4
+    tr = rng.integers(0, 65536, size=(Ke // 16, Ne // 16, 16 * bits)).astype(np.uint16)
+    suh = orc.f32_to_f16(rng.choice([-1.0, 1.0], Ke).astype(np.float32))
+    svh = orc.f32_to_f16((rng.choice([-1.0, 1.0], Ne) / np.sqrt(Ke)).astype(np.float32))
+    xe = orc.f32_to_f16((rng.standard_normal((2, Ke)) * 0.5).astype(np.float32))
+    efull = orc.f16_to_f32(orc.exl3_gemm(xe, tr.reshape(-1), suh, svh, Ke, Ne, bits, 0))
+    ctr, csu, csv = (a.numpy() for a in shard_exl3_column(t(tr.view(np.int16)), t(suh.view(np.int16)), t(svh.view(np.int16)), rank, world))
+    epart = torch.from_numpy(orc.f16_to_f32(orc.exl3_gemm(xe, ctr.view(np.uint16).reshape(-1), csu.view(np.uint16), csv.view(np.uint16),
+                                                          Ke, Ne // world, bits, 0)))
+    eparts = [torch.empty_like(epart) for _ in range(world)]
+    dist.all_gather(eparts, epart)
+    ok_ecol = np.array_equal(torch.cat(eparts, 1).numpy(), efull)
+    rtr, rsu, rsv = (a.numpy() for a in shard_exl3_row(t(tr.view(np.int16)), t(suh.view(np.int16)), t(svh.view(np.int16)), rank, world))
+    xes = np.ascontiguousarray(xe[:, rank * (Ke // world):(rank + 1) * (Ke // world)])
+    erp = torch.from_numpy(orc.f16_to_f32(orc.exl3_gemm(xes, rtr.view(np.uint16).reshape(-1), rsu.view(np.uint16), rsv.view(np.uint16),
+                                                        Ke // world, Ne, bits, 0)))
+    dist.all_reduce(erp)
+    eerr = float(np.abs(erp.numpy() - efull).max() / np.abs(efull).max())
     s = shard_spec(Qwen3Spec.qwen3_8b(), rank, world)
     ok_spec = (s.num_heads, s.num_kv_heads, s.intermediate_size, s.vocab_size, s.tp_rank) == (16, 4, 6144, 151936, rank)
     if rank == 0:
         ret["col"], ret["row_err"], ret["spec"] = ok_col, err, ok_spec
+        ret["ecol"], ret["erow_err"] = ok_ecol, eerr
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,6 +92,8 @@ def test_tp_sharding_world2_gloo():
     assert ret["col"] is True
     assert ret["row_err"] <= 2 ** -6                    # each rank rounds its partial to bf16 before the sum
     assert ret["spec"] is True
+    assert ret["ecol"] is True
+    assert ret["erow_err"] <= 2 ** -8                   # each rank rounds its output to fp16 before the sum
 
 
 def test_shard_spec_rejects_bad_divisors():

@@ -82,3 +82,24 @@ def shard_awq_row(qweight, qzeros, scales, tp_rank: int, tp_size: int, group_siz
     k, g = K // tp_size, G // tp_size
     return (qweight[tp_rank * k:(tp_rank + 1) * k].contiguous(), qzeros[tp_rank * g:(tp_rank + 1) * g].contiguous(),
             scales[tp_rank * g:(tp_rank + 1) * g].contiguous())
+
+
+def shard_exl3_column(trellis, suh, svh, tp_rank: int, tp_size: int):
+    """Column-parallel shard of an EXL3 linear (output features): trellis [K/16, N/16, 16*bits] by column tiles, svh [N]
+    by columns, suh [K] whole.  A shard must hold whole 128-column blocks (the output Hadamard works on them), so the
+    shards' outputs concatenate to the unsharded output bit for bit."""
+    n16 = trellis.shape[1]
+    assert n16 % tp_size == 0 and (n16 // tp_size * 16) % 128 == 0, "column shard must be a multiple of 128 outputs"
+    w = n16 // tp_size
+    return (trellis[:, tp_rank * w:(tp_rank + 1) * w].contiguous(), suh.contiguous(),
+            svh[tp_rank * w * 16:(tp_rank + 1) * w * 16].contiguous())
+
+
+def shard_exl3_row(trellis, suh, svh, tp_rank: int, tp_size: int):
+    """Row-parallel shard (input features): trellis by row tiles, suh [K] by rows (whole 128-row input Hadamard blocks),
+    svh [N] whole; every rank runs the complete linear on its slice of the input and the fp16 outputs are summed."""
+    k16 = trellis.shape[0]
+    assert k16 % tp_size == 0 and (k16 // tp_size * 16) % 128 == 0, "row shard must be a multiple of 128 inputs"
+    h = k16 // tp_size
+    return (trellis[tp_rank * h:(tp_rank + 1) * h].contiguous(), suh[tp_rank * h * 16:(tp_rank + 1) * h * 16].contiguous(),
+            svh.contiguous())
