@@ -475,7 +475,7 @@ def main():
                        "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
                        "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
             "prefill": {"tokens": args.prompt, "ms": round(prefill_s * 1e3, 3), "tok_s": round(args.prompt / prefill_s, 1),
-                        "note": "one vmx_qwen3_prefill call (int4 GEMM 16 rows per pass, MFMA prefill attention); untimed part of the job"},
+                        "note": "one vmx_qwen3_prefill call (64x128-tile MFMA int4 GEMM, MFMA prefill attention); untimed part of the job"},
             "roofline": roofline,
             "cpu_baseline": None if (args.no_cpu_baseline or exl3) else cpu_baseline(spec),
             "secondary": secondary,

@@ -105,7 +105,10 @@ def test_gemm_reference_lcg_cases(gpu, m):
     (2, 4096, 14336, 128, False, False),   # Mixtral expert, GPTQ symmetric
     (5, 11008 // 128 * 128, 4096, 128, True, True),  # K/128 = 86, not a multiple of 4*UPW
     (1, 2048, 2048, 2048, True, False),    # one group spanning K
-    (37, 1024, 2048, 128, True, True),     # prefill-sized M: chunks of 16 rows
+    (37, 1024, 2048, 128, True, True),     # prompt-sized M, ragged last row tile: 64 x 128 output tiles
+    (100, 2048, 3072, 128, True, False),   # two row blocks, split-K slices summed
+    (64, 12288, 1024, 128, False, True),   # long k, three slices, bias
+    (40, 1024, 208, 128, True, False),     # N not a multiple of 128: passes of 16 rows
 ])
 def test_gemm_model_shapes(gpu, M, K, N, group, zeros, bias):
     from oracle import oracle as orc

@@ -321,6 +321,128 @@ __global__ __launch_bounds__(256) void int4_gemm_glu_kernel(const uint4 *__restr
     int4_gemm_body<UPW, TAIL, true>(W, SZ, x, nullptr, act, nullptr, 0, M, N, K, group, blockIdx.x);
 }
 
+// ---------------------------------------------------------------- prompt-shaped M (more than one 16-row tile)
+// The small-M kernel streams the whole weight matrix once per 16 rows.  For prompt chunks a workgroup instead owns a
+// 64-row x 128-column output tile and walks k in 128-deep blocks: the activation tile goes through LDS (double buffered,
+// rows padded by 16 bytes against bank conflicts) and is shared by the 4 waves; a wave owns two column tiles, so one
+// A-fragment read feeds two MFMAs and an unpacked weight unit is used for 4 row tiles: the weights are streamed once per
+// 64 rows and the kernel is MFMA-bound.  Same arithmetic as above: per k-block s * (sum x*(128+nib) - (128+zp) * sum x).
+// grid (N/128, ceil(M/64), splits); partial [splits][slice_rows][N] f32, or with GLU (splits == 1, gate|up interleaved
+// per tile) act [M][N/2] bf16.
+constexpr int PF_BM = 64, PF_XROW = KB + 8;
+
+template <bool GLU>
+__global__ __launch_bounds__(256) void int4_gemm_tiled_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                               const uint16_t *__restrict__ x, float *__restrict__ partial,
+                                                               uint16_t *__restrict__ act, int M, int N, int K, int group,
+                                                               int kb_per_split, int slice_rows) {
+    __shared__ __align__(16) uint16_t xs[2][PF_BM * PF_XROW];
+    __shared__ float sumx[2][PF_BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = lane & 15, h = lane >> 4;
+    const int kblocks = K / KB, G = K / group;
+    const int row0 = blockIdx.y * PF_BM, ks = blockIdx.z;
+    const int nt0 = blockIdx.x * 8 + wave * 2;   // this wave's two column tiles
+    const int kb_begin = ks * kb_per_split, kb_end = min(kblocks, kb_begin + kb_per_split);
+
+    vmx_f32x4 fin[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) fin[mt][c] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // activation tile of one k-block: 64 rows x 16 chunks of 16 bytes, 4 chunks per thread (16 consecutive lanes = one row)
+    uint4 xr[4];
+    uint4 wr[2];
+    uint32_t szr[2];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = tid + 256 * j, row = row0 + (c >> 4);
+            xr[j] = make_uint4(0, 0, 0, 0);
+            if (row < M) xr[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)row * K + kb * KB + (c & 15) * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            wr[c] = W[((int64_t)(nt0 + c) * kblocks + kb) * 64 + lane];
+            szr[c] = SZ[((int64_t)(nt0 + c) * G + (kb * KB) / group) * 16 + nl];
+        }
+    };
+    if (kb_begin < kb_end) fetch(kb_begin);
+    int buf = 0;
+    for (int kb = kb_begin; kb < kb_end; kb++) {
+        uint16_t *xb = xs[buf];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = tid + 256 * j;
+            *reinterpret_cast<uint4 *>(xb + (c >> 4) * PF_XROW + (c & 15) * 8) = xr[j];
+            const float sm = chunk_sum16(xr[j]);
+            if ((tid & 15) == 0) sumx[buf][c >> 4] = sm;
+        }
+        const uint4 wc[2] = {wr[0], wr[1]};
+        const uint32_t szc[2] = {szr[0], szr[1]};
+        __syncthreads();
+        if (kb + 1 < kb_end) fetch(kb + 1);   // next block's loads fly under this block's matrix work
+
+        vmx_f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) acc[mt][c] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint4 bu[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t w = i == 0 ? wc[c].x : (i == 1 ? wc[c].y : (i == 2 ? wc[c].z : wc[c].w));
+                bu[c].x = (w & 0x000F000Fu) | 0x43004300u;
+                bu[c].y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+                bu[c].z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+                bu[c].w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const uint4 au = *reinterpret_cast<const uint4 *>(xb + (mt * 16 + nl) * PF_XROW + 32 * i + 8 * h);
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+                    acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, bu[c]),
+                                                                         acc[mt][c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const float4 sx = *reinterpret_cast<const float4 *>(&sumx[buf][mt * 16 + 4 * h]);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float s = __uint_as_float(szc[c] << 16), zo = __uint_as_float(szc[c] & 0xFFFF0000u);
+                fin[mt][c][0] += s * (acc[mt][c][0] - zo * sx.x);
+                fin[mt][c][1] += s * (acc[mt][c][1] - zo * sx.y);
+                fin[mt][c][2] += s * (acc[mt][c][2] - zo * sx.z);
+                fin[mt][c][3] += s * (acc[mt][c][3] - zo * sx.w);
+            }
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = row0 + mt * 16 + 4 * h + r;
+                if constexpr (GLU) {
+                    const float up = __shfl_xor(fin[mt][c][r], 8, 64);
+                    if (row < M && nl < 8) {
+                        const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(fin[mt][c][r]));
+                        const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
+                        act[(int64_t)row * (N >> 1) + (nt0 + c) * 8 + nl] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
+                    }
+                } else if (row < M) {
+                    partial[((int64_t)ks * slice_rows + row) * N + (nt0 + c) * 16 + nl] = fin[mt][c][r];
+                }
+            }
+}
+
 // Grouped form for mixture-of-experts decode: blockIdx.y = p selects one (token, expert slot) pair;
 // its weights are packed_table[expert_ids[p]], its activation row is x[p / x_row_div] and it writes
 // row p of partial[splits][pairs][N].  M = 1 per pair.
@@ -498,6 +620,12 @@ extern "C" int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K,
     return VMX_OK;
 }
 
+// rows beyond one MFMA row tile and whole 128-column groups: the tiled kernel (VMX_INT4_NO_TILED=1 keeps the 16-row passes)
+static bool tiled_ok(int M, int N) {
+    static const bool off = getenv("VMX_INT4_NO_TILED") && atoi(getenv("VMX_INT4_NO_TILED"));
+    return !off && M > 16 && N % 128 == 0;
+}
+
 // ---- internal (C++) entry points used by the decoder ---------------------------------------
 int vmx_int4_splits(int N, int K) { return plan_gemm(N, K).splits; }
 
@@ -506,6 +634,13 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
     const GemmPlan p = plan_gemm(N, K);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, the same split-K slices as the small-M plan
+        const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
+        hipLaunchKernelGGL(int4_gemm_tiled_kernel<false>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, p.splits), dim3(256), 0, st, W, SZ, x, partial,
+                           (uint16_t *)nullptr, M, N, K, group, kbs, M);
+        VMX_CHECK_LAUNCH("int4_gemm(tiled)");
+        return VMX_OK;
+    }
     for (int m0 = 0; m0 < M; m0 += 16) {   // 16 rows (one MFMA row tile) per launch; every launch re-streams the weights
         const int mm = M - m0 < 16 ? M - m0 : 16;
         if (int rc = launch_gemm(p, W, SZ, x + (int64_t)m0 * K, nullptr, nullptr, partial + (int64_t)m0 * N, mm, N, K, group, st, M)) return rc;
@@ -521,6 +656,12 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
     VMX_REQUIRE(p.splits == 1, "int4_gemm_glu: linear [%d -> %d] is split over k", K, N);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    if (tiled_ok(M, N)) {
+        hipLaunchKernelGGL(int4_gemm_tiled_kernel<true>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, 1), dim3(256), 0, st, W, SZ, x, (float *)nullptr,
+                           act, M, N, K, group, K / KB, M);
+        VMX_CHECK_LAUNCH("int4_gemm(tiled glu)");
+        return VMX_OK;
+    }
     const bool tail = (K / KB) % (4 * p.upw) != 0;
     const dim3 grid((unsigned)(N / NT)), block(256);
     for (int m0 = 0; m0 < M; m0 += 16) {
@@ -608,6 +749,7 @@ int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros
 extern "C" size_t vmx_int4_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % KB || N % NT) return 0;
     const GemmPlan p = plan_gemm(N, K);
+    if (tiled_ok(M, N)) return (size_t)p.splits * M * N * sizeof(float);   // prompt-shaped M: f32 slices of every row
     return p.splits > 1 ? (size_t)p.splits * (M < 16 ? M : 16) * N * sizeof(float) : 0;
 }
 
@@ -617,14 +759,25 @@ extern "C" int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *pa
     VMX_REQUIRE(M >= 1, "int4_gemm: M (%d) must be positive", M);
     if (int rc = check_int4_shape("int4_gemm", K, N, group)) return rc;
     const GemmPlan p = plan_gemm(N, K);
-    const int mc = M < 16 ? M : 16;  // rows per launch; larger M (prefill) walks the rows in chunks of 16
-    const size_t need = p.splits > 1 ? (size_t)p.splits * mc * N * sizeof(float) : 0;
+    const int mc = M < 16 ? M : 16;  // rows per launch of the small-M kernel
+    const size_t need = vmx_int4_gemm_workspace_bytes(M, N, K);
     VMX_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), "int4_gemm: workspace %zu B < required %zu B", workspace_bytes,
                 need);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
     hipStream_t st = vmx_stream(stream);
     float *partial = (float *)workspace;
+    (void)mc;
+    if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, then the slices are summed (+ bias) into bf16
+        const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
+        hipLaunchKernelGGL(int4_gemm_tiled_kernel<false>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, p.splits), dim3(256), 0, st, W, SZ, x, partial,
+                           (uint16_t *)nullptr, M, N, K, group, kbs, M);
+        VMX_CHECK_LAUNCH("int4_gemm(tiled)");
+        const int64_t total = (int64_t)M * N;
+        hipLaunchKernelGGL(int4_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, bias, y, M, N, p.splits);
+        VMX_CHECK_LAUNCH("int4_reduce");
+        return VMX_OK;
+    }
     for (int m0 = 0; m0 < M; m0 += 16) {
         const int mm = M - m0 < 16 ? M - m0 : 16;
         uint16_t *yc = y + (int64_t)m0 * N;
