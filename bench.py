@@ -251,6 +251,56 @@ def exl3_decode_secondary(prompt, steps, warmup):
             "weight_bytes_per_token": int(per_tok), "GBps_weights_only": round(per_tok / (dt / steps) / 1e9, 1)}
 
 
+def batch_sweep_secondary(prompt, steps, warmup, batches=(1, 4, 8, 16)):
+    """Concurrent decode streams on one GPU (the reference's c = 1/4/8/16 table, docs/perf/bench-history/
+    2026-05-09-python-vllm-comparison.md): Qwen3-8B AWQ, B sequences of `prompt` tokens each, one hipGraph per step.
+    The small-M GEMM streams the weights once for up to 16 rows; every batch size of the sweep is reported as measured
+    (first measurement: 464 / 1518 / 2094 / 1916 tok/s at B = 1 / 4 / 8 / 16 -- B = 16 is SLOWER in aggregate than B = 8)."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    total = prompt + warmup + steps + 8
+    per_seq = (total + 15) // 16 + 1
+    BM = max(batches)
+    spec = Qwen3Spec.qwen3_8b(max_position=max(4096, total + 1), num_blocks=per_seq * BM, max_batch=BM, max_seq_len=total + 1,
+                              max_prefill_tokens=prompt)
+    model = QuantizedQwen3ForCausalLM(spec)
+    model.load_synthetic(seed=1234)
+    dev = model.device
+    out = {}
+    for B in batches:
+        bt = torch.arange(per_seq * B, dtype=torch.int32, device=dev).reshape(B, per_seq).contiguous()
+        g7 = torch.Generator(device=dev).manual_seed(7)
+        ids = torch.empty(B, dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            for b in range(B):   # every sequence gets its own prompt through the native prefill
+                pids = torch.randint(0, spec.vocab_size, (prompt,), dtype=torch.int32, device=dev, generator=g7)
+                model.prefill(pids, 0, bt[b], out_id=ids[b:b + 1])
+            pos = torch.full((B,), prompt, dtype=torch.int32, device=dev)
+            slots = (bt[:, prompt // 16] * 16 + prompt % 16).to(torch.int32).contiguous()
+            sl = torch.full((B,), prompt + 1, dtype=torch.int32, device=dev)
+            o = torch.empty(B, dtype=torch.int32, device=dev)
+
+            def step():
+                model.forward_decode_batch(ids, pos, slots, bt, sl, max_seq_len=spec.max_seq_len, out_ids=o)
+                model.advance(ids, o, pos, slots, sl, bt)
+            step()
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                step()
+            for _ in range(warmup):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out[str(B)] = {"tok_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
+    model.close()
+    return {"metric": "aggregate decode tok/s at B concurrent sequences, Qwen3-8B AWQ, TP=1", "prompt": prompt, "steps": steps, "by_batch": out}
+
+
 def mixtral_secondary(prompt, steps, warmup):
     """BASELINE.json configs[4] on one GPU: decode tok/s of a Mixtral-8x7B-shaped model (AWQ attention projections, 8 GPTQ
     int4 experts top-2 per layer behind a dense router) through the executor's device-side fused MoE path."""
@@ -447,6 +497,7 @@ def main():
     secondary = None
     secondary_moe = None
     secondary_exl3 = None
+    batch_sweep = None
     if rank == 0 and not dist_on and not args.no_secondary and not args.layers and not exl3:
         model.close()
         del model, graph
@@ -458,6 +509,8 @@ def main():
         torch.cuda.empty_cache()
         secondary_exl3 = exl3_decode_secondary(args.prompt, min(args.steps, 64), args.warmup)
         secondary_exl3["linears_only"] = exl3_secondary()
+        torch.cuda.empty_cache()
+        batch_sweep = batch_sweep_secondary(args.prompt, 32, 4)
 
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed
@@ -481,6 +534,7 @@ def main():
             "secondary": secondary,
             "secondary_moe": secondary_moe,
             "secondary_exl3": secondary_exl3,
+            "batch_sweep": batch_sweep,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

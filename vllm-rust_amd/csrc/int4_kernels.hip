@@ -623,7 +623,9 @@ extern "C" int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K,
 // rows beyond one MFMA row tile and whole 128-column groups: the tiled kernel (VMX_INT4_NO_TILED=1 keeps the 16-row passes)
 static bool tiled_ok(int M, int N) {
     static const bool off = getenv("VMX_INT4_NO_TILED") && atoi(getenv("VMX_INT4_NO_TILED"));
-    return !off && M > 16 && N % 128 == 0;
+    // rows from which the tiled kernel takes over (VMX_INT4_TILED_MIN_M overrides, for measurement)
+    static const int min_m = getenv("VMX_INT4_TILED_MIN_M") ? atoi(getenv("VMX_INT4_TILED_MIN_M")) : 17;
+    return !off && M >= min_m && N % 128 == 0;
 }
 
 // ---- internal (C++) entry points used by the decoder ---------------------------------------
