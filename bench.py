@@ -254,8 +254,8 @@ def exl3_decode_secondary(prompt, steps, warmup):
 def batch_sweep_secondary(prompt, steps, warmup, batches=(1, 4, 8, 16)):
     """Concurrent decode streams on one GPU (the reference's c = 1/4/8/16 table, docs/perf/bench-history/
     2026-05-09-python-vllm-comparison.md): Qwen3-8B AWQ, B sequences of `prompt` tokens each, one hipGraph per step.
-    The small-M GEMM streams the weights once for up to 16 rows; every batch size of the sweep is reported as measured
-    (first measurement: 464 / 1518 / 2094 / 1916 tok/s at B = 1 / 4 / 8 / 16 -- B = 16 is SLOWER in aggregate than B = 8)."""
+    The small-M GEMM streams the weights once for up to 16 rows, but a step still grows with B (activation staging, the
+    16-row lm_head); every batch size of the sweep is reported as measured, whether or not it scales."""
     from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
     total = prompt + warmup + steps + 8
     per_seq = (total + 15) // 16 + 1

@@ -161,6 +161,45 @@ __device__ __forceinline__ float chunk_sum16(const uint4 v) {
     return s;
 }
 
+// Sum of the 4 waves' accumulators and the store.  Lane holds rows m = 4h + r, column n = nt*16 + nl.
+template <bool GLU>
+__device__ __forceinline__ void int4_gemm_epilogue(float *red, const vmx_f32x4 fin, const uint16_t *__restrict__ bias,
+                                                   uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride, int M,
+                                                   int N, int nt, int ks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 15, h = lane >> 4;
+    *reinterpret_cast<float4 *>(red + (wave * 64 + lane) * 4) = make_float4(fin[0], fin[1], fin[2], fin[3]);
+    __syncthreads();
+    if (wave != 0) return;
+    float4 a = *reinterpret_cast<const float4 *>(red + lane * 4);
+#pragma unroll
+    for (int wv = 1; wv < 4; wv++) {
+        const float4 b = *reinterpret_cast<const float4 *>(red + (wv * 64 + lane) * 4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float out4[4] = {a.x, a.y, a.z, a.w};
+    const int n = nt * NT + nl;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int mrow = 4 * h + r;
+        if (GLU) {
+            const float up = __shfl_xor(out4[r], 8, 64);
+            if (mrow < M && nl < 8) {
+                const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(out4[r]));
+                const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
+                y[(int64_t)mrow * (N >> 1) + nt * 8 + nl] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
+            }
+        } else if (mrow < M) {
+            if (y) {
+                float v = out4[r];
+                if (bias) v += vmx_bf16_to_f32(bias[n]);
+                y[(int64_t)mrow * N + n] = vmx_f32_to_bf16(v);
+            } else {
+                partial[(int64_t)ks * slice_stride + (int64_t)mrow * N + n] = out4[r];
+            }
+        }
+    }
+}
+
 // GLU: the linear is a merged gate|up packed with glu_half = N/2 and runs unsplit; y is act[M][N/2] =
 // bf16(silu(bf16(gate)) * bf16(up)), the rounding points of silu_and_mul on the bf16 linear output (activations.cu:148-164).
 template <int UPW, bool TAIL, bool GLU = false>
@@ -270,39 +309,114 @@ __device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, cons
         }
     }
 
-    // 5. sum the 4 waves, write out.  Lane holds rows m = 4h + r, column n = nt*16 + nl.
-    *reinterpret_cast<float4 *>(red + (wave * 64 + lane) * 4) = make_float4(fin[0], fin[1], fin[2], fin[3]);
-    __syncthreads();
-    if (wave == 0) {
-        float4 a = *reinterpret_cast<const float4 *>(red + lane * 4);
+    int4_gemm_epilogue<GLU>(red, fin, bias, y, partial, slice_stride, M, N, nt, ks);
+}
+
+// Several activation rows (M > 4) with a long k-slice: the body above stages M x (4*UPW*128) activations at once -- 131 KB
+// at M = 16, UPW = 8, one workgroup per CU, and the launch is 3x (M = 8) to 8x (M = 16) its one-row time.  Here the slice is
+// staged XS = 8 k-blocks at a time (M = 16: 33 KB, four workgroups per CU).  Every weight unit is still requested at kernel
+// start; units are dealt to the waves round-robin (k-block 4u + wave), so each pass feeds all four waves.  Same arithmetic
+// per k-block; only the order in which a wave meets its k-blocks differs from the body above.
+template <int UPW, bool TAIL, bool GLU>
+__device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                      const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+                                                      uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride,
+                                                      int M, int N, int K, int group, int block) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int XS = 8;                  // k-blocks staged per pass
+    static_assert((4 * UPW) % XS == 0 && XS % 4 == 0, "slice must be whole passes, a pass whole rounds of the 4 waves");
+    constexpr int PASSES = 4 * UPW / XS, UPP = XS / 4;   // units per wave per pass
+    constexpr int XROW = XS * KB + 8, CPR = XS * KB / 8;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                     // [M][XROW]
+    float *sumx = reinterpret_cast<float *>(smem + (size_t)M * XROW * 2);  // [4*UPW][16]
+    float *red = sumx + 4 * UPW * 16;                                      // [4][64][4]
+    uint32_t *szs = reinterpret_cast<uint32_t *>(red + 4 * 64 * 4);        // [4*UPW][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = N / NT, kblocks = K / KB, G = K / group;
+    const int nt = block % n_tiles, ks = block / n_tiles;
+    const int kb_wg = ks * 4 * UPW;
+    const int nl = lane & 15, h = lane >> 4;
+    const int total = M * CPR;
+
+    uint32_t szv[(4 * UPW * 16 + 255) / 256];
 #pragma unroll
-        for (int wv = 1; wv < 4; wv++) {
-            const float4 b = *reinterpret_cast<const float4 *>(red + (wv * 64 + lane) * 4);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    for (int j = 0; j < (4 * UPW * 16 + 255) / 256; j++) {
+        const int i = tid + 256 * j, kb = kb_wg + (i >> 4);
+        szv[j] = (i < 4 * UPW * 16 && (!TAIL || kb < kblocks)) ? SZ[((int64_t)nt * G + (kb * KB) / group) * 16 + (i & 15)] : 0u;
+    }
+    uint4 wreg[UPW];   // unit u of this wave = k-block 4u + wave of the slice
+#pragma unroll
+    for (int u = 0; u < UPW; u++) {
+        const int kb = kb_wg + 4 * u + wave;
+        if (!TAIL || kb < kblocks) wreg[u] = W[((int64_t)nt * kblocks + kb) * 64 + lane];
+        else wreg[u] = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < (4 * UPW * 16 + 255) / 256; j++)
+        if (tid + 256 * j < 4 * UPW * 16) szs[tid + 256 * j] = szv[j];
+
+    const uint16_t *xrow = xs + min(nl, M - 1) * XROW + 8 * h;
+    vmx_f32x4 fin = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) {
+        if (p) __syncthreads();   // the previous pass has been read by every wave
+        const int kp0 = (kb_wg + p * XS) * KB;
+        for (int c0 = 0; c0 < total; c0 += 256) {
+            const int c = c0 + tid;
+            const bool live = c < total;
+            const int m = live ? c / CPR : 0, cc = live ? c % CPR : 0, k = kp0 + cc * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (live && (!TAIL || k < K)) v = *reinterpret_cast<const uint4 *>(x + (int64_t)m * K + k);
+            if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = v;
+            const float sm = chunk_sum16(v);
+            if (live && (tid & 15) == 0) sumx[(p * XS + (cc >> 4)) * 16 + m] = sm;
         }
-        const float out4[4] = {a.x, a.y, a.z, a.w};
-        const int n = nt * NT + nl;
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int mrow = 4 * h + r;
-            if (GLU) {
-                const float up = __shfl_xor(out4[r], 8, 64);
-                if (mrow < M && nl < 8) {
-                    const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(out4[r]));
-                    const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
-                    y[(int64_t)mrow * (N >> 1) + nt * 8 + nl] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
+        for (int q = 0; q < UPP; q++) {
+            const int u = p * UPP + q, kbl = 4 * u + wave, kin = kbl - p * XS;   // k-block inside the slice / inside the pass
+            if (!TAIL || kb_wg + kbl < kblocks) {  // wave-uniform
+                vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const uint32_t w4[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t w = w4[i];
+                    uint4 bu;
+                    bu.x = (w & 0x000F000Fu) | 0x43004300u;
+                    bu.y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+                    bu.z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+                    bu.w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+                    const uint4 au = *reinterpret_cast<const uint4 *>(xrow + kin * KB + 32 * i);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, bu),
+                                                                  acc, 0, 0, 0);
                 }
-            } else if (mrow < M) {
-                if (y) {
-                    float v = out4[r];
-                    if (bias) v += vmx_bf16_to_f32(bias[n]);
-                    y[(int64_t)mrow * N + n] = vmx_f32_to_bf16(v);
-                } else {
-                    partial[(int64_t)ks * slice_stride + (int64_t)mrow * N + n] = out4[r];
-                }
+                const uint32_t szw = szs[kbl * 16 + nl];
+                const float s = __uint_as_float(szw << 16);
+                const float zo = __uint_as_float(szw & 0xFFFF0000u);
+                const float4 sx = *reinterpret_cast<const float4 *>(sumx + kbl * 16 + 4 * h);
+                fin[0] += s * (acc[0] - zo * sx.x);
+                fin[1] += s * (acc[1] - zo * sx.y);
+                fin[2] += s * (acc[2] - zo * sx.z);
+                fin[3] += s * (acc[3] - zo * sx.w);
             }
         }
     }
+    int4_gemm_epilogue<GLU>(red, fin, bias, y, partial, slice_stride, M, N, nt, ks);
+}
+
+template <int UPW, bool TAIL>
+__global__ __launch_bounds__(256) void int4_gemm_looped_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                                const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+                                                                uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N,
+                                                                int K, int group, int slice_rows) {
+    int4_gemm_body_looped<UPW, TAIL, false>(W, SZ, x, bias, y, partial, (int64_t)slice_rows * N, M, N, K, group, blockIdx.x);
+}
+
+template <int UPW, bool TAIL>
+__global__ __launch_bounds__(256) void int4_gemm_glu_looped_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                                    const uint16_t *__restrict__ x, uint16_t *__restrict__ act, int M,
+                                                                    int N, int K, int group) {
+    int4_gemm_body_looped<UPW, TAIL, true>(W, SZ, x, nullptr, act, nullptr, 0, M, N, K, group, blockIdx.x);
 }
 
 template <int UPW, bool TAIL>
@@ -512,6 +626,15 @@ inline GemmPlan plan_gemm(int N, int K) {
     return p;
 }
 
+// rows from which the activation staging is looped (VMX_INT4_LOOPED_MIN_M overrides for measurement; 0 disables)
+inline bool use_looped(int M, int upw) {
+    static const int min_m = getenv("VMX_INT4_LOOPED_MIN_M") ? atoi(getenv("VMX_INT4_LOOPED_MIN_M")) : 5;
+    return min_m > 0 && M >= min_m && upw >= 4;
+}
+inline size_t gemm_lds_bytes_looped(int M, int upw) {
+    return (size_t)M * (8 * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + 4 * 64 * 4 * 4 + (size_t)4 * upw * 16 * 4;
+}
+
 inline size_t gemm_lds_bytes(int M, int upw) {
     return (size_t)M * (4 * upw * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + 4 * 64 * 4 * 4 + (size_t)4 * upw * 16 * 4;
 }
@@ -519,6 +642,21 @@ inline size_t gemm_lds_bytes(int M, int upw) {
 int launch_gemm(const GemmPlan &p, const uint4 *W, const uint32_t *SZ, const uint16_t *x, const uint16_t *bias, uint16_t *y,
                 float *partial, int M, int N, int K, int group, hipStream_t st, int slice_rows = 0) {
     if (slice_rows <= 0) slice_rows = M;
+    if (use_looped(M, p.upw)) {
+        const size_t ll = gemm_lds_bytes_looped(M, p.upw);
+        const dim3 lgrid((unsigned)((N / NT) * p.splits));
+        const bool ltail = (K / KB) % (4 * p.upw) != 0;
+#define LOOPED(U)                                                                                                                          \
+        do {                                                                                                                               \
+            if (ltail) hipLaunchKernelGGL((int4_gemm_looped_kernel<U, true>), lgrid, dim3(256), ll, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows); \
+            else hipLaunchKernelGGL((int4_gemm_looped_kernel<U, false>), lgrid, dim3(256), ll, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows);      \
+        } while (0)
+        if (p.upw == 8) LOOPED(8);
+        else LOOPED(4);
+#undef LOOPED
+        VMX_CHECK_LAUNCH("int4_gemm(looped)");
+        return VMX_OK;
+    }
     const size_t lds = gemm_lds_bytes(M, p.upw);
     if (lds > 160 * 1024) {
         vmx_set_error("int4_gemm: LDS need %zu B exceeds 160 KiB", lds);
@@ -668,10 +806,22 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
     const dim3 grid((unsigned)(N / NT)), block(256);
     for (int m0 = 0; m0 < M; m0 += 16) {
         const int mm = M - m0 < 16 ? M - m0 : 16;
-        const size_t lds = gemm_lds_bytes(mm, p.upw);
-        VMX_REQUIRE(lds <= 160 * 1024, "int4_gemm_glu: LDS need %zu B exceeds 160 KiB", lds);
         const uint16_t *xc = x + (int64_t)m0 * K;
         uint16_t *ac = act + (int64_t)m0 * (N / 2);
+        if (use_looped(mm, p.upw)) {
+            const size_t ll = gemm_lds_bytes_looped(mm, p.upw);
+#define GLOOPED(U)                                                                                                                 \
+            do {                                                                                                                   \
+                if (tail) hipLaunchKernelGGL((int4_gemm_glu_looped_kernel<U, true>), grid, block, ll, st, W, SZ, xc, ac, mm, N, K, group); \
+                else hipLaunchKernelGGL((int4_gemm_glu_looped_kernel<U, false>), grid, block, ll, st, W, SZ, xc, ac, mm, N, K, group);      \
+            } while (0)
+            if (p.upw == 8) GLOOPED(8);
+            else GLOOPED(4);
+#undef GLOOPED
+            continue;
+        }
+        const size_t lds = gemm_lds_bytes(mm, p.upw);
+        VMX_REQUIRE(lds <= 160 * 1024, "int4_gemm_glu: LDS need %zu B exceeds 160 KiB", lds);
 #define GLU_T(U, T)                                                                                                                \
     do {                                                                                                                           \
         if (lds > 64 * 1024)                                                                                                       \
