@@ -136,7 +136,10 @@ def test_dense_gemv_and_embedding(gpu):
     from oracle import oracle as orc
     vmx, torch = gpu
     rng = np.random.default_rng(8)
-    for M, N, K in [(1, 1000, 256), (3, 5003, 4096), (16, 777, 1024)]:
+    # rows 5..16 with K % 128 == 0 run on the matrix cores with activations staged 1024 k at a time: several passes, a short
+    # last pass, ragged last 16-row tile of W, fewer tiles than waves; K % 128 != 0 stays on the vector kernel
+    for M, N, K in [(1, 1000, 256), (3, 5003, 4096), (16, 777, 1024), (16, 5003, 4096), (5, 40, 1152), (11, 3000, 2176),
+                    (8, 333, 1000), (4, 2048, 4096)]:
         x = orc.f32_to_bf16(rng.standard_normal((M, K)).astype(np.float32))
         W = orc.f32_to_bf16(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
         xd = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16)

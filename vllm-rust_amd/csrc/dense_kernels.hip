@@ -68,6 +68,66 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(uint16_t *__restrict__ 
     }
 }
 
+// 5..16 activation rows: GEMM-shaped, on the matrix cores.  The kernel above stages M x K activations (128 KB at 16 rows of
+// 4096: one workgroup per CU) and spends M*R*4 dot2 per 16 weight bytes; measured 218 / 454 / 1428 us at 1 / 8 / 16 rows on
+// the 151936 x 4096 lm_head.  Here a wave owns 16 consecutive rows of W (= 16 output columns of one v_mfma_f32_16x16x32_bf16,
+// A = the activation rows, so 1..16 rows cost the same matrix instructions).  Lane (n = lane & 15, g = lane >> 4) reads the 64
+// contiguous bytes W[row0 + n][128 b + 32 g .. + 32) of every 128-deep k-block b; its j-th 16 bytes serve MFMA step j, and the
+// A fragment of step j is read from LDS at the matching k (x[m][128 b + 32 g + 8 j .. + 8]): the matrix instruction only needs
+// A and B to agree on which k sits where.  Activations are staged PK = 1024 k at a time (33 KB at 16 rows).  f32 accumulation
+// in k order within a lane group, groups summed by the MFMA: re-associated against the kernel above, same products.
+template <bool DUMMY = false>
+__global__ __launch_bounds__(256) void dense_gemm16_kernel(uint16_t *__restrict__ y, const uint16_t *__restrict__ x,
+                                                            const uint16_t *__restrict__ W, const uint16_t *__restrict__ bias, int M,
+                                                            int N, int K) {
+    constexpr int PK = 1024, XROW = PK + 8;   // k per pass; staged row stride (+16 B against bank conflicts)
+    __shared__ __align__(16) uint16_t xs[16 * XROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = lane & 15, g = lane >> 4;
+    const int tiles = (N + 15) >> 4;
+    const int waves_total = gridDim.x * 4;
+    // every wave of the workgroup walks the same number of tiles (barriers inside): tiles past the end are clamped, not stored
+    const int rounds = (tiles + waves_total - 1) / waves_total;
+    for (int rd = 0; rd < rounds; rd++) {
+        const int tile = rd * waves_total + blockIdx.x * 4 + wave;
+        const int row = min(tile * 16 + nl, N - 1);
+        const uint16_t *wrow = W + (int64_t)row * K;
+        vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += PK) {
+            const int pk = min(PK, K - k0);   // K % 128 == 0 (checked on the host)
+            if (k0 || rd) __syncthreads();    // the previous pass has been read by every wave
+            for (int c = tid; c < 16 * (PK / 8); c += 256) {
+                const int m = c / (PK / 8), cc = c % (PK / 8);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (m < M && cc * 8 < pk) v = *reinterpret_cast<const uint4 *>(x + (int64_t)m * K + k0 + cc * 8);
+                *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = v;
+            }
+            __syncthreads();
+            for (int b = 0; b < pk; b += 128) {
+                uint4 wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) wv[j] = *reinterpret_cast<const uint4 *>(wrow + k0 + b + 32 * g + 8 * j);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint4 au = *reinterpret_cast<const uint4 *>(xs + nl * XROW + b + 32 * g + 8 * j);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, wv[j]), acc,
+                                                                  0, 0, 0);
+                }
+            }
+        }
+        // lane holds activation rows m = 4 g + r of output column (W row) tile * 16 + nl
+        const int col = tile * 16 + nl;
+        if (tile < tiles && col < N) {
+            const float bv = bias ? vmx_bf16_to_f32(bias[col]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = 4 * g + r;
+                if (m < M) y[(int64_t)m * N + col] = vmx_f32_to_bf16(acc[r] + bv);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void embedding_lookup_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ table,
                                                                 const int32_t *__restrict__ ids, int hidden, int vocab) {
     const int t = blockIdx.x;
@@ -82,6 +142,14 @@ __global__ __launch_bounds__(256) void embedding_lookup_kernel(uint16_t *__restr
 
 int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
                           hipStream_t st) {
+    static const int mfma_min_m = getenv("VMX_DENSE_MFMA_MIN_M") ? atoi(getenv("VMX_DENSE_MFMA_MIN_M")) : 5;   // 0 disables
+    if (mfma_min_m > 0 && M >= mfma_min_m && K % 128 == 0) {   // GEMM-shaped: matrix cores, activations staged in k-passes
+        int g16 = ((N + 15) / 16 + 3) / 4;   // 4 waves x one 16-row tile of W per round
+        if (g16 > 2048) g16 = 2048;
+        hipLaunchKernelGGL((dense_gemm16_kernel<false>), dim3(g16), dim3(256), 0, st, y, x, W, bias, M, N, K);
+        VMX_CHECK_LAUNCH("dense_gemm16");
+        return VMX_OK;
+    }
     const size_t lds = (size_t)M * K * 2;
     int grid = (N + 7) / 8;  // 4 waves x R=2 rows per workgroup
     if (grid > 4096) grid = 4096;
