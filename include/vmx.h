@@ -230,7 +230,7 @@ int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_ca
 
 /* Replaces paged_attention_v2_* + paged_attention_v2_reduce_* (crates/core/kernels/paged_attention.cu:558-954;
  * launcher signature cuda_kernels.rs:641-658): decode attention for q [seqs, heads, head_dim] bf16 over the
- * paged cache.  window = 0 means full causal.  workspace >= vmx_paged_attention_workspace_bytes. */
+ * paged cache.  window = 0 means full causal.  Any num_heads / num_kv_heads ratio up to 16.  workspace >= vmx_paged_attention_workspace_bytes. */
 size_t vmx_paged_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim, int max_seq_len);
 int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
                              const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs,
@@ -428,6 +428,11 @@ int vmx_debug_stream_read(const void *p, size_t bytes, int upw, void *sink, void
  * spreads consecutive workgroup ids over the 8 dies, each with its own L2). */
 int vmx_debug_xcc_ids(int *out, int n_wgs, int wg_threads, void *stream);
 
+/* Measurement / parity aid: the executors run q/k/v post-processing + attention + merge as ONE launch for contexts of up to
+ * 1024 tokens and head_dim <= 128, as three launches otherwise; enable = 0 forces the three-launch form (default on, or off
+ * when the environment has VMX_NO_FUSED_ATTN=1). */
+int vmx_debug_set_fused_attention(int enable);
+
 /* Rows of a decode call normally are different sequences with disjoint cache blocks (execute_batched_decode,
  * engine/helpers.rs:1076).  on != 0: the rows are consecutive tokens of one sequence over a shared block table (a prompt fed
  * through the decode path); the executor then writes every row's K/V before any row's attention starts. */
@@ -439,6 +444,9 @@ int vmx_qwen3_set_comm(vmx_qwen3 *m, vmx_comm *comm);
 /* Parity aid: read back an internal activation of the last step (0 = residual stream h,
  * 1 = final normed x, 2 = logits), bf16. */
 int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t bytes, void *stream);
+/* Parity aid: copy one layer's whole K (which = 0) or V (1) cache [blocks, block_size, kv_heads, head_dim] to buf
+ * (write = 0) or from it (write = 1); device or host pointer.  Lets a test start a sequence at an arbitrary length. */
+int vmx_qwen3_debug_kv(vmx_qwen3 *m, int layer, int which, int write, void *buf, size_t bytes, void *stream);
 
 
 /* ---------------------------------------------------- whole-token decoder, Gemma 4 (GGUF) */
@@ -501,6 +509,8 @@ int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_by
 int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream);
 /* Parity aid: 0 = residual stream h, 1 = final normed x (bf16 [batch, hidden]). */
 int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, void *stream);
+/* Parity aid: as vmx_qwen3_debug_kv, for a layer's cache in its own geometry (sliding or full). */
+int vmx_gemma4_debug_kv(vmx_gemma4 *m, int layer, int which, int write, void *buf, size_t bytes, void *stream);
 
 
 /* ------------------------------------------------------------------ GGUF container (host only) */

@@ -113,7 +113,9 @@ def test_reshape_and_cache(gpu, kv_dtype):
     assert np.array_equal(vc.cpu().numpy().view(dt), vc_ref)
 
 
-@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (16, 1, 512), (4, 4, 64)])
+# (40, 8) = 5, (28, 4) = 7, (24, 8) = 3, (12, 1) = 12 query heads per KV head: ratios between the compiled capacities
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (16, 1, 512), (4, 4, 64), (40, 8, 128), (28, 4, 128), (24, 8, 64),
+                                     (12, 1, 256)])
 @pytest.mark.parametrize("kv_dtype", [0, 1])
 def test_paged_attention(gpu, H, KVH, D, kv_dtype):
     from oracle import oracle as orc

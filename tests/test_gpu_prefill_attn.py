@@ -16,6 +16,8 @@ def _dequant_cache(orc, cache, kv_dtype, scale):
 
 @pytest.mark.parametrize("hd,H,KVH,q_len,offset,window,kv_dtype", [
     (128, 8, 2, 37, 0, 0, 0),       # ragged last tile, QPK 4
+    (128, 10, 2, 41, 3, 0, 0),      # 5 query heads per KV head (Qwen3-14B's ratio): capacity 8, three idle head slots
+    (64, 6, 2, 33, 0, 12, 1),       # 3 per KV head: capacity 4, one idle wave per workgroup
     (64, 4, 4, 16, 5, 0, 0),        # QPK 1: four token tiles per workgroup, chunk with history
     (256, 4, 2, 50, 20, 8, 1),      # sliding window smaller than a tile, FP8 cache, QPK 2
     (512, 16, 1, 19, 3, 0, 1),      # Gemma full-attention geometry: 16 query heads on one 512-wide KV head

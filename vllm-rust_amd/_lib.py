@@ -91,7 +91,9 @@ _SIGS = {
     "vmx_qwen3_set_rows_share_cache": (_i, [_p, _i]),
     "vmx_qwen3_load_exl3_linear": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vmx_qwen3_decode": (_i, [_p] * 6 + [_i, _i, _i, _p, _p, _p]),
+    "vmx_debug_set_fused_attention": (_i, [_i]),
     "vmx_qwen3_debug_read": (_i, [_p, _i, _p, _sz, _p]),
+    "vmx_qwen3_debug_kv": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "vmx_debug_stream_read": (_i, [_p, _sz, _i, _p, _p]),
     "vmx_debug_xcc_ids": (_i, [_p, _i, _i, _p]),
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
@@ -124,6 +126,7 @@ _SIGS = {
     "vmx_gemma4_mmvq_info": (_i, [_p, _i, _p, _p]),
     "vmx_gemma4_mmvq_only": (_i, [_p, _i, _p]),
     "vmx_gemma4_debug_read": (_i, [_p, _i, _p, _sz, _p]),
+    "vmx_gemma4_debug_kv": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
 }
 
 

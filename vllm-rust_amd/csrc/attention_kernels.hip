@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
     const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
     const int32_t *__restrict__ seq_lens, float scale, int num_heads, int num_kv_heads, int max_blocks_per_seq, int block_size,
-    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part) {
+    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part, int nq) {
+    // nq = query heads per KV head (<= QPK, the compiled capacity: rows nq..QPK-1 of the A fragment stay zero)
     constexpr int KSTEPS = HD / 32;                 // MFMA k-steps per tile
     constexpr int NP = HD >= 128 ? HD / 128 : 1;    // V: pairs of dims per lane
     constexpr int HG = (QPK + 3) / 4;               // 16-lane row groups that hold live heads
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
     const float lscale = scale * ksc;
     const int64_t tok_stride = (int64_t)num_kv_heads * HD;
-    const int head0 = kvh * QPK;
+    const int head0 = kvh * nq;
     const bool lane_live = (HD >= 128) || (lane < 32);
 
     // q rows as MFMA A fragments: lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) {
         qa[i] = make_uint4(0, 0, 0, 0);
-        if (tl < QPK) qa[i] = *reinterpret_cast<const uint4 *>(q + ((int64_t)seq * num_heads + head0 + tl) * HD + 32 * i + 8 * dg);
+        if (tl < nq) qa[i] = *reinterpret_cast<const uint4 *>(q + ((int64_t)seq * num_heads + head0 + tl) * HD + 32 * i + 8 * dg);
     }
 
     float m_run[4], s_run[4];  // per head row 4*dg + r (replicated over the 16 lanes of the group)
@@ -244,15 +245,17 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     // ---- partition result: locally normalised output, max and sum per head
 #pragma unroll
     for (int h = 0; h < QPK; h++) {
-        const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_run[h & 3]), 16 * (h >> 2)));
-        const float mh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run[h & 3]), 16 * (h >> 2)));
-        const float inv = 1.0f / (sh + 1e-6f);
-        const int64_t mo = ((int64_t)seq * num_heads + head0 + h) * max_parts + part;
-        if (lane == 0) { max_logits[mo] = mh; exp_sums[mo] = sh; }
-        if (lane_live) {
+        if (h < nq) {   // wave-uniform
+            const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_run[h & 3]), 16 * (h >> 2)));
+            const float mh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run[h & 3]), 16 * (h >> 2)));
+            const float inv = 1.0f / (sh + 1e-6f);
+            const int64_t mo = ((int64_t)seq * num_heads + head0 + h) * max_parts + part;
+            if (lane == 0) { max_logits[mo] = mh; exp_sums[mo] = sh; }
+            if (lane_live) {
 #pragma unroll
-            for (int p = 0; p < NP; p++)
-                *reinterpret_cast<float2 *>(tmp_out + mo * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
+                for (int p = 0; p < NP; p++)
+                    *reinterpret_cast<float2 *>(tmp_out + mo * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
+            }
         }
     }
     (void)HG;
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     int max_blocks_per_seq, int block_size, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr,
     int8_t *__restrict__ aq, float *__restrict__ ad, int v_norm) {
     constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1, EPL = HD / 64;   // EPL: elements per lane in phase A
+    const int nq = Hq / Hkv;   // query heads per KV head (<= QPK, the compiled capacity)
     extern __shared__ __align__(16) unsigned char smem_attn[];
     uint16_t *qs = reinterpret_cast<uint16_t *>(smem_attn);                      // [QPK][HD] bf16
     float *mo = reinterpret_cast<float *>(smem_attn + QPK * HD * 2);             // [NW][QPK][HD]
@@ -356,13 +360,13 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     const bool active = seq_len > 0 && p0 < seq_len;
     const int32_t *bt_row = block_tables + (int64_t)seq * max_blocks_per_seq;
     AttnTile<HD, FP8> tile;
-    const bool pre = active && wave >= QPK + 2 && p0 + 16 < seq_len;
+    const bool pre = active && wave >= nq + 2 && p0 + 16 < seq_len;
     if (pre) attn_tile_load<HD, FP8>(tile, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, lane);
 
     // ---- A: this token's q / k / v heads
-    if (wave < QPK + 2) {
-        const bool is_q = wave < QPK, is_k = wave == QPK;
-        const int head = is_q ? kvh * QPK + wave : (is_k ? Hq + kvh : Hq + Hkv + kvh);
+    if (wave < nq + 2) {
+        const bool is_q = wave < nq, is_k = wave == nq;
+        const int head = is_q ? kvh * nq + wave : (is_k ? Hq + kvh : Hq + Hkv + kvh);
         const int ntot = (Hq + 2 * Hkv) * HD;
         const int64_t slice = (int64_t)tokens * ntot, base = (int64_t)seq * ntot + (int64_t)head * HD;
         float v[EPL];
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
 #pragma unroll
         for (int i = 0; i < KSTEPS; i++) {
             qa[i] = make_uint4(0, 0, 0, 0);
-            if (tl < QPK) qa[i] = *reinterpret_cast<const uint4 *>(qs + tl * HD + 32 * i + 8 * dg);
+            if (tl < nq) qa[i] = *reinterpret_cast<const uint4 *>(qs + tl * HD + 32 * i + 8 * dg);
         }
         attn_walk<HD, QPK, FP8>(qa, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, scale * ksc, vsc, lane, m_run,
                                 s_run, o, tile, pre);
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
 
     // ---- C: merge the partitions (a partition that saw no token has sum 0 and contributes nothing)
     const int np = min(NW, (seq_len - start + part_tokens - 1) / part_tokens);
-    for (int idx = tid; idx < QPK * HD; idx += 64 * NW) {   // QPK * HD is a multiple of 64: a wave is all in or all out
+    for (int idx = tid; idx < nq * HD; idx += 64 * NW) {   // nq * HD is a multiple of 64: a wave is all in or all out
         const int h = idx / HD, d = idx % HD;
         float val;
         if (np == 1) {
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
             }
             val = acc * (1.0f / (gsum + 1e-6f));
         }
-        const int64_t ob = ((int64_t)seq * Hq + kvh * QPK + h) * HD + d;
+        const int64_t ob = ((int64_t)seq * Hq + kvh * nq + h) * HD + d;
         const uint16_t vb = vmx_f32_to_bf16(val);
         out[ob] = vb;
         if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block
@@ -520,10 +524,14 @@ int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, floa
                 const void *vc, const int32_t *bt, const int32_t *sl, float scale, int H, int KVH, int mbps, int bs, int max_parts,
                 int window, const float *ks, const float *vs, int tiles_per_part) {
     hipLaunchKernelGGL((paged_attn_partition_kernel<HD, QPK, FP8>), grid, dim3(64), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
-                       bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part);
+                       bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part, H / KVH);
     VMX_CHECK_LAUNCH("paged_attention(partition)");
     return VMX_OK;
 }
+
+// Compiled query-heads-per-KV-head capacities are 1, 2, 4, 8, 16; a ratio in between runs on the next one up with the
+// surplus rows of the q fragment left zero (kv_head = head / (H / KVH) for any ratio, paged_attention.cu:558-600).
+static int qpk_capacity(int ratio) { return ratio <= 1 ? 1 : ratio <= 2 ? 2 : ratio <= 4 ? 4 : ratio <= 8 ? 8 : ratio <= 16 ? 16 : 0; }
 
 // Partition geometry: 16-token tiles; at most 64 partitions per sequence, so a partition is
 // ceil(tiles / 64) tiles.
@@ -565,11 +573,13 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
     const int hh = wave % HPW, tt = wave / HPW;
     constexpr int HGROUPS = QPK / HPW;
     const int kvh = blockIdx.y / HGROUPS, hgrp = blockIdx.y % HGROUPS;
-    const int head = kvh * QPK + hgrp * HPW + hh;
+    const int nq = num_heads / num_kv_heads;           // query heads per KV head (<= QPK, the compiled capacity)
+    const bool head_ok = hgrp * HPW + hh < nq;         // a wave past the last real head only helps staging the KV tiles
+    const int head = kvh * nq + min(hgrp * HPW + hh, nq - 1);
     const int wg_q0 = blockIdx.x * TT * 16, wg_q1 = min(q_len, wg_q0 + TT * 16);
     const int qt0 = wg_q0 + tt * 16;                     // the wave's first query token
     const int qi = qt0 + n;                              // this lane's query row
-    const bool q_valid = qi < q_len;
+    const bool q_valid = qi < q_len && head_ok;
     const int qpos = offset + min(qi, q_len - 1);
     const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f, vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
     const float lscale = scale * ksc;
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
     const int hi = offset + wg_q1;                                                    // tokens [lo, hi) are needed by the workgroup
     int lo = window > 0 ? max(0, offset + wg_q0 - window + 1) : 0;
     lo &= ~15;
-    const bool wave_live = qt0 < q_len;
+    const bool wave_live = qt0 < q_len && head_ok;
     const int wave_last_pos = offset + min(qt0 + 15, q_len - 1), wave_first_pos = offset + qt0;
     const int64_t tok_stride = (int64_t)num_kv_heads * HD;
 
@@ -688,7 +698,7 @@ extern "C" int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, cons
     VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3, "prefill_attention: unsupported kv dtype %d", kv_dtype);
     if (q_len == 0) return VMX_OK;
     hipStream_t st = vmx_stream(stream);
-    const int qpk = num_heads / num_kv_heads;
+    const int qpk = qpk_capacity(num_heads / num_kv_heads);   // any ratio up to 16 runs on the next compiled capacity
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
     int rc = VMX_EUNSUPPORTED;
 #define ARGS st, out, q, k_cache, v_cache, block_table, q_len, seqlen_offset, scale, num_heads, num_kv_heads, block_size, window, k_scale, v_scale
@@ -699,7 +709,7 @@ extern "C" int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, cons
         case 4: rc = fp8 ? launch_prefill<HD, 4, true>(ARGS) : launch_prefill<HD, 4, false>(ARGS); break;                   \
         case 8: rc = fp8 ? launch_prefill<HD, 8, true>(ARGS) : launch_prefill<HD, 8, false>(ARGS); break;                   \
         case 16: rc = fp8 ? launch_prefill<HD, 16, true>(ARGS) : launch_prefill<HD, 16, false>(ARGS); break;                \
-        default: vmx_set_error("prefill_attention: %d query heads per KV head unsupported (1,2,4,8,16)", qpk); return VMX_EUNSUPPORTED; \
+        default: vmx_set_error("prefill_attention: %d query heads per KV head unsupported (1..16)", num_heads / num_kv_heads); return VMX_EUNSUPPORTED; \
     }
     switch (head_dim) {
         case 64: BY_QPK(64) break;
@@ -733,7 +743,7 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
                               int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window, int kv_dtype,
                               const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st) {
     const int P = parts_for_impl(max_seq_len);
-    const int qpk = num_heads / num_kv_heads;
+    const int qpk = qpk_capacity(num_heads / num_kv_heads);
     float *tmp_out = (float *)workspace;
     float *exp_sums = tmp_out + (size_t)num_seqs * num_heads * P * head_dim;
     float *max_logits = exp_sums + (size_t)num_seqs * num_heads * P;
@@ -755,7 +765,7 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
         case 4: rc = fp8 ? launch_part<HD, 4, true>(ARGS) : launch_part<HD, 4, false>(ARGS); break;                        \
         case 8: rc = fp8 ? launch_part<HD, 8, true>(ARGS) : launch_part<HD, 8, false>(ARGS); break;                        \
         case 16: rc = fp8 ? launch_part<HD, 16, true>(ARGS) : launch_part<HD, 16, false>(ARGS); break;                     \
-        default: vmx_set_error("paged_attention: %d query heads per KV head unsupported (1,2,4,8,16)", qpk); return VMX_EUNSUPPORTED; \
+        default: vmx_set_error("paged_attention: %d query heads per KV head unsupported (1..16)", num_heads / num_kv_heads); return VMX_EUNSUPPORTED; \
     }
     switch (head_dim) {
         case 64: BY_QPK(64) break;
@@ -780,12 +790,21 @@ int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const in
 }
 
 // Whether the one-launch short-context path covers this geometry (otherwise: qkv post kernel + parts + merge).
+static int g_fused_attn_enabled = -1;   // -1: not decided yet (environment VMX_NO_FUSED_ATTN), 0 off, 1 on
+
+// Measurement / parity aid: switch the one-launch short-context attention off (0) or on (1) for the calls that follow, so
+// that both forms can be compared on the same inputs in one process.
+extern "C" int vmx_debug_set_fused_attention(int enable) {
+    g_fused_attn_enabled = enable ? 1 : 0;
+    return VMX_OK;
+}
+
 bool vmx_fused_decode_attention_ok(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
-    static const bool off = getenv("VMX_NO_FUSED_ATTN") && atoi(getenv("VMX_NO_FUSED_ATTN"));
-    if (off) return false;
+    if (g_fused_attn_enabled < 0) g_fused_attn_enabled = (getenv("VMX_NO_FUSED_ATTN") && atoi(getenv("VMX_NO_FUSED_ATTN"))) ? 0 : 1;
+    if (!g_fused_attn_enabled) return false;
     // 256-wide heads were measured slower here than the three-launch path (8 waves, 3+ tiles each): not covered
     if (head_dim != 64 && head_dim != 128) return false;
-    if (qpk != 1 && qpk != 2 && qpk != 4 && qpk != 8) return false;
+    if (qpk < 1 || qpk > 8) return false;
     const int half = rot_dim / 2;
     if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return false;
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
@@ -798,7 +817,7 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
                                float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
                                int max_blocks_per_seq, int block_size, int window, int kv_dtype, const float *k_scale,
                                const float *v_scale, int8_t *aq, float *ad, int v_norm, hipStream_t st) {
-    const int qpk = num_heads / num_kv_heads;
+    const int qpk = qpk_capacity(num_heads / num_kv_heads);
     const dim3 grid(num_kv_heads, num_seqs);
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
     int rc = VMX_EUNSUPPORTED;
@@ -815,7 +834,8 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
     if (head_dim == 64) { F_QPK(64) } else if (head_dim == 128) { F_QPK(128) }
 #undef F_QPK
 #undef FARGS
-    if (rc == VMX_EUNSUPPORTED) vmx_set_error("fused_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head)", head_dim, qpk);
+    if (rc == VMX_EUNSUPPORTED)
+        vmx_set_error("fused_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head)", head_dim, num_heads / num_kv_heads);
     return rc;
 }
 

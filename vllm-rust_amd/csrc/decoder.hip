@@ -534,6 +534,10 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
                 c.intermediate_size);
     VMX_REQUIRE(c.num_layers > 0 && c.num_heads > 0 && c.num_kv_heads > 0 && c.num_heads % c.num_kv_heads == 0,
                 "qwen3_create: bad head counts");
+    VMX_REQUIRE(c.num_heads / c.num_kv_heads <= 16, "qwen3_create: %d query heads per KV head (the attention kernels take at most 16)",
+                c.num_heads / c.num_kv_heads);
+    VMX_REQUIRE(c.max_prefill_tokens >= 0 && c.max_prefill_tokens <= 8192, "qwen3_create: max_prefill_tokens (%d) must be in 0..8192",
+                c.max_prefill_tokens);
     VMX_REQUIRE(c.head_dim == 64 || c.head_dim == 128 || c.head_dim == 256 || c.head_dim == 512, "qwen3_create: head_dim %d unsupported",
                 c.head_dim);
     VMX_REQUIRE(c.max_batch >= 1 && c.max_batch <= 16, "qwen3_create: max_batch (%d) must be in 1..16", c.max_batch);
@@ -550,8 +554,6 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     VMX_REQUIRE(m, "qwen3_create: out of host memory");
     m->cfg = c;
     m->layers.resize(c.num_layers);
-    VMX_REQUIRE(c.max_prefill_tokens >= 0 && c.max_prefill_tokens <= 8192, "qwen3_create: max_prefill_tokens (%d) must be in 0..8192",
-                c.max_prefill_tokens);
     // activation buffers hold max(decode batch, prefill chunk) token rows
     const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, B = c.max_batch > c.max_prefill_tokens ? c.max_batch : c.max_prefill_tokens;
     const int NQKV = m->qkv_n(), NO = c.num_heads * hd;
@@ -1135,6 +1137,18 @@ extern "C" int vmx_qwen3_debug_read(vmx_qwen3 *m, int which, void *dst, size_t b
     DevBuf *src = which == 0 ? &m->h : which == 1 ? &m->x : which == 2 ? &m->logits : nullptr;
     VMX_REQUIRE(src && bytes <= src->bytes, "qwen3_debug_read: bad request");
     VMX_CHECK_HIP(hipMemcpyAsync(dst, src->p, bytes, hipMemcpyDefault, vmx_stream(stream)));
+    return VMX_OK;
+}
+
+// Parity aid: copy a layer's K (which = 0) or V (1) cache to `buf` (write = 0) or from it (write = 1); device or host pointer,
+// bytes = the whole cache [blocks, block_size, kv_heads, head_dim] in the cache dtype.
+extern "C" int vmx_qwen3_debug_kv(vmx_qwen3 *m, int layer, int which, int write, void *buf, size_t bytes, void *stream) {
+    VMX_REQUIRE(m && buf, "qwen3_debug_kv: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && (which == 0 || which == 1), "qwen3_debug_kv: layer %d / which %d", layer, which);
+    DevBuf &c = which == 0 ? m->layers[layer].k_cache : m->layers[layer].v_cache;
+    VMX_REQUIRE(bytes == c.bytes, "qwen3_debug_kv: the cache holds %zu bytes, got %zu", c.bytes, bytes);
+    VMX_CHECK_HIP(write ? hipMemcpyAsync(c.p, buf, bytes, hipMemcpyDefault, vmx_stream(stream))
+                        : hipMemcpyAsync(buf, c.p, bytes, hipMemcpyDefault, vmx_stream(stream)));
     return VMX_OK;
 }
 

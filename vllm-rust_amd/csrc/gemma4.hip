@@ -326,6 +326,9 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     VMX_REQUIRE(c.num_layers > 0 && c.num_heads > 0 && c.kv_heads_sliding > 0 && c.kv_heads_full > 0 &&
                     c.num_heads % c.kv_heads_sliding == 0 && c.num_heads % c.kv_heads_full == 0,
                 "gemma4_create: bad head counts");
+    VMX_REQUIRE(c.num_heads / c.kv_heads_sliding <= 16 && c.num_heads / c.kv_heads_full <= 16,
+                "gemma4_create: more than 16 query heads per KV head (%d / %d, %d / %d)", c.num_heads, c.kv_heads_sliding, c.num_heads,
+                c.kv_heads_full);
     for (int hd : {c.head_dim_sliding, c.head_dim_full})
         VMX_REQUIRE(hd == 64 || hd == 128 || hd == 256 || hd == 512, "gemma4_create: head_dim %d unsupported", hd);
     VMX_REQUIRE(c.rot_dim_sliding > 0 && c.rot_dim_sliding % 2 == 0 && c.rot_dim_sliding <= c.head_dim_sliding && c.rot_dim_full > 0 &&
@@ -630,6 +633,17 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
         if (int rc = vmx_iq_mmvq_multi(gu, 2, aq_of(m), ad_of(m, batch, H), proj, H, batch, 2 * I, st)) return rc;
         if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
     }
+    return VMX_OK;
+}
+
+// Parity aid: copy a layer's K (which = 0) or V (1) cache to `buf` (write = 0) or from it (write = 1)
+extern "C" int vmx_gemma4_debug_kv(vmx_gemma4 *m, int layer, int which, int write, void *buf, size_t bytes, void *stream) {
+    VMX_REQUIRE(m && buf, "gemma4_debug_kv: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && (which == 0 || which == 1), "gemma4_debug_kv: layer %d / which %d", layer, which);
+    Buf &c = which == 0 ? m->layers[layer].k_cache : m->layers[layer].v_cache;
+    VMX_REQUIRE(bytes == c.bytes, "gemma4_debug_kv: the cache holds %zu bytes, got %zu", c.bytes, bytes);
+    VMX_CHECK_HIP(write ? hipMemcpyAsync(c.p, buf, bytes, hipMemcpyDefault, vmx_stream(stream))
+                        : hipMemcpyAsync(buf, c.p, bytes, hipMemcpyDefault, vmx_stream(stream)));
     return VMX_OK;
 }
 

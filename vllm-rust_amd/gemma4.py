@@ -308,6 +308,11 @@ class QuantizedGemma4ForCausalLM:
         check(lib.vmx_gemma4_mmvq_info(self._h, batch, C.byref(n), C.byref(by)))
         return n.value, by.value
 
+    def debug_kv(self, layer: int, which: int, t: torch.Tensor, write: bool) -> None:
+        """Parity aid: copy a layer's whole K (which = 0) / V (1) cache into `t` or from it (contiguous CUDA tensor of the cache's size)."""
+        check(lib.vmx_gemma4_debug_kv(self._h, layer, which, int(write), t.data_ptr(), t.numel() * t.element_size(), self._stream()))
+        torch.cuda.current_stream().synchronize()
+
     def debug_read(self, which: int, shape) -> torch.Tensor:
         t = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
         check(lib.vmx_gemma4_debug_read(self._h, which, t.data_ptr(), t.numel() * 2, self._stream()))

@@ -336,6 +336,11 @@ class QuantizedQwen3ForCausalLM:
             self.forward_decode_batch(input_ids[c0:c0 + n].contiguous(), pos, slots, bt, (pos + 1).contiguous(),
                                       out_ids=ids_out[c0:c0 + n], logits=None if logits is None else logits[c0:c0 + n])
 
+    def debug_kv(self, layer: int, which: int, t: torch.Tensor, write: bool) -> None:
+        """Parity aid: copy a layer's whole K (which = 0) / V (1) cache into `t` or from it (contiguous CUDA tensor of the cache's size)."""
+        check(lib.vmx_qwen3_debug_kv(self._h, layer, which, int(write), t.data_ptr(), t.numel() * t.element_size(), self._stream()))
+        torch.cuda.current_stream().synchronize()
+
     def debug_read(self, which: int, shape) -> torch.Tensor:
         t = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
         check(lib.vmx_qwen3_debug_read(self._h, which, t.data_ptr(), t.numel() * 2, self._stream()))
