@@ -32,13 +32,15 @@ def _rel(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
 
 
-def _fill_kv(torch, model, ref, num_layers, shapes, kv_dtype, seed):
-    """Same random cache rows in the model and in the oracle; shapes[li] = (blocks, block_size, kv_heads, head_dim)."""
+def _fill_kv(torch, model, ref, num_layers, shapes, kv_dtype, seed, k_std=1.0):
+    """Same random cache rows in the model and in the oracle; shapes[li] = (blocks, block_size, kv_heads, head_dim).
+    k_std: standard deviation of the bf16 K rows (Gemma attends with scale 1.0 over 256 / 512 dims: unit-variance keys would
+    make every softmax row one-hot and the comparison a coin flip between near-tied tokens)."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     for li in range(num_layers):
         for which, cache in ((0, ref.k_cache), (1, ref.v_cache)):
             if kv_dtype == 0:
-                t = torch.randn(shapes[li], device="cuda", generator=g).to(torch.bfloat16)
+                t = (torch.randn(shapes[li], device="cuda", generator=g) * (k_std if which == 0 else 1.0)).to(torch.bfloat16)
                 host = _u16(torch, t)
             else:   # finite e4m3 bytes of moderate magnitude (exponent field <= 5: |x| < 0.5, so that softmax rows stay spread), random sign
                 mag = torch.randint(0, 0x30, shapes[li], device="cuda", generator=g, dtype=torch.int32)
@@ -170,16 +172,18 @@ def test_qwen3_0_6b_tied(gpu):
     _qwen3_case(gpu, spec, "load_synthetic", start_lens=[0, 15, 255, 1023], steps=3, first_ids=[9, 8, 7, 6])
 
 
-@pytest.mark.parametrize("B", [1, 4])
-def test_gemma4_12b_layers(gpu, B):
+@pytest.mark.parametrize("B,kv_dtype", [(1, 0), (4, 0), (1, 1), (4, 1)])
+def test_gemma4_12b_layers(gpu, B, kv_dtype):
     """Gemma-4-12B layers: hidden 3840, 16 query heads, one sliding layer (8 x 256, window 1024) and one full layer
     (1 x 512, proportional partial rotary), intermediate 15360, the UD-IQ3_XXS type mix, Q3_K token embedding / tied lm_head,
-    FP8 KV cache.  Sequence lengths on both sides of the sliding window."""
+    bf16 and FP8 KV cache.  Sequence lengths on both sides of the sliding window.  Bars: 2e-2 with the bf16 cache; 5e-2 with the
+    FP8 cache (the decoder tests' FP8 bar): a new token's K/V row is rounded to 3 mantissa bits on both sides, so a 1-ulp bf16
+    difference in front of that rounding flips an e4m3 step (6 %) on a few per cent of the row's elements."""
     from tests.model_oracle import OracleGemma4
     from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
     vmx, torch = gpu
     spec = Gemma4Spec(3840, 2, 16, 15360, VOCAB, full_every=2, max_position=2048, num_blocks=320, max_batch=B, max_seq_len=2048,
-                      embed_ggml_type=11)
+                      embed_ggml_type=11, kv_cache_dtype=kv_dtype)
     model = QuantizedGemma4ForCausalLM(spec)
     try:
         ck = model.load_synthetic(seed=21, keep_host_copy=True)
@@ -188,9 +192,8 @@ def test_gemma4_12b_layers(gpu, B):
         for li in range(spec.num_layers):
             hd, kvh, _, _, _ = spec.layer_geom(li)
             shapes.append((spec.num_blocks, spec.block_size, kvh, hd))
-        _fill_kv(torch, model, ref, spec.num_layers, shapes, spec.kv_cache_dtype, seed=3)
+        _fill_kv(torch, model, ref, spec.num_layers, shapes, spec.kv_cache_dtype, seed=3, k_std=0.08)
         starts = [1023] if B == 1 else [15, 300, 1022, 1100]
-        # FP8 cache rows of the new tokens carry 3 mantissa bits: the decoder tests' FP8 bar
-        _decode_and_compare(torch, model, ref, spec, starts, 3, [17, 900, 4000, 8000][:B], bar=3e-2)
+        _decode_and_compare(torch, model, ref, spec, starts, 3, [17, 900, 4000, 8000][:B], bar=2e-2 if kv_dtype == 0 else 5e-2)
     finally:
         model.close()
