@@ -238,6 +238,18 @@ int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cac
                              int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
                              const float *v_scale, void *workspace, size_t workspace_bytes, void *stream);
 
+/* No counterpart in the reference: vmx_paged_attention_bf16 for callers that cannot allocate or size a workspace (code
+ * under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  The split-KV partials live in a static
+ * per-GPU device array of vmx_paged_attention_static_max_bytes() = 32 MiB that the library resolves in vmx_init(device);
+ * a geometry whose vmx_paged_attention_workspace_bytes exceeds that is rejected with VMX_EINVAL.  Calls on one GPU share
+ * the array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream are ordered. */
+size_t vmx_paged_attention_static_max_bytes(void);
+int vmx_paged_attention_bf16_static(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                    const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs,
+                                    int num_heads, int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim,
+                                    int block_size, int window, int kv_dtype, const float *k_scale, const float *v_scale,
+                                    void *stream);
+
 /* Replaces AttentionBackend::prefill_attention (crates/core/src/layers/attention/backend.rs:60-71; semantics of the naive
  * backend, naive.rs:38-83; the reference's GPU build goes through the third-party FlashInfer wrapper): causal attention of
  * q_len new tokens at positions seqlen_offset .. seqlen_offset + q_len - 1 over the paged cache, which must already hold

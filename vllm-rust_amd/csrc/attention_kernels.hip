@@ -13,6 +13,30 @@
 // merges them.
 #include "vmx_kernels.h"
 #include <float.h>
+#include <mutex>
+
+// Split-KV partials of vmx_paged_attention_bf16_static: one array per GPU, held until the process ends.  In host code this
+// name is only a handle for hipGetSymbolAddress; the device address of each GPU's copy is kept in g_attn_scratch.
+constexpr size_t VMX_ATTN_SCRATCH_BYTES = (size_t)32 << 20;
+static __device__ __align__(256) unsigned char scratch[VMX_ATTN_SCRATCH_BYTES];
+constexpr int VMX_MAX_DEVICES = 64;
+static void *g_attn_scratch[VMX_MAX_DEVICES];
+static std::mutex g_attn_scratch_mu;
+
+// Called by vmx_init with `device` current: resolve this GPU's copy of the array once.
+int vmx_attention_scratch_init(int device) {
+    VMX_REQUIRE(device >= 0 && device < VMX_MAX_DEVICES, "vmx_init: device %d beyond the %d this library tracks", device, VMX_MAX_DEVICES);
+    std::lock_guard<std::mutex> lk(g_attn_scratch_mu);
+    if (g_attn_scratch[device]) return VMX_OK;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+        vmx_set_error("vmx_init: hipGetSymbolAddress(attention scratch) failed on device %d: %s", device, hipGetErrorString(e));
+        return VMX_ELAUNCH;
+    }
+    g_attn_scratch[device] = ptr;
+    return VMX_OK;
+}
 
 namespace {
 
@@ -863,4 +887,29 @@ extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const 
                        (float *)nullptr);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
+}
+
+extern "C" size_t vmx_paged_attention_static_max_bytes(void) { return VMX_ATTN_SCRATCH_BYTES; }
+
+// vmx_paged_attention_bf16 with the split-KV partials in the library's per-GPU static array instead of a caller workspace:
+// no allocation of any kind.  Calls on one GPU share that array, so calls that overlap on one GPU (different streams or
+// threads) race; calls on one stream are ordered.  Nothing in the array has to start at zero: the merge kernel reads only the
+// partition slots the partition kernel of the same call wrote.
+extern "C" int vmx_paged_attention_bf16_static(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                               const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs,
+                                               int num_heads, int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim,
+                                               int block_size, int window, int kv_dtype, const float *k_scale, const float *v_scale,
+                                               void *stream) {
+    int dev = -1;
+    VMX_CHECK_HIP(hipGetDevice(&dev));
+    VMX_REQUIRE(dev >= 0 && dev < VMX_MAX_DEVICES && g_attn_scratch[dev],
+                "paged_attention(static): vmx_init(%d) has not run on this device", dev);
+    const size_t need = vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len);
+    VMX_REQUIRE(need <= VMX_ATTN_SCRATCH_BYTES,
+                "paged_attention(static): %d seqs x %d heads x head_dim %d at max_seq_len %d needs %zu bytes of partials, the static "
+                "array holds %zu; use vmx_paged_attention_bf16 with a workspace", num_seqs, num_heads, head_dim, max_seq_len, need,
+                VMX_ATTN_SCRATCH_BYTES);
+    return vmx_paged_attention_bf16(out, q, k_cache, v_cache, block_tables, seq_lens, scale, num_seqs, num_heads, num_kv_heads,
+                                    max_blocks_per_seq, max_seq_len, head_dim, block_size, window, kv_dtype, k_scale, v_scale,
+                                    g_attn_scratch[dev], VMX_ATTN_SCRATCH_BYTES, stream);
 }

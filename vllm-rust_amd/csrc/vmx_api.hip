@@ -3,6 +3,8 @@
 
 #include <mutex>
 
+int vmx_attention_scratch_init(int device);   // attention_kernels.hip
+
 namespace {
 thread_local char g_err[512] = "";
 }
@@ -44,5 +46,5 @@ extern "C" int vmx_init(int device) {
         vmx_set_error("vmx_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return VMX_EUNSUPPORTED;
     }
-    return VMX_OK;
+    return vmx_attention_scratch_init(device);
 }

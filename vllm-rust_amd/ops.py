@@ -13,7 +13,7 @@ from ._lib import check, lib
 __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
-    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention", "dense_gemv",
+    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant",
     "topk_softmax", "moe_align_block_size", "moe_int4_forward",
 ]
@@ -161,6 +161,20 @@ def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, scale: float, n
                                        scale, num_seqs, num_heads, num_kv_heads, block_tables.shape[1], max_seq_len, head_dim,
                                        block_size, window, kv_dtype, _ptr(k_scale), _ptr(v_scale), _ptr(ws), ws.numel(),
                                        _stream()))
+    return out
+
+
+def paged_attention_static(q, k_cache, v_cache, block_tables, seq_lens, scale: float, num_heads: int, num_kv_heads: int,
+                           head_dim: int, block_size: int, max_seq_len: int, window: int = 0, kv_dtype: int = 0, k_scale=None,
+                           v_scale=None, out=None) -> torch.Tensor:
+    """vmx_paged_attention_bf16_static: split-KV partials in the library's static per-GPU array (no workspace, no allocation
+    when `out` is given)."""
+    num_seqs = seq_lens.numel()
+    if out is None:
+        out = torch.zeros((num_seqs, num_heads * head_dim), dtype=torch.bfloat16, device=q.device)
+    check(lib.vmx_paged_attention_bf16_static(_ptr(out), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(block_tables), _ptr(seq_lens),
+                                              scale, num_seqs, num_heads, num_kv_heads, block_tables.shape[1], max_seq_len, head_dim,
+                                              block_size, window, kv_dtype, _ptr(k_scale), _ptr(v_scale), _stream()))
     return out
 
 
