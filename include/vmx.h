@@ -83,6 +83,23 @@ int vmx_iq_matmul_f32(int ggml_type, const void *w, const float *x, float *y, in
 int vmx_iq_subdots_i32(int ggml_type, const void *w, const int8_t *aq, int32_t *out, int n_out, int n_in,
                        int m, void *stream);
 
+/* Load-time repack of an I-quant weight [n_out, n_in] (IQ3_XXS, IQ3_S, IQ2_S) into the order a gfx950 wave consumes it:
+ * the same bytes (rows rounded up to a multiple of 8, no other padding), grouped as 8 rows x one K-slice of at most 16
+ * super-blocks, every field a region of 16-byte lane entries, so that the decode kernel streams it with coalesced
+ * 16-byte loads.  The reference keeps the raw GGUF bytes (GgufWeightLoader::load_linear, gguf/mod.rs:1612-1662); this is
+ * the load_weights-time layout step of this library's IqLinear.  `packed` needs vmx_iq_packed_bytes (0 = type without a
+ * packed form) and 16-byte alignment. */
+size_t vmx_iq_packed_bytes(int ggml_type, int n_out, int n_in);
+int vmx_iq_pack(int ggml_type, const void *raw, void *packed, int n_out, int n_in, void *stream);
+
+/* mmvq_iq*_f32 (iq_dequant.cu:388-423) for ONE activation row over the packed form: same integer sub-dots, f32 sums in a
+ * different order.  aq 16-byte aligned, ad 8-byte aligned. */
+int vmx_iq_mmvq_packed_f32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, float *y, int n_out, int n_in,
+                           void *stream);
+
+/* Parity aid: the integer sub-dots of the packed kernel, out[o * (n_in/32) + g] (the layout of vmx_iq_subdots_i32 at m = 1). */
+int vmx_iq_subdots_packed_i32(int ggml_type, const void *packed, const int8_t *aq, int32_t *out, int n_out, int n_in, void *stream);
+
 /* Replaces gather_dequant_q6k_f32 (crates/core/kernels/gather_dequant.cu:31-83):
  * out[i, :] = dequant(row ids[i]) of a Q6_K table [num_embeddings, dim];
  * out-of-range ids leave zeros. */

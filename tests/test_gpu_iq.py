@@ -167,3 +167,46 @@ def test_gather_dequant_q6k(gpu):
     for i, t in enumerate(ids):
         exp = table[t] if 0 <= t < rows else np.zeros(dim, np.float32)
         assert np.array_equal(got[i], exp)      # gguf/mod.rs:2112-2154: gather == full dequant, bit-exact
+
+
+PACKED_TYPES = [("iq3_xxs", 18, 98), ("iq3_s", 21, 110), ("iq2_s", 22, 82)]
+
+
+@pytest.mark.parametrize("name,tid,ts", PACKED_TYPES)
+@pytest.mark.parametrize("n_out,n_in", [(6, 256), (13, 768), (64, 3840), (40, 15360), (24, 11008), (8, 4096), (33, 14336), (2050, 512)])
+def test_packed_mmvq_subdots_bit_exact_and_sums(gpu, name, tid, ts, n_out, n_in):
+    """The load-time repacked stream (8-row x K-slice units, wave-ordered fields): integer sub-dots bit for bit those of the
+    CPU oracle, row sums within the reference's MMVQ gate (rel-L2 1e-3, cuda_tests.rs:100-104).  Shapes: one super-block,
+    ragged row counts, Gemma's 3840 (60 of 64 lanes live) and 15360 (4 equal slices), 11008 (3 uneven slices), 14336, and
+    more row groups than one workgroup holds."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(n_out + n_in + tid)
+    if n_in == 256 and n_out == 6:
+        _, w_raw, _ = load_iq_fixture(name)      # the reference's real blocks
+    else:
+        w_raw = random_iq_blocks(rng, ts, n_out * (n_in // 256))
+    x = (rng.standard_normal((1, n_in)) * 2).astype(np.float32)
+    aq, ad = orc.quantize_q8_1(x)
+    wd = _dev(torch, w_raw)
+    packed = vmx.iq_pack(tid, wd, n_out, n_in)
+    assert packed.numel() == (n_out + 7) // 8 * 8 * (n_in // 256) * ts
+    # a permutation of the same bytes (plus zero rows up to a multiple of 8)
+    assert np.array_equal(np.sort(packed.cpu().numpy()[: (n_out // 8) * 8 * (n_in // 256) * ts]),
+                          np.sort(w_raw[: (n_out // 8) * 8 * (n_in // 256) * ts]))
+    aqd, add = _dev(torch, aq), _dev(torch, ad)
+    got_sub = vmx.iq_subdots_packed(tid, packed, aqd, n_out, n_in).cpu().numpy()
+    assert np.array_equal(got_sub, orc.iq_subdots(tid, w_raw, aq, n_out, n_in))
+    got = vmx.iq_mmvq_packed(tid, packed, aqd, add, n_out, n_in).cpu().numpy()
+    ref = orc.iq_matmul(tid, w_raw, x, n_out, n_in)
+    assert rel_l2(got, ref) <= 1e-3
+    # and against the raw-layout kernel on the same q8_1 input
+    raw_y = vmx.iq_mmvq(tid, wd, aqd, add, n_out, n_in).cpu().numpy()
+    assert np.abs(got - raw_y).max() <= 1e-5 * np.abs(raw_y).max() + 1e-6
+
+
+def test_packed_rejects_types_without_packed_form(gpu):
+    from vllm_rust_amd._lib import lib
+    assert lib.vmx_iq_packed_bytes(17, 8, 256) == 0 and lib.vmx_iq_packed_bytes(18, 9, 512) == 16 * 2 * 98
+    assert lib.vmx_iq_pack(23, 1, 1, 8, 256, None) == -1
+    assert b"packed form" in lib.vmx_last_error()

@@ -36,6 +36,10 @@ _SIGS = {
     "vmx_iq_matmul_workspace_bytes": (_sz, [_i, _i]),
     "vmx_iq_matmul_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vmx_iq_subdots_i32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_iq_packed_bytes": (_sz, [_i, _i, _i]),
+    "vmx_iq_pack": (_i, [_i, _p, _p, _i, _i, _p]),
+    "vmx_iq_mmvq_packed_f32": (_i, [_i, _p, _p, _p, _p, _i, _i, _p]),
+    "vmx_iq_subdots_packed_i32": (_i, [_i, _p, _p, _p, _i, _i, _p]),
     "vmx_gather_dequant_q6k_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "vmx_ggml_type_size": (_i, [_i]),
     "vmx_ggml_block_elems": (_i, [_i]),

@@ -1,0 +1,558 @@
+// q8_1 MMVQ over a load-time REPACKED form of GGUF I-quant weights (IQ3_XXS, IQ3_S, IQ2_S), one activation row.
+//
+// Semantics are those of mmvq_iq*_f32 / vec_dot_iq*_q8_1 (crates/core/kernels/iq_dequant.cu:274-423; CPU form
+// crates/core/src/quantization/gguf/iq/mod.rs:556-725): y[o] = sum_g w_d(o, g/8) * a_d(g) * int_dot(block, g%8, u), the
+// integer sub-dots bit for bit (vmx_iq_subdots_packed_i32 exposes them), only the f32 summation order differs.
+//
+// Why a repack.  A GGUF row is a string of 74..136-byte super-blocks, 2-byte aligned, fields of one sub-block scattered over
+// the block: a lane that owns a sub-block needs 3-4 narrow unaligned loads for 12 bytes, and the stream runs at well under
+// half of what 16-byte coalesced loads reach.  The packed form holds exactly the same bytes (a permutation, no padding
+// beyond rounding the row count up to 8) ordered the way a wave consumes them:
+//
+//   unit   = 8 consecutive rows x one K-slice of nb <= 16 super-blocks (a row of n_in / 256 super-blocks is cut into
+//            S = ceil(n_sb / 16) slices of near-equal length); units of a row group are stored slice after slice.
+//   lane l of the wave that owns a unit (l < L = 4 nb) owns sub-blocks 2l and 2l + 1 of every row of the slice; inside the
+//   unit each field is a region of 16-byte lane entries, so that every load is one coalesced dwordx4 per lane:
+//     IQ3_XXS  A [row][lane]      16 B  qs of both sub-blocks         B [row pair][lane] 2 x 8 B  scales_and_signs words
+//              C [super-block]    8 x 2 B  f16 d of the 8 rows (shared by the 4 lanes of the super-block)
+//     IQ3_S    A qs as above      B [row pair][lane] 2 x 8 B signs    Q [lane] 8 x 2 B qh     Sc [lane] 8 x 1 B scales    C d
+//     IQ2_S    A [row][lane]      qs (8 B) | signs (8 B)              Q [row quad][lane] 4 x (qh 2 B | scales 2 B)        C d
+//   13 / 15 / 11 loads per lane move a unit's 196 / 220 / 164 bytes per lane, all requested before anything is decoded.
+//
+// The decode is bound by vector-ALU issue (a wave64 integer instruction occupies its SIMD for 4 cycles), so the kernel is
+// built to spend as few instructions per sub-block as the format allows (~45 for IQ3_XXS against ~77 for the first packed
+// version and for the raw-layout kernel):
+//   * the activations of a lane's two sub-blocks never change: 64 int8 + their bytewise negation + 2 scales in registers;
+//   * codebook and sign tables sit in LDS in 256-byte slots: slot e = 32 copies of grid entry e (lane l reads copy l % 32 =
+//     its own bank: conflict-free) followed by 16 copies of sign entry e.  With a 256-byte stride the address of a gather is
+//     (index byte << 8) | lane offset, which ONE v_perm_b32 assembles from the code word and the lane's offset register;
+//   * a sign entry holds two v_perm selectors: signed activations = perm(-u, u, selector), then one v_dot4 per 4 weights
+//     (instead of xor / and / add on the codebook word, or two dot products).
+#include "iq_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int PK_ROWS = 8;
+
+__host__ __device__ inline int pk_num_slices(int nsb) { return (nsb + 15) / 16; }
+__host__ __device__ inline void pk_slice(int nsb, int S, int s, int &sb0, int &nb) {
+    const int base = nsb / S, rem = nsb % S;
+    nb = base + (s < rem ? 1 : 0);
+    sb0 = s * base + (s < rem ? s : rem);
+}
+
+template <int T> struct Pk;
+// byte offsets of the regions inside a unit of L = 4 nb lanes, LDS table bytes
+template <> struct Pk<18> { static constexpr int TS = 98; };
+template <> struct Pk<21> { static constexpr int TS = 110; };
+template <> struct Pk<22> { static constexpr int TS = 82; };
+
+__host__ __device__ inline bool pk_supported(int t) { return t == 18 || t == 21 || t == 22; }
+__host__ __device__ inline int pk_type_size(int t) { return t == 18 ? 98 : t == 21 ? 110 : t == 22 ? 82 : 0; }
+inline int pk_lds_bytes(int t) { return t == 18 ? 65536 : t == 21 ? 131072 : 98304; }
+
+// ------------------------------------------------------------------ repack (load time)
+// One thread per (padded row, super-block): scatter the raw block's fields to their places in the unit.
+__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, int n) {
+    for (int i = 0; i < n; i++) dst[i] = src[i];
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void iq_pack_kernel(const uint8_t *__restrict__ raw, uint8_t *__restrict__ packed, int n_out, int nsb) {
+    constexpr int TS = Pk<T>::TS;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n_out * nsb;
+    if (idx >= total) return;
+    const int row = (int)(idx / nsb), bg = (int)(idx % nsb);
+    const int S = pk_num_slices(nsb);
+    // slice of super-block bg
+    const int base = nsb / S, rem = nsb % S;
+    int s = bg < rem * (base + 1) ? bg / (base + 1) : rem + (bg - rem * (base + 1)) / base;
+    int sb0, nb;
+    pk_slice(nsb, S, s, sb0, nb);
+    const int b = bg - sb0, L = 4 * nb, r = row & 7;
+    uint8_t *U = packed + (int64_t)(row >> 3) * PK_ROWS * nsb * TS + (int64_t)PK_ROWS * TS * sb0;
+    const uint8_t *blk = raw + ((int64_t)row * nsb + bg) * TS;
+    copy_bytes(U + (T == 18 ? 192 * L : T == 21 ? 216 * L : 160 * L) + 16 * b + 2 * r, blk, 2);   // C: d
+#pragma unroll
+    for (int h = 0; h < 4; h++) {   // the four lanes of the super-block: sub-blocks ib0 = 2h, 2h + 1
+        const int l = 4 * b + h, ib0 = 2 * h;
+        if constexpr (T == 18) {
+            copy_bytes(U + r * 16 * L + 16 * l, blk + 2 + 8 * ib0, 16);
+            copy_bytes(U + 128 * L + (r >> 1) * 16 * L + 16 * l + 8 * (r & 1), blk + 66 + 4 * ib0, 8);
+        } else if constexpr (T == 21) {
+            copy_bytes(U + r * 16 * L + 16 * l, blk + 2 + 8 * ib0, 16);
+            copy_bytes(U + 128 * L + (r >> 1) * 16 * L + 16 * l + 8 * (r & 1), blk + 74 + 4 * ib0, 8);
+            copy_bytes(U + 192 * L + 16 * l + 2 * r, blk + 66 + ib0, 2);
+            copy_bytes(U + 208 * L + 8 * l + r, blk + 106 + (ib0 >> 1), 1);
+        } else {
+            copy_bytes(U + r * 16 * L + 16 * l, blk + 2 + 4 * ib0, 8);
+            copy_bytes(U + r * 16 * L + 16 * l + 8, blk + 34 + 4 * ib0, 8);
+            copy_bytes(U + 128 * L + (r >> 2) * 16 * L + 16 * l + 4 * (r & 3), blk + 66 + ib0, 2);
+            copy_bytes(U + 128 * L + (r >> 2) * 16 * L + 16 * l + 4 * (r & 3) + 2, blk + 74 + ib0, 2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ tables
+// The type's codebook words a thread will replicate, fetched BEFORE the weight loads are issued (vmcnt retires in order: a
+// load behind the weight stream would only return with it).  Thread t owns entries t, t + nthreads, ... (clamped: surplus
+// iterations re-read the last entry and write nothing).
+template <int T> struct PkTableRegs {
+    static constexpr int N = T == 18 ? 256 : T == 21 ? 512 : 1024;   // grid entries
+    static constexpr int PER = N / 64;                                // entries per thread in a one-wave workgroup
+    uint32_t lo[PER], hi[T == 22 ? PER : 1];
+};
+
+template <int T> __device__ __forceinline__ PkTableRegs<T> pk_tables_fetch(int tid, int nthreads) {
+    PkTableRegs<T> t;
+    constexpr int N = PkTableRegs<T>::N;
+#pragma unroll
+    for (int k = 0; k < PkTableRegs<T>::PER; k++) {
+        const int e = min(tid + k * nthreads, N - 1);
+        if constexpr (T == 18) t.lo[k] = iq3xxs_grid[e];
+        else if constexpr (T == 21) t.lo[k] = iq3s_grid[e];
+        else {
+            const uint2 v = reinterpret_cast<const uint2 *>(iq2s_grid)[e];
+            t.lo[k] = v.x;
+            t.hi[k] = v.y;
+        }
+    }
+    return t;
+}
+
+// Sign entry of sign byte s8 as two v_perm_b32 selectors: byte j = j (keep u_j) or 4 + j (take -u_j) for weights j and 4 + j.
+__device__ __forceinline__ uint2 sign_sel_entry(uint32_t s8) {
+    const uint32_t l0 = __umul24(s8 & 0xFu, 0x00204081u) & 0x01010101u, l1 = __umul24(s8 >> 4, 0x00204081u) & 0x01010101u;
+    return make_uint2(0x03020100u | (l0 << 2), 0x03020100u | (l1 << 2));
+}
+
+// Write the tables.  IQ3_XXS / IQ3_S: 256-byte slots, slot e = grid entry e x 32 copies (128 B) | sign entry e x 16 copies
+// (128 B; IQ3_XXS: entry of the 7-bit index e & 127 with its parity bit, IQ3_S: of sign byte e, slots 0..255 only).
+// IQ2_S: grid (8-byte entries) x 8 copies = 64 B at e * 64; sign entries x 16 copies at 65536 + e * 128.
+template <int T> __device__ __forceinline__ void pk_tables_commit(const PkTableRegs<T> &t, unsigned char *smem, int tid, int nthreads) {
+    constexpr int N = PkTableRegs<T>::N;
+#pragma unroll
+    for (int k = 0; k < PkTableRegs<T>::PER; k++) {
+        const int e = tid + k * nthreads;
+        if (e < N) {
+            if constexpr (T == 22) {
+                uint4 *d = reinterpret_cast<uint4 *>(smem + e * 64);
+                const uint4 v = make_uint4(t.lo[k], t.hi[k], t.lo[k], t.hi[k]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) d[c] = v;
+            } else {
+                uint4 *d = reinterpret_cast<uint4 *>(smem + e * 256);
+                const uint4 v = make_uint4(t.lo[k], t.lo[k], t.lo[k], t.lo[k]);
+#pragma unroll
+                for (int c = 0; c < 8; c++) d[c] = v;
+                if (T == 18 || e < 256) {
+                    uint32_t s8 = (uint32_t)e & (T == 18 ? 127u : 255u);
+                    if constexpr (T == 18) s8 |= (__popc(s8) & 1u) << 7;
+                    const uint2 m = sign_sel_entry(s8);
+                    const uint4 sv = make_uint4(m.x, m.y, m.x, m.y);
+#pragma unroll
+                    for (int c = 8; c < 16; c++) d[c] = sv;
+                }
+            }
+        }
+    }
+    if constexpr (T == 22) {
+        for (int e = tid; e < 256; e += nthreads) {
+            const uint2 m = sign_sel_entry((uint32_t)e);
+            uint4 *d = reinterpret_cast<uint4 *>(smem + 65536 + e * 128);
+            const uint4 v = make_uint4(m.x, m.y, m.x, m.y);
+#pragma unroll
+            for (int c = 0; c < 8; c++) d[c] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ part registers
+// A wave works on PPW consecutive "parts" (row pairs) of a unit.  Everything a part needs is requested small fields first,
+// then the sign / scale words, then the 16-byte code entries, part after part: vmcnt retires in issue order, so part 0 can
+// be decoded while the later parts are still in flight.
+template <int T> struct PkPart;
+template <> struct PkPart<18> { uint4 A[2], B; uint32_t d2; };
+template <> struct PkPart<21> { uint4 A[2], B; uint32_t d2, qh2, sc2; };
+template <> struct PkPart<22> { uint4 A[2]; uint2 Q; uint32_t d2; };
+
+template <int T> __device__ __forceinline__ void pk_load_small(PkPart<T> &r, const uint8_t *__restrict__ U, int L, int lc, int rp) {
+    if constexpr (T == 18) {
+        r.d2 = *reinterpret_cast<const uint32_t *>(U + 192 * L + 16 * (lc >> 2) + 4 * rp);
+    } else if constexpr (T == 21) {
+        r.d2 = *reinterpret_cast<const uint32_t *>(U + 216 * L + 16 * (lc >> 2) + 4 * rp);
+        r.qh2 = *reinterpret_cast<const uint32_t *>(U + 192 * L + 16 * lc + 4 * rp);
+        r.sc2 = *reinterpret_cast<const uint16_t *>(U + 208 * L + 8 * lc + 2 * rp);
+    } else {
+        r.d2 = *reinterpret_cast<const uint32_t *>(U + 160 * L + 16 * (lc >> 2) + 4 * rp);
+        r.Q = *reinterpret_cast<const uint2 *>(U + 128 * L + (rp >> 1) * 16 * L + 16 * lc + 8 * (rp & 1));
+    }
+}
+
+template <int T> __device__ __forceinline__ void pk_load_wide(PkPart<T> &r, const uint8_t *__restrict__ U, int L, int lc, int rp) {
+    if constexpr (T != 22) r.B = *reinterpret_cast<const uint4 *>(U + 128 * L + rp * 16 * L + 16 * lc);
+    r.A[0] = *reinterpret_cast<const uint4 *>(U + (2 * rp) * 16 * L + 16 * lc);
+    r.A[1] = *reinterpret_cast<const uint4 *>(U + (2 * rp + 1) * 16 * L + 16 * lc);
+}
+
+__device__ __forceinline__ uint32_t w4(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// C truncating division by 2 and 4 without a divide
+__device__ __forceinline__ int div2(int x) { return (x + (int)((uint32_t)x >> 31)) >> 1; }
+__device__ __forceinline__ int div4(int x) { return (x + (int)(((uint32_t)(x >> 31)) >> 30)) >> 2; }
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }   // |a|, |b| < 2^23 here: full-rate multiply
+
+// Address of the table slot of index byte k of `w`: (byte << 8) | off, off < 256 held in byte 0 of `off`
+template <int K> __device__ __forceinline__ uint32_t slot_addr(uint32_t w, uint32_t off) {
+    return __builtin_amdgcn_perm(w, off, 0x0c0c0000u | ((4u + K) << 8));
+}
+
+// Integer sub-dot (already scaled: what vec_dot_iq*_q8_1 multiplies by d * a_d) of sub-block j (0 / 1) of row ri (0 / 1) of a
+// part.  u / nu = the 8 activation words of that sub-block and their bytewise negation; smem = tables; lane_g / lane_s = the
+// lane's byte offsets of its grid copy and its sign copy inside a slot.
+template <int T>
+__device__ __forceinline__ int pk_subdot(const PkPart<T> &raw, int ri, int j, const int u[8], const int nu[8], const unsigned char *smem,
+                                         uint32_t lane_g, uint32_t lane_s) {
+    auto signed_u = [&](int k, uint32_t sel) { return (int)__builtin_amdgcn_perm((uint32_t)nu[k], (uint32_t)u[k], sel); };
+    if constexpr (T == 18) {
+        const uint32_t q0 = j ? raw.A[ri].z : raw.A[ri].x, q1 = j ? raw.A[ri].w : raw.A[ri].y;
+        const uint32_t aux = w4(raw.B, ri * 2 + j);
+        const uint32_t ga[8] = {slot_addr<0>(q0, lane_g), slot_addr<1>(q0, lane_g), slot_addr<2>(q0, lane_g), slot_addr<3>(q0, lane_g),
+                                slot_addr<0>(q1, lane_g), slot_addr<1>(q1, lane_g), slot_addr<2>(q1, lane_g), slot_addr<3>(q1, lane_g)};
+        const uint32_t sa[4] = {((aux << 8) & 0x7F00u) | lane_s, ((aux << 1) & 0x7F00u) | lane_s, ((aux >> 6) & 0x7F00u) | lane_s,
+                                ((aux >> 13) & 0x7F00u) | lane_s};
+        int a = 0;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const uint32_t g0 = *reinterpret_cast<const uint32_t *>(smem + ga[2 * l]);
+            const uint32_t g1 = *reinterpret_cast<const uint32_t *>(smem + ga[2 * l + 1]);
+            const uint2 mk = *reinterpret_cast<const uint2 *>(smem + sa[l]);
+            a = dot4((int)g0, signed_u(2 * l, mk.x), a);
+            a = dot4((int)g1, signed_u(2 * l + 1, mk.y), a);
+        }
+        const int ls = (int)(aux >> 28);
+        return div2(mul24(ls, a) + div2(a));
+    } else if constexpr (T == 21) {
+        const uint32_t q0 = j ? raw.A[ri].z : raw.A[ri].x, q1 = j ? raw.A[ri].w : raw.A[ri].y;
+        const uint32_t sgn = w4(raw.B, ri * 2 + j);
+        const uint32_t qh = raw.qh2 >> (16 * ri + 8 * j);   // bit k = ninth index bit of lookup k (higher bits are masked off below)
+        const uint32_t scb = (raw.sc2 >> (8 * ri)) & 0xFFu;
+        const uint32_t gb[8] = {slot_addr<0>(q0, lane_g), slot_addr<1>(q0, lane_g), slot_addr<2>(q0, lane_g), slot_addr<3>(q0, lane_g),
+                                slot_addr<0>(q1, lane_g), slot_addr<1>(q1, lane_g), slot_addr<2>(q1, lane_g), slot_addr<3>(q1, lane_g)};
+        const uint32_t sa[4] = {slot_addr<0>(sgn, lane_s), slot_addr<1>(sgn, lane_s), slot_addr<2>(sgn, lane_s), slot_addr<3>(sgn, lane_s)};
+        int a = 0;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            // iq3s index = byte | bit << 8: lookups 2l, 2l + 1 take qh bits 2l, 2l + 1 (iq/mod.rs:223-271) -> address bit 16
+            const uint32_t a0 = gb[2 * l] | ((qh << (16 - 2 * l)) & 0x10000u);
+            const uint32_t a1 = gb[2 * l + 1] | ((qh << (15 - 2 * l)) & 0x10000u);
+            const uint32_t g0 = *reinterpret_cast<const uint32_t *>(smem + a0);
+            const uint32_t g1 = *reinterpret_cast<const uint32_t *>(smem + a1);
+            const uint2 mk = *reinterpret_cast<const uint2 *>(smem + sa[l]);
+            a = dot4((int)g0, signed_u(2 * l, mk.x), a);
+            a = dot4((int)g1, signed_u(2 * l + 1, mk.y), a);
+        }
+        const int nib = (int)((scb >> (4 * j)) & 0xFu);
+        return mul24(a, 1 + 2 * nib);
+    } else {
+        const uint32_t qs = j ? raw.A[ri].y : raw.A[ri].x, sgn = j ? raw.A[ri].w : raw.A[ri].z;
+        const uint32_t qw = ri ? raw.Q.y : raw.Q.x;
+        const uint32_t qh = (qw >> (8 * j)) & 0xFFu, sc = (qw >> (16 + 8 * j)) & 0xFFu;
+        const unsigned char *sg = smem + 65536;
+        int a[2] = {0, 0};
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const uint32_t idx = ((qs >> (8 * l)) & 0xFFu) | ((qh << (8 - 2 * l)) & 0x300u);
+            const uint2 g = *reinterpret_cast<const uint2 *>(smem + (idx << 6) + lane_g);
+            const uint2 mk = *reinterpret_cast<const uint2 *>(sg + (((sgn >> (8 * l)) & 0xFFu) << 7) + lane_s);
+            a[l >> 1] = dot4((int)g.x, signed_u(2 * l, mk.x), a[l >> 1]);
+            a[l >> 1] = dot4((int)g.y, signed_u(2 * l + 1, mk.y), a[l >> 1]);
+        }
+        const int ls0 = (int)(sc & 0xFu), ls1 = (int)(sc >> 4);
+        return div4(mul24(a[0], ls0) + mul24(a[1], ls1) + div2(a[0] + a[1]));
+    }
+}
+
+// Sum NR (2, 4 or 8) values per lane over the wave: afterwards the lanes with (lane & 7) == 0 hold the total of value
+// index built from lane bits 5, 4, 3 (the top log2(NR) of them).  Halving exchanges first, then plain butterflies.
+template <int NR> __device__ __forceinline__ float reduce_rows(const float *v, int lane, int &rsel) {
+    float w[4], x[2], z;
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+    if constexpr (NR == 8) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = (h5 ? v[i + 4] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 4], 32, 64);
+#pragma unroll
+        for (int i = 0; i < 2; i++) x[i] = (h4 ? w[i + 2] : w[i]) + __shfl_xor(h4 ? w[i] : w[i + 2], 16, 64);
+        z = (h3 ? x[1] : x[0]) + __shfl_xor(h3 ? x[0] : x[1], 8, 64);
+        rsel = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
+    } else if constexpr (NR == 4) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) x[i] = (h5 ? v[i + 2] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 2], 32, 64);
+        z = (h4 ? x[1] : x[0]) + __shfl_xor(h4 ? x[0] : x[1], 16, 64);
+        z += __shfl_xor(z, 8, 64);
+        rsel = (h5 ? 2 : 0) + (h4 ? 1 : 0);
+    } else {
+        z = (h5 ? v[1] : v[0]) + __shfl_xor(h5 ? v[0] : v[1], 32, 64);
+        z += __shfl_xor(z, 16, 64);
+        z += __shfl_xor(z, 8, 64);
+        rsel = h5 ? 1 : 0;
+    }
+    z += __shfl_xor(z, 4, 64);
+    z += __shfl_xor(z, 2, 64);
+    z += __shfl_xor(z, 1, 64);
+    return z;
+}
+
+struct PkSeg {
+    const uint8_t *w;   // packed weights
+    float *y;           // output of this segment
+    int type, n_out, wg0;
+};
+struct PkArgs {
+    PkSeg seg[3];
+    int nseg;
+};
+
+// One wave = one work item = PPW row pairs of one unit (rows 2 PPW c .. 2 PPW (c + 1) - 1 of row group g, K-slice s; item
+// index ((g * (4 / PPW) + c) * S + s).  Workgroup = W waves on consecutive items of one segment (W % S == 0, so the S slices
+// of a row set sit in one workgroup and are combined through LDS in slice order).
+template <int T, int PPW, bool DBG, int ABL = 0>
+__device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const PkSeg &sg, int wg, const int8_t *__restrict__ aq,
+                                        const float *__restrict__ ad, int n_in, int S, int32_t *__restrict__ dbg) {
+    constexpr int TS = Pk<T>::TS, CPU_ = 4 / PPW, NR = 2 * PPW;   // chunks per unit, rows per item
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = nthreads >> 6;
+    const PkTableRegs<T> treg = pk_tables_fetch<T>(tid, nthreads);
+    const int nsb = n_in >> 8;
+    const int groups = (sg.n_out + PK_ROWS - 1) / PK_ROWS, items = groups * CPU_ * S;
+    const int item = wg * W + wave;
+    const bool valid = item < items;
+    const int ic = valid ? item : items - 1;
+    const int slice = ic % S, gc = ic / S, group = gc / CPU_, chunk = gc % CPU_;
+    int sb0, nb;
+    pk_slice(nsb, S, slice, sb0, nb);
+    const int L = 4 * nb, lc = min(lane, L - 1);
+    const bool live = valid && lane < L;
+    // activations of the lane's two sub-blocks
+    const int g0 = sb0 * 8 + 2 * lc;
+    const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)g0 * 32);
+    const int4 u0 = up[0], u1 = up[1], u2 = up[2], u3 = up[3];
+    const float2 dav = *reinterpret_cast<const float2 *>(ad + g0);
+    const float da[2] = {live ? dav.x : 0.f, live ? dav.y : 0.f};
+    // weights: every load of the item, in the order the decode wants them back
+    const uint8_t *U = sg.w + (int64_t)group * PK_ROWS * nsb * TS + (int64_t)PK_ROWS * TS * sb0;
+    PkPart<T> raw[PPW];
+    if constexpr (ABL == 2) {   // measurement: no weight stream, register data that the compiler cannot fold
+#pragma unroll
+        for (int p = 0; p < PPW; p++) {
+            uint32_t *wr = reinterpret_cast<uint32_t *>(&raw[p]);
+            for (int k = 0; k < (int)(sizeof(PkPart<T>) / 4); k++) wr[k] = ((uint32_t)(lane * 2654435761u) ^ (uint32_t)(u0.x + k + 16 * p)) & 0x7F7F7F7Fu;
+        }
+    } else {
+#pragma unroll
+    for (int p = 0; p < PPW; p++) pk_load_small<T>(raw[p], U, L, lc, chunk * PPW + p);
+#pragma unroll
+    for (int p = 0; p < PPW; p++) pk_load_wide<T>(raw[p], U, L, lc, chunk * PPW + p);
+    }
+    pk_tables_commit<T>(treg, smem, tid, nthreads);
+    __syncthreads();
+    if constexpr (ABL == 1) {   // measurement: the weight stream alone
+        uint32_t x = 0;
+#pragma unroll
+        for (int p = 0; p < PPW; p++) {
+            x ^= raw[p].A[0].x ^ raw[p].A[0].y ^ raw[p].A[0].z ^ raw[p].A[0].w ^ raw[p].A[1].x ^ raw[p].A[1].y ^ raw[p].A[1].z ^ raw[p].A[1].w ^ raw[p].d2;
+            if constexpr (T != 22) x ^= raw[p].B.x ^ raw[p].B.y ^ raw[p].B.z ^ raw[p].B.w;
+        }
+        if (x == 0x12345678u && valid) sg.y[0] = 1.0f;
+        return;
+    }
+
+    const int ua[2][8] = {{u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w}, {u2.x, u2.y, u2.z, u2.w, u3.x, u3.y, u3.z, u3.w}};
+    int nua[2][8];   // bytewise -u (q8_1 values lie in -127..127, so the negation is representable)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t x = (uint32_t)ua[j][k];
+            // per byte ~x + 1 without carries between bytes: add inside the low 7 bits, fold the carry into bit 7 with xor
+            const uint32_t t = (~x & 0x7F7F7F7Fu) + 0x01010101u;
+            nua[j][k] = (int)(t ^ (~x & 0x80808080u));
+            asm volatile("" : "+v"(nua[j][k]));   // keep it in a register: recomputing it at every use costs 3 instructions per word
+        }
+    const uint32_t lane_g = T == 22 ? (uint32_t)(lane & 7) * 8u : (uint32_t)(lane & 31) * 4u;
+    const uint32_t lane_s = T == 22 ? (uint32_t)(lane & 15) * 8u : 128u + (uint32_t)(lane & 15) * 8u;
+    float acc[NR];
+#pragma unroll
+    for (int p = 0; p < PPW; p++) {
+#pragma unroll
+        for (int ri = 0; ri < 2; ri++) {
+            const float wd = vmx_f16_to_f32((uint16_t)(raw[p].d2 >> (16 * ri)));
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int sub = pk_subdot<T>(raw[p], ri, j, ua[j], nua[j], smem, lane_g, lane_s);
+                a += (wd * da[j]) * (float)sub;
+                if constexpr (DBG) {
+                    const int row = group * PK_ROWS + chunk * NR + 2 * p + ri;
+                    if (live && row < sg.n_out) dbg[(int64_t)row * (n_in >> 5) + g0 + j] = sub;
+                }
+            }
+            acc[2 * p + ri] = a;
+        }
+    }
+    if constexpr (DBG) return;
+    int rsel;
+    const float z = reduce_rows<NR>(acc, lane, rsel);
+    if (S == 1) {
+        const int row = group * PK_ROWS + chunk * NR + rsel;
+        if ((lane & 7) == 0 && valid && row < sg.n_out) sg.y[row] = z;
+    } else {
+        if ((lane & 7) == 0) part[wave * 8 + rsel] = valid ? z : 0.f;
+        __syncthreads();
+        const int ns = W / S;   // row sets of this workgroup
+        if (tid < ns * NR) {
+            const int si = tid / NR, r = tid % NR;
+            float s = 0.f;
+            for (int k = 0; k < S; k++) s += part[(si * S + k) * 8 + r];
+            const int gcw = (wg * W) / S + si;   // (group, chunk) of this row set
+            const int row = (gcw / CPU_) * PK_ROWS + (gcw % CPU_) * NR + r;
+            if (gcw < groups * CPU_ && row < sg.n_out) sg.y[row] = s;
+        }
+    }
+}
+
+template <int PPW, bool DBG, int ABL = 0>
+__global__ __launch_bounds__(1024) void iq_pk_mmvq_kernel(PkArgs a, const int8_t *__restrict__ aq, const float *__restrict__ ad, int n_in,
+                                                           int S, int32_t *__restrict__ dbg, int lds_tables) {
+    // the only LDS object of the kernel, so the tables start at LDS address 0 and a gather needs no base add
+    extern __shared__ __align__(16) unsigned char pk_smem[];
+    const int b = blockIdx.x;
+    const int si = (a.nseg > 2 && b >= a.seg[2].wg0) ? 2 : ((a.nseg > 1 && b >= a.seg[1].wg0) ? 1 : 0);
+    const PkSeg &sg = a.seg[si];
+    const int wg = b - sg.wg0;
+    float *part = reinterpret_cast<float *>(pk_smem + lds_tables);   // [waves][8] slice sums, behind the tables
+    switch (sg.type) {   // workgroup-uniform
+        case 18: pk_body<18, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg); break;
+        case 21: pk_body<21, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg); break;
+        default: pk_body<22, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg); break;
+    }
+}
+
+template <int PPW, bool DBG, int ABL = 0> int pk_launch_ppw(const PkArgs &a, int wgs, int W, int lds, const int8_t *aq, const float *ad, int n_in, int S,
+                                               int32_t *dbg, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)iq_pk_mmvq_kernel<PPW, DBG, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+        if (e != hipSuccess) {
+            vmx_set_error("iq_mmvq(packed): hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return VMX_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL>), dim3(wgs), dim3(64 * W), lds + 512, st, a, aq, ad, n_in, S, dbg, lds);
+    VMX_CHECK_LAUNCH("iq_mmvq(packed)");
+    return VMX_OK;
+}
+
+int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int32_t *dbg, hipStream_t st) {
+    const int nsb = n_in / 256, S = pk_num_slices(nsb);
+    if (S > 16) {
+        vmx_set_error("iq_mmvq(packed): n_in %d beyond 65536", n_in);
+        return VMX_EUNSUPPORTED;
+    }
+    int units_total = 0, lds = 0;
+    for (int i = 0; i < nseg; i++) {
+        units_total += (segs[i].n_out + PK_ROWS - 1) / PK_ROWS * S;
+        const int l = pk_lds_bytes(segs[i].ggml_type);
+        lds = l > lds ? l : lds;
+    }
+    // row pairs per wave: whole units where that already gives every SIMD several waves, fewer rows per wave for small tensors
+    static const int force_ppw = getenv("VMX_IQ_PPW") ? atoi(getenv("VMX_IQ_PPW")) : 0;
+    int ppw = units_total >= 2048 ? 4 : (units_total >= 1024 ? 2 : 1);
+    if (force_ppw == 1 || force_ppw == 2 || force_ppw == 4) ppw = force_ppw;
+    if (dbg) ppw = 4;
+    const int cpu_ = 4 / ppw;
+    // waves per workgroup: spread the items over all compute units, the slices of a row set together
+    const int cus = vmx_num_cus();
+    int W = (units_total * cpu_ + cus - 1) / cus;
+    W = W < 1 ? 1 : (W > 16 ? 16 : W);
+    W = ((W + S - 1) / S) * S;
+    if (W > 16) W = (16 / S) * S;
+    PkArgs a = {};
+    a.nseg = nseg;
+    int wg = 0;
+    for (int i = 0; i < nseg; i++) {
+        const int items = (segs[i].n_out + PK_ROWS - 1) / PK_ROWS * cpu_ * S;
+        a.seg[i] = PkSeg{(const uint8_t *)segs[i].w, y + segs[i].y_off, segs[i].ggml_type, segs[i].n_out, wg};
+        wg += (items + W - 1) / W;
+    }
+    if (dbg) return pk_launch_ppw<4, true>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
+    static const int abl = getenv("VMX_IQ_ABL") ? atoi(getenv("VMX_IQ_ABL")) : 0;   // measurement only: 1 = stream alone, 2 = decode alone
+    if (abl == 1 && ppw == 4) return pk_launch_ppw<4, false, 1>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
+    if (abl == 2 && ppw == 4) return pk_launch_ppw<4, false, 2>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
+    if (ppw == 4) return pk_launch_ppw<4, false>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
+    if (ppw == 2) return pk_launch_ppw<2, false>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
+    return pk_launch_ppw<1, false>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
+}
+
+}  // namespace
+
+bool vmx_iq_packed_supported(int ggml_type) { return pk_supported(ggml_type); }
+
+extern "C" size_t vmx_iq_packed_bytes(int ggml_type, int n_out, int n_in) {
+    if (!pk_supported(ggml_type) || n_out <= 0 || n_in <= 0 || n_in % 256) return 0;
+    return (size_t)((n_out + PK_ROWS - 1) / PK_ROWS) * PK_ROWS * (size_t)(n_in / 256) * pk_type_size(ggml_type);
+}
+
+extern "C" int vmx_iq_pack(int ggml_type, const void *raw, void *packed, int n_out, int n_in, void *stream) {
+    VMX_REQUIRE(raw && packed, "iq_pack: null pointer");
+    VMX_REQUIRE(pk_supported(ggml_type), "iq_pack: ggml type %d has no packed form (IQ3_XXS 18, IQ3_S 21, IQ2_S 22)", ggml_type);
+    VMX_REQUIRE(n_out > 0 && n_in > 0 && n_in % 256 == 0, "iq_pack: n_in %d not a multiple of 256", n_in);
+    VMX_REQUIRE(((uintptr_t)packed & 15) == 0, "iq_pack: packed buffer must be 16-byte aligned");
+    hipStream_t st = vmx_stream(stream);
+    const int nsb = n_in / 256;
+    VMX_CHECK_HIP(hipMemsetAsync(packed, 0, vmx_iq_packed_bytes(ggml_type, n_out, n_in), st));   // rows of the last group past n_out: d = 0
+    const int64_t total = (int64_t)n_out * nsb;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (ggml_type == 18) hipLaunchKernelGGL(iq_pack_kernel<18>, grid, dim3(256), 0, st, (const uint8_t *)raw, (uint8_t *)packed, n_out, nsb);
+    else if (ggml_type == 21) hipLaunchKernelGGL(iq_pack_kernel<21>, grid, dim3(256), 0, st, (const uint8_t *)raw, (uint8_t *)packed, n_out, nsb);
+    else hipLaunchKernelGGL(iq_pack_kernel<22>, grid, dim3(256), 0, st, (const uint8_t *)raw, (uint8_t *)packed, n_out, nsb);
+    VMX_CHECK_LAUNCH("iq_pack");
+    return VMX_OK;
+}
+
+// Up to three packed tensors that share one q8_1 activation row, one launch; outputs at y + y_off[i]
+int vmx_iq_mmvq_packed_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, hipStream_t st) {
+    if (nseg < 1 || nseg > 3) {
+        vmx_set_error("iq_mmvq(packed): %d segments (1..3)", nseg);
+        return VMX_EINVAL;
+    }
+    for (int i = 0; i < nseg; i++)
+        if (!pk_supported(segs[i].ggml_type)) {
+            vmx_set_error("iq_mmvq(packed): ggml type %d has no packed form", segs[i].ggml_type);
+            return VMX_EUNSUPPORTED;
+        }
+    return pk_launch(segs, nseg, aq, ad, y, n_in, nullptr, st);
+}
+
+extern "C" int vmx_iq_mmvq_packed_f32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, float *y, int n_out, int n_in,
+                                      void *stream) {
+    VMX_REQUIRE(packed && aq && ad && y, "iq_mmvq(packed): null pointer");
+    VMX_REQUIRE(pk_supported(ggml_type), "iq_mmvq(packed): ggml type %d has no packed form (IQ3_XXS 18, IQ3_S 21, IQ2_S 22)", ggml_type);
+    VMX_REQUIRE(n_in > 0 && n_in % 256 == 0, "iq_matmul: n_in %d not a multiple of 256", n_in);
+    VMX_REQUIRE(n_out > 0, "iq_matmul: n_out %d", n_out);
+    VMX_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)aq & 15) == 0 && ((uintptr_t)ad & 7) == 0, "iq_mmvq(packed): misaligned pointer");
+    const VmxMmvqSeg seg = {packed, ggml_type, n_out, 0};
+    return pk_launch(&seg, 1, aq, ad, y, n_in, nullptr, vmx_stream(stream));
+}
+
+extern "C" int vmx_iq_subdots_packed_i32(int ggml_type, const void *packed, const int8_t *aq, int32_t *out, int n_out, int n_in, void *stream) {
+    VMX_REQUIRE(packed && aq && out, "iq_subdots(packed): null pointer");
+    VMX_REQUIRE(pk_supported(ggml_type), "iq_subdots(packed): ggml type %d has no packed form", ggml_type);
+    VMX_REQUIRE(n_in > 0 && n_in % 256 == 0 && n_out > 0, "iq_subdots(packed): bad shape");
+    const VmxMmvqSeg seg = {packed, ggml_type, n_out, 0};
+    // the activation scales are not used for the integer sub-dots: any readable f32 array of n_in / 32 entries will do
+    return pk_launch(&seg, 1, aq, reinterpret_cast<const float *>(aq), nullptr, n_in, out, vmx_stream(stream));
+}

@@ -68,6 +68,10 @@ struct VmxMmvqSeg {
 int vmx_iq_mmvq_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int m, int ldy,
                       hipStream_t st);
 
+// iq_packed.hip: the same MMVQ over the load-time repacked form (vmx_iq_pack), one activation row; segs[i].w = packed weights
+bool vmx_iq_packed_supported(int ggml_type);
+int vmx_iq_mmvq_packed_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, hipStream_t st);
+
 // kquant_kernels.hip
 int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_t *ids, uint16_t *out, int tokens, int dim, int vocab,
                                   float scale, hipStream_t st);

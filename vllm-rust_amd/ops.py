@@ -11,7 +11,7 @@ import torch
 from ._lib import check, lib
 
 __all__ = [
-    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots",
+    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_subdots_packed",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant",
@@ -56,6 +56,27 @@ def iq_mmvq(ggml_type: int, w: torch.Tensor, aq: torch.Tensor, ad: torch.Tensor,
     y = out if out is not None else torch.empty((m, n_out), dtype=torch.float32, device=w.device)
     check(lib.vmx_iq_mmvq_f32(ggml_type, _ptr(w), _ptr(aq), _ptr(ad), _ptr(y), n_out, n_in, m, _stream()))
     return y
+
+
+def iq_pack(ggml_type: int, raw: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
+    """Load-time repack of raw I-quant blocks [n_out, n_in] (uint8 CUDA tensor) into the wave-ordered stream of iq_mmvq_packed."""
+    need = lib.vmx_iq_packed_bytes(ggml_type, n_out, n_in)
+    packed = torch.empty(max(need, 16), dtype=torch.uint8, device=raw.device)
+    check(lib.vmx_iq_pack(ggml_type, _ptr(raw), _ptr(packed), n_out, n_in, _stream()))
+    return packed
+
+
+def iq_mmvq_packed(ggml_type: int, packed: torch.Tensor, aq: torch.Tensor, ad: torch.Tensor, n_out: int, n_in: int, out=None):
+    """One activation row (aq int8 [1, n_in], ad f32 [1, n_in / 32]) against packed weights -> f32 [1, n_out]."""
+    y = out if out is not None else torch.empty((1, n_out), dtype=torch.float32, device=packed.device)
+    check(lib.vmx_iq_mmvq_packed_f32(ggml_type, _ptr(packed), _ptr(aq), _ptr(ad), _ptr(y), n_out, n_in, _stream()))
+    return y
+
+
+def iq_subdots_packed(ggml_type: int, packed: torch.Tensor, aq: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
+    out = torch.zeros((n_out, 1, n_in // 32), dtype=torch.int32, device=packed.device)
+    check(lib.vmx_iq_subdots_packed_i32(ggml_type, _ptr(packed), _ptr(aq), _ptr(out), n_out, n_in, _stream()))
+    return out
 
 
 def iq_matmul(ggml_type: int, w: torch.Tensor, x: torch.Tensor, n_out: int, n_in: int, workspace=None):
