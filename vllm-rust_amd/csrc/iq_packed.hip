@@ -209,36 +209,55 @@ template <int K> __device__ __forceinline__ uint32_t slot_addr(uint32_t w, uint3
     return __builtin_amdgcn_perm(w, off, 0x0c0c0000u | ((4u + K) << 8));
 }
 
+// (a & mask) | c in one instruction (the compiler splits the C expression into v_and + v_add)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(c));
+    return r;
+}
+
+// Table reads by absolute LDS address: the tables are the kernel's only LDS object and start at address 0, so a gather
+// address needs no base add (through the array's symbol every address costs one more v_add).
+typedef __attribute__((address_space(3))) const uint32_t pk_lds_u32;
+typedef uint32_t pk_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const pk_u32x2 pk_lds_u64;
+__device__ __forceinline__ uint32_t lds32(uint32_t addr) { return *reinterpret_cast<pk_lds_u32 *>(addr); }
+__device__ __forceinline__ uint2 lds64(uint32_t addr) {
+    const pk_u32x2 v = *reinterpret_cast<pk_lds_u64 *>(addr);
+    return make_uint2(v.x, v.y);
+}
+
 // Integer sub-dot (already scaled: what vec_dot_iq*_q8_1 multiplies by d * a_d) of sub-block j (0 / 1) of row ri (0 / 1) of a
-// part.  u / nu = the 8 activation words of that sub-block and their bytewise negation; smem = tables; lane_g / lane_s = the
-// lane's byte offsets of its grid copy and its sign copy inside a slot.
+// part, returned as a float (exact: |value| < 2^24).  u / nu = the 8 activation words of that sub-block and their bytewise
+// negation; lane_g / lane_s = the lane's byte offsets of its grid copy and its sign copy inside a slot.
 template <int T>
-__device__ __forceinline__ int pk_subdot(const PkPart<T> &raw, int ri, int j, const int u[8], const int nu[8], const unsigned char *smem,
-                                         uint32_t lane_g, uint32_t lane_s) {
+__device__ __forceinline__ float pk_subdot(const PkPart<T> &raw, int ri, int j, const int u[8], const int nu[8], uint32_t lane_g,
+                                           uint32_t lane_s) {
     auto signed_u = [&](int k, uint32_t sel) { return (int)__builtin_amdgcn_perm((uint32_t)nu[k], (uint32_t)u[k], sel); };
     if constexpr (T == 18) {
         const uint32_t q0 = j ? raw.A[ri].z : raw.A[ri].x, q1 = j ? raw.A[ri].w : raw.A[ri].y;
         const uint32_t aux = w4(raw.B, ri * 2 + j);
         const uint32_t ga[8] = {slot_addr<0>(q0, lane_g), slot_addr<1>(q0, lane_g), slot_addr<2>(q0, lane_g), slot_addr<3>(q0, lane_g),
                                 slot_addr<0>(q1, lane_g), slot_addr<1>(q1, lane_g), slot_addr<2>(q1, lane_g), slot_addr<3>(q1, lane_g)};
-        const uint32_t sa[4] = {((aux << 8) & 0x7F00u) | lane_s, ((aux << 1) & 0x7F00u) | lane_s, ((aux >> 6) & 0x7F00u) | lane_s,
-                                ((aux >> 13) & 0x7F00u) | lane_s};
+        const uint32_t sa[4] = {and_or(aux << 8, 0x7F00u, lane_s), and_or(aux << 1, 0x7F00u, lane_s), and_or(aux >> 6, 0x7F00u, lane_s),
+                                and_or(aux >> 13, 0x7F00u, lane_s)};
         int a = 0;
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            const uint32_t g0 = *reinterpret_cast<const uint32_t *>(smem + ga[2 * l]);
-            const uint32_t g1 = *reinterpret_cast<const uint32_t *>(smem + ga[2 * l + 1]);
-            const uint2 mk = *reinterpret_cast<const uint2 *>(smem + sa[l]);
+            const uint32_t g0 = lds32(ga[2 * l]), g1 = lds32(ga[2 * l + 1]);
+            const uint2 mk = lds64(sa[l]);
             a = dot4((int)g0, signed_u(2 * l, mk.x), a);
             a = dot4((int)g1, signed_u(2 * l + 1, mk.y), a);
         }
-        const int ls = (int)(aux >> 28);
-        return div2(mul24(ls, a) + div2(a));
+        // (ls * sumi + sumi / 2) / 2 with C truncating divisions (iq_dequant.cu vec_dot_iq3_xxs_q8_1) == trunc((2 ls + 1) sumi / 4):
+        // 2 ls + 1 is odd, so y = (2 ls + 1) sumi has the parity of sumi and dropping that parity bit towards zero before the
+        // division by 4 cannot change the truncated quotient.  |y| < 2^23: exact in the 24-bit multiply and in f32.
+        const int y = mul24(a, (int)((aux >> 27) | 1u));
+        return truncf(0.25f * (float)y);
     } else if constexpr (T == 21) {
         const uint32_t q0 = j ? raw.A[ri].z : raw.A[ri].x, q1 = j ? raw.A[ri].w : raw.A[ri].y;
         const uint32_t sgn = w4(raw.B, ri * 2 + j);
         const uint32_t qh = raw.qh2 >> (16 * ri + 8 * j);   // bit k = ninth index bit of lookup k (higher bits are masked off below)
-        const uint32_t scb = (raw.sc2 >> (8 * ri)) & 0xFFu;
         const uint32_t gb[8] = {slot_addr<0>(q0, lane_g), slot_addr<1>(q0, lane_g), slot_addr<2>(q0, lane_g), slot_addr<3>(q0, lane_g),
                                 slot_addr<0>(q1, lane_g), slot_addr<1>(q1, lane_g), slot_addr<2>(q1, lane_g), slot_addr<3>(q1, lane_g)};
         const uint32_t sa[4] = {slot_addr<0>(sgn, lane_s), slot_addr<1>(sgn, lane_s), slot_addr<2>(sgn, lane_s), slot_addr<3>(sgn, lane_s)};
@@ -246,32 +265,30 @@ __device__ __forceinline__ int pk_subdot(const PkPart<T> &raw, int ri, int j, co
 #pragma unroll
         for (int l = 0; l < 4; l++) {
             // iq3s index = byte | bit << 8: lookups 2l, 2l + 1 take qh bits 2l, 2l + 1 (iq/mod.rs:223-271) -> address bit 16
-            const uint32_t a0 = gb[2 * l] | ((qh << (16 - 2 * l)) & 0x10000u);
-            const uint32_t a1 = gb[2 * l + 1] | ((qh << (15 - 2 * l)) & 0x10000u);
-            const uint32_t g0 = *reinterpret_cast<const uint32_t *>(smem + a0);
-            const uint32_t g1 = *reinterpret_cast<const uint32_t *>(smem + a1);
-            const uint2 mk = *reinterpret_cast<const uint2 *>(smem + sa[l]);
+            const uint32_t a0 = and_or(qh << (16 - 2 * l), 0x10000u, gb[2 * l]);
+            const uint32_t a1 = and_or(qh << (15 - 2 * l), 0x10000u, gb[2 * l + 1]);
+            const uint32_t g0 = lds32(a0), g1 = lds32(a1);
+            const uint2 mk = lds64(sa[l]);
             a = dot4((int)g0, signed_u(2 * l, mk.x), a);
             a = dot4((int)g1, signed_u(2 * l + 1, mk.y), a);
         }
-        const int nib = (int)((scb >> (4 * j)) & 0xFu);
-        return mul24(a, 1 + 2 * nib);
+        const uint32_t nib = (raw.sc2 >> (8 * ri + 4 * j)) & 0xFu;
+        return (float)mul24(a, (int)(2u * nib + 1u));
     } else {
         const uint32_t qs = j ? raw.A[ri].y : raw.A[ri].x, sgn = j ? raw.A[ri].w : raw.A[ri].z;
         const uint32_t qw = ri ? raw.Q.y : raw.Q.x;
         const uint32_t qh = (qw >> (8 * j)) & 0xFFu, sc = (qw >> (16 + 8 * j)) & 0xFFu;
-        const unsigned char *sg = smem + 65536;
         int a[2] = {0, 0};
 #pragma unroll
         for (int l = 0; l < 4; l++) {
             const uint32_t idx = ((qs >> (8 * l)) & 0xFFu) | ((qh << (8 - 2 * l)) & 0x300u);
-            const uint2 g = *reinterpret_cast<const uint2 *>(smem + (idx << 6) + lane_g);
-            const uint2 mk = *reinterpret_cast<const uint2 *>(sg + (((sgn >> (8 * l)) & 0xFFu) << 7) + lane_s);
+            const uint2 g = lds64((idx << 6) + lane_g);
+            const uint2 mk = lds64(65536u + (((sgn >> (8 * l)) & 0xFFu) << 7) + lane_s);
             a[l >> 1] = dot4((int)g.x, signed_u(2 * l, mk.x), a[l >> 1]);
             a[l >> 1] = dot4((int)g.y, signed_u(2 * l + 1, mk.y), a[l >> 1]);
         }
         const int ls0 = (int)(sc & 0xFu), ls1 = (int)(sc >> 4);
-        return div4(mul24(a[0], ls0) + mul24(a[1], ls1) + div2(a[0] + a[1]));
+        return (float)div4(mul24(a[0], ls0) + mul24(a[1], ls1) + div2(a[0] + a[1]));
     }
 }
 
@@ -340,7 +357,8 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
     const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)g0 * 32);
     const int4 u0 = up[0], u1 = up[1], u2 = up[2], u3 = up[3];
     const float2 dav = *reinterpret_cast<const float2 *>(ad + g0);
-    const float da[2] = {live ? dav.x : 0.f, live ? dav.y : 0.f};
+    float da[2] = {live ? dav.x : 0.f, live ? dav.y : 0.f};
+    asm volatile("" : "+v"(da[0]), "+v"(da[1]));   // computed once (otherwise the select is redone per row)
     // weights: every load of the item, in the order the decode wants them back
     const uint8_t *U = sg.w + (int64_t)group * PK_ROWS * nsb * TS + (int64_t)PK_ROWS * TS * sb0;
     PkPart<T> raw[PPW];
@@ -392,11 +410,11 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
             float a = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int sub = pk_subdot<T>(raw[p], ri, j, ua[j], nua[j], smem, lane_g, lane_s);
-                a += (wd * da[j]) * (float)sub;
+                const float sub = pk_subdot<T>(raw[p], ri, j, ua[j], nua[j], lane_g, lane_s);
+                a += (wd * da[j]) * sub;
                 if constexpr (DBG) {
                     const int row = group * PK_ROWS + chunk * NR + 2 * p + ri;
-                    if (live && row < sg.n_out) dbg[(int64_t)row * (n_in >> 5) + g0 + j] = sub;
+                    if (live && row < sg.n_out) dbg[(int64_t)row * (n_in >> 5) + g0 + j] = (int)sub;
                 }
             }
             acc[2 * p + ri] = a;
