@@ -100,6 +100,11 @@ int vmx_iq_mmvq_packed_f32(int ggml_type, const void *packed, const int8_t *aq, 
 /* Parity aid: the integer sub-dots of the packed kernel, out[o * (n_in/32) + g] (the layout of vmx_iq_subdots_i32 at m = 1). */
 int vmx_iq_subdots_packed_i32(int ggml_type, const void *packed, const int8_t *aq, int32_t *out, int n_out, int n_in, void *stream);
 
+/* Measurement aid: while buf != NULL, vmx_iq_mmvq_packed_f32 launches that work on whole 8-row units record per wave 8
+ * shader-clock stamps (u64: entry, loads issued, tables built, after each of the four row pairs, end) at
+ * buf[(workgroup * 16 + wave) * 10 ..]; buf must hold 160 u64 per workgroup. */
+int vmx_debug_iq_packed_stamps(void *buf);
+
 /* Replaces gather_dequant_q6k_f32 (crates/core/kernels/gather_dequant.cu:31-83):
  * out[i, :] = dequant(row ids[i]) of a Q6_K table [num_embeddings, dim];
  * out-of-range ids leave zeros. */

@@ -13,7 +13,10 @@ from pathlib import Path
 import torch  # noqa: F401  (plumbing: device memory, streams)
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libvmx.so"
+import os
+
+# VMX_LIB_VARIANT=name loads lib/libvmx_name.so instead: A/B builds of one kernel for measurement (development aid)
+LIB_PATH = _PKG / "lib" / ("libvmx_%s.so" % os.environ["VMX_LIB_VARIANT"] if os.environ.get("VMX_LIB_VARIANT") else "libvmx.so")
 
 if not LIB_PATH.exists():
     raise ImportError(
@@ -39,6 +42,7 @@ _SIGS = {
     "vmx_iq_packed_bytes": (_sz, [_i, _i, _i]),
     "vmx_iq_pack": (_i, [_i, _p, _p, _i, _i, _p]),
     "vmx_iq_mmvq_packed_f32": (_i, [_i, _p, _p, _p, _p, _i, _i, _p]),
+    "vmx_debug_iq_packed_stamps": (_i, [_p]),
     "vmx_iq_subdots_packed_i32": (_i, [_i, _p, _p, _p, _i, _i, _p]),
     "vmx_gather_dequant_q6k_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "vmx_ggml_type_size": (_i, [_i]),

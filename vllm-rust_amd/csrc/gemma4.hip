@@ -268,6 +268,7 @@ struct Buf {
 struct IqLin {
     int ggml_type = 0, in_features = 0, out_features = 0;
     Buf raw;
+    Buf packed;   // load-time repack for the one-row decode kernel (IQ3_XXS, IQ3_S, IQ2_S); the raw blocks stay for m > 1
     bool loaded = false;
     double alg_bytes(int m) const {
         return (double)out_features * (in_features / 256) * vmx_iq_type_size(ggml_type) + (double)m * in_features * (1.0 + 4.0 / 32.0) +
@@ -303,7 +304,25 @@ namespace {
 int8_t *aq_of(vmx_gemma4 *m) { return (int8_t *)m->q8.p; }
 float *ad_of(vmx_gemma4 *m, int tokens, int k) { return (float *)((char *)m->q8.p + (((size_t)tokens * k + 255) & ~(size_t)255)); }
 
+// Projections that share the q8_1 activations (1..3 of them: q|k|v, gate|up, or a single one), outputs at y + off[i]
+int mmvq_group(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, float *y, int ldy, int tokens, hipStream_t st) {
+    VmxMmvqSeg raw[3], pk[3];
+    const int k = lins[0]->in_features;
+    for (int i = 0; i < n; i++) {
+        raw[i] = VmxMmvqSeg{lins[i]->raw.p, lins[i]->ggml_type, lins[i]->out_features, offs[i]};
+        pk[i] = VmxMmvqSeg{lins[i]->packed.p, lins[i]->ggml_type, lins[i]->out_features, offs[i]};
+    }
+    if (vmx_iq_packed_preferred(pk, n, k, tokens)) return vmx_iq_mmvq_packed_multi(pk, n, aq_of(m), ad_of(m, tokens, k), y, k, st);
+    return vmx_iq_mmvq_multi(raw, n, aq_of(m), ad_of(m, tokens, k), y, k, tokens, ldy, st);
+}
+
 int mmvq(vmx_gemma4 *m, const IqLin &l, float *y, int ldy, int tokens, hipStream_t st) {
+    const IqLin *one[1] = {&l};
+    const int off[1] = {0};
+    if (l.packed.p) {
+        const VmxMmvqSeg pk = {l.packed.p, l.ggml_type, l.out_features, 0};
+        if (vmx_iq_packed_preferred(&pk, 1, l.in_features, tokens)) return mmvq_group(m, one, off, 1, y, ldy, tokens, st);
+    }
     return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq_of(m), ad_of(m, tokens, l.in_features), y, l.out_features, l.in_features, tokens, ldy, st);
 }
 
@@ -431,7 +450,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
 extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     if (!m) return;
     for (G4Layer &L : m->layers) {
-        for (IqLin &l : L.lin) l.raw.release();
+        for (IqLin &l : L.lin) { l.raw.release(); l.packed.release(); }
         for (Buf *b : {&L.input_ln, &L.post_attn_ln, &L.pre_ffn_ln, &L.post_ffn_ln, &L.q_norm, &L.k_norm, &L.scalar, &L.k_cache, &L.v_cache,
                        &L.kv_scales})
             b->release();
@@ -482,6 +501,11 @@ extern "C" int vmx_gemma4_load_iq_linear(vmx_gemma4 *m, int layer, int slot, int
     if (int rc = l.raw.alloc(need)) return rc;
     VMX_CHECK_HIP(hipMemcpyAsync(l.raw.p, blocks, need, hipMemcpyDefault, vmx_stream(stream)));
     l.ggml_type = ggml_type;
+    l.packed.release();
+    if (const size_t pb = vmx_iq_packed_bytes(ggml_type, l.out_features, l.in_features)) {   // types with a packed form
+        if (int rc = l.packed.alloc(pb)) return rc;
+        if (int rc = vmx_iq_pack(ggml_type, l.raw.p, l.packed.p, l.out_features, l.in_features, stream)) return rc;
+    }
     l.loaded = true;
     return VMX_OK;
 }
@@ -518,10 +542,9 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
         launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H, aq_of(m),
                     ad_of(m, B, H));
         {
-            const VmxMmvqSeg segs[3] = {{L.lin[VMX_L_Q].raw.p, L.lin[VMX_L_Q].ggml_type, NQ, 0},
-                                        {L.lin[VMX_L_K].raw.p, L.lin[VMX_L_K].ggml_type, NKV, NQ},
-                                        {L.lin[VMX_L_V].raw.p, L.lin[VMX_L_V].ggml_type, NKV, NQ + NKV}};
-            if (int rc = vmx_iq_mmvq_multi(segs, L.k_eq_v ? 2 : 3, aq_of(m), ad_of(m, B, H), proj, H, B, ntot, st)) return rc;
+            const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
+            const int offs[3] = {0, NQ, NQ + NKV};
+            if (int rc = mmvq_group(m, qkv, offs, L.k_eq_v ? 2 : 3, proj, ntot, B, st)) return rc;
         }
         const float *ks = (const float *)L.kv_scales.p;
         // short contexts: per-head norms + RoPE + KV write + attention + merge in one launch (not for K == V layers)
@@ -549,9 +572,9 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
         launch_norm(st, B, h, x, out, (const uint16_t *)L.post_attn_ln.p, nullptr, (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, H,
                     aq_of(m), ad_of(m, B, H));
         {
-            const VmxMmvqSeg segs[2] = {{L.lin[VMX_L_GATE].raw.p, L.lin[VMX_L_GATE].ggml_type, I, 0},
-                                        {L.lin[VMX_L_UP].raw.p, L.lin[VMX_L_UP].ggml_type, I, I}};
-            if (int rc = vmx_iq_mmvq_multi(segs, 2, aq_of(m), ad_of(m, B, H), proj, H, B, 2 * I, st)) return rc;
+            const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
+            const int offs[2] = {0, I};
+            if (int rc = mmvq_group(m, gu, offs, 2, proj, 2 * I, B, st)) return rc;
         }
         int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
         hipLaunchKernelGGL(g4_geglu_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, proj, B, act, I, aq_of(m),
@@ -623,14 +646,13 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
     const int I = c.intermediate_size, H = c.hidden_size;
     for (const G4Layer &L : m->layers) {
         const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd, ntot = NQ + (L.k_eq_v ? 1 : 2) * NKV;
-        const VmxMmvqSeg qkv[3] = {{L.lin[VMX_L_Q].raw.p, L.lin[VMX_L_Q].ggml_type, NQ, 0},
-                                   {L.lin[VMX_L_K].raw.p, L.lin[VMX_L_K].ggml_type, NKV, NQ},
-                                   {L.lin[VMX_L_V].raw.p, L.lin[VMX_L_V].ggml_type, NKV, NQ + NKV}};
-        if (int rc = vmx_iq_mmvq_multi(qkv, L.k_eq_v ? 2 : 3, aq_of(m), ad_of(m, batch, H), proj, H, batch, ntot, st)) return rc;
+        const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
+        const int qoffs[3] = {0, NQ, NQ + NKV};
+        if (int rc = mmvq_group(m, qkv, qoffs, L.k_eq_v ? 2 : 3, proj, ntot, batch, st)) return rc;
         if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
-        const VmxMmvqSeg gu[2] = {{L.lin[VMX_L_GATE].raw.p, L.lin[VMX_L_GATE].ggml_type, I, 0},
-                                  {L.lin[VMX_L_UP].raw.p, L.lin[VMX_L_UP].ggml_type, I, I}};
-        if (int rc = vmx_iq_mmvq_multi(gu, 2, aq_of(m), ad_of(m, batch, H), proj, H, batch, 2 * I, st)) return rc;
+        const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
+        const int goffs[2] = {0, I};
+        if (int rc = mmvq_group(m, gu, goffs, 2, proj, 2 * I, batch, st)) return rc;
         if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
     }
     return VMX_OK;

@@ -31,6 +31,10 @@
 #include "iq_common.h"
 #include <stdlib.h>
 
+#ifndef VMX_IQ_AHEAD
+#define VMX_IQ_AHEAD 3
+#endif
+
 namespace {
 
 constexpr int PK_ROWS = 8;
@@ -96,77 +100,64 @@ __global__ __launch_bounds__(256) void iq_pack_kernel(const uint8_t *__restrict_
 }
 
 // ------------------------------------------------------------------ tables
-// The type's codebook words a thread will replicate, fetched BEFORE the weight loads are issued (vmcnt retires in order: a
-// load behind the weight stream would only return with it).  Thread t owns entries t, t + nthreads, ... (clamped: surplus
-// iterations re-read the last entry and write nothing).
-template <int T> struct PkTableRegs {
-    static constexpr int N = T == 18 ? 256 : T == 21 ? 512 : 1024;   // grid entries
-    static constexpr int PER = N / 64;                                // entries per thread in a one-wave workgroup
-    uint32_t lo[PER], hi[T == 22 ? PER : 1];
-};
-
-template <int T> __device__ __forceinline__ PkTableRegs<T> pk_tables_fetch(int tid, int nthreads) {
-    PkTableRegs<T> t;
-    constexpr int N = PkTableRegs<T>::N;
-#pragma unroll
-    for (int k = 0; k < PkTableRegs<T>::PER; k++) {
-        const int e = min(tid + k * nthreads, N - 1);
-        if constexpr (T == 18) t.lo[k] = iq3xxs_grid[e];
-        else if constexpr (T == 21) t.lo[k] = iq3s_grid[e];
-        else {
-            const uint2 v = reinterpret_cast<const uint2 *>(iq2s_grid)[e];
-            t.lo[k] = v.x;
-            t.hi[k] = v.y;
-        }
-    }
-    return t;
-}
-
 // Sign entry of sign byte s8 as two v_perm_b32 selectors: byte j = j (keep u_j) or 4 + j (take -u_j) for weights j and 4 + j.
 __device__ __forceinline__ uint2 sign_sel_entry(uint32_t s8) {
     const uint32_t l0 = __umul24(s8 & 0xFu, 0x00204081u) & 0x01010101u, l1 = __umul24(s8 >> 4, 0x00204081u) & 0x01010101u;
     return make_uint2(0x03020100u | (l0 << 2), 0x03020100u | (l1 << 2));
 }
 
-// Write the tables.  IQ3_XXS / IQ3_S: 256-byte slots, slot e = grid entry e x 32 copies (128 B) | sign entry e x 16 copies
-// (128 B; IQ3_XXS: entry of the 7-bit index e & 127 with its parity bit, IQ3_S: of sign byte e, slots 0..255 only).
-// IQ2_S: grid (8-byte entries) x 8 copies = 64 B at e * 64; sign entries x 16 copies at 65536 + e * 128.
-template <int T> __device__ __forceinline__ void pk_tables_commit(const PkTableRegs<T> &t, unsigned char *smem, int tid, int nthreads) {
-    constexpr int N = PkTableRegs<T>::N;
-#pragma unroll
-    for (int k = 0; k < PkTableRegs<T>::PER; k++) {
-        const int e = tid + k * nthreads;
-        if (e < N) {
-            if constexpr (T == 22) {
-                uint4 *d = reinterpret_cast<uint4 *>(smem + e * 64);
-                const uint4 v = make_uint4(t.lo[k], t.hi[k], t.lo[k], t.hi[k]);
-#pragma unroll
-                for (int c = 0; c < 4; c++) d[c] = v;
-            } else {
-                uint4 *d = reinterpret_cast<uint4 *>(smem + e * 256);
-                const uint4 v = make_uint4(t.lo[k], t.lo[k], t.lo[k], t.lo[k]);
-#pragma unroll
-                for (int c = 0; c < 8; c++) d[c] = v;
-                if (T == 18 || e < 256) {
-                    uint32_t s8 = (uint32_t)e & (T == 18 ? 127u : 255u);
-                    if constexpr (T == 18) s8 |= (__popc(s8) & 1u) << 7;
-                    const uint2 m = sign_sel_entry(s8);
-                    const uint4 sv = make_uint4(m.x, m.y, m.x, m.y);
-#pragma unroll
-                    for (int c = 8; c < 16; c++) d[c] = sv;
-                }
-            }
-        }
-    }
+// The LDS image of each type's tables, byte for byte, kept in device memory (built once per GPU by vmx_init): a workgroup
+// fills its LDS with plain LDS-DMA copies of it (no registers, no vector-ALU work, served from L2 after the first workgroup).
+//   IQ3_XXS / IQ3_S: 256-byte slots, slot e = grid entry e x 32 copies (128 B) | 16 copies of a sign entry (128 B; IQ3_XXS: the
+//   entry of the 7-bit index e & 127 with its parity bit, IQ3_S: of sign byte e & 255).  Every sign entry thus exists in two
+//   slots, N / 2 apart: lanes 0..15 of a half-wave read the first, lanes 16..31 the second.
+//   IQ2_S: grid (8-byte entries) x 8 copies = 64 B at e * 64; sign entries x 16 copies at 65536 + e * 128.
+static __device__ __align__(16) unsigned char g_pk_tab18[65536];
+static __device__ __align__(16) unsigned char g_pk_tab21[131072];
+static __device__ __align__(16) unsigned char g_pk_tab22[98304];
+
+template <int T> __device__ __forceinline__ unsigned char *pk_table_image() {
+    if constexpr (T == 18) return g_pk_tab18;
+    else if constexpr (T == 21) return g_pk_tab21;
+    else return g_pk_tab22;
+}
+template <int T> struct PkTab { static constexpr int BYTES = T == 18 ? 65536 : T == 21 ? 131072 : 98304; };
+
+// one thread per 16-byte chunk of the image
+template <int T> __global__ __launch_bounds__(256) void pk_build_tables_kernel() {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= PkTab<T>::BYTES / 16) return;
+    uint4 v;
     if constexpr (T == 22) {
-        for (int e = tid; e < 256; e += nthreads) {
-            const uint2 m = sign_sel_entry((uint32_t)e);
-            uint4 *d = reinterpret_cast<uint4 *>(smem + 65536 + e * 128);
-            const uint4 v = make_uint4(m.x, m.y, m.x, m.y);
-#pragma unroll
-            for (int c = 0; c < 8; c++) d[c] = v;
+        if (c < 1024 * 4) {
+            const uint2 g = reinterpret_cast<const uint2 *>(iq2s_grid)[c >> 2];
+            v = make_uint4(g.x, g.y, g.x, g.y);
+        } else {
+            const uint2 m = sign_sel_entry((uint32_t)((c - 4096) >> 3));
+            v = make_uint4(m.x, m.y, m.x, m.y);
+        }
+    } else {
+        const int e = c >> 4;
+        if ((c & 15) < 8) {
+            const uint32_t g = T == 18 ? iq3xxs_grid[e] : iq3s_grid[e];
+            v = make_uint4(g, g, g, g);
+        } else {
+            uint32_t s8 = (uint32_t)e & (T == 18 ? 127u : 255u);
+            if constexpr (T == 18) s8 |= (__popc(s8) & 1u) << 7;
+            const uint2 m = sign_sel_entry(s8);
+            v = make_uint4(m.x, m.y, m.x, m.y);
         }
     }
+    reinterpret_cast<uint4 *>(pk_table_image<T>())[c] = v;
+}
+
+// Request the workgroup's copy of the image: wave w takes the 1 KiB pieces w, w + W, ...; lane l of a piece brings 16 bytes.
+// Asynchronous (counted in vmcnt like any load); issued before the weight requests so that it completes first.
+template <int T> __device__ __forceinline__ void pk_tables_request(unsigned char *smem, int wave, int W, int lane) {
+    const unsigned char *img = pk_table_image<T>();
+    for (int c0 = wave * 64; c0 < PkTab<T>::BYTES / 16; c0 += W * 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (c0 + lane) * 16),
+                                         (__attribute__((address_space(3))) void *)(smem + c0 * 16), 16, 0, 0);
 }
 
 // ------------------------------------------------------------------ part registers
@@ -191,10 +182,14 @@ template <int T> __device__ __forceinline__ void pk_load_small(PkPart<T> &r, con
     }
 }
 
-template <int T> __device__ __forceinline__ void pk_load_wide(PkPart<T> &r, const uint8_t *__restrict__ U, int L, int lc, int rp) {
-    if constexpr (T != 22) r.B = *reinterpret_cast<const uint4 *>(U + 128 * L + rp * 16 * L + 16 * lc);
-    r.A[0] = *reinterpret_cast<const uint4 *>(U + (2 * rp) * 16 * L + 16 * lc);
-    r.A[1] = *reinterpret_cast<const uint4 *>(U + (2 * rp + 1) * 16 * L + 16 * lc);
+// Row r (0 .. 2 PPW - 1) of an item: its 16-byte code entry, and with an even row the sign / scale words of its pair
+template <int T> __device__ __forceinline__ void pk_load_row(PkPart<T> *raw, const uint8_t *__restrict__ U, int L, int lc, int rp0, int r) {
+    const int rp = rp0 + (r >> 1);
+    PkPart<T> &d = raw[r >> 1];
+    if constexpr (T != 22) {
+        if ((r & 1) == 0) d.B = *reinterpret_cast<const uint4 *>(U + 128 * L + rp * 16 * L + 16 * lc);
+    }
+    d.A[r & 1] = *reinterpret_cast<const uint4 *>(U + (2 * rp + (r & 1)) * 16 * L + 16 * lc);
 }
 
 __device__ __forceinline__ uint32_t w4(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
@@ -204,9 +199,9 @@ __device__ __forceinline__ int div2(int x) { return (x + (int)((uint32_t)x >> 31
 __device__ __forceinline__ int div4(int x) { return (x + (int)(((uint32_t)(x >> 31)) >> 30)) >> 2; }
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }   // |a|, |b| < 2^23 here: full-rate multiply
 
-// Address of the table slot of index byte k of `w`: (byte << 8) | off, off < 256 held in byte 0 of `off`
+// Address of the table slot of index byte k of `w`: (byte << 8) | off, where off has bits only in its bytes 0 and 2
 template <int K> __device__ __forceinline__ uint32_t slot_addr(uint32_t w, uint32_t off) {
-    return __builtin_amdgcn_perm(w, off, 0x0c0c0000u | ((4u + K) << 8));
+    return __builtin_amdgcn_perm(w, off, 0x0c020000u | ((4u + K) << 8));
 }
 
 // (a & mask) | c in one instruction (the compiler splits the C expression into v_and + v_add)
@@ -337,11 +332,21 @@ struct PkArgs {
 // of a row set sit in one workgroup and are combined through LDS in slice order).
 template <int T, int PPW, bool DBG, int ABL = 0>
 __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const PkSeg &sg, int wg, const int8_t *__restrict__ aq,
-                                        const float *__restrict__ ad, int n_in, int S, int32_t *__restrict__ dbg) {
+                                        const float *__restrict__ ad, int n_in, int S, int32_t *__restrict__ dbg, int issue_barrier) {
     constexpr int TS = Pk<T>::TS, CPU_ = 4 / PPW, NR = 2 * PPW;   // chunks per unit, rows per item
+    constexpr int AHEAD = VMX_IQ_AHEAD;                           // rows requested ahead of the one being decoded
     const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = nthreads >> 6;
-    const PkTableRegs<T> treg = pk_tables_fetch<T>(tid, nthreads);
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ABL == 3: shader-clock stamps of this wave
+    auto stamp = [&](int i, float dep) {
+        if constexpr (ABL == 3) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[i]) : "v"(dep) : "memory");
+    };
+    stamp(0, 0.f);
+    unsigned long long rt0 = 0;
+    if constexpr (ABL == 3) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+#ifndef VMX_IQ_NOTAB
+    pk_tables_request<T>(smem, wave, W, lane);
+#endif
     const int nsb = n_in >> 8;
     const int groups = (sg.n_out + PK_ROWS - 1) / PK_ROWS, items = groups * CPU_ * S;
     const int item = wg * W + wave;
@@ -354,11 +359,13 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
     const bool live = valid && lane < L;
     // activations of the lane's two sub-blocks
     const int g0 = sb0 * 8 + 2 * lc;
+#ifdef VMX_IQ_NOACT
+    const int4 *up = reinterpret_cast<const int4 *>(aq);   // measurement only: every wave reads the same 64 bytes
+#else
     const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)g0 * 32);
+#endif
     const int4 u0 = up[0], u1 = up[1], u2 = up[2], u3 = up[3];
     const float2 dav = *reinterpret_cast<const float2 *>(ad + g0);
-    float da[2] = {live ? dav.x : 0.f, live ? dav.y : 0.f};
-    asm volatile("" : "+v"(da[0]), "+v"(da[1]));   // computed once (otherwise the select is redone per row)
     // weights: every load of the item, in the order the decode wants them back
     const uint8_t *U = sg.w + (int64_t)group * PK_ROWS * nsb * TS + (int64_t)PK_ROWS * TS * sb0;
     PkPart<T> raw[PPW];
@@ -369,14 +376,23 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
             for (int k = 0; k < (int)(sizeof(PkPart<T>) / 4); k++) wr[k] = ((uint32_t)(lane * 2654435761u) ^ (uint32_t)(u0.x + k + 16 * p)) & 0x7F7F7F7Fu;
         }
     } else {
+        // A compute unit's memory pipeline holds only so many requests: once it is full, issuing a load BLOCKS the wave until
+        // earlier data has arrived (measured: a wave that requests its whole unit up front spends as long issuing as the
+        // stream takes, and decodes only afterwards).  So only the small fields and the first AHEAD rows are requested here, and
+        // row r + AHEAD right before row r is decoded.
 #pragma unroll
-    for (int p = 0; p < PPW; p++) pk_load_small<T>(raw[p], U, L, lc, chunk * PPW + p);
+        for (int p = 0; p < PPW; p++) pk_load_small<T>(raw[p], U, L, lc, chunk * PPW + p);
 #pragma unroll
-    for (int p = 0; p < PPW; p++) pk_load_wide<T>(raw[p], U, L, lc, chunk * PPW + p);
+        for (int r = 0; r < (NR < AHEAD ? NR : AHEAD); r++) pk_load_row<T>(raw, U, L, lc, chunk * PPW, r);
     }
-    pk_tables_commit<T>(treg, smem, tid, nthreads);
-    __syncthreads();
+    stamp(1, 0.f);
+    // tables of every wave of the workgroup (and this wave's first row pair) have landed
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    stamp(5, 0.f);
+    float da[2] = {live ? dav.x : 0.f, live ? dav.y : 0.f};
     if constexpr (ABL == 1) {   // measurement: the weight stream alone
+#pragma unroll
+        for (int r = AHEAD; r < NR; r++) pk_load_row<T>(raw, U, L, lc, chunk * PPW, r);
         uint32_t x = 0;
 #pragma unroll
         for (int p = 0; p < PPW; p++) {
@@ -387,6 +403,7 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
         return;
     }
 
+    asm volatile("" : "+v"(da[0]), "+v"(da[1]));   // computed once (otherwise the select is redone per row); after the requests above
     const int ua[2][8] = {{u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w}, {u2.x, u2.y, u2.z, u2.w, u3.x, u3.y, u3.z, u3.w}};
     int nua[2][8];   // bytewise -u (q8_1 values lie in -127..127, so the negation is representable)
 #pragma unroll
@@ -400,12 +417,20 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
             asm volatile("" : "+v"(nua[j][k]));   // keep it in a register: recomputing it at every use costs 3 instructions per word
         }
     const uint32_t lane_g = T == 22 ? (uint32_t)(lane & 7) * 8u : (uint32_t)(lane & 31) * 4u;
-    const uint32_t lane_s = T == 22 ? (uint32_t)(lane & 15) * 8u : 128u + (uint32_t)(lane & 15) * 8u;
+    const uint32_t lane_s = T == 22 ? (uint32_t)(lane & 15) * 8u
+                                    : 128u + (uint32_t)(lane & 15) * 8u + ((lane & 16) ? (T == 18 ? 32768u : 65536u) : 0u);
     float acc[NR];
 #pragma unroll
     for (int p = 0; p < PPW; p++) {
 #pragma unroll
         for (int ri = 0; ri < 2; ri++) {
+            if constexpr (ABL != 2) {
+                if (2 * p + ri + AHEAD < NR) {   // rows 0 .. AHEAD - 1 were requested above
+                    __builtin_amdgcn_sched_barrier(0);   // keep the request here: hoisted to the top it would block the wave again
+                    pk_load_row<T>(raw, U, L, lc, chunk * PPW, 2 * p + ri + AHEAD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             const float wd = vmx_f16_to_f32((uint16_t)(raw[p].d2 >> (16 * ri)));
             float a = 0.f;
 #pragma unroll
@@ -419,6 +444,7 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
             }
             acc[2 * p + ri] = a;
         }
+        if (p == 0) stamp(6, acc[1]);
     }
     if constexpr (DBG) return;
     int rsel;
@@ -439,22 +465,33 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
             if (gcw < groups * CPU_ && row < sg.n_out) sg.y[row] = s;
         }
     }
+    if constexpr (ABL == 3) {
+        stamp(7, z);
+        unsigned long long rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
+        if (lane == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(dbg) + ((int64_t)blockIdx.x * 16 + wave) * 10;
+            for (int i = 0; i < 8; i++) o[i] = ts[i];
+            o[8] = rt0;   // 100 MHz wall clock at entry and end
+            o[9] = rt1;
+        }
+    }
 }
 
 template <int PPW, bool DBG, int ABL = 0>
 __global__ __launch_bounds__(1024) void iq_pk_mmvq_kernel(PkArgs a, const int8_t *__restrict__ aq, const float *__restrict__ ad, int n_in,
-                                                           int S, int32_t *__restrict__ dbg, int lds_tables) {
+                                                           int S, int32_t *__restrict__ dbg, int lds_tables, int issue_barrier) {
     // the only LDS object of the kernel, so the tables start at LDS address 0 and a gather needs no base add
     extern __shared__ __align__(16) unsigned char pk_smem[];
     const int b = blockIdx.x;
     const int si = (a.nseg > 2 && b >= a.seg[2].wg0) ? 2 : ((a.nseg > 1 && b >= a.seg[1].wg0) ? 1 : 0);
     const PkSeg &sg = a.seg[si];
     const int wg = b - sg.wg0;
-    float *part = reinterpret_cast<float *>(pk_smem + lds_tables);   // [waves][8] slice sums, behind the tables
+    float *part = reinterpret_cast<float *>(pk_smem + lds_tables);   // [waves][8] slice sums (512 B) behind the tables, then the compact table copy
     switch (sg.type) {   // workgroup-uniform
-        case 18: pk_body<18, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg); break;
-        case 21: pk_body<21, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg); break;
-        default: pk_body<22, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg); break;
+        case 18: pk_body<18, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
+        case 21: pk_body<21, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
+        default: pk_body<22, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
     }
 }
 
@@ -462,19 +499,28 @@ template <int PPW, bool DBG, int ABL = 0> int pk_launch_ppw(const PkArgs &a, int
                                                int32_t *dbg, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)iq_pk_mmvq_kernel<PPW, DBG, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512);
+        hipError_t e = hipFuncSetAttribute((const void *)iq_pk_mmvq_kernel<PPW, DBG, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512 + 8192);
         if (e != hipSuccess) {
             vmx_set_error("iq_mmvq(packed): hipFuncSetAttribute: %s", hipGetErrorString(e));
             return VMX_ELAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL>), dim3(wgs), dim3(64 * W), lds + 512, st, a, aq, ad, n_in, S, dbg, lds);
+    static const int issue_barrier = getenv("VMX_IQ_ISSUE_BARRIER") ? atoi(getenv("VMX_IQ_ISSUE_BARRIER")) : 1;
+    hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL>), dim3(wgs), dim3(64 * W), lds + 512 + 8192, st, a, aq, ad, n_in, S, dbg, lds, issue_barrier);
     VMX_CHECK_LAUNCH("iq_mmvq(packed)");
     return VMX_OK;
 }
 
+bool g_pk_tables_ready[64] = {};   // per device: the table images exist (vmx_init)
+void *g_pk_stamps = nullptr;   // measurement: per-wave clock stamps of the next launches (vmx_debug_iq_packed_stamps)
+
 int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int32_t *dbg, hipStream_t st) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_pk_tables_ready[dev]) {
+        vmx_set_error("iq_mmvq(packed): vmx_init(%d) has not run on this device (it builds the decode tables)", dev);
+        return VMX_EINVAL;
+    }
     const int nsb = n_in / 256, S = pk_num_slices(nsb);
     if (S > 16) {
         vmx_set_error("iq_mmvq(packed): n_in %d beyond 65536", n_in);
@@ -496,6 +542,8 @@ int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
     const int cus = vmx_num_cus();
     int W = (units_total * cpu_ + cus - 1) / cus;
     W = W < 1 ? 1 : (W > 16 ? 16 : W);
+    static const int force_w = getenv("VMX_IQ_W") ? atoi(getenv("VMX_IQ_W")) : 0;   // measurement only
+    if (force_w >= 1 && force_w <= 16) W = force_w;
     W = ((W + S - 1) / S) * S;
     if (W > 16) W = (16 / S) * S;
     PkArgs a = {};
@@ -510,6 +558,7 @@ int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
     static const int abl = getenv("VMX_IQ_ABL") ? atoi(getenv("VMX_IQ_ABL")) : 0;   // measurement only: 1 = stream alone, 2 = decode alone
     if (abl == 1 && ppw == 4) return pk_launch_ppw<4, false, 1>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
     if (abl == 2 && ppw == 4) return pk_launch_ppw<4, false, 2>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
+    if (g_pk_stamps && ppw == 4) return pk_launch_ppw<4, false, 3>(a, wg, W, lds, aq, ad, n_in, S, (int32_t *)g_pk_stamps, st);
     if (ppw == 4) return pk_launch_ppw<4, false>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
     if (ppw == 2) return pk_launch_ppw<2, false>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
     return pk_launch_ppw<1, false>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
@@ -518,6 +567,27 @@ int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
 }  // namespace
 
 bool vmx_iq_packed_supported(int ggml_type) { return pk_supported(ggml_type); }
+
+// Called by vmx_init with `device` current: build the three table images in this GPU's memory (once).
+int vmx_iq_packed_init(int device) {
+    VMX_REQUIRE(device >= 0 && device < 64, "vmx_init: device %d beyond the 64 this library tracks", device);
+    if (g_pk_tables_ready[device]) return VMX_OK;
+    hipLaunchKernelGGL(pk_build_tables_kernel<18>, dim3(PkTab<18>::BYTES / 16 / 256), dim3(256), 0, nullptr);
+    hipLaunchKernelGGL(pk_build_tables_kernel<21>, dim3(PkTab<21>::BYTES / 16 / 256), dim3(256), 0, nullptr);
+    hipLaunchKernelGGL(pk_build_tables_kernel<22>, dim3(PkTab<22>::BYTES / 16 / 256), dim3(256), 0, nullptr);
+    VMX_CHECK_LAUNCH("iq_packed table build");
+    VMX_CHECK_HIP(hipDeviceSynchronize());
+    g_pk_tables_ready[device] = true;
+    return VMX_OK;
+}
+
+// Measurement aid: while `buf` is non-NULL, packed MMVQ launches over whole 8-row units run a variant that records, per wave,
+// 8 shader-clock stamps (entry, loads issued, tables built, after each of the four row pairs, end) at
+// buf[(workgroup * 16 + wave) * 8 ..] (u64).
+extern "C" int vmx_debug_iq_packed_stamps(void *buf) {
+    g_pk_stamps = buf;
+    return VMX_OK;
+}
 
 extern "C" size_t vmx_iq_packed_bytes(int ggml_type, int n_out, int n_in) {
     if (!pk_supported(ggml_type) || n_out <= 0 || n_in <= 0 || n_in % 256) return 0;
@@ -539,6 +609,22 @@ extern "C" int vmx_iq_pack(int ggml_type, const void *raw, void *packed, int n_o
     else hipLaunchKernelGGL(iq_pack_kernel<22>, grid, dim3(256), 0, st, (const uint8_t *)raw, (uint8_t *)packed, n_out, nsb);
     VMX_CHECK_LAUNCH("iq_pack");
     return VMX_OK;
+}
+
+// Whether the packed kernel is the faster one for this group of tensors (measured on MI355X: it wins where one launch holds
+// at least ~2000 8-row units of one K-slice; smaller launches are bound by the launch prologue either way, and rows cut
+// into several K-slices pay an LDS combine).  VMX_IQ_PACKED_MIN_UNITS overrides the threshold (0 = always, -1 = never).
+bool vmx_iq_packed_preferred(const VmxMmvqSeg *segs, int nseg, int n_in, int m) {
+    static const int min_units = getenv("VMX_IQ_PACKED_MIN_UNITS") ? atoi(getenv("VMX_IQ_PACKED_MIN_UNITS")) : 2048;
+    if (m != 1 || min_units < 0 || n_in % 256) return false;
+    const int S = pk_num_slices(n_in / 256);
+    int units = 0;
+    for (int i = 0; i < nseg; i++) {
+        if (!pk_supported(segs[i].ggml_type) || !segs[i].w) return false;
+        units += (segs[i].n_out + PK_ROWS - 1) / PK_ROWS * S;
+    }
+    if (min_units == 0) return true;
+    return S == 1 && units >= min_units;
 }
 
 // Up to three packed tensors that share one q8_1 activation row, one launch; outputs at y + y_off[i]

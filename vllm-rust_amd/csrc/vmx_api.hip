@@ -4,6 +4,7 @@
 #include <mutex>
 
 int vmx_attention_scratch_init(int device);   // attention_kernels.hip
+int vmx_iq_packed_init(int device);          // iq_packed.hip
 
 namespace {
 thread_local char g_err[512] = "";
@@ -46,5 +47,6 @@ extern "C" int vmx_init(int device) {
         vmx_set_error("vmx_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return VMX_EUNSUPPORTED;
     }
-    return vmx_attention_scratch_init(device);
+    if (int rc = vmx_attention_scratch_init(device)) return rc;
+    return vmx_iq_packed_init(device);
 }

@@ -70,6 +70,7 @@ int vmx_iq_mmvq_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const 
 
 // iq_packed.hip: the same MMVQ over the load-time repacked form (vmx_iq_pack), one activation row; segs[i].w = packed weights
 bool vmx_iq_packed_supported(int ggml_type);
+bool vmx_iq_packed_preferred(const VmxMmvqSeg *segs_packed, int nseg, int n_in, int m);   // segs[i].w = packed copy or NULL
 int vmx_iq_mmvq_packed_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, hipStream_t st);
 
 // kquant_kernels.hip
