@@ -127,6 +127,14 @@ def test_qwen3_8b_awq_three_launch_attention_forced(gpu):
     _qwen3_case(gpu, _spec_8b(max_batch=1), "load_synthetic", start_lens=[300], steps=3, first_ids=[77])
 
 
+def test_qwen3_8b_awq_five_launch_layers(gpu):
+    """One and two decode rows take the five-launch layer (RMSNorm in the prologue of q|k|v and gate|up, residual add in the
+    epilogue of o_proj and down_proj); three layers, so that the first (norm kernel after the embedding), a middle and the
+    last layer (final norm kernel) are all covered; B = 2 with one row in each attention regime."""
+    _qwen3_case(gpu, _spec_8b(max_batch=1, num_layers=3), "load_synthetic", start_lens=[41], steps=3, first_ids=[5])
+    _qwen3_case(gpu, _spec_8b(max_batch=2, num_layers=3), "load_synthetic", start_lens=[7, 1023], steps=3, first_ids=[11, 4242])
+
+
 def test_qwen3_8b_awq_fp8_kv_batch16(gpu):
     """16 concurrent sequences (looped activation staging in the int4 GEMM, matrix-core lm_head) over an FP8 cache."""
     spec = _spec_8b(max_batch=16, kv_cache_dtype=1, num_blocks=16 * 12)

@@ -400,7 +400,7 @@ struct vmx_qwen3 {
     std::vector<Layer> layers;
     DevBuf embed, lm_head, final_norm, cos_sin;
     bool lm_head_tied = false;
-    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8, positions;
+    DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8, positions, ssq;
     DevBuf router_logits, topk_w, topk_ids, moe_ws, moe_out;   // MoE models only
     DevBuf exl3_ws;                                            // EXL3 models only: grown by the loader
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
@@ -594,7 +594,8 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     }
     if (!rc) {
         const Layer &L = m->layers[0];
-        const size_t cands[4] = {(size_t)L.qkv.splits() * NQKV, (size_t)L.o.splits() * H, (size_t)L.gate_up.splits() * 2 * I,
+        const int qkv_wide = vmx_int4_norm_splits(1, NQKV, H, 0);   // decode rows may take the wide kernel's k slicing
+        const size_t cands[4] = {(size_t)(L.qkv.splits() > qkv_wide ? L.qkv.splits() : qkv_wide) * NQKV, (size_t)L.o.splits() * H, (size_t)L.gate_up.splits() * 2 * I,
                                  (size_t)L.down.splits() * H};
         for (size_t v : cands) max_partial = v > max_partial ? v : max_partial;
         if (L.qkv.splits() > SMAX || L.o.splits() > SMAX || L.gate_up.splits() > SMAX || L.down.splits() > SMAX) {
@@ -611,6 +612,7 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     TRY(m->act.alloc((size_t)B * I * 2));
     TRY(m->logits.alloc((size_t)c.max_batch * VL * 2));
     TRY(m->positions.alloc((size_t)B * 4));
+    TRY(m->ssq.alloc((size_t)2 * (H / 16 + 4) * 4));   // two decode rows' per-tile sums of squares
     TRY(m->red_bf16.alloc((size_t)B * H * 2));
     {   // q8_1 staging for I-quant linears: int8 [B][Kmax] + f32 [B][Kmax/32]
         const size_t kmax = (size_t)(H > I ? (H > NO ? H : NO) : (I > NO ? I : NO));
@@ -654,7 +656,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
     }
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
                       &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8, &m->positions, &m->router_logits, &m->topk_w, &m->topk_ids,
-                      &m->moe_ws, &m->moe_out, &m->exl3_ws})
+                      &m->moe_ws, &m->moe_out, &m->exl3_ws, &m->ssq})
         b->release();
     delete m;
 }
@@ -878,6 +880,12 @@ extern "C" int vmx_qwen3_load_exl3_linear(vmx_qwen3 *m, int layer, int slot, con
 }
 
 namespace {
+// VMX_NO_FOLDED_LAYERS=1 keeps the seven-launch layer (norm kernels of their own) for A/B measurements
+bool folded_layers_enabled() {
+    static const bool on = !(getenv("VMX_NO_FOLDED_LAYERS") && atoi(getenv("VMX_NO_FOLDED_LAYERS")));
+    return on;
+}
+
 __global__ void iota_positions_kernel(int32_t *pos, int offset, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) pos[i] = offset + i;
@@ -905,20 +913,36 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     const uint16_t *pending_svh = nullptr;  // EXL3: `pending` holds raw split-K sums whose output transform the norm kernel applies
     uint16_t *attn = (uint16_t *)m->attn.p, *act = (uint16_t *)m->act.p;
     const int NQ = Hq * hd, NKV = Hkv * hd;
+    float *ssq = (float *)m->ssq.p;
+    bool have_ssq = false;   // ssq holds the tile sums of squares of the current h (left by a residual-epilogue linear)
     for (const Layer &L : m->layers) {
         const bool moe = c.num_experts > 0;  // int4 attention projections + mixture-of-experts MLP
         const bool ex = !moe && !L.int4_ready() && L.exl3_ready();   // EXL3 layer: every projection an Exl3Linear
         const bool iq = !moe && !L.int4_ready() && !ex;              // GGUF I-quant layer: every projection is an IqLinear
         const bool one = iq || ex;                                   // linear outputs arrive as one f32 slice
-        const int s_qkv = one ? 1 : L.qkv.splits(), s_o = one ? 1 : L.o.splits(), s_gu = one ? 1 : L.gate_up.splits(),
+        int s_qkv = one ? 1 : L.qkv.splits();
+        const int s_o = one ? 1 : L.o.splits(), s_gu = one ? 1 : L.gate_up.splits(),
                   s_down = one ? 1 : L.down.splits();
         // h += pending; x = rms_norm(h);  q|k|v = linear(x)
         // EXL3 decode rows: the consumers of o, gate|up and down apply the output transform themselves (one launch less each)
         const bool ex_fold = ex && B <= 4 && !tp && H % 128 == 0 && I % 128 == 0 && L.ex_svh_gu.p;
-        launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
-                          iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh);
+        // Dense int4 layer on one or two decode rows: both norms move into the prologue of the linear that reads them and both
+        // residual adds into the epilogue of the linear that feeds them -- five launches (q|k|v, attention, o, gate|up, down).
+        const bool fold = folded_layers_enabled() && !tp && !moe && !one && L.int4_ready() && L.gate_up.glu && !pending &&
+                          vmx_int4_norm_splits(B, NQKV_, H, 0) > 0 && vmx_int4_norm_splits(B, 2 * I, H, 1) == 1 &&
+                          vmx_int4_resid_fusable(B, H, NQ) && vmx_int4_resid_fusable(B, H, I);
+        const bool fold_in = fold && have_ssq;   // the first layer's h comes from the embedding: no tile sums yet
+        if (!fold_in)
+            launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
+                              iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh);
         pending_svh = nullptr;
-        if (ex && B <= 4 && L.ex_svh_qkv.p) {
+        have_ssq = false;
+        if (fold_in) s_qkv = vmx_int4_norm_splits(B, NQKV_, H, 0);   // the wide kernel has its own k slicing
+        if (fold_in) {
+            if (int rc = vmx_int4_gemm_partial_norm(L.qkv.packed.p, h, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, ssq, PA, B, NQKV_, H,
+                                                    L.qkv.group, st))
+                return rc;
+        } else if (ex && B <= 4 && L.ex_svh_qkv.p) {
             if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, PA, NQKV_, B, st)) return rc;
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_Q], x, PA, NQKV_, B, st)) return rc;
@@ -959,6 +983,16 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st, iq ? q8_aq(m) : nullptr,
                                                    iq ? q8_ad(m, B, NQ) : nullptr))
                 return rc;
+        }
+        if (fold) {   // h += o_proj(attn);  act = glu(gate|up(rms_norm(h)));  h += down(act)
+            if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, B, H, NQ, L.o.group, st)) return rc;
+            if (int rc = vmx_int4_gemm_glu_norm(L.gate_up.packed.p, h, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, ssq, act, B, 2 * I, H,
+                                                L.gate_up.group, st))
+                return rc;
+            if (int rc = vmx_int4_gemm_resid(L.down.packed.p, act, h, ssq, B, H, I, L.down.group, st)) return rc;
+            pending = nullptr;
+            have_ssq = true;
+            continue;
         }
         const float *o_src = PB;
         int o_splits = s_o;
@@ -1161,7 +1195,25 @@ extern "C" int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream) {
     hipStream_t st = vmx_stream(stream);
     const uint16_t *x = (const uint16_t *)m->x.p, *attn = (const uint16_t *)m->attn.p, *act = (const uint16_t *)m->act.p;
     float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;
+    const vmx_qwen3_config &c = m->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, NQ = c.num_heads * c.head_dim, NQKV_ = m->qkv_n();
+    uint16_t *h = (uint16_t *)m->h.p;
     for (const Layer &L : m->layers) {
+        const bool fold = folded_layers_enabled() && !m->comm && c.tp_size <= 1 && c.num_experts == 0 && L.gate_up.glu &&
+                          vmx_int4_norm_splits(batch, NQKV_, H, 0) > 0 && vmx_int4_norm_splits(batch, 2 * I, H, 1) == 1 &&
+                          vmx_int4_resid_fusable(batch, H, NQ) && vmx_int4_resid_fusable(batch, H, I);
+        if (fold) {   // what the step launches for such a layer
+            float *ssq = (float *)m->ssq.p;
+            if (int rc = vmx_int4_gemm_partial_norm(L.qkv.packed.p, h, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, ssq, PA, batch, NQKV_,
+                                                    H, L.qkv.group, st))
+                return rc;
+            if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, batch, H, NQ, L.o.group, st)) return rc;
+            if (int rc = vmx_int4_gemm_glu_norm(L.gate_up.packed.p, h, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, ssq, (uint16_t *)m->act.p,
+                                                batch, 2 * I, H, L.gate_up.group, st))
+                return rc;
+            if (int rc = vmx_int4_gemm_resid(L.down.packed.p, act, h, ssq, batch, H, I, L.down.group, st)) return rc;
+            continue;
+        }
         if (int rc = L.qkv.forward_partial(x, PA, batch, st)) return rc;
         if (int rc = L.o.forward_partial(attn, PB, batch, st)) return rc;
         if (int rc = L.gate_up.glu ? L.gate_up.forward_glu(x, (uint16_t *)m->act.p, batch, st) : L.gate_up.forward_partial(x, PA, batch, st)) return rc;

@@ -202,11 +202,17 @@ __device__ __forceinline__ void int4_gemm_epilogue(float *red, const vmx_f32x4 f
 
 // GLU: the linear is a merged gate|up packed with glu_half = N/2 and runs unsplit; y is act[M][N/2] =
 // bf16(silu(bf16(gate)) * bf16(up)), the rounding points of silu_and_mul on the bf16 linear output (activations.cu:148-164).
-template <int UPW, bool TAIL, bool GLU = false>
+//
+// NORM (M <= 2, K <= 8192, K % 64 == 0): `x` is the bf16 residual stream h [M][K] and the activations are its RMSNorm,
+// computed here: x = bf16(h * rsqrt(mean(h^2) + eps) * w) (rms_norm_bf16 of the reference, layer_norm.cu), so that the norm
+// is not a launch of its own.  The mean comes from ssq [M][K/16]: the sums of squares of each 16-column tile of h, left
+// there by the kernel that wrote h (int4_gemm_resid_kernel); a workgroup normalises only its own k-slice.
+template <int UPW, bool TAIL, bool GLU = false, bool NORM = false>
 __device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
                                                uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride, int M,
-                                               int N, int K, int group, int block) {
+                                               int N, int K, int group, int block, const uint16_t *__restrict__ norm_w = nullptr,
+                                               float eps = 0.f, const float *__restrict__ ssq = nullptr) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int KS = 4 * UPW * KB;       // k-values per workgroup
     constexpr int XROW = KS + 8;           // bf16 per staged row (+16 B pad against bank conflicts)
@@ -235,6 +241,26 @@ __device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, cons
             if (!TAIL || k < K) xv[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)m * K + k);
         }
     }
+    uint4 nwv[XCH];
+    float4 nss[2][2];   // NORM: per row, this lane's share of the K/16 per-tile sums of squares (K <= 8192)
+    if constexpr (NORM) {
+        const int nsq = K >> 4;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                // unconditional loads from clamped addresses (a branch here would put a wait in front of the weight requests);
+                // the surplus ones are zeroed where they are used
+                const int i = 4 * (lane + 64 * j);
+                nss[m][j] = *reinterpret_cast<const float4 *>(ssq + min(m, M - 1) * nsq + min(i, nsq - 4));
+            }
+#pragma unroll
+        for (int j = 0; j < XCH; j++) {
+            const int c = tid + 256 * j, k = k0 + (c % CPR) * 8;
+            nwv[j] = make_uint4(0, 0, 0, 0);
+            if (c < total && (!TAIL || k < K)) nwv[j] = *reinterpret_cast<const uint4 *>(norm_w + k);
+        }
+    }
     uint32_t szv[(4 * UPW * 16 + 255) / 256];
 #pragma unroll
     for (int j = 0; j < (4 * UPW * 16 + 255) / 256; j++) {
@@ -248,6 +274,31 @@ __device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, cons
         const int kb = kb_wg + wave * UPW + u;
         if (!TAIL || kb < kblocks) wreg[u] = W[((int64_t)nt * kblocks + kb) * 64 + lane];
         else wreg[u] = make_uint4(0, 0, 0, 0);
+    }
+    if constexpr (NORM) {   // mean of squares from the per-tile sums (every wave adds them up itself), then normalise the slice
+        float inv[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const float4 a4 = nss[m][0], b4 = nss[m][1];
+            const int nsq = K >> 4;
+            const float ta = 4 * lane < nsq ? (a4.x + a4.y) + (a4.z + a4.w) : 0.f;
+            const float tb = 4 * (lane + 64) < nsq ? (b4.x + b4.y) + (b4.z + b4.w) : 0.f;
+            const float t = vmx_wave_sum(ta + tb);
+            inv[m] = rsqrtf(t / (float)K + eps);
+        }
+#pragma unroll
+        for (int j = 0; j < XCH; j++) {
+            const int c = tid + 256 * j;
+            float hv[8], wv[8];
+            bf16x8_to_f32(xv[j], hv);
+            bf16x8_to_f32(nwv[j], wv);
+            const float iv = (c < total && c / CPR == 1) ? inv[1] : inv[0];
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                pk[e] = (uint32_t)vmx_f32_to_bf16(hv[2 * e] * iv * wv[2 * e]) | ((uint32_t)vmx_f32_to_bf16(hv[2 * e + 1] * iv * wv[2 * e + 1]) << 16);
+            xv[j] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
     }
     // 3. stage activations (+ per-(k-block,row) sums) and scale|zero words in LDS
 #pragma unroll
@@ -433,6 +484,269 @@ __global__ __launch_bounds__(256) void int4_gemm_glu_kernel(const uint4 *__restr
                                                              const uint16_t *__restrict__ x, uint16_t *__restrict__ act, int M, int N,
                                                              int K, int group) {
     int4_gemm_body<UPW, TAIL, true>(W, SZ, x, nullptr, act, nullptr, 0, M, N, K, group, blockIdx.x);
+}
+
+// ---------------------------------------------------------------- decode rows (M <= 2): wide workgroups, norm in the prologue
+// Every workgroup of the kernels above fetches (and here also normalises) its whole activation slice, so with one
+// 16-column tile per workgroup the activations cross the L2 -> CU path once per tile: 1536 times for a 24576-wide
+// gate|up.  Here a workgroup of NWV waves owns NTW adjacent column tiles over a k-slice of NWV*UPW k-blocks; wave w holds
+// the units (tile t, k-block w*UPW + u) -- NTW*UPW of them, all requested at kernel start -- and one A fragment read from
+// LDS feeds NTW matrix instructions.  The launcher picks (NWV, UPW, NTW, split-K) so that the workgroup count is a whole
+// multiple of the CU count where the shape allows it.  No bounds checks: K is a whole number of slices, N of NTW tiles.
+// The activations are the RMSNorm of the residual stream h (see NORM above).  Output: f32 split-K slices, or with GLU
+// (one slice) the gated activation.
+template <int NWV, int UPW, int NTW, bool GLU, int MR>
+__global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                                   const uint16_t *__restrict__ hres, const uint16_t *__restrict__ norm_w,
+                                                                   float eps, const float *__restrict__ ssq, float *__restrict__ partial,
+                                                                   uint16_t *__restrict__ act, int N, int K, int group) {
+    // MR = rows (1 or 2), compiled in: every load instruction a wave issues costs the CU's memory pipeline time, used or not
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int M = MR;
+    constexpr int TH = 64 * NWV, KBS = NWV * UPW, KS = KBS * KB, XROW = KS + 8, CPR = KS / 8;
+    constexpr int XCF = (MR * CPR + TH - 1) / TH, SZW = (NTW * KBS * 16 + TH - 1) / TH;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                                          // [2][XROW]
+    float *sumx = reinterpret_cast<float *>(smem + (((size_t)2 * XROW * 2 + 15) & ~(size_t)15));  // [KBS][16]
+    float *red = sumx + KBS * 16;                                                                // [NTW][NWV][16 columns][4 rows]
+    uint32_t *szs = reinterpret_cast<uint32_t *>(red + NTW * NWV * 64);                          // [NTW][KBS][16]
+    float *invs = reinterpret_cast<float *>(szs + NTW * KBS * 16);                               // [2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 15, hh = lane >> 4;
+    const int groups = (N / NT) / NTW, kblocks = K / KB, G = K / group;
+    const int nt0 = ((int)blockIdx.x % groups) * NTW, ks = (int)blockIdx.x / groups;
+    const int kb_wg = ks * KBS, k0 = kb_wg * KB, nsq = K >> 4;
+    constexpr int total = MR * CPR;
+
+    // The mean of squares is the business of wave 0 alone (one or two 1 KiB loads per row): the 256..512 tile sums are the
+    // same few cache lines for every workgroup of the launch, and fetched by every wave they cost more than the barrier
+    // that shares the result.
+    float4 nss[MR][2];
+    if (wave == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; m++) {
+            nss[m][0] = *reinterpret_cast<const float4 *>(ssq + m * nsq + min(4 * lane, nsq - 4));
+            nss[m][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nsq > 256) nss[m][1] = *reinterpret_cast<const float4 *>(ssq + m * nsq + min(4 * (lane + 64), nsq - 4));
+        }
+    }
+    uint4 xv[XCF], nwv[XCF];
+#pragma unroll
+    for (int j = 0; j < XCF; j++) {
+        const int c = min(tid + TH * j, total - 1), k = k0 + (c % CPR) * 8;
+        xv[j] = *reinterpret_cast<const uint4 *>(hres + (int64_t)(c / CPR) * K + k);
+        nwv[j] = *reinterpret_cast<const uint4 *>(norm_w + k);
+    }
+    uint32_t szv[SZW];
+#pragma unroll
+    for (int j = 0; j < SZW; j++) {
+        const int i = min(tid + TH * j, NTW * KBS * 16 - 1), t = i / (KBS * 16), kb = kb_wg + (i / 16) % KBS;
+        szv[j] = SZ[((int64_t)(nt0 + t) * G + (kb * KB) / group) * 16 + (i & 15)];
+    }
+    uint4 wreg[NTW][UPW];
+#pragma unroll
+    for (int u = 0; u < UPW; u++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) wreg[t][u] = W[((int64_t)(nt0 + t) * kblocks + kb_wg + wave * UPW + u) * 64 + lane];
+
+    if (wave == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; m++) {
+            const float4 a4 = nss[m][0], b4 = nss[m][1];
+            const float ta = 4 * lane < nsq ? (a4.x + a4.y) + (a4.z + a4.w) : 0.f;
+            const float tb = 4 * (lane + 64) < nsq ? (b4.x + b4.y) + (b4.z + b4.w) : 0.f;
+            const float iv = rsqrtf(vmx_wave_sum(ta + tb) / (float)K + eps);
+            if (lane == 0) invs[m] = iv;
+        }
+    }
+    __syncthreads();
+    float inv[2];
+    inv[0] = invs[0];
+    inv[1] = MR > 1 ? invs[1] : 0.f;
+#pragma unroll
+    for (int j = 0; j < XCF; j++) {
+        const int c = tid + TH * j;
+        const bool live = c < total;
+        const int m = live ? c / CPR : 0, cc = live ? c % CPR : 0;
+        float hv[8], wv[8];
+        bf16x8_to_f32(xv[j], hv);
+        bf16x8_to_f32(nwv[j], wv);
+        const float iv = m == 1 ? inv[1] : inv[0];
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            pk[e] = (uint32_t)vmx_f32_to_bf16(hv[2 * e] * iv * wv[2 * e]) | ((uint32_t)vmx_f32_to_bf16(hv[2 * e + 1] * iv * wv[2 * e + 1]) << 16);
+        const uint4 xn = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = xn;
+        const float sm = chunk_sum16(xn);   // 16 consecutive chunks = one (row, k-block)
+        if (live && (tid & 15) == 0) sumx[(cc >> 4) * 16 + m] = sm;
+    }
+#pragma unroll
+    for (int j = 0; j < SZW; j++)
+        if (tid + TH * j < NTW * KBS * 16) szs[tid + TH * j] = szv[j];
+    __syncthreads();
+
+    const uint16_t *xrow = xs + min(nl, M - 1) * XROW + 8 * hh;
+    vmx_f32x4 fin[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) fin[t] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < UPW; u++) {
+        const int kbl = wave * UPW + u;
+        uint4 au[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) au[i] = *reinterpret_cast<const uint4 *>(xrow + kbl * KB + 32 * i);
+        const float4 sx = *reinterpret_cast<const float4 *>(sumx + kbl * 16 + 4 * hh);
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t w4[4] = {wreg[t][u].x, wreg[t][u].y, wreg[t][u].z, wreg[t][u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t w = w4[i];
+                uint4 bu;
+                bu.x = (w & 0x000F000Fu) | 0x43004300u;
+                bu.y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+                bu.z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+                bu.w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au[i]), __builtin_bit_cast(vmx_bf16x8, bu), acc, 0, 0, 0);
+            }
+            const uint32_t szw = szs[(t * KBS + kbl) * 16 + nl];
+            const float sc = __uint_as_float(szw << 16);
+            const float zo = __uint_as_float(szw & 0xFFFF0000u);
+            fin[t][0] += sc * (acc[0] - zo * sx.x);
+            fin[t][1] += sc * (acc[1] - zo * sx.y);
+            fin[t][2] += sc * (acc[2] - zo * sx.z);
+            fin[t][3] += sc * (acc[3] - zo * sx.w);
+        }
+    }
+    if (hh == 0) {   // rows 0..3 of the MFMA tile (M <= 2)
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+            *reinterpret_cast<float4 *>(red + ((t * NWV + wave) * 16 + nl) * 4) = make_float4(fin[t][0], fin[t][1], fin[t][2], fin[t][3]);
+    }
+    __syncthreads();
+    // thread = (tile t, row m, column c): sum over the waves in wave order
+    for (int i = tid; i < NTW * 32; i += TH) {
+        const int t = i >> 5, m = (i >> 4) & 1, c = i & 15;
+        if (m >= M) continue;
+        if (GLU) {
+            if (c >= 8) continue;
+            float g = 0.f, up = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NWV; wv++) {
+                g += red[((t * NWV + wv) * 16 + c) * 4 + m];
+                up += red[((t * NWV + wv) * 16 + c + 8) * 4 + m];
+            }
+            const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(g)), uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
+            act[(int64_t)m * (N >> 1) + (nt0 + t) * 8 + c] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
+        } else {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NWV; wv++) v += red[((t * NWV + wv) * 16 + c) * 4 + m];
+            partial[((int64_t)ks * M + m) * N + (nt0 + t) * NT + c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- whole-K workgroups with the residual add in the epilogue
+// The two linears whose output goes back into the residual stream (o_proj, down_proj), for M <= 2 rows: one workgroup of 16
+// waves owns a 16-column tile over ALL of K (wave w the k-blocks [w*UPW, (w+1)*UPW)), so the sum needs no split-K slices
+// and the epilogue can finish the job of the reference's separate add: h = bf16(h + bf16(y)) (the linear's bf16 output,
+// then add_bf16).  N/16 workgroups of 1024 threads: the launch keeps the whole matrix in flight like the kernel above.
+template <int UPW>
+__global__ __launch_bounds__(1024) void int4_gemm_resid_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                                const uint16_t *__restrict__ x, uint16_t *__restrict__ h,
+                                                                float *__restrict__ ssq, int M, int N, int K, int group) {
+    // K == 16 * UPW * 128 exactly (checked by the launcher): no bounds checks, so every load below is unconditional and
+    // issued back to back (surplus threads re-read a valid address and drop the value)
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NWV = 16, KBLK = NWV * UPW, KK = KBLK * KB, XROW = KK + 8, CPR = KK / 8;
+    constexpr int XCF = (2 * CPR + 1023) / 1024;   // chunks per thread for two rows
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                                   // [2][XROW]
+    float *sumx = reinterpret_cast<float *>(smem + (((size_t)2 * XROW * 2 + 15) & ~(size_t)15));   // [KBLK][16]
+    float *red = sumx + KBLK * 16;                                                        // [16 waves][16 columns][4 rows]
+    uint32_t *szs = reinterpret_cast<uint32_t *>(red + NWV * 16 * 4);                     // [KBLK][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x, nl = lane & 15, hh = lane >> 4;
+    const int G = K / group, total = M * CPR;
+
+    // the residual values of the epilogue, requested first: thread (row m, column c) for tid < 16 * M
+    const int64_t hidx = (int64_t)min(tid >> 4, M - 1) * N + nt * NT + (tid & 15);
+    const uint16_t hold = h[hidx];
+    uint4 xv[XCF];
+#pragma unroll
+    for (int j = 0; j < XCF; j++) {
+        const int c = min(tid + 1024 * j, total - 1);
+        xv[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)(c / CPR) * K + (c % CPR) * 8);
+    }
+    constexpr int SZW = (KBLK * 16 + 1023) / 1024;
+    uint32_t szv[SZW];
+#pragma unroll
+    for (int j = 0; j < SZW; j++) {
+        const int i = min(tid + 1024 * j, KBLK * 16 - 1), kb = i >> 4;
+        szv[j] = SZ[((int64_t)nt * G + (kb * KB) / group) * 16 + (i & 15)];
+    }
+    uint4 wreg[UPW];
+#pragma unroll
+    for (int u = 0; u < UPW; u++) wreg[u] = W[((int64_t)nt * KBLK + wave * UPW + u) * 64 + lane];
+
+#pragma unroll
+    for (int j = 0; j < XCF; j++) {
+        const int c = tid + 1024 * j;
+        const bool live = c < total;
+        const int m = live ? c / CPR : 0, cc = live ? c % CPR : 0;
+        if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = xv[j];
+        const float sm = chunk_sum16(xv[j]);   // 16 consecutive chunks = one (row, k-block); CPR % 16 == 0
+        if (live && (tid & 15) == 0) sumx[(cc >> 4) * 16 + m] = sm;
+    }
+#pragma unroll
+    for (int j = 0; j < SZW; j++)
+        if (tid + 1024 * j < KBLK * 16) szs[tid + 1024 * j] = szv[j];
+    __syncthreads();
+
+    const uint16_t *xrow = xs + min(nl, M - 1) * XROW + 8 * hh;
+    vmx_f32x4 fin = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < UPW; u++) {
+        const int kb = wave * UPW + u;
+        vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const uint32_t w4[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w = w4[i];
+            uint4 bu;
+            bu.x = (w & 0x000F000Fu) | 0x43004300u;
+            bu.y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+            bu.z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+            bu.w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+            const uint4 au = *reinterpret_cast<const uint4 *>(xrow + kb * KB + 32 * i);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, bu), acc, 0, 0, 0);
+        }
+        const uint32_t szw = szs[kb * 16 + nl];
+        const float s = __uint_as_float(szw << 16);
+        const float zo = __uint_as_float(szw & 0xFFFF0000u);
+        const float4 sx = *reinterpret_cast<const float4 *>(sumx + kb * 16 + 4 * hh);
+        fin[0] += s * (acc[0] - zo * sx.x);
+        fin[1] += s * (acc[1] - zo * sx.y);
+        fin[2] += s * (acc[2] - zo * sx.z);
+        fin[3] += s * (acc[3] - zo * sx.w);
+    }
+    if (hh == 0) *reinterpret_cast<float4 *>(red + (wave * 16 + nl) * 4) = make_float4(fin[0], fin[1], fin[2], fin[3]);   // rows 0..3 (M <= 2)
+    __syncthreads();
+    if (tid < 64) {   // wave 0; thread = (row m, column c): sum of the 16 waves in wave order
+        const int m = tid >> 4, c = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NWV; wv++) v += red[(wv * 16 + c) * 4 + m];
+        const uint16_t hn = vmx_f32_to_bf16(vmx_bf16_to_f32(hold) + vmx_bf16_to_f32(vmx_f32_to_bf16(v)));
+        if (m < M) h[hidx] = hn;
+        float sq = vmx_bf16_to_f32(hn);   // sum of squares of the tile's 16 new residual values, for the norm in the next linear
+        sq *= sq;
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        sq += __shfl_xor(sq, 8, 64);
+        if (m < M && c == 0) ssq[m * (N / NT) + nt] = sq;
+    }
 }
 
 // ---------------------------------------------------------------- prompt-shaped M (more than one 16-row tile)
@@ -785,6 +1099,140 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
         const int mm = M - m0 < 16 ? M - m0 : 16;
         if (int rc = launch_gemm(p, W, SZ, x + (int64_t)m0 * K, nullptr, nullptr, partial + (int64_t)m0 * N, mm, N, K, group, st, M)) return rc;
     }
+    return VMX_OK;
+}
+
+// ---- the norm-in-prologue / residual-in-epilogue forms (M <= 2): see int4_gemm_body<NORM> and int4_gemm_resid_kernel
+bool vmx_int4_resid_fusable(int M, int N, int K) {
+    return M >= 1 && M <= 2 && K % (16 * KB) == 0 && K / (16 * KB) <= 8 && N % NT == 0;   // whole k-blocks for each of the 16 waves
+}
+
+namespace {
+struct WidePlan { int nwv, upw, ntw, splits; };
+
+// (waves, units per wave and tile, tiles per workgroup, k slices) for int4_gemm_wide_kernel.  Measured on MI355X (Qwen3-8B
+// shapes, one row): one tile per workgroup and the largest k slice that still gives about three workgroups per CU is
+// fastest -- the same rule as plan_gemm; two or more tiles per workgroup (fewer activation fetches, but fewer and longer
+// workgroups) lost 3..20 %.  VMX_INT4_WIDE / VMX_INT4_WIDE_GLU=nwv,upw,ntw force a shape for measurements.
+bool plan_wide(int N, int K, bool glu, WidePlan *out) {
+    static const int cfgs[4][2] = {{4, 8}, {4, 4}, {4, 2}, {8, 4}};
+    static const int min_items = tune("VMX_INT4_MIN_ITEMS", 768);
+    const int n_tiles = N / NT, kblocks = K / KB;
+    int f_nwv = 0, f_upw = 0, f_ntw = 0;
+    if (const char *e = getenv(glu ? "VMX_INT4_WIDE_GLU" : "VMX_INT4_WIDE")) sscanf(e, "%d,%d,%d", &f_nwv, &f_upw, &f_ntw);
+    bool found = false;
+    for (const auto &cfg : cfgs) {
+        const int nwv = cfg[0], upw = cfg[1], kbs = nwv * upw, ntw = f_nwv ? f_ntw : 1;
+        if (kblocks % kbs || ntw < 1 || n_tiles % ntw || upw * ntw > 24) continue;
+        if (f_nwv ? (f_nwv != nwv || f_upw != upw) : nwv != 4) continue;
+        const int splits = kblocks / kbs;
+        if (splits > SPLIT_MAX || (glu && splits != 1)) continue;
+        *out = WidePlan{nwv, upw, ntw, splits};
+        found = true;
+        if (f_nwv || (int64_t)n_tiles * splits >= min_items) break;   // else try the next smaller slice
+    }
+    return found;
+}
+
+template <int NWV, int UPW, int NTW, bool GLU, int MR>
+int launch_wide_m(const WidePlan &p, const uint4 *W, const uint32_t *SZ, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq,
+                  float *partial, uint16_t *act, int N, int K, int group, hipStream_t st) {
+    constexpr int KBS = NWV * UPW;
+    const size_t lds = (((size_t)2 * (KBS * KB + 8) * 2 + 15) & ~(size_t)15) + (size_t)KBS * 64 + (size_t)NTW * NWV * 256 + (size_t)NTW * KBS * 64 + 16;
+    if (lds > 64 * 1024)
+        VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+    hipLaunchKernelGGL((int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR>), dim3((unsigned)((N / NT) / NTW * p.splits)), dim3(64 * NWV), lds, st, W, SZ,
+                       h, norm_w, eps, ssq, partial, act, N, K, group);
+    VMX_CHECK_LAUNCH("int4_gemm(wide)");
+    return VMX_OK;
+}
+
+template <int NWV, int UPW, int NTW, bool GLU>
+int launch_wide_t(const WidePlan &p, const uint4 *W, const uint32_t *SZ, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq,
+                  float *partial, uint16_t *act, int M, int N, int K, int group, hipStream_t st) {
+    if constexpr (UPW * NTW > 24) {
+        return VMX_EINVAL;
+    } else {
+        if (M == 1) return launch_wide_m<NWV, UPW, NTW, GLU, 1>(p, W, SZ, h, norm_w, eps, ssq, partial, act, N, K, group, st);
+        return launch_wide_m<NWV, UPW, NTW, GLU, 2>(p, W, SZ, h, norm_w, eps, ssq, partial, act, N, K, group, st);
+    }
+}
+
+template <int NWV, int UPW, bool GLU>
+int launch_wide_n(const WidePlan &p, const uint4 *W, const uint32_t *SZ, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq,
+                  float *partial, uint16_t *act, int M, int N, int K, int group, hipStream_t st) {
+    switch (p.ntw) {
+        case 6: return launch_wide_t<NWV, UPW, 6, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+        case 4: return launch_wide_t<NWV, UPW, 4, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+        case 3: return launch_wide_t<NWV, UPW, 3, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+        case 2: return launch_wide_t<NWV, UPW, 2, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+        default: return launch_wide_t<NWV, UPW, 1, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+    }
+}
+
+template <bool GLU>
+int launch_wide(const WidePlan &p, const void *packed, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq, float *partial,
+                uint16_t *act, int M, int N, int K, int group, hipStream_t st) {
+    const uint4 *W = (const uint4 *)packed;
+    const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    if (p.nwv == 8) return launch_wide_n<8, 4, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+    if (p.upw == 8) return launch_wide_n<4, 8, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+    if (p.upw == 4) return launch_wide_n<4, 4, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+    return launch_wide_n<4, 2, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
+}
+}  // namespace
+
+// split-K slices the norm-in-prologue form leaves in `partial` (0: shape not supported)
+int vmx_int4_norm_splits(int M, int N, int K, int glu) {
+    WidePlan p;
+    if (M < 1 || M > 2 || K > 8192 || K % KB || N % NT || (glu && N % 32)) return 0;
+    return plan_wide(N, K, glu != 0, &p) ? p.splits : 0;
+}
+
+int vmx_int4_gemm_partial_norm(const void *packed, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq, float *partial,
+                               int M, int N, int K, int group, hipStream_t st) {
+    WidePlan p;
+    VMX_REQUIRE(vmx_int4_norm_splits(M, N, K, 0) > 0 && plan_wide(N, K, false, &p), "int4_gemm_partial_norm: shape [%d x %d -> %d] not supported", M, K, N);
+    return launch_wide<false>(p, packed, h, norm_w, eps, ssq, partial, nullptr, M, N, K, group, st);
+}
+
+int vmx_int4_gemm_glu_norm(const void *packed, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq, uint16_t *act, int M,
+                           int N, int K, int group, hipStream_t st) {
+    WidePlan p;
+    VMX_REQUIRE(vmx_int4_norm_splits(M, N, K, 1) == 1 && plan_wide(N, K, true, &p), "int4_gemm_glu_norm: shape [%d x %d -> %d] not supported", M, K, N);
+    return launch_wide<true>(p, packed, h, norm_w, eps, ssq, nullptr, act, M, N, K, group, st);
+}
+
+// h[M][N] = bf16(h + bf16(x W)) in one launch; ssq[M][N/16] = per-tile sums of squares of the new h
+int vmx_int4_gemm_resid(const void *packed, const uint16_t *x, uint16_t *h, float *ssq, int M, int N, int K, int group, hipStream_t st) {
+    VMX_REQUIRE(vmx_int4_resid_fusable(M, N, K), "int4_gemm_resid: shape [%d x %d -> %d] not supported", M, K, N);
+    const uint4 *W = (const uint4 *)packed;
+    const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
+    const int upw = K / (16 * KB);
+    // VMX_INT4_RESID_LDS: pad the workgroup's LDS request (bytes) to steer how many workgroups share a CU (measurement aid)
+    static const int lds_pad = tune("VMX_INT4_RESID_LDS", 0);
+    size_t lds = (((size_t)2 * (K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(K / KB) * 16 * 4 * 2 + 16 * 16 * 4 * 4;
+    if ((size_t)lds_pad > lds) lds = lds_pad;
+    const dim3 grid((unsigned)(N / NT)), block(1024);
+#define RSD(U)                                                                                                                         \
+    do {                                                                                                                               \
+        if (lds > 64 * 1024)                                                                                                           \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_resid_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((int4_gemm_resid_kernel<U>), grid, block, lds, st, W, SZ, x, h, ssq, M, N, K, group);                            \
+    } while (0)
+    switch (upw) {
+        case 1: RSD(1); break;
+        case 2: RSD(2); break;
+        case 3: RSD(3); break;
+        case 4: RSD(4); break;
+        case 5: RSD(5); break;
+        case 6: RSD(6); break;
+        case 7: RSD(7); break;
+        default: RSD(8); break;
+    }
+#undef RSD
+    VMX_CHECK_LAUNCH("int4_gemm(resid)");
     return VMX_OK;
 }
 

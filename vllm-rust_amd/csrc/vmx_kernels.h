@@ -18,6 +18,16 @@ int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk
                              const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts, int hidden,
                              int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st);
 int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int M, int N, int K, int group, hipStream_t st);
+// decode rows (M <= 2): RMSNorm of the residual stream in the prologue (q|k|v, gate|up) and the residual add in the epilogue
+// (o_proj, down_proj), so that a dense int4 layer is five launches
+int vmx_int4_norm_splits(int M, int N, int K, int glu);   // split-K slices of the _norm forms; 0 = shape not supported
+bool vmx_int4_resid_fusable(int M, int N, int K);
+// ssq [M][hidden/16] f32: sums of squares of the 16-column tiles of h, written by _resid and read by the _norm forms
+int vmx_int4_gemm_partial_norm(const void *packed, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq, float *partial,
+                               int M, int N, int K, int group, hipStream_t st);
+int vmx_int4_gemm_glu_norm(const void *packed, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq, uint16_t *act, int M,
+                           int N, int K, int group, hipStream_t st);
+int vmx_int4_gemm_resid(const void *packed, const uint16_t *x, uint16_t *h, float *ssq, int M, int N, int K, int group, hipStream_t st);
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
                          int N, int group, int Ntot, int col0, hipStream_t st);
 
