@@ -178,3 +178,24 @@ def test_llama_cpp_name_map():
         assert got == exp, c
     assert go.llama_cpp_names("model.layers.5.post_attention_layernorm") == ["blk.5.post_attention_norm", "blk.5.ffn_norm"]
     assert lib.vmx_gguf_llama_cpp_name(b"model.norm", 0, C.create_string_buffer(4), 4) == 0   # buffer too small
+
+
+def test_crafted_lengths_do_not_allocate_or_overflow():
+    """Length fields larger than the data that follows are refused before anything is resized (a 2^27-element array or a
+    1 GiB string announced by a 40-byte header), and a tensor whose element count wraps around 2^64 or is not a whole
+    number of blocks is an error instead of an undersized tensor."""
+    from vllm_rust_amd._lib import lib
+    hdr = b"GGUF" + struct.pack("<IQQ", 3, 0, 1) + _s("k", 3)
+    big_array = hdr + struct.pack("<I", 9) + struct.pack("<I", 4) + struct.pack("<Q", 1 << 27)
+    rc, _ = _open(lib, big_array)
+    assert rc == -1 and b"unexpected end of data" in lib.vmx_last_error()
+    big_string = hdr + struct.pack("<I", 8) + struct.pack("<Q", 1 << 30)
+    rc, _ = _open(lib, big_string)
+    assert rc == -1
+    wrap = b"GGUF" + struct.pack("<IQQ", 3, 1, 0) + _s("w", 3) + struct.pack("<I", 2) + struct.pack("<QQ", 1 << 33, 1 << 33)
+    wrap += struct.pack("<I", 0) + struct.pack("<Q", 0)
+    rc, _ = _open(lib, wrap)
+    assert rc == -1 and b"'w'" in lib.vmx_last_error() and b"overflows" in lib.vmx_last_error()
+    ragged, _ = build_gguf(3, [], [("r", [100, 3], 18)], payload=False)   # 300 elements, 256-element blocks
+    rc, _ = _open(lib, ragged)
+    assert rc == -1 and b"not a multiple" in lib.vmx_last_error()

@@ -94,16 +94,18 @@ template <int HD, bool FP8> struct AttnTile {
 // Request tile [t0, min(t0 + 16, p1)): lane (token tl, dim group dg) takes 16-byte pieces of its token's K row, and every
 // V row of the tile is one coalesced wave access (row base broadcast from the lane that owns the token).  Lanes past the
 // end re-read the last valid row; their logits are masked later.
-template <int HD, bool FP8>
+// BTREG: lane l of bt_reg holds the sequence's block-table entry l (read once at kernel start) and the lookup is a lane
+// exchange instead of a dependent global load.
+template <int HD, bool FP8, bool BTREG = false>
 __device__ __forceinline__ void attn_tile_load(AttnTile<HD, FP8> &t, const void *__restrict__ k_cache, const void *__restrict__ v_cache,
                                                const int32_t *__restrict__ bt_row, int t0, int p1, int block_size, int64_t tok_stride,
-                                               int kvh, int lane) {
+                                               int kvh, int lane, int bt_reg = 0) {
     constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1;
     const int tl = lane & 15, dg = lane >> 4;
     const bool lane_live = (HD >= 128) || (lane < 32);
     const int ntok = min(16, p1 - t0);
     const int tok = t0 + min(tl, ntok - 1);
-    const int blk = bt_row[tok / block_size];
+    const int blk = BTREG ? __shfl(bt_reg, tok / block_size, 64) : bt_row[tok / block_size];
     const int64_t base = ((int64_t)blk * block_size + tok % block_size) * tok_stride + (int64_t)kvh * HD;
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) t.kraw[i] = load8_raw<FP8>(k_cache, base + 32 * i + 8 * dg);
@@ -192,11 +194,12 @@ __device__ __forceinline__ void attn_tile_fold(const AttnTile<HD, FP8> &t, int n
 // qa: the q rows as MFMA A fragments (lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)); bt_row: the
 // sequence's block-table row.  `first` holds tile p0 when first_loaded (requested by the caller ahead of other work).
 // Returns running max / sum per head row 4*dg + r and the un-normalised output accumulator.
-template <int HD, int QPK, bool FP8>
+template <int HD, int QPK, bool FP8, bool BTREG = false>
 __device__ __forceinline__ void attn_walk(const uint4 (&qa)[HD / 32], const void *__restrict__ k_cache, const void *__restrict__ v_cache,
                                           const int32_t *__restrict__ bt_row, int p0, int p1, int block_size, int64_t tok_stride,
                                           int kvh, float lscale, float vsc, int lane, float (&m_run)[4], float (&s_run)[4],
-                                          float (&o)[QPK][HD >= 128 ? HD / 128 : 1][2], AttnTile<HD, FP8> &first, bool first_loaded) {
+                                          float (&o)[QPK][HD >= 128 ? HD / 128 : 1][2], AttnTile<HD, FP8> &first, bool first_loaded,
+                                          int bt_reg = 0) {
     constexpr int NP = HD >= 128 ? HD / 128 : 1;
 #pragma unroll
     for (int r = 0; r < 4; r++) { m_run[r] = -FLT_MAX; s_run[r] = 0.f; }
@@ -204,11 +207,11 @@ __device__ __forceinline__ void attn_walk(const uint4 (&qa)[HD / 32], const void
     for (int h = 0; h < QPK; h++)
 #pragma unroll
         for (int p = 0; p < NP; p++) o[h][p][0] = o[h][p][1] = 0.f;
-    if (!first_loaded) attn_tile_load<HD, FP8>(first, k_cache, v_cache, bt_row, p0, p1, block_size, tok_stride, kvh, lane);
+    if (!first_loaded) attn_tile_load<HD, FP8, BTREG>(first, k_cache, v_cache, bt_row, p0, p1, block_size, tok_stride, kvh, lane, bt_reg);
     for (int t0 = p0; t0 < p1; t0 += 16) {   // the next tile is requested before the current one is folded
         AttnTile<HD, FP8> next;
         const bool more = t0 + 16 < p1;
-        if (more) attn_tile_load<HD, FP8>(next, k_cache, v_cache, bt_row, t0 + 16, p1, block_size, tok_stride, kvh, lane);
+        if (more) attn_tile_load<HD, FP8, BTREG>(next, k_cache, v_cache, bt_row, t0 + 16, p1, block_size, tok_stride, kvh, lane, bt_reg);
         attn_tile_fold<HD, QPK, FP8>(first, min(16, p1 - t0), qa, lscale, vsc, lane, m_run, s_run, o);
         if (more) first = next;
     }
@@ -522,6 +525,213 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The one-launch kernel above puts a KV head's whole context on ONE compute unit, and a CU can only keep so many cache
+// lines in flight: at a few hundred tokens it spends most of its time waiting for K/V rows (measured with in-kernel
+// clock stamps: ~5 us of a 13 us launch until the tiles have landed, the rest a chain of dependent round trips).  This
+// variant spreads a KV head over P workgroups -- grid (kv_heads, seqs, P), NW waves each, P * kv_heads CUs pulling rows --
+// and leaves the merge of the P partition results to the consumer (the o_proj linear merges them while it stages its
+// activations: vmx_int4_gemm_resid_attn), so it is still one launch:
+//   A  every workgroup derives the q heads of its KV head from the qkv linear's split-K sums (same arithmetic and
+//      rounding points as above); only the workgroup whose range holds the new token also derives k and v and writes them
+//      to the cache -- no other workgroup reads that row;
+//   B  the tiles of [start, seq_len) are dealt to the workgroups in P contiguous ranges (balanced from seq_len), inside a
+//      workgroup to its waves in contiguous sub-ranges, each walked with the online softmax of attn_walk;
+//   C  the waves' states are merged through LDS and the partition's normalised output, max logit and sum go to
+//      tmp_out / max_logits / exp_sums [seq][head][P] (a partition without tokens writes sum 0 and a zero row).
+template <int HD, int QPK, bool FP8, int NW>
+__global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
+    float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const float *__restrict__ partial, int splits,
+    int tokens, void *__restrict__ k_cache, void *__restrict__ v_cache, const uint16_t *__restrict__ q_norm_w,
+    const uint16_t *__restrict__ k_norm_w, float eps, const float *__restrict__ cos_sin, const int32_t *__restrict__ positions,
+    const int32_t *__restrict__ slots, const int32_t *__restrict__ block_tables, const int32_t *__restrict__ seq_lens, float scale, int Hq,
+    int Hkv, int rot_dim, int max_blocks_per_seq, int block_size, int window, const float *__restrict__ k_scale_ptr,
+    const float *__restrict__ v_scale_ptr, int v_norm) {
+    constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1, EPL = HD / 64;
+    const int nq = Hq / Hkv, P = gridDim.z;
+    extern __shared__ __align__(16) unsigned char smem_attn[];
+    uint16_t *qs = reinterpret_cast<uint16_t *>(smem_attn);                      // [QPK][HD] bf16
+    float *mo = reinterpret_cast<float *>(smem_attn + QPK * HD * 2);             // [NW][QPK][HD]
+    float *mm = mo + NW * QPK * HD;                                              // [NW][QPK] max
+    float *ms = mm + NW * QPK;                                                   // [NW][QPK] sum
+    const int kvh = blockIdx.x, seq = blockIdx.y, part = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tl = lane & 15, dg = lane >> 4;
+    // The launch is a chain of memory round trips, so whatever has a known address is requested at once: the three per-row
+    // scalars, the block-table row (lane l = entry l; tile lookups are then lane exchanges), and below the wave's head of the
+    // qkv sums with its norm weights -- none of them waits for seq_len.
+    const int seq_len = seq_lens[seq];
+    const int pos = positions[seq];
+    const int slot = slots[seq];
+    const int32_t *bt_row = block_tables + (int64_t)seq * max_blocks_per_seq;
+    const int bt_reg = bt_row[min(lane, max_blocks_per_seq - 1)];
+    const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
+    const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
+
+    // ---- A (loads): head `wave` of this KV head's q heads, then k, then v (NW >= nq + 2 waves, checked on the host)
+    const bool has_head = wave < nq + 2;
+    const bool is_q = wave < nq, is_k = wave == nq;
+    float v[EPL], nwf[EPL];
+    {
+        const int head = is_q ? kvh * nq + wave : (is_k ? Hq + kvh : Hq + Hkv + kvh);
+        const int ntot = (Hq + 2 * Hkv) * HD;
+        const int64_t slice = (int64_t)tokens * ntot, base = (int64_t)seq * ntot + (int64_t)(has_head ? head : 0) * HD;
+        const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            float a = 0.f;
+            for (int sp = 0; sp < splits; sp++) a += partial[sp * slice + base + lane + 64 * j];
+            v[j] = a;
+            nwf[j] = nw ? vmx_bf16_to_f32(nw[lane + 64 * j]) : 1.0f;
+        }
+    }
+    // rotation factors of this lane's pairs (position known after the first round trip)
+    const int half = rot_dim >> 1;
+    const float *cs = cos_sin + (int64_t)pos * rot_dim;
+    float rc[EPL], rs[EPL];   // (half & 63) == 0: cos / sin of pair j < half/64; half == 32: of pair lane & 31 in [0]
+#pragma unroll
+    for (int j = 0; j < EPL; j++) { rc[j] = 1.f; rs[j] = 0.f; }
+    if ((half & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < EPL / 2; j++)
+            if (j < (half >> 6)) { rc[j] = cs[lane + 64 * j]; rs[j] = cs[half + lane + 64 * j]; }
+    } else {
+        rc[0] = cs[lane & 31];
+        rs[0] = cs[32 + (lane & 31)];
+    }
+
+    // ---- tiles of this workgroup / wave (needs seq_len), and the wave's first tile if it lies before the new token
+    const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
+    const int T = (seq_len - start + 15) >> 4;                  // tiles of this sequence
+    const int tpp = (T + P - 1) / P;                            // tiles per workgroup
+    const int g0 = part * tpp, g1 = min(g0 + tpp, T);           // this workgroup's tiles
+    const bool owner = seq_len > 0 && g0 < T && g1 == T;        // its range ends with the tile of the new token
+    const int tpw = (max(g1 - g0, 0) + NW - 1) / NW;            // tiles per wave
+    const int w0 = g0 + wave * tpw, w1 = min(w0 + tpw, g1);
+    const bool active = seq_len > 0 && w0 < w1;
+    const int p0 = start + 16 * w0, p1 = min(start + 16 * w1, seq_len);
+    // block-table entries in a register: every token of the walk lies in the first 64 blocks
+    const bool bt_regs = (seq_len + block_size - 1) / block_size <= 64;
+    AttnTile<HD, FP8> tile;
+    const bool pre = active && p0 + 16 < seq_len;
+    if (pre) {
+        if (bt_regs) attn_tile_load<HD, FP8, true>(tile, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, lane, bt_reg);
+        else attn_tile_load<HD, FP8, false>(tile, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, lane);
+    }
+
+    // ---- A (arithmetic): bf16 round, optional per-head RMSNorm, NeoX RoPE; q -> LDS, k and v -> cache (owner only)
+    if (has_head && g0 < T && (is_q || owner)) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j]));
+            ss += v[j] * v[j];
+        }
+        const bool normed = is_q ? q_norm_w != nullptr : (is_k ? k_norm_w != nullptr : v_norm != 0);
+        if (normed) {   // v_norm: RMSNorm without weight on the value head (gemma4_quantized.rs:1311-1424)
+            ss = vmx_wave_sum(ss);
+            const float inv = rsqrtf(ss / (float)HD + eps);
+#pragma unroll
+            for (int j = 0; j < EPL; j++) v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j] * inv * nwf[j]));
+        }
+        if (is_q || is_k) {   // NeoX rotation of the first rot_dim dims: pairs (i, i + rot_dim/2)
+            if ((half & 63) == 0) {   // partner in the same lane: element j pairs with j + half/64
+                const int hj = half >> 6;
+#pragma unroll
+                for (int j = 0; j < EPL / 2; j++) {
+                    if (j < hj) {
+                        const float xv = v[j], yv = v[j + hj];
+                        v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(xv * rc[j] - yv * rs[j]));
+                        v[j + hj] = vmx_bf16_to_f32(vmx_f32_to_bf16(yv * rc[j] + xv * rs[j]));
+                    }
+                }
+            } else {                  // half == 32 (checked on the host): partner is lane ^ 32 of element 0
+                const float other = __shfl_xor(v[0], 32, 64);
+                v[0] = vmx_bf16_to_f32(vmx_f32_to_bf16(lane < 32 ? v[0] * rc[0] - other * rs[0] : v[0] * rc[0] + other * rs[0]));
+            }
+        }
+        if (is_q) {
+#pragma unroll
+            for (int j = 0; j < EPL; j++) qs[wave * HD + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+        } else if (slot >= 0) {
+            const int64_t dst = ((int64_t)slot * Hkv + kvh) * HD;
+            void *cache = is_k ? k_cache : v_cache;
+            if constexpr (!FP8) {
+#pragma unroll
+                for (int j = 0; j < EPL; j++) ((uint16_t *)cache)[dst + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+            } else {
+                const float sc = is_k ? ksc : vsc;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) {
+                    float a = v[j] / sc;
+                    a = fminf(fmaxf(a, -448.0f), 448.0f);
+                    a = vmx_bf16_to_f32(vmx_f32_to_bf16(a));
+                    ((uint8_t *)cache)[dst + lane + 64 * j] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, a, 0, false) & 0xFFu);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- B
+    float m_run[4], s_run[4];
+    float o[QPK][NP][2];
+    if (active) {   // wave-uniform
+        uint4 qa[KSTEPS];
+#pragma unroll
+        for (int i = 0; i < KSTEPS; i++) {
+            qa[i] = make_uint4(0, 0, 0, 0);
+            if (tl < nq) qa[i] = *reinterpret_cast<const uint4 *>(qs + tl * HD + 32 * i + 8 * dg);
+        }
+        if (bt_regs)
+            attn_walk<HD, QPK, FP8, true>(qa, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, scale * ksc, vsc, lane,
+                                          m_run, s_run, o, tile, pre, bt_reg);
+        else
+            attn_walk<HD, QPK, FP8, false>(qa, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, scale * ksc, vsc, lane,
+                                           m_run, s_run, o, tile, pre);
+    }
+    const bool lane_live = (HD >= 128) || (lane < 32);
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        float sh = 0.f, mh = -FLT_MAX;
+        if (active) {
+            sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_run[h & 3]), 16 * (h >> 2)));
+            mh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run[h & 3]), 16 * (h >> 2)));
+        }
+        if (lane == 0) { mm[wave * QPK + h] = mh; ms[wave * QPK + h] = sh; }
+        if (active && lane_live) {
+            const float inv = 1.0f / (sh + 1e-6f);
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                *reinterpret_cast<float2 *>(mo + (wave * QPK + h) * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
+        }
+    }
+    __syncthreads();
+
+    // ---- C: this workgroup's partition result
+    const int nwv = g0 < g1 ? min(NW, (g1 - g0 + tpw - 1) / tpw) : 0;   // waves that saw tokens
+    for (int idx = tid; idx < nq * HD; idx += 64 * NW) {
+        const int h = idx / HD, d = idx % HD;
+        float val = 0.f, gmax = -FLT_MAX, gsum = 0.f;
+        if (nwv == 1) {
+            val = mo[h * HD + d];
+            gmax = mm[h];
+            gsum = ms[h];
+        } else if (nwv > 1) {
+            for (int w = 0; w < nwv; w++) gmax = fmaxf(gmax, mm[w * QPK + h]);
+            float acc = 0.f;
+            for (int w = 0; w < nwv; w++) {
+                const float wt = ms[w * QPK + h] * __expf(mm[w * QPK + h] - gmax);
+                gsum += wt;
+                acc += mo[(w * QPK + h) * HD + d] * wt;
+            }
+            val = acc * (1.0f / (gsum + 1e-6f));
+        }
+        const int64_t po = ((int64_t)seq * Hq + kvh * nq + h) * P + part;
+        tmp_out[po * HD + d] = val;
+        if (d == 0) { max_logits[po] = gmax; exp_sums[po] = gsum; }
+    }
+}
+
 // waves per workgroup: 16 where a thread may hold 128 registers' worth of tiles, 8 for 256-wide heads; context bound = 4 tiles
 // per wave
 constexpr int fused_nw(int hd) { return hd <= 128 ? 16 : 8; }
@@ -540,6 +750,22 @@ int launch_fused(dim3 grid, hipStream_t st, uint16_t *out, const float *partial,
     hipLaunchKernelGGL((fused_decode_attn_kernel<HD, QPK, FP8, FUSED_NW>), grid, dim3(64 * FUSED_NW), lds, st, out, partial, splits, tokens,
                        kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks, vs, aq, ad, v_norm);
     VMX_CHECK_LAUNCH("fused_decode_attention");
+    return VMX_OK;
+}
+
+template <int HD, int QPK, bool FP8, int NW>
+int launch_split(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const float *partial, int splits, int tokens,
+                 void *kc, void *vc, const uint16_t *qn, const uint16_t *kn, float eps, const float *cos_sin, const int32_t *positions,
+                 const int32_t *slots, const int32_t *bt, const int32_t *sl, float scale, int Hq, int Hkv, int rot_dim, int mbps, int bs,
+                 int window, const float *ks, const float *vs, int v_norm) {
+    const size_t lds = (size_t)QPK * HD * 2 + (size_t)NW * QPK * HD * 4 + (size_t)2 * NW * QPK * 4;
+    if (lds > 64 * 1024)
+        VMX_CHECK_HIP(hipFuncSetAttribute((const void *)split_decode_attn_kernel<HD, QPK, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+    hipLaunchKernelGGL((split_decode_attn_kernel<HD, QPK, FP8, NW>), grid, dim3(64 * NW), lds, st, tmp_out, exp_sums, max_logits, partial,
+                       splits, tokens, kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks,
+                       vs, v_norm);
+    VMX_CHECK_LAUNCH("split_decode_attention");
     return VMX_OK;
 }
 
@@ -860,6 +1086,68 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
 #undef FARGS
     if (rc == VMX_EUNSUPPORTED)
         vmx_set_error("fused_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head)", head_dim, num_heads / num_kv_heads);
+    return rc;
+}
+
+// ---- decode attention spread over P workgroups per KV head, merged by the consumer (split_decode_attn_kernel)
+// Partition count for a context bound, 0 = not covered.  VMX_SPLIT_ATTN_P overrides the count for contexts up to 1024
+// tokens (measurement), VMX_NO_SPLIT_ATTN=1 switches the path off.
+int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
+    static const bool off = getenv("VMX_NO_SPLIT_ATTN") && atoi(getenv("VMX_NO_SPLIT_ATTN"));
+    static const int p_env = getenv("VMX_SPLIT_ATTN_P") ? atoi(getenv("VMX_SPLIT_ATTN_P")) : 0;
+    if (off || (head_dim != 64 && head_dim != 128) || qpk < 1 || qpk > 8) return 0;
+    const int half = rot_dim / 2;
+    if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return 0;
+    const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
+    if (ctx <= 0 || ctx > 8192) return 0;
+    if (ctx <= 1024) return p_env >= 1 && p_env <= 8 ? p_env : 4;
+    return 8;
+}
+
+size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim) {
+    return (size_t)num_seqs * num_heads * 8 * ((size_t)head_dim + 2) * 4;
+}
+
+int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
+                               const uint16_t *q_norm_w, const uint16_t *k_norm_w, float eps, const float *cos_sin,
+                               const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
+                               float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
+                               int max_blocks_per_seq, int max_seq_len, int block_size, int window, int kv_dtype, const float *k_scale,
+                               const float *v_scale, int v_norm, hipStream_t st) {
+    const int qpk = qpk_capacity(num_heads / num_kv_heads);
+    const int P = vmx_split_decode_attention_parts(head_dim, num_heads / num_kv_heads, rot_dim, max_seq_len, window);
+    VMX_REQUIRE(P > 0 && workspace && out, "split_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head, context %d)",
+                head_dim, num_heads / num_kv_heads, max_seq_len);
+    const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
+    const bool wide = ctx > 1024;   // 16 waves per workgroup for the long contexts, else 8 (one per head of phase A)
+    const size_t rows = (size_t)num_seqs * num_heads * P;
+    out->tmp_out = (float *)workspace;
+    out->exp_sums = out->tmp_out + rows * head_dim;
+    out->max_logits = out->exp_sums + rows;
+    out->max_parts = P;
+    out->part_tokens = 0;
+    const dim3 grid(num_kv_heads, num_seqs, P);
+    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
+    int rc = VMX_EUNSUPPORTED;
+#define SARGS grid, st, out->tmp_out, out->exp_sums, out->max_logits, qkv_partial, splits, num_seqs, k_cache, v_cache, q_norm_w, k_norm_w, eps, \
+              cos_sin, positions, slots, block_tables, seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size,     \
+              window, k_scale, v_scale, v_norm
+#define S_ONE(HD, Q)                                                                                                          \
+    rc = wide ? (fp8 ? launch_split<HD, Q, true, 16>(SARGS) : launch_split<HD, Q, false, 16>(SARGS))                           \
+              : (fp8 ? launch_split<HD, Q, true, (Q + 2 > 8 ? 16 : 8)>(SARGS) : launch_split<HD, Q, false, (Q + 2 > 8 ? 16 : 8)>(SARGS))
+#define S_QPK(HD)                       \
+    switch (qpk) {                      \
+        case 1: S_ONE(HD, 1); break;    \
+        case 2: S_ONE(HD, 2); break;    \
+        case 4: S_ONE(HD, 4); break;    \
+        case 8: S_ONE(HD, 8); break;    \
+        default: break;                 \
+    }
+    if (head_dim == 64) { S_QPK(64) } else if (head_dim == 128) { S_QPK(128) }
+#undef S_QPK
+#undef S_ONE
+#undef SARGS
+    if (rc == VMX_EUNSUPPORTED) vmx_set_error("split_decode_attention: geometry not covered");
     return rc;
 }
 

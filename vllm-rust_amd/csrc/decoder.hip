@@ -626,7 +626,11 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
         TRY(m->moe_out.alloc((size_t)B * H * 2));
     }
     TRY(m->keys.alloc((size_t)c.max_batch * 8));
-    TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(c.max_batch, c.num_heads, hd, c.max_seq_len)));
+    {
+        const size_t a = vmx_paged_attention_workspace_bytes(c.max_batch, c.num_heads, hd, c.max_seq_len);
+        const size_t b = vmx_split_decode_attention_workspace_bytes(c.max_batch, c.num_heads, hd);
+        TRY(m->attn_ws.alloc(a > b ? a : b));
+    }
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(c.max_batch, VL)));
 #undef TRY
     if (rc) {
@@ -880,6 +884,13 @@ extern "C" int vmx_qwen3_load_exl3_linear(vmx_qwen3 *m, int layer, int slot, con
 }
 
 namespace {
+// A mixture-of-experts model runs int4 attention projections plus the expert tables; a dense one needs all seven
+// projections in ONE of the three formats.
+bool layer_ready(const vmx_qwen3 *m, const Layer &L) {
+    if (m->cfg.num_experts > 0) return L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts);
+    return L.int4_ready() || L.iq_ready() || L.exl3_ready();
+}
+
 // VMX_NO_FOLDED_LAYERS=1 keeps the seven-launch layer (norm kernels of their own) for A/B measurements
 bool folded_layers_enabled() {
     static const bool on = !(getenv("VMX_NO_FOLDED_LAYERS") && atoi(getenv("VMX_NO_FOLDED_LAYERS")));
@@ -954,8 +965,21 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             if (int rc = iq_forward(m, L.iq[VMX_L_V], PA + NQ + NKV, NQKV_, B, st)) return rc;
         } else if (int rc = run_linear(m, L.qkv, x, PA, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
-        const bool fused_attn = prefill_offset < 0 && !m->rows_share_cache && vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
-        if (fused_attn) {
+        // five-launch layers: attention spread over several workgroups per KV head, merged by o_proj while it stages its activations
+        const bool split_attn = fold && prefill_offset < 0 && !m->rows_share_cache && NQ <= 4 * 16 * 128 &&
+                                vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0) > 0;
+        VmxAttnParts sparts{};
+        const bool fused_attn = !split_attn && prefill_offset < 0 && !m->rows_share_cache &&
+                                vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
+        if (split_attn) {
+            if (int rc = vmx_split_decode_attention(&sparts, m->attn_ws.p, PA, s_qkv, L.k_cache.p, L.v_cache.p,
+                                                    c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
+                                                    c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
+                                                    (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
+                                                    Hkv, hd, hd, max_blocks_per_seq, max_seq_len, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, 0,
+                                                    st))
+                return rc;
+        } else if (fused_attn) {
             if (int rc = vmx_fused_decode_attention(attn, PA, s_qkv, L.k_cache.p, L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
@@ -967,7 +991,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                            c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
                            slot_mapping, Hq, Hkv, hd, hd, fp8, ks, ks + 1);
-        if (fused_attn) {
+        if (fused_attn || split_attn) {
         } else if (prefill_offset >= 0) {
             if (int rc = vmx_prefill_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, scale, Hq, Hkv, hd,
                                                     c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, st))
@@ -985,7 +1009,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                 return rc;
         }
         if (fold) {   // h += o_proj(attn);  act = glu(gate|up(rms_norm(h)));  h += down(act)
-            if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, B, H, NQ, L.o.group, st)) return rc;
+            if (split_attn) {
+                if (int rc = vmx_int4_gemm_resid_attn(L.o.packed.p, &sparts, hd, h, ssq, B, H, NQ, L.o.group, st)) return rc;
+            } else if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, B, H, NQ, L.o.group, st)) return rc;
             if (int rc = vmx_int4_gemm_glu_norm(L.gate_up.packed.p, h, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, ssq, act, B, 2 * I, H,
                                                 L.gate_up.group, st))
                 return rc;
@@ -1114,8 +1140,7 @@ extern "C" int vmx_qwen3_decode(vmx_qwen3 *m, const int32_t *input_ids, const in
     VMX_REQUIRE(batch >= 1 && batch <= c.max_batch, "qwen3_decode: batch %d exceeds max_batch %d", batch, c.max_batch);
     VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "qwen3_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
                 c.max_seq_len);
-    for (const Layer &L : m->layers)
-        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || L.exl3_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_decode: weights not fully loaded");
+    for (const Layer &L : m->layers) VMX_REQUIRE(layer_ready(m, L), "qwen3_decode: weights not fully loaded");
     const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
     VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
     if (int rc = run_layers(m, input_ids, positions, slot_mapping, block_tables, seq_lens, batch, max_blocks_per_seq, max_seq_len, -1,
@@ -1135,8 +1160,7 @@ extern "C" int vmx_qwen3_prefill(vmx_qwen3 *m, const int32_t *input_ids, int seq
     VMX_REQUIRE(q_len >= 1 && q_len <= c.max_prefill_tokens, "qwen3_prefill: q_len %d exceeds max_prefill_tokens %d", q_len, c.max_prefill_tokens);
     VMX_REQUIRE(seqlen_offset >= 0 && seqlen_offset + q_len <= c.max_position, "qwen3_prefill: positions %d..%d exceed max_position %d",
                 seqlen_offset, seqlen_offset + q_len - 1, c.max_position);
-    for (const Layer &L : m->layers)
-        VMX_REQUIRE((L.int4_ready() || L.iq_ready() || L.exl3_ready() || (L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts))), "qwen3_prefill: weights not fully loaded");
+    for (const Layer &L : m->layers) VMX_REQUIRE(layer_ready(m, L), "qwen3_prefill: weights not fully loaded");
     const bool tp = c.tp_size > 1 || m->comm != nullptr;
     VMX_REQUIRE(!tp || m->comm, "qwen3_prefill: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
     hipStream_t st = vmx_stream(stream);
@@ -1240,17 +1264,23 @@ extern "C" int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, do
 
 namespace {
 // ids <- next token; position, seq_len += 1; slot from the block table (host-side engine bookkeeping of
-// the reference, done on the device so that consecutive steps can be replayed from one graph).
+// the reference, done on the device so that consecutive steps can be replayed from one graph).  A row whose next position
+// would fall outside its block-table row (max_blocks_per_seq * block_size tokens) is frozen: slot = -1, position and seq_len
+// keep their values, so replaying a graph past the capacity cannot overwrite live cache rows.  The caller keeps that
+// capacity within the model's max_position / max_seq_len.
 __global__ void decode_advance_kernel(int32_t *ids, const int32_t *next_ids, int32_t *positions, int32_t *slots, int32_t *seq_lens,
                                       const int32_t *block_tables, int batch, int max_blocks_per_seq, int block_size) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const int p = positions[b] + 1;
     ids[b] = next_ids[b];
+    if (p >= max_blocks_per_seq * block_size) {   // the row's block table is full: it stops advancing and writes no more K/V rows
+        slots[b] = -1;
+        return;
+    }
     positions[b] = p;
     seq_lens[b] = p + 1;
-    const int blk = min(p / block_size, max_blocks_per_seq - 1);
-    slots[b] = block_tables[b * max_blocks_per_seq + blk] * block_size + p % block_size;
+    slots[b] = block_tables[b * max_blocks_per_seq + p / block_size] * block_size + p % block_size;
 }
 }  // namespace
 

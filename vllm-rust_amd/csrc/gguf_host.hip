@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <map>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -53,7 +54,10 @@ struct Reader {
     const uint8_t *p = nullptr;
     size_t n = 0, pos = 0;
     FILE *f = nullptr;
+    uint64_t fsize = 0;   // file mode: total bytes
     bool fail = false;
+    // bytes that can still be read: every length field of the header is checked against it before anything is resized
+    uint64_t remaining() const { return f ? (fsize > pos ? fsize - pos : 0) : (uint64_t)(n - pos); }
     bool take(void *dst, size_t k) {
         if (fail) return false;
         if (f) {
@@ -78,7 +82,7 @@ struct Reader {
     uint64_t count(bool is64) { return is64 ? le<uint64_t>() : (uint64_t)le<uint32_t>(); }
     bool str(bool is64, std::string &out) {
         const uint64_t len = count(is64);
-        if (fail || len > ((uint64_t)1 << 31)) { fail = true; return false; }
+        if (fail || len > ((uint64_t)1 << 31) || len > remaining()) { fail = true; return false; }
         out.resize((size_t)len);
         return len == 0 || take(&out[0], (size_t)len);
     }
@@ -108,6 +112,7 @@ int read_value(Reader &r, uint32_t type, bool is64, MetaValue &v, int depth) {
             const uint64_t len = r.count(is64);
             if (r.fail) return 0;
             if (len > ((uint64_t)1 << 28)) { vmx_set_error("GGUF: metadata array of %llu elements", (unsigned long long)len); return -1; }
+            if (len > r.remaining()) { r.fail = true; return 0; }   // an element takes at least one byte
             v.arr.resize((size_t)len);
             for (size_t i = 0; i < v.arr.size(); i++) {
                 const int rc = read_value(r, v.elem_type, is64, v.arr[i], depth + 1);
@@ -136,7 +141,33 @@ struct vmx_gguf {
 };
 
 namespace {
+// product of the dims with overflow check
+bool element_count(const TensorInfo &t, uint64_t *out) {
+    uint64_t n = 1;
+    for (uint64_t d : t.shape) {
+        if (d != 0 && n > UINT64_MAX / d) return false;
+        n *= d;
+    }
+    *out = n;
+    return true;
+}
+
+int parse_unguarded(Reader &r, vmx_gguf *g);
+
+// The parser allocates from lengths it reads; an allocation failure or any other C++ exception must not cross the C ABI.
 int parse(Reader &r, vmx_gguf *g) {
+    try {
+        return parse_unguarded(r, g);
+    } catch (const std::bad_alloc &) {
+        vmx_set_error("GGUF: out of host memory while reading the header");
+        return VMX_ENOMEM;
+    } catch (const std::exception &e) {
+        vmx_set_error("GGUF: %s", e.what());
+        return VMX_EINVAL;
+    }
+}
+
+int parse_unguarded(Reader &r, vmx_gguf *g) {
     char magic[4] = {0, 0, 0, 0};
     r.take(magic, 4);
     if (r.fail || memcmp(magic, "GGUF", 4) != 0) {
@@ -177,6 +208,12 @@ int parse(Reader &r, vmx_gguf *g) {
             vmx_set_error("GGUF tensor '%s': unsupported GGML type id %u", ti.name.c_str(), ti.ggml_type);
             return VMX_EUNSUPPORTED;
         }
+        uint64_t elems = 0;
+        if (!element_count(ti, &elems) || elems % bs != 0 || elems / bs > UINT64_MAX / ts) {
+            vmx_set_error("GGUF tensor '%s': element count overflows or is not a multiple of the %u-element block of type %u", ti.name.c_str(),
+                          bs, ti.ggml_type);
+            return VMX_EINVAL;
+        }
         g->by_name[ti.name] = (int)g->tensors.size();
         g->tensors.push_back(std::move(ti));
     }
@@ -199,11 +236,11 @@ int parse(Reader &r, vmx_gguf *g) {
     return VMX_OK;
 }
 
-uint64_t tensor_bytes(const TensorInfo &t) {
+uint64_t tensor_bytes(const TensorInfo &t) {   // cannot overflow: checked when the header was parsed
     uint32_t ts = 0, bs = 1;
     type_geometry(t.ggml_type, &ts, &bs);
     uint64_t n = 1;
-    for (uint64_t d : t.shape) n *= d;
+    element_count(t, &n);
     return n / bs * ts;
 }
 }  // namespace
@@ -229,6 +266,11 @@ extern "C" int vmx_gguf_open(const char *path, vmx_gguf **out) {
     if (!g) { fclose(f); vmx_set_error("gguf_open: out of host memory"); return VMX_ENOMEM; }
     Reader r;
     r.f = f;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long end = ftell(f);
+        r.fsize = end > 0 ? (uint64_t)end : 0;
+    }
+    rewind(f);
     const int rc = parse(r, g);
     fclose(f);
     if (rc) { delete g; return rc; }

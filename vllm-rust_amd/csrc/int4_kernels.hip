@@ -652,10 +652,20 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
 // waves owns a 16-column tile over ALL of K (wave w the k-blocks [w*UPW, (w+1)*UPW)), so the sum needs no split-K slices
 // and the epilogue can finish the job of the reference's separate add: h = bf16(h + bf16(y)) (the linear's bf16 output,
 // then add_bf16).  N/16 workgroups of 1024 threads: the launch keeps the whole matrix in flight like the kernel above.
-template <int UPW>
-__global__ __launch_bounds__(1024) void int4_gemm_resid_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
-                                                                const uint16_t *__restrict__ x, uint16_t *__restrict__ h,
-                                                                float *__restrict__ ssq, int M, int N, int K, int group) {
+//
+// PM > 0: the activations are the decode-attention output still split into P <= PM partitions per (row, head)
+// (split_decode_attn_kernel): tmp [M][K/HD][P][HD] f32 with max logit / sum [M][K/HD][P]; staging merges them,
+//   x = bf16( sum_p tmp_p w_p / (sum_p w_p + 1e-6) ),  w_p = sum_p * exp(max_p - max over p)   (paged_attention.cu:840-953),
+// which is what the separate merge kernel writes.
+struct AttnMergeArgs {
+    const float *tmp, *mx, *sm;
+    int P, HD;
+};
+
+template <int UPW, int PM>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void int4_gemm_resid_kernel(
+    const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ, const uint16_t *__restrict__ x, uint16_t *__restrict__ h,
+    float *__restrict__ ssq, int M, int N, int K, int group, AttnMergeArgs am) {
     // K == 16 * UPW * 128 exactly (checked by the launcher): no bounds checks, so every load below is unconditional and
     // issued back to back (surplus threads re-read a valid address and drop the value)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -673,10 +683,30 @@ __global__ __launch_bounds__(1024) void int4_gemm_resid_kernel(const uint4 *__re
     const int64_t hidx = (int64_t)min(tid >> 4, M - 1) * N + nt * NT + (tid & 15);
     const uint16_t hold = h[hidx];
     uint4 xv[XCF];
+    constexpr int PMA = PM > 0 ? PM : 1;
+    float4 pa[PM > 0 ? XCF : 1][PMA], pb[PM > 0 ? XCF : 1][PMA];
+    float pmx[PM > 0 ? XCF : 1][PMA], psm[PM > 0 ? XCF : 1][PMA];
+    if constexpr (PM == 0) {
 #pragma unroll
-    for (int j = 0; j < XCF; j++) {
-        const int c = min(tid + 1024 * j, total - 1);
-        xv[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)(c / CPR) * K + (c % CPR) * 8);
+        for (int j = 0; j < XCF; j++) {
+            const int c = min(tid + 1024 * j, total - 1);
+            xv[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)(c / CPR) * K + (c % CPR) * 8);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < XCF; j++) {
+            const int c = min(tid + 1024 * j, total - 1), k = (c % CPR) * 8;
+            const int64_t row = ((int64_t)(c / CPR) * (K / am.HD) + k / am.HD) * am.P;   // (activation row, head)
+#pragma unroll
+            for (int p = 0; p < PM; p++) {   // partitions past P re-read the last one; their weight is zeroed below
+                const int64_t rp = row + min(p, am.P - 1);
+                const float *src = am.tmp + rp * am.HD + k % am.HD;
+                pa[j][p] = *reinterpret_cast<const float4 *>(src);
+                pb[j][p] = *reinterpret_cast<const float4 *>(src + 4);
+                pmx[j][p] = am.mx[rp];
+                psm[j][p] = am.sm[rp];
+            }
+        }
     }
     constexpr int SZW = (KBLK * 16 + 1023) / 1024;
     uint32_t szv[SZW];
@@ -689,6 +719,28 @@ __global__ __launch_bounds__(1024) void int4_gemm_resid_kernel(const uint4 *__re
 #pragma unroll
     for (int u = 0; u < UPW; u++) wreg[u] = W[((int64_t)nt * KBLK + wave * UPW + u) * 64 + lane];
 
+    if constexpr (PM > 0) {
+#pragma unroll
+        for (int j = 0; j < XCF; j++) {
+            float gmax = -3.402823466e+38f;
+#pragma unroll
+            for (int p = 0; p < PM; p++) gmax = fmaxf(gmax, p < am.P ? pmx[j][p] : -3.402823466e+38f);
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gsum = 0.f;
+#pragma unroll
+            for (int p = 0; p < PM; p++) {
+                const float wt = p < am.P ? psm[j][p] * __expf(pmx[j][p] - gmax) : 0.f;
+                gsum += wt;
+                acc[0] += pa[j][p].x * wt; acc[1] += pa[j][p].y * wt; acc[2] += pa[j][p].z * wt; acc[3] += pa[j][p].w * wt;
+                acc[4] += pb[j][p].x * wt; acc[5] += pb[j][p].y * wt; acc[6] += pb[j][p].z * wt; acc[7] += pb[j][p].w * wt;
+            }
+            const float inv = 1.0f / (gsum + 1e-6f);
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                pk[e] = (uint32_t)vmx_f32_to_bf16(acc[2 * e] * inv) | ((uint32_t)vmx_f32_to_bf16(acc[2 * e + 1] * inv) << 16);
+            xv[j] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < XCF; j++) {
         const int c = tid + 1024 * j;
@@ -730,22 +782,29 @@ __global__ __launch_bounds__(1024) void int4_gemm_resid_kernel(const uint4 *__re
         fin[2] += s * (acc[2] - zo * sx.z);
         fin[3] += s * (acc[3] - zo * sx.w);
     }
-    if (hh == 0) *reinterpret_cast<float4 *>(red + (wave * 16 + nl) * 4) = make_float4(fin[0], fin[1], fin[2], fin[3]);   // rows 0..3 (M <= 2)
+    if (hh == 0) {   // rows 0 and 1 of the MFMA tile (M <= 2), laid out [row][column][wave] so that the sum below reads 4 x 16 bytes
+        red[(nl) * 16 + wave] = fin[0];
+        red[(16 + nl) * 16 + wave] = fin[1];
+    }
     __syncthreads();
     if (tid < 64) {   // wave 0; thread = (row m, column c): sum of the 16 waves in wave order
-        const int m = tid >> 4, c = tid & 15;
+        const int m = (tid >> 4) & 1, c = tid & 15;
         float v = 0.f;
+        const float4 *rp = reinterpret_cast<const float4 *>(red + (m * 16 + c) * 16);
 #pragma unroll
-        for (int wv = 0; wv < NWV; wv++) v += red[(wv * 16 + c) * 4 + m];
+        for (int q = 0; q < 4; q++) {
+            const float4 r4 = rp[q];
+            v += r4.x; v += r4.y; v += r4.z; v += r4.w;
+        }
         const uint16_t hn = vmx_f32_to_bf16(vmx_bf16_to_f32(hold) + vmx_bf16_to_f32(vmx_f32_to_bf16(v)));
-        if (m < M) h[hidx] = hn;
+        if (tid < 16 * M) h[hidx] = hn;
         float sq = vmx_bf16_to_f32(hn);   // sum of squares of the tile's 16 new residual values, for the norm in the next linear
         sq *= sq;
         sq += __shfl_xor(sq, 1, 64);
         sq += __shfl_xor(sq, 2, 64);
         sq += __shfl_xor(sq, 4, 64);
         sq += __shfl_xor(sq, 8, 64);
-        if (m < M && c == 0) ssq[m * (N / NT) + nt] = sq;
+        if (tid < 16 * M && c == 0) ssq[m * (N / NT) + nt] = sq;
     }
 }
 
@@ -1204,36 +1263,63 @@ int vmx_int4_gemm_glu_norm(const void *packed, const uint16_t *h, const uint16_t
     return launch_wide<true>(p, packed, h, norm_w, eps, ssq, nullptr, act, M, N, K, group, st);
 }
 
-// h[M][N] = bf16(h + bf16(x W)) in one launch; ssq[M][N/16] = per-tile sums of squares of the new h
-int vmx_int4_gemm_resid(const void *packed, const uint16_t *x, uint16_t *h, float *ssq, int M, int N, int K, int group, hipStream_t st) {
+// h[M][N] = bf16(h + bf16(x W)) in one launch; ssq[M][N/16] = per-tile sums of squares of the new h.  parts != NULL: x is
+// the merge of the decode-attention partitions (head_dim-wide heads) instead of a bf16 tensor.
+static int resid_launch(const void *packed, const uint16_t *x, const VmxAttnParts *parts, int head_dim, uint16_t *h, float *ssq, int M, int N,
+                        int K, int group, hipStream_t st) {
     VMX_REQUIRE(vmx_int4_resid_fusable(M, N, K), "int4_gemm_resid: shape [%d x %d -> %d] not supported", M, K, N);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
     const int upw = K / (16 * KB);
+    AttnMergeArgs am{nullptr, nullptr, nullptr, 1, 128};
+    int pm = 0;
+    if (parts) {
+        VMX_REQUIRE(parts->max_parts >= 1 && parts->max_parts <= 8 && head_dim >= 8 && head_dim % 8 == 0 && K % head_dim == 0 && upw <= 4,
+                    "int4_gemm_resid_attn: %d partitions / head_dim %d / K %d not supported", parts->max_parts, head_dim, K);
+        am = AttnMergeArgs{parts->tmp_out, parts->max_logits, parts->exp_sums, parts->max_parts, head_dim};
+        pm = parts->max_parts <= 4 ? 4 : 8;
+    }
     // VMX_INT4_RESID_LDS: pad the workgroup's LDS request (bytes) to steer how many workgroups share a CU (measurement aid)
     static const int lds_pad = tune("VMX_INT4_RESID_LDS", 0);
     size_t lds = (((size_t)2 * (K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(K / KB) * 16 * 4 * 2 + 16 * 16 * 4 * 4;
     if ((size_t)lds_pad > lds) lds = lds_pad;
     const dim3 grid((unsigned)(N / NT)), block(1024);
-#define RSD(U)                                                                                                                         \
+#define RSD_P(U, PMV)                                                                                                                  \
     do {                                                                                                                               \
         if (lds > 64 * 1024)                                                                                                           \
-            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_resid_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((int4_gemm_resid_kernel<U>), grid, block, lds, st, W, SZ, x, h, ssq, M, N, K, group);                            \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_resid_kernel<U, PMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((int4_gemm_resid_kernel<U, PMV>), grid, block, lds, st, W, SZ, x, h, ssq, M, N, K, group, am);              \
+    } while (0)
+#define RSD(U)                                  \
+    do {                                        \
+        if (pm == 0) RSD_P(U, 0);               \
+        else if (U <= 4 && pm == 4) RSD_P((U <= 4 ? U : 1), 4); \
+        else RSD_P((U <= 4 ? U : 1), 8);        \
     } while (0)
     switch (upw) {
         case 1: RSD(1); break;
         case 2: RSD(2); break;
         case 3: RSD(3); break;
         case 4: RSD(4); break;
-        case 5: RSD(5); break;
-        case 6: RSD(6); break;
-        case 7: RSD(7); break;
-        default: RSD(8); break;
+        case 5: RSD_P(5, 0); break;
+        case 6: RSD_P(6, 0); break;
+        case 7: RSD_P(7, 0); break;
+        default: RSD_P(8, 0); break;
     }
 #undef RSD
+#undef RSD_P
     VMX_CHECK_LAUNCH("int4_gemm(resid)");
     return VMX_OK;
+}
+
+int vmx_int4_gemm_resid(const void *packed, const uint16_t *x, uint16_t *h, float *ssq, int M, int N, int K, int group, hipStream_t st) {
+    return resid_launch(packed, x, nullptr, 0, h, ssq, M, N, K, group, st);
+}
+
+int vmx_int4_gemm_resid_attn(const void *packed, const VmxAttnParts *parts, int head_dim, uint16_t *h, float *ssq, int M, int N, int K,
+                             int group, hipStream_t st) {
+    VMX_REQUIRE(parts, "int4_gemm_resid_attn: null partitions");
+    return resid_launch(packed, nullptr, parts, head_dim, h, ssq, M, N, K, group, st);
 }
 
 // act[M][N/2] = silu(gate) * up straight from the GEMM epilogue; the linear must be GLU-packed and plan to one k slice.

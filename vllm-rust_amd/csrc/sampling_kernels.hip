@@ -154,14 +154,17 @@ __global__ __launch_bounds__(256) void top_k_top_p_kernel(int32_t *__restrict__ 
         return;
     }
     if (tid == owner) {
+        // The slice was chosen from its separately rounded sum; re-adding its elements one by one from `run` can stay at or
+        // below the target by a rounding error.  The sample then is the slice's last kept token, never a filtered one.
         float run = bcast[0];
-        int sel = vocab - 1;
+        int sel = -1, last_kept = -1;
         for (int i = lo; i < hi; i++)
             if (p[i] >= threshold) {
+                last_kept = i;
                 run += p[i];
                 if (run > target) { sel = i; break; }
             }
-        out[seq] = sel;
+        out[seq] = sel >= 0 ? sel : (last_kept >= 0 ? last_kept : vocab - 1);
     }
 }
 

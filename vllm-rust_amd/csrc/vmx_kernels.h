@@ -62,6 +62,20 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
                               int head_dim, int window, hipStream_t st, int8_t *aq = nullptr, float *ad = nullptr);
 
+// attention_kernels.hip: the same work as vmx_fused_decode_attention spread over P workgroups per KV head; the P partition
+// results stay in `workspace` (described by *out) for a consumer that merges them (vmx_int4_gemm_resid_attn)
+int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window);   // 0 = not covered
+size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim);
+int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
+                               const uint16_t *q_norm_w, const uint16_t *k_norm_w, float eps, const float *cos_sin,
+                               const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
+                               float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
+                               int max_blocks_per_seq, int max_seq_len, int block_size, int window, int kv_dtype, const float *k_scale,
+                               const float *v_scale, int v_norm, hipStream_t st);
+// int4_kernels.hip: vmx_int4_gemm_resid whose activations are the merge of those partitions (K = heads * head_dim)
+int vmx_int4_gemm_resid_attn(const void *packed, const VmxAttnParts *parts, int head_dim, uint16_t *h, float *ssq, int M, int N, int K,
+                             int group, hipStream_t st);
+
 // glue_kernels.hip
 int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,
                     hipStream_t st);
