@@ -458,40 +458,55 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- roofline of the dominant kernel (int4 linear): the step's linear launches alone (same weights,
-    # same buffers), captured into a graph and replayed back to back between two HIP events recorded on
-    # the stream the kernels run on; duration per launch = elapsed / launches (boundaries included, as in
-    # rocprofv3's back-to-back kernel timestamps).
+    # ---- roofline of the dominant kernel: the step's int4 linear launches alone (same weights, same buffers), one kind at
+    # a time, captured into a graph and replayed back to back between two HIP events recorded on the stream the kernels run
+    # on; duration per launch = elapsed / launches (boundaries included, as in rocprofv3's back-to-back kernel timestamps).
+    # The four linears of a layer are four different kernels (norm prologue / residual epilogue variants); `roofline` is the
+    # one the step spends most time in (gate|up), `linears` lists all four and their launch-weighted total.
     roofline = None
     if rank == 0 and not exl3:
-        launches, alg = model.linears_info(B)
-        with torch.cuda.stream(side):
-            model.linears_only(B)
-            lg = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(lg, stream=side):
+        def time_linears(mask):
+            model.linears_select(mask)
+            launches, alg = model.linears_info(B)
+            with torch.cuda.stream(side):
                 model.linears_only(B)
-            reps = max(8, K_steps // 4)
-            lg.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(side)
-            for _ in range(reps):
+                lg = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(lg, stream=side):
+                    model.linears_only(B)
+                reps = max(8, K_steps // 4)
                 lg.replay()
-            e1.record(side)
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / reps
-        achieved = alg / us / 1e3 if us > 0 else 0.0  # bytes/us -> GB/s
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for _ in range(reps):
+                    lg.replay()
+                e1.record(side)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            del lg
+            return launches, alg, us
+
+        kinds = {}
+        for name, mask in (("qkv", 1), ("o_proj", 2), ("gate_up", 4), ("down_proj", 8), ("all", 15)):
+            launches, alg, us = time_linears(mask)
+            kinds[name] = {"launches_per_step": launches, "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches),
+                           "GB_s": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_step": round(us, 1)}
+        model.linears_select(15)
+        dom = max(("qkv", "o_proj", "gate_up", "down_proj"), key=lambda k: kinds[k]["us_per_step"])
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 cannot run inside this process):
         # committed summary of `rocprofv3 --pmc ... -- python3 tools/pmc_linears.py`, same kernel, same shapes.
         traffic = None
         try:
-            traffic = json.loads((ROOT / "profiles" / "r01_pmc_traffic_int4_gemm.json").read_text())["hbm_bytes_per_launch"]
+            traffic = json.loads((ROOT / "profiles" / "r02_pmc_traffic_int4_gemm.json").read_text())[dom]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": "int4_gemm_kernel / int4_gemm_glu_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "launches_per_step": launches, "avg_launch_us": round(us / launches, 3),
-                    "alg_bytes_per_launch": round(alg / launches)}
+        kernel_names = {"qkv": "int4_gemm_wide_kernel (q|k|v: RMSNorm prologue)", "o_proj": "int4_gemm_resid_kernel (o_proj: residual epilogue)",
+                        "gate_up": "int4_gemm_wide_kernel<GLU> (gate|up: RMSNorm prologue, SiLU*mul epilogue)",
+                        "down_proj": "int4_gemm_resid_kernel (down_proj: residual epilogue)"}
+        d = kinds[dom]
+        roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+                    "traffic": traffic, "launches_per_step": d["launches_per_step"], "avg_launch_us": d["avg_launch_us"],
+                    "alg_bytes_per_launch": d["alg_bytes_per_launch"], "linears": kinds}
 
     # ---- secondary (rank 0, N = 1 only): BASELINE.json's other headline model, GGUF I-quant decode
     secondary = None

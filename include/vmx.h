@@ -452,6 +452,8 @@ int vmx_decode_advance(int32_t *input_ids, const int32_t *next_ids, int32_t *pos
  * gives the kernel's average launch duration; _info returns the launch count and the summed
  * algorithmic bytes of one such pass. */
 int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream);
+/* Restrict both measurement calls to some of a layer's linears: mask bit 0 q|k|v, 1 o_proj, 2 gate|up, 3 down_proj (15 = all). */
+int vmx_qwen3_linears_select(vmx_qwen3 *m, int mask);
 int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, double *alg_bytes);
 
 /* Measurement aid: stream `bytes` from p with the int4 linear's access shape (upw 1 KiB units per wave,

@@ -110,6 +110,7 @@ _SIGS = {
     "vmx_qwen3_load_gptq_expert": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "vmx_qwen3_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "vmx_qwen3_linears_only": (_i, [_p, _i, _p]),
+    "vmx_qwen3_linears_select": (_i, [_p, _i]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
     "vmx_prefill_attention_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vmx_gguf_open": (_i, [C.c_char_p, _p]),

@@ -404,6 +404,7 @@ struct vmx_qwen3 {
     DevBuf router_logits, topk_w, topk_ids, moe_ws, moe_out;   // MoE models only
     DevBuf exl3_ws;                                            // EXL3 models only: grown by the loader
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
+    int lin_mask = 15;  // measurement aid: which linears vmx_qwen3_linears_only launches (1 q|k|v, 2 o, 4 gate|up, 8 down)
     bool rows_share_cache = false;  // rows of a decode batch attend to K/V rows written by other rows of the same call
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
@@ -1226,23 +1227,39 @@ extern "C" int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream) {
         const bool fold = folded_layers_enabled() && !m->comm && c.tp_size <= 1 && c.num_experts == 0 && L.gate_up.glu &&
                           vmx_int4_norm_splits(batch, NQKV_, H, 0) > 0 && vmx_int4_norm_splits(batch, 2 * I, H, 1) == 1 &&
                           vmx_int4_resid_fusable(batch, H, NQ) && vmx_int4_resid_fusable(batch, H, I);
+        const int mk = m->lin_mask;
         if (fold) {   // what the step launches for such a layer
             float *ssq = (float *)m->ssq.p;
-            if (int rc = vmx_int4_gemm_partial_norm(L.qkv.packed.p, h, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, ssq, PA, batch, NQKV_,
-                                                    H, L.qkv.group, st))
-                return rc;
-            if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, batch, H, NQ, L.o.group, st)) return rc;
-            if (int rc = vmx_int4_gemm_glu_norm(L.gate_up.packed.p, h, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, ssq, (uint16_t *)m->act.p,
-                                                batch, 2 * I, H, L.gate_up.group, st))
-                return rc;
-            if (int rc = vmx_int4_gemm_resid(L.down.packed.p, act, h, ssq, batch, H, I, L.down.group, st)) return rc;
+            if (mk & 1)
+                if (int rc = vmx_int4_gemm_partial_norm(L.qkv.packed.p, h, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, ssq, PA, batch, NQKV_,
+                                                        H, L.qkv.group, st))
+                    return rc;
+            if (mk & 2)
+                if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, batch, H, NQ, L.o.group, st)) return rc;
+            if (mk & 4)
+                if (int rc = vmx_int4_gemm_glu_norm(L.gate_up.packed.p, h, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, ssq,
+                                                    (uint16_t *)m->act.p, batch, 2 * I, H, L.gate_up.group, st))
+                    return rc;
+            if (mk & 8)
+                if (int rc = vmx_int4_gemm_resid(L.down.packed.p, act, h, ssq, batch, H, I, L.down.group, st)) return rc;
             continue;
         }
-        if (int rc = L.qkv.forward_partial(x, PA, batch, st)) return rc;
-        if (int rc = L.o.forward_partial(attn, PB, batch, st)) return rc;
-        if (int rc = L.gate_up.glu ? L.gate_up.forward_glu(x, (uint16_t *)m->act.p, batch, st) : L.gate_up.forward_partial(x, PA, batch, st)) return rc;
-        if (int rc = L.down.forward_partial(act, PB, batch, st)) return rc;
+        if (mk & 1)
+            if (int rc = L.qkv.forward_partial(x, PA, batch, st)) return rc;
+        if (mk & 2)
+            if (int rc = L.o.forward_partial(attn, PB, batch, st)) return rc;
+        if (mk & 4)
+            if (int rc = L.gate_up.glu ? L.gate_up.forward_glu(x, (uint16_t *)m->act.p, batch, st) : L.gate_up.forward_partial(x, PA, batch, st)) return rc;
+        if (mk & 8)
+            if (int rc = L.down.forward_partial(act, PB, batch, st)) return rc;
     }
+    return VMX_OK;
+}
+
+// Which of a layer's four linears the two measurement calls cover: bit 0 q|k|v, 1 o_proj, 2 gate|up, 3 down_proj.
+extern "C" int vmx_qwen3_linears_select(vmx_qwen3 *m, int mask) {
+    VMX_REQUIRE(m && mask >= 1 && mask <= 15, "qwen3_linears_select: mask must be 1..15");
+    m->lin_mask = mask;
     return VMX_OK;
 }
 
@@ -1252,11 +1269,16 @@ extern "C" int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, do
     VMX_REQUIRE(m && launches && alg_bytes, "qwen3_linears_info: null pointer");
     double by = 0.0;
     int n = 0;
-    for (const Layer &L : m->layers)
+    for (const Layer &L : m->layers) {
+        int bit = 1;
         for (const Int4Linear *l : {&L.qkv, &L.o, &L.gate_up, &L.down}) {
-            by += int4_alg_bytes(*l, batch);
-            n++;
+            if (m->lin_mask & bit) {
+                by += int4_alg_bytes(*l, batch);
+                n++;
+            }
+            bit <<= 1;
         }
+    }
     *launches = n;
     *alg_bytes = by;
     return VMX_OK;

@@ -26,6 +26,13 @@ namespace {
 constexpr int KB = 128;     // k-values per unit
 constexpr int NT = 16;      // columns per unit
 
+// Registers (vector + accumulation) are capped so that at least this many waves fit a SIMD: a launch of ~6 workgroups per
+// CU must be resident all at once, or the second half of the grid only starts when the first retires (measured: at 120
+// registers exactly half of the 1536 gate|up workgroups of a Qwen3-8B layer entered 4.5 us after the others).
+#ifndef WIDE_WAVES_PER_EU
+#define WIDE_WAVES_PER_EU 6
+#endif
+
 __host__ __device__ inline size_t sz_offset_bytes(int K, int N) { return ((size_t)K * N / 2 + 255) & ~(size_t)255; }
 
 // ---------------------------------------------------------------- repacks
@@ -138,6 +145,18 @@ __global__ __launch_bounds__(256) void int4_dequant_kernel(const uint32_t *__res
 // TAIL: the last split-K slice may run past K (k-blocks not a multiple of 4*UPW); only then are the
 // per-unit bounds checks compiled in.
 constexpr int XCH = 4;  // activation chunks (16 B) a thread keeps in registers across the weight requests
+
+// Weight units are read once per launch by one CU: the non-temporal policy keeps them from displacing the activations and
+// partial sums that ARE re-read from the caches (VMX_INT4_NT_OFF at build time restores the default policy for A/B runs).
+__device__ __forceinline__ uint4 ld_weights(const uint4 *p) {
+#ifdef VMX_INT4_NT_OFF
+    return *p;
+#else
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+}
 
 __device__ __forceinline__ void bf16x8_to_f32(const uint4 v, float f[8]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(256) void int4_gemm_glu_looped_kernel(const uint4 *
 }
 
 template <int UPW, bool TAIL>
-__global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE_WAVES_PER_EU))) void int4_gemm_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                          const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
                                                          uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N, int K,
                                                          int group, int slice_rows) {
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(256) void int4_gemm_kernel(const uint4 *__restrict_
 }
 
 template <int UPW, bool TAIL>
-__global__ __launch_bounds__(256) void int4_gemm_glu_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE_WAVES_PER_EU))) void int4_gemm_glu_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                              const uint16_t *__restrict__ x, uint16_t *__restrict__ act, int M, int N,
                                                              int K, int group) {
     int4_gemm_body<UPW, TAIL, true>(W, SZ, x, nullptr, act, nullptr, 0, M, N, K, group, blockIdx.x);
@@ -495,8 +514,23 @@ __global__ __launch_bounds__(256) void int4_gemm_glu_kernel(const uint4 *__restr
 // multiple of the CU count where the shape allows it.  No bounds checks: K is a whole number of slices, N of NTW tiles.
 // The activations are the RMSNorm of the residual stream h (see NORM above).  Output: f32 split-K slices, or with GLU
 // (one slice) the gated activation.
+#ifdef VMX_WIDE_STAMPS
+// build-time measurement variant: per-wave clock stamps of the last wide-kernel launch (8 u64 per wave, up to 8192 waves)
+__device__ unsigned long long vmx_wide_stamp_buf[8192 * 8];
+#define WIDE_STAMP(i)                                                                                          \
+    do {                                                                                                       \
+        unsigned long long t__;                                                                                \
+        if ((i) == 0 || (i) == 7) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
+        else asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                        \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * NWV + (threadIdx.x >> 6) < 8192)                           \
+            vmx_wide_stamp_buf[(blockIdx.x * NWV + (threadIdx.x >> 6)) * 8 + (i)] = t__;                       \
+    } while (0)
+#else
+#define WIDE_STAMP(i) do { } while (0)
+#endif
+
 template <int NWV, int UPW, int NTW, bool GLU, int MR>
-__global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 1 ? WIDE_WAVES_PER_EU : 4))) void int4_gemm_wide_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                                    const uint16_t *__restrict__ hres, const uint16_t *__restrict__ norm_w,
                                                                    float eps, const float *__restrict__ ssq, float *__restrict__ partial,
                                                                    uint16_t *__restrict__ act, int N, int K, int group) {
@@ -505,9 +539,10 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
     constexpr int M = MR;
     constexpr int TH = 64 * NWV, KBS = NWV * UPW, KS = KBS * KB, XROW = KS + 8, CPR = KS / 8;
     constexpr int XCF = (MR * CPR + TH - 1) / TH, SZW = (NTW * KBS * 16 + TH - 1) / TH;
-    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                                          // [2][XROW]
-    float *sumx = reinterpret_cast<float *>(smem + (((size_t)2 * XROW * 2 + 15) & ~(size_t)15));  // [KBS][16]
-    float *red = sumx + KBS * 16;                                                                // [NTW][NWV][16 columns][4 rows]
+    // LDS is kept small on purpose: the number of workgroups a CU holds at once is what keeps its loads flowing
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                                           // [MR][XROW]
+    float *sumx = reinterpret_cast<float *>(smem + (((size_t)MR * XROW * 2 + 15) & ~(size_t)15));  // [KBS][4 rows]
+    float *red = sumx + KBS * 4;                                                                 // [NTW][NWV][16 columns][4 rows]
     uint32_t *szs = reinterpret_cast<uint32_t *>(red + NTW * NWV * 64);                          // [NTW][KBS][16]
     float *invs = reinterpret_cast<float *>(szs + NTW * KBS * 16);                               // [2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 15, hh = lane >> 4;
@@ -515,6 +550,8 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
     const int nt0 = ((int)blockIdx.x % groups) * NTW, ks = (int)blockIdx.x / groups;
     const int kb_wg = ks * KBS, k0 = kb_wg * KB, nsq = K >> 4;
     constexpr int total = MR * CPR;
+    WIDE_STAMP(0);
+    WIDE_STAMP(1);
 
     // The mean of squares is the business of wave 0 alone (one or two 1 KiB loads per row): the 256..512 tile sums are the
     // same few cache lines for every workgroup of the launch, and fetched by every wave they cost more than the barrier
@@ -545,7 +582,8 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
 #pragma unroll
     for (int u = 0; u < UPW; u++)
 #pragma unroll
-        for (int t = 0; t < NTW; t++) wreg[t][u] = W[((int64_t)(nt0 + t) * kblocks + kb_wg + wave * UPW + u) * 64 + lane];
+        for (int t = 0; t < NTW; t++) wreg[t][u] = ld_weights(&W[((int64_t)(nt0 + t) * kblocks + kb_wg + wave * UPW + u) * 64 + lane]);
+    WIDE_STAMP(2);
 
     if (wave == 0) {
 #pragma unroll
@@ -577,12 +615,13 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
         const uint4 xn = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = xn;
         const float sm = chunk_sum16(xn);   // 16 consecutive chunks = one (row, k-block)
-        if (live && (tid & 15) == 0) sumx[(cc >> 4) * 16 + m] = sm;
+        if (live && (tid & 15) == 0) sumx[(cc >> 4) * 4 + m] = sm;
     }
 #pragma unroll
     for (int j = 0; j < SZW; j++)
         if (tid + TH * j < NTW * KBS * 16) szs[tid + TH * j] = szv[j];
     __syncthreads();
+    WIDE_STAMP(3);
 
     const uint16_t *xrow = xs + min(nl, M - 1) * XROW + 8 * hh;
     vmx_f32x4 fin[NTW];
@@ -594,7 +633,7 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
         uint4 au[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) au[i] = *reinterpret_cast<const uint4 *>(xrow + kbl * KB + 32 * i);
-        const float4 sx = *reinterpret_cast<const float4 *>(sumx + kbl * 16 + 4 * hh);
+        const float4 sx = *reinterpret_cast<const float4 *>(sumx + kbl * 4);   // rows 0..3; the other row groups' outputs are never stored
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
             vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -618,6 +657,7 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
             fin[t][3] += sc * (acc[3] - zo * sx.w);
         }
     }
+    WIDE_STAMP(4);
     if (hh == 0) {   // rows 0..3 of the MFMA tile (M <= 2)
 #pragma unroll
         for (int t = 0; t < NTW; t++)
@@ -645,6 +685,7 @@ __global__ __launch_bounds__(64 * NWV) void int4_gemm_wide_kernel(const uint4 *_
             partial[((int64_t)ks * M + m) * N + (nt0 + t) * NT + c] = v;
         }
     }
+    WIDE_STAMP(7);
 }
 
 // ---------------------------------------------------------------- whole-K workgroups with the residual add in the epilogue
@@ -717,7 +758,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     }
     uint4 wreg[UPW];
 #pragma unroll
-    for (int u = 0; u < UPW; u++) wreg[u] = W[((int64_t)nt * KBLK + wave * UPW + u) * 64 + lane];
+    for (int u = 0; u < UPW; u++) wreg[u] = ld_weights(&W[((int64_t)nt * KBLK + wave * UPW + u) * 64 + lane]);
 
     if constexpr (PM > 0) {
 #pragma unroll
@@ -1197,7 +1238,7 @@ template <int NWV, int UPW, int NTW, bool GLU, int MR>
 int launch_wide_m(const WidePlan &p, const uint4 *W, const uint32_t *SZ, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq,
                   float *partial, uint16_t *act, int N, int K, int group, hipStream_t st) {
     constexpr int KBS = NWV * UPW;
-    const size_t lds = (((size_t)2 * (KBS * KB + 8) * 2 + 15) & ~(size_t)15) + (size_t)KBS * 64 + (size_t)NTW * NWV * 256 + (size_t)NTW * KBS * 64 + 16;
+    const size_t lds = (((size_t)MR * (KBS * KB + 8) * 2 + 15) & ~(size_t)15) + (size_t)KBS * 16 + (size_t)NTW * NWV * 256 + (size_t)NTW * KBS * 64 + 16;
     if (lds > 64 * 1024)
         VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
@@ -1241,6 +1282,13 @@ int launch_wide(const WidePlan &p, const void *packed, const uint16_t *h, const 
     return launch_wide_n<4, 2, GLU>(p, W, SZ, h, norm_w, eps, ssq, partial, act, M, N, K, group, st);
 }
 }  // namespace
+
+#ifdef VMX_WIDE_STAMPS
+extern "C" int vmx_debug_wide_stamps_read(void *dst, size_t bytes) {
+    VMX_CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(vmx_wide_stamp_buf), bytes < sizeof(vmx_wide_stamp_buf) ? bytes : sizeof(vmx_wide_stamp_buf)));
+    return VMX_OK;
+}
+#endif
 
 // split-K slices the norm-in-prologue form leaves in `partial` (0: shape not supported)
 int vmx_int4_norm_splits(int M, int N, int K, int glu) {

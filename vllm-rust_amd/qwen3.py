@@ -355,6 +355,10 @@ class QuantizedQwen3ForCausalLM:
     def linears_only(self, batch: int = 1) -> None:
         check(lib.vmx_qwen3_linears_only(self._h, batch, self._stream()))
 
+    def linears_select(self, mask: int = 15) -> None:
+        """Which linears linears_only / linears_info cover: bit 0 q|k|v, 1 o_proj, 2 gate|up, 3 down_proj."""
+        check(lib.vmx_qwen3_linears_select(self._h, int(mask)))
+
     def linears_info(self, batch: int = 1):
         n, by = C.c_int(), C.c_double()
         check(lib.vmx_qwen3_linears_info(self._h, batch, C.byref(n), C.byref(by)))
