@@ -33,10 +33,28 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
-def cpu_baseline(spec, budget_s=12.0):
-    """Time the oracle's int4 GEMV (bf16 in/out, f32 accumulate; the arithmetic of the reference's
-    CPU-side scalar reference) on the projections of ONE decoder layer, repeated while the budget
-    lasts, and convert to tokens/s for the full model (layers x per-layer time + bf16 lm_head)."""
+def _host_cores():
+    cores = len(os.sched_getaffinity(0))
+    return max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+
+
+def _timed(fn, budget_s, max_reps=10 ** 6):
+    """Average seconds of fn() over as many repetitions as fit the budget (at least one)."""
+    t_sum, reps, t_start = 0.0, 0, time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        fn()
+        t_sum += time.perf_counter() - t0
+        reps += 1
+        if time.perf_counter() - t_start > budget_s or reps >= max_reps:
+            return t_sum / reps, reps
+
+
+def cpu_baseline(spec, budget_s=10.0):
+    """The CPU oracle timed on the GPU box's host cores, on a bounded sample of the same workload: the int4 GEMV (bf16 in/out,
+    f32 accumulate) of ONE decoder layer's seven projections and the dense bf16 lm_head dot on 1/16 of the vocabulary, with all
+    the cores this process may use (OpenMP over output columns) and again with one thread; tokens/s = 1 / (layers x per-layer
+    time + lm_head time).  Norms, RoPE and attention are left out (a few per cent of the CPU step)."""
     from oracle import oracle as orc
     rng = np.random.default_rng(0)
     H, I = spec.hidden_size, spec.intermediate_size
@@ -49,31 +67,85 @@ def cpu_baseline(spec, budget_s=12.0):
         sc = orc.f32_to_bf16((rng.random((K // spec.group_size, N), dtype=np.float32) * 0.01))
         x = orc.f32_to_bf16(rng.standard_normal((1, K)).astype(np.float32))
         mats.append((x, qw, sc, qz, K, N))
-    cores = len(os.sched_getaffinity(0))
-    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
-    t_layer, reps = 0.0, 0
-    t_start = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
+    Vs = spec.vocab_size // 16
+    Wh = orc.f32_to_bf16(rng.standard_normal((Vs, H)).astype(np.float32) * 0.02)
+    xh = orc.f32_to_bf16(rng.standard_normal((1, H)).astype(np.float32))
+
+    def layer():
         for x, qw, sc, qz, K, N in mats:
             orc.int4_gemv_bf16(x, qw, sc, qz, None, K, N, spec.group_size)
-        t_layer += time.perf_counter() - t0
-        reps += 1
-        if time.perf_counter() - t_start > budget_s or reps >= 8:
-            break
-    t_layer /= reps
-    # lm_head: dense bf16 [V, H] dot in numpy (float32), timed on a 1/16 slice of the vocabulary
-    Vs = spec.vocab_size // 16
-    W = rng.standard_normal((Vs, H)).astype(np.float32)
-    xv = rng.standard_normal(H).astype(np.float32)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        W @ xv
-    t_head = (time.perf_counter() - t0) / 3 * 16
+
+    def head():
+        orc.dense_gemv_bf16(xh, Wh)
+
+    cores = _host_cores()
+    prev = orc.set_threads(cores)
+    t_layer, reps = _timed(layer, budget_s * 0.5)
+    t_head, _ = _timed(head, budget_s * 0.1)
+    t_head *= 16
+    orc.set_threads(1)
+    t_layer1, reps1 = _timed(layer, budget_s * 0.3, max_reps=2)
+    t_head1, _ = _timed(head, budget_s * 0.1, max_reps=2)
+    t_head1 *= 16
+    orc.set_threads(prev)
     tok_s = 1.0 / (spec.num_layers * t_layer + t_head)
+    tok_s1 = 1.0 / (spec.num_layers * t_layer1 + t_head1)
     return {"value": round(tok_s, 3), "unit": "tok/s", "cores": cores, "kind": "port",
             "sample": f"oracle int4 GEMV of one decoder layer's 7 projections x{reps} ({t_layer * 1e3:.1f} ms/layer), scaled to "
-                      f"{spec.num_layers} layers + numpy f32 lm_head on 1/16 of the vocabulary ({t_head * 1e3:.1f} ms)"}
+                      f"{spec.num_layers} layers + oracle bf16 lm_head dot on 1/16 of the vocabulary ({t_head * 1e3:.1f} ms for all of it)",
+            "single_thread": {"value": round(tok_s1, 4), "unit": "tok/s", "cores": 1,
+                              "sample": f"the same sample with one OpenMP thread x{reps1} ({t_layer1 * 1e3:.0f} ms/layer, lm_head {t_head1 * 1e3:.0f} ms)"}}
+
+
+def cpu_baseline_mmvq(spec, slot_types, budget_s=8.0):
+    """CPU leg of the GGUF I-quant path: the oracle's q8_1 MMVQ (integer sub-dots, f32 scales) of one Gemma-4-12B sliding layer's
+    seven projections in the model's tensor-type mix, all cores and one thread; tokens/s over the layer count (token embedding
+    and lm_head left out)."""
+    from oracle import oracle as orc
+    from vllm_rust_amd.gemma4 import IQ_TYPE_SIZE
+    rng = np.random.default_rng(1)
+    mats = []
+    for slot, (K, N) in spec.linear_shapes(0).items():
+        t = slot_types[slot]
+        w = rng.integers(0, 256, size=(N * (K // 256), IQ_TYPE_SIZE[t]), dtype=np.uint8)
+        w[:, 0:2] = np.frombuffer(np.float16(0.01).tobytes(), dtype=np.uint8)
+        aq = rng.integers(-127, 128, size=(1, K), dtype=np.int8)
+        ad = (rng.random((1, K // 32), dtype=np.float32) * 0.01).astype(np.float32)
+        mats.append((t, w, aq, ad, N, K))
+
+    def layer(threads):
+        for t, w, aq, ad, N, K in mats:
+            orc.iq_mmvq_q8(t, w, aq, ad, N, K, threads=threads)
+
+    cores = _host_cores()
+    prev = orc.set_threads(cores)
+    t_mt, reps = _timed(lambda: layer(True), budget_s * 0.6)
+    orc.set_threads(prev)
+    t_1, reps1 = _timed(lambda: layer(False), budget_s * 0.4, max_reps=2)
+    return {"value": round(1.0 / (spec.num_layers * t_mt), 3), "unit": "tok/s", "cores": cores, "kind": "port",
+            "sample": f"oracle q8_1 MMVQ of one sliding layer's 7 I-quant projections x{reps} ({t_mt * 1e3:.1f} ms/layer), scaled to {spec.num_layers} layers",
+            "single_thread": {"value": round(1.0 / (spec.num_layers * t_1), 4), "unit": "tok/s", "cores": 1,
+                              "sample": f"the same layer with one thread x{reps1} ({t_1 * 1e3:.0f} ms/layer)"}}
+
+
+def cpu_baseline_exl3(budget_s=8.0):
+    """CPU leg of the EXL3 path: the oracle's Exl3Linear forward (Hadamard, trellis decode, fp16 GEMM, Hadamard) on a 1/8-wide
+    slice of a Qwen3-8B q_proj at 4.0 bpw, all cores; scaled by weight count to the 36 layers' seven projections."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(2)
+    K, N, bits = 4096, 512, 4
+    tr = rng.integers(0, 65536, size=(K // 16, N // 16, 16 * bits), dtype=np.uint16)
+    suh = orc.f32_to_f16(np.sign(rng.standard_normal(K)).astype(np.float32))
+    svh = orc.f32_to_f16(np.sign(rng.standard_normal(N)).astype(np.float32))
+    x = orc.f32_to_f16(rng.standard_normal((1, K)).astype(np.float32))
+    cores = _host_cores()
+    prev = orc.set_threads(cores)
+    t, reps = _timed(lambda: orc.exl3_gemm(x, tr, suh, svh, K, N, bits, 0), budget_s)
+    orc.set_threads(prev)
+    per_weight = t / (K * N)
+    layer_weights = 4096 * (4096 + 1024 + 1024) + 4096 * 4096 + 2 * 4096 * 12288 + 12288 * 4096
+    return {"value": round(1.0 / (36 * layer_weights * per_weight), 4), "unit": "tok/s", "cores": cores, "kind": "port",
+            "sample": f"oracle EXL3 linear [4096 -> 512] at 4.0 bpw x{reps} ({t * 1e3:.1f} ms), scaled by weight count to 36 layers x 7 projections"}
 
 
 def gemma4_secondary(prompt, steps, warmup):
@@ -139,13 +211,19 @@ def gemma4_secondary(prompt, steps, warmup):
     wbytes = model.iq_weight_bytes()
     embed_bytes = spec.vocab_size * (spec.hidden_size // 256) * 110
     model.close()
-    return {"metric": "decode tok/s (greedy, batch=1), Gemma-4-12B GGUF UD-IQ3_XXS mix + FP8 KV", "value": round(steps / dt, 2), "unit": "tok/s",
+    from vllm_rust_amd.gemma4 import GEMMA4_12B_IQ3_MIX
+    cpu = None
+    try:
+        cpu = cpu_baseline_mmvq(spec, GEMMA4_12B_IQ3_MIX)
+    except Exception as e:   # the CPU leg must not cost the GPU numbers
+        cpu = {"error": repr(e)}
+    return {"metric": "decode tok/s (greedy, batch=1), Gemma-4-12B GGUF UD-IQ3_XXS mix + FP8 KV", "cpu_baseline": cpu, "value": round(steps / dt, 2), "unit": "tok/s",
             "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
             "config": {"workload": "Gemma-4-12B-shaped GGUF (187 IQ3_XXS / IQ2_S / IQ3_S projections per the UD-IQ3_XXS mix, Q3_K tied "
                                    "token embedding), 48 layers (40 sliding 8x256 window 1024, 8 full 1x512), FP8 e4m3 KV, soft-cap 30",
                        "weights": "seeded random-init blocks of the architecture", "execution": "one hipGraph per step"},
             "weight_bytes_per_token": wbytes + embed_bytes,
-            "roofline": {"bound": "hbm", "kernel": "iq_mmvq_kernel / iq_mmvq_multi_kernel / iq_mmvq_pipe_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "iq_pk_mmvq_kernel (packed, large one-row launches) / iq_mmvq_multi_kernel / iq_mmvq_pipe_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": launches,
                          "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches)}}
 
@@ -524,6 +602,11 @@ def main():
         torch.cuda.empty_cache()
         secondary_exl3 = exl3_decode_secondary(args.prompt, min(args.steps, 64), args.warmup)
         secondary_exl3["linears_only"] = exl3_secondary()
+        if not args.no_cpu_baseline:
+            try:
+                secondary_exl3["cpu_baseline"] = cpu_baseline_exl3()
+            except Exception as e:
+                secondary_exl3["cpu_baseline"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         batch_sweep = batch_sweep_secondary(args.prompt, 32, 4)
 

@@ -349,3 +349,19 @@ void orc_fp8_dequant_bf16(const uint8_t *in, const float *scale, int64_t rows, i
         for (int64_t c = 0; c < cols; c++)
             out[r * cols + c] = orc_f32_to_bf16(orc_fp8_e4m3_decode(in[r * cols + c]) * (per_row ? scale[r] : scale[0]));
 }
+
+/* Dense bf16 linear without bias, one row at a time: y[m,n] = bf16(sum_k x[m,k] * W[n,k]), f32 sequential accumulate
+ * over k.  This is the arithmetic of the reference's unquantized Linear on the decode path (candle matmul of bf16
+ * operands with f32 accumulation, result cast to bf16): the lm_head of the quantized models
+ * (crates/core/src/models/qwen3_quantized.rs:1258-1302) and the projections of an unquantized checkpoint
+ * (crates/core/src/models/qwen3.rs).  bf16 x bf16 products are exact in f32; only the summation order is a choice. */
+void orc_dense_gemv_bf16(const uint16_t *x, const uint16_t *W, int64_t M, int64_t N, int64_t K, uint16_t *y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; n++) {
+        for (int64_t m = 0; m < M; m++) {
+            float acc = 0.0f;
+            for (int64_t k = 0; k < K; k++) acc += orc_bf16_to_f32(x[m * K + k]) * orc_bf16_to_f32(W[n * K + k]);
+            y[m * N + n] = orc_f32_to_bf16(acc);
+        }
+    }
+}

@@ -87,6 +87,7 @@ for _name, _res, _args in [
     ("orc_fp8_gemm_bf16", None, [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_void_p]),
     ("orc_fp8_quant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("orc_fp8_dequant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    ("orc_dense_gemv_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
 ]:
     _f = getattr(_lib, _name)
     _f.restype = _res
@@ -327,6 +328,24 @@ def fp8_gemm_bf16(x_bf16, W_u8, scale, bias_bf16, per_channel: bool) -> np.ndarr
     y = np.empty((M, N), np.uint16)
     _lib.orc_fp8_gemm_bf16(_p(x), _p(W), _p(sc), _p(b) if b is not None else None, M, N, K, int(per_channel), _p(y))
     return y
+
+
+def dense_gemv_bf16(x_bf16, W_bf16) -> np.ndarray:
+    """y[m, n] = bf16(sum_k x[m, k] * W[n, k]) (f32 sequential accumulate): the unquantized Linear / lm_head on decode rows."""
+    x = _c(x_bf16, np.uint16); W = _c(W_bf16, np.uint16)
+    M, K = x.shape; N = W.shape[0]
+    assert W.shape[1] == K
+    y = np.empty((M, N), np.uint16)
+    _lib.orc_dense_gemv_bf16(_p(x), _p(W), M, N, K, _p(y))
+    return y
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads the oracle's parallel loops use from now on (libgomp of this process); returns the previous maximum."""
+    gomp = C.CDLL("libgomp.so.1")
+    prev = gomp.omp_get_max_threads()
+    gomp.omp_set_num_threads(int(n))
+    return prev
 
 
 def fp8_quant_bf16(x_bf16, scale=None, dynamic: bool = True, per_token: bool = False):
