@@ -410,6 +410,11 @@ int vmx_qwen3_load_gptq_expert(vmx_qwen3 *m, int layer, int expert, const uint32
                                const uint32_t *w3_qweight, const uint16_t *w3_scales_f16, const uint32_t *w2_qweight,
                                const uint16_t *w2_scales_f16, void *stream);
 
+/* Load one projection of an UNQUANTIZED checkpoint: bf16 [out, in], the dense Linear of the reference's plain model
+ * (crates/core/src/models/qwen3.rs; BASELINE's "Qwen3-0.6B bf16" configuration).  When all seven slots of a layer were
+ * loaded this way and no quantized form was, the layer runs on dense bf16 GEMVs (f32 accumulate, bf16 output). */
+int vmx_qwen3_load_dense_linear(vmx_qwen3 *m, int layer, int slot, const uint16_t *weight_bf16, size_t bytes, void *stream);
+
 /* Load one projection as a GGUF I-quant tensor (IqLinear, crates/core/src/quantization/gguf/mod.rs:262-377;
  * GgufWeightLoader::load_linear :1612-1662): raw block bytes of the [out, in] weight, ggml_type one of the I-quant ids.
  * A layer runs either on its int4 linears or, when all seven projections were loaded this way, on I-quant MMVQ

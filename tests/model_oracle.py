@@ -30,8 +30,12 @@ class OracleQwen3:
         self.lin = {}
         self.iq = {}
         self.ex = {}
+        self.dense = {}
         for li in range(s.num_layers):
             for slot in range(7):
+                if f"{li}.{slot}.dense" in ck:   # unquantized Linear: bf16 [out, in]
+                    self.dense[(li, slot)] = self.ck[f"{li}.{slot}.dense"]
+                    continue
                 if f"{li}.{slot}.exl3" in ck:
                     import torch
                     bits, cb, tr, suh, svh = ck[f"{li}.{slot}.exl3"]
@@ -57,6 +61,8 @@ class OracleQwen3:
         self.kv_scales = (1.0, 1.0)
 
     def linear(self, li, slot, x_u16):
+        if (li, slot) in self.dense:   # plain Linear of models/qwen3.rs: bf16 matmul, f32 accumulate, bf16 result
+            return orc.dense_gemv_bf16(x_u16, self.dense[(li, slot)])
         if (li, slot) in self.ex:   # Exl3Linear::forward (exl3.rs:216-286): cast to fp16, exl3_gemm, cast back to bf16
             bits, cb, tr, K, N, suh, svh = self.ex[(li, slot)]
             x16 = orc.f32_to_f16(orc.bf16_to_f32(x_u16))
@@ -124,8 +130,10 @@ class OracleQwen3:
             a = orc.silu_and_mul_bf16(self.linear(li, 4, x), self.linear(li, 5, x))
             h = add_bf16(h, self.linear(li, 6, a))
         x = orc.rms_norm_bf16(h, self.ck["final_norm"], s.rms_norm_eps)
-        head = self.ck["embed"] if s.tie_word_embeddings else self.ck["lm_head"]
-        logits = orc.f32_to_bf16((orc.bf16_to_f32(x).astype(np.float64) @ orc.bf16_to_f32(head).astype(np.float64).T).astype(np.float32))
+        if getattr(self, "_head64", None) is None:   # widened once: a 150k-row head is 1.2 GB in f64
+            head = self.ck["embed"] if s.tie_word_embeddings else self.ck["lm_head"]
+            self._head64 = orc.bf16_to_f32(head).astype(np.float64).T.copy()
+        logits = orc.f32_to_bf16((orc.bf16_to_f32(x).astype(np.float64) @ self._head64).astype(np.float32))
         return logits, h, x
 
 

@@ -1,0 +1,98 @@
+"""BASELINE's first configuration -- Qwen3-0.6B in bf16 (unquantized), greedy decode -- through the same executor as the
+quantized models: every projection a dense bf16 Linear (vmx_qwen3_load_dense_linear), tied lm_head.  Checked against the CPU
+oracle model: activations per step (teacher-forced), and a free-running greedy loop whose token ids must agree exactly
+(the engine's loop, crates/core/src/engine/mod.rs:352-400: prompt pass, then feed back the argmax)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import vllm_rust_amd as vmx
+    vmx.init(0)
+    return vmx, torch
+
+
+def _spec(layers, vocab, **kw):
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    return Qwen3Spec(1024, layers, 16, 8, 128, 3072, vocab, tie_word_embeddings=True, max_position=512, num_blocks=40, max_batch=2,
+                     max_seq_len=256, max_prefill_tokens=32, **kw)
+
+
+def test_dense_layers_match_oracle_per_step(gpu):
+    """Three layers of the 0.6B geometry, two sequences at different positions, teacher-forced: hidden state and logits
+    within 2e-2 relative L2 of the oracle at every step (bf16 rounding points are the reference's; only f32 summation
+    order differs)."""
+    from tests.test_gpu_true_geometry import _decode_and_compare, _fill_kv
+    from tests.model_oracle import OracleQwen3
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache
+    vmx, torch = gpu
+    spec = _spec(3, 8192)
+    model = QuantizedQwen3ForCausalLM(spec)
+    try:
+        ck = model.load_synthetic_bf16(seed=21, keep_host_copy=True)
+        ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta))
+        shape = (spec.num_blocks, spec.block_size, spec.num_kv_heads, spec.head_dim)
+        _fill_kv(torch, model, ref, spec.num_layers, [shape] * spec.num_layers, spec.kv_cache_dtype, seed=3)
+        _decode_and_compare(torch, model, ref, spec, [5, 130], 3, [17, 4000])
+    finally:
+        model.close()
+
+
+def test_qwen3_0_6b_bf16_greedy_tokens_equal_the_oracle(gpu):
+    """The whole model (28 layers, vocabulary 151936, tied head): a 12-token prompt through the native prompt pass, then 10
+    greedy tokens; the oracle runs the same loop on the CPU (its prompt one token at a time).  The token ids must be equal.
+    Seeded weights make this deterministic; a logit tie within bf16 rounding would show up as a fixed failure, not a flake."""
+    from tests.model_oracle import OracleQwen3
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache
+    vmx, torch = gpu
+    spec = _spec(28, 151936)
+    model = QuantizedQwen3ForCausalLM(spec)
+    try:
+        ck = model.load_synthetic_bf16(seed=4, keep_host_copy=True)
+        # a small token embedding, so that the layers and not the (tied) embedding row of the input token decide the next
+        # token -- with the default one the greedy loop repeats one id for ever, which would test little
+        from vllm_rust_amd.qwen3 import T_EMBED
+        emb = (torch.randn((spec.vocab_size, spec.hidden_size), device=model.device, generator=torch.Generator(device=model.device).manual_seed(77))
+               * 0.02).to(torch.bfloat16)
+        model.load_tensor(T_EMBED, 0, emb)
+        ck["embed"] = emb.cpu()
+        ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta))
+        P, N, bs = 12, 10, spec.block_size
+        prompt = np.random.default_rng(8).integers(0, spec.vocab_size, P).astype(np.int32)
+        nblk = (P + N + bs - 1) // bs + 1
+        bt = np.arange(nblk, dtype=np.int32)[::-1].copy().reshape(1, nblk)
+
+        def slot(p):
+            return np.asarray([bt[0, p // bs] * bs + p % bs], np.int32)
+
+        # executor: prompt pass, then decode steps
+        dev = model.device
+        bt_t = torch.from_numpy(bt).to(dev)
+        first = model.prefill(torch.from_numpy(prompt).to(dev), 0, bt_t[0])
+        got = [int(first.item())]
+        for i in range(N - 1):
+            p = P + i
+            out = model.forward_decode_batch(torch.tensor([got[-1]], dtype=torch.int32, device=dev), torch.tensor([p], dtype=torch.int32, device=dev),
+                                             torch.from_numpy(slot(p)).to(dev), bt_t, torch.tensor([p + 1], dtype=torch.int32, device=dev),
+                                             max_seq_len=P + N)
+            got.append(int(out.item()))
+        # oracle: the same loop
+        exp, logits = [], None
+        for p in range(P):
+            logits, _, _ = ref.decode(prompt[p:p + 1], np.asarray([p], np.int32), slot(p), bt, np.asarray([p + 1], np.int32))
+        from oracle import oracle as orc
+        exp.append(int(orc.argmax_bf16(logits)[0]))
+        for i in range(N - 1):
+            p = P + i
+            logits, _, _ = ref.decode(np.asarray([exp[-1]], np.int32), np.asarray([p], np.int32), slot(p), bt, np.asarray([p + 1], np.int32))
+            exp.append(int(orc.argmax_bf16(logits)[0]))
+        print("executor", got)
+        print("oracle  ", exp)
+        assert got == exp
+        assert len(set(got)) > 3, "degenerate greedy loop: the comparison would say little"
+    finally:
+        model.close()

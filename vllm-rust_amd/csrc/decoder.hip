@@ -381,6 +381,10 @@ struct Layer {
     Exl3Lin ex[7];   // ... or as EXL3 trellis-coded linears
     DevBuf ex_svh_qkv, ex_svh_gu;   // svh of q|k|v and of gate|up back to back, when the group can go out as one launch
     bool exl3_ready() const { for (const Exl3Lin &l : ex) if (!l.loaded) return false; return true; }
+    // ... or as plain bf16 matrices [out, in] (an unquantized checkpoint): q|k|v, o, gate|up, down, rows concatenated
+    DevBuf dn[4];
+    int dn_filled = 0;   // bit per slot VMX_L_Q .. VMX_L_DOWN
+    bool dense_ready() const { return dn_filled == 0x7f; }
     bool int4_ready() const { return qkv.loaded && o.loaded && gate_up.loaded && down.loaded; }
     bool int4_attn_ready() const { return qkv.loaded && o.loaded; }
     MergeStage qkv_stage, gu_stage;
@@ -402,6 +406,7 @@ struct vmx_qwen3 {
     bool lm_head_tied = false;
     DevBuf h, x, q, attn, act, partial, partial_b, logits, attn_ws, argmax_ws, red_bf16, keys, q8, positions, ssq;
     DevBuf router_logits, topk_w, topk_ids, moe_ws, moe_out;   // MoE models only
+    DevBuf dense_tmp;                                          // unquantized layers only: bf16 [16][widest projection], grown by the loader
     DevBuf exl3_ws;                                            // EXL3 models only: grown by the loader
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
     int lin_mask = 15;  // measurement aid: which linears vmx_qwen3_linears_only launches (1 q|k|v, 2 o, 4 gate|up, 8 down)
@@ -466,6 +471,26 @@ int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> 
     const Exl3Lin &f = L.ex[*slots.begin()];
     return vmx_exl3_forward_multi_f32(x, 1, n, tr, suh, n_out, (const uint16_t *)svh.p, y, ldy, tokens, f.in_features, f.bits, f.codebook,
                                       m->exl3_ws.p, m->exl3_ws.bytes, st, partial_out, splits_out);
+}
+
+__global__ __launch_bounds__(256) void bf16_rows_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int rows, int cols,
+                                                                 int ldo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)rows * cols) out[(i / cols) * ldo + (i % cols)] = vmx_bf16_to_f32(in[i]);
+}
+
+// Unquantized Linear (no bias) on decode / prompt rows: y = bf16(x W^T), 16 rows per launch, widened to the f32 form the
+// vector kernels take with one slice (they round to bf16 again, which changes nothing).
+int dense_forward(vmx_qwen3 *m, const void *W, const uint16_t *x, float *y, int ldy, int N, int K, int tokens, hipStream_t st) {
+    uint16_t *tmp = (uint16_t *)m->dense_tmp.p;
+    for (int r0 = 0; r0 < tokens; r0 += 16) {
+        const int mr = tokens - r0 < 16 ? tokens - r0 : 16;
+        if (int rc = vmx_dense_gemv_launch(tmp, x + (size_t)r0 * K, (const uint16_t *)W, nullptr, mr, N, K, st)) return rc;
+        const int64_t n = (int64_t)mr * N;
+        hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, y + (size_t)r0 * ldy, mr, N, ldy);
+    }
+    VMX_CHECK_LAUNCH("dense_forward");
+    return VMX_OK;
 }
 
 // Row-parallel epilogue: red_bf16 = all_reduce_sum(bf16(sum of this rank's split-K slices)) — what composing the
@@ -653,6 +678,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
             for (DevBuf *b : {&e.trellis, &e.suh, &e.svh}) b->release();
         L.ex_svh_qkv.release();
         L.ex_svh_gu.release();
+        for (DevBuf &b : L.dn) b.release();
         for (DevBuf *b : {&L.qkv.packed, &L.o.packed, &L.gate_up.packed, &L.down.packed, &L.input_ln, &L.post_ln, &L.q_norm, &L.k_norm,
                           &L.k_cache, &L.v_cache, &L.kv_scales})
             b->release();
@@ -661,7 +687,7 @@ extern "C" void vmx_qwen3_destroy(vmx_qwen3 *m) {
     }
     for (DevBuf *b : {&m->embed, &m->lm_head, &m->final_norm, &m->cos_sin, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->partial, &m->partial_b,
                       &m->logits, &m->attn_ws, &m->argmax_ws, &m->red_bf16, &m->keys, &m->q8, &m->positions, &m->router_logits, &m->topk_w, &m->topk_ids,
-                      &m->moe_ws, &m->moe_out, &m->exl3_ws, &m->ssq})
+                      &m->moe_ws, &m->moe_out, &m->exl3_ws, &m->ssq, &m->dense_tmp})
         b->release();
     delete m;
 }
@@ -817,6 +843,36 @@ extern "C" int vmx_qwen3_load_iq_linear(vmx_qwen3 *m, int layer, int slot, int g
     return VMX_OK;
 }
 
+// One projection of an unquantized checkpoint: bf16 [out, in] (the reference's dense Linear of models/qwen3.rs).  q, k, v and
+// gate, up land in merged matrices (rows concatenated), so a layer is four dense GEMVs.
+extern "C" int vmx_qwen3_load_dense_linear(vmx_qwen3 *m, int layer, int slot, const uint16_t *weight_bf16, size_t bytes, void *stream) {
+    VMX_REQUIRE(m && weight_bf16, "qwen3_load_dense_linear: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && slot >= VMX_L_Q && slot <= VMX_L_DOWN,
+                "qwen3_load_dense_linear: layer %d / slot %d out of range", layer, slot);
+    VMX_REQUIRE(m->cfg.num_experts == 0, "qwen3_load_dense_linear: mixture-of-experts models take int4 projections");
+    const vmx_qwen3_config &c = m->cfg;
+    const int H = c.hidden_size, I = c.intermediate_size, NQ = c.num_heads * c.head_dim, NKV = c.num_kv_heads * c.head_dim;
+    const int in_f[7] = {H, H, H, NQ, H, H, I}, out_f[7] = {NQ, NKV, NKV, H, I, I, H};
+    const int buf_of[7] = {0, 0, 0, 1, 2, 2, 3}, row0[7] = {0, NQ, NQ + NKV, 0, 0, I, 0}, rows_of[4] = {NQ + 2 * NKV, H, 2 * I, H};
+    const int K = in_f[slot], N = out_f[slot];
+    VMX_REQUIRE(K % 8 == 0, "qwen3_load_dense_linear: in_features %d not a multiple of 8", K);
+    const size_t need = (size_t)N * K * 2;
+    VMX_REQUIRE(bytes == need, "qwen3_load_dense_linear: expected %zu bytes for bf16 [%d, %d], got %zu", need, N, K, bytes);
+    Layer &L = m->layers[layer];
+    DevBuf &b = L.dn[buf_of[slot]];
+    if (!b.p)
+        if (int rc = b.alloc((size_t)rows_of[buf_of[slot]] * K * 2)) return rc;
+    VMX_CHECK_HIP(hipMemcpyAsync((char *)b.p + (size_t)row0[slot] * K * 2, weight_bf16, need, hipMemcpyDefault, vmx_stream(stream)));
+    const size_t tmp_need = (size_t)16 * (2 * I > NQ + 2 * NKV ? 2 * I : NQ + 2 * NKV) * 2;
+    if (m->dense_tmp.bytes < tmp_need) {
+        VMX_CHECK_HIP(hipStreamSynchronize(vmx_stream(stream)));
+        m->dense_tmp.release();
+        if (int rc = m->dense_tmp.alloc(tmp_need)) return rc;
+    }
+    L.dn_filled |= 1 << slot;
+    return VMX_OK;
+}
+
 extern "C" int vmx_qwen3_load_exl3_linear(vmx_qwen3 *m, int layer, int slot, const void *trellis, const uint16_t *suh,
                                           const uint16_t *svh, int in_features, int out_features, int bits, int codebook, void *stream) {
     VMX_REQUIRE(m && trellis && suh && svh, "qwen3_load_exl3_linear: null pointer");
@@ -889,7 +945,7 @@ namespace {
 // projections in ONE of the three formats.
 bool layer_ready(const vmx_qwen3 *m, const Layer &L) {
     if (m->cfg.num_experts > 0) return L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts);
-    return L.int4_ready() || L.iq_ready() || L.exl3_ready();
+    return L.int4_ready() || L.iq_ready() || L.exl3_ready() || L.dense_ready();
 }
 
 // VMX_NO_FOLDED_LAYERS=1 keeps the seven-launch layer (norm kernels of their own) for A/B measurements
@@ -930,8 +986,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     for (const Layer &L : m->layers) {
         const bool moe = c.num_experts > 0;  // int4 attention projections + mixture-of-experts MLP
         const bool ex = !moe && !L.int4_ready() && L.exl3_ready();   // EXL3 layer: every projection an Exl3Linear
-        const bool iq = !moe && !L.int4_ready() && !ex;              // GGUF I-quant layer: every projection is an IqLinear
-        const bool one = iq || ex;                                   // linear outputs arrive as one f32 slice
+        const bool dn = !moe && !L.int4_ready() && !ex && !L.iq_ready() && L.dense_ready();   // unquantized layer: bf16 matrices
+        const bool iq = !moe && !L.int4_ready() && !ex && !dn;       // GGUF I-quant layer: every projection is an IqLinear
+        const bool one = iq || ex || dn;                             // linear outputs arrive as one f32 slice
         int s_qkv = one ? 1 : L.qkv.splits();
         const int s_o = one ? 1 : L.o.splits(), s_gu = one ? 1 : L.gate_up.splits(),
                   s_down = one ? 1 : L.down.splits();
@@ -960,6 +1017,8 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             if (int rc = exl3_forward(m, L.ex[VMX_L_Q], x, PA, NQKV_, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_K], x, PA + NQ, NQKV_, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_V], x, PA + NQ + NKV, NQKV_, B, st)) return rc;
+        } else if (dn) {
+            if (int rc = dense_forward(m, L.dn[0].p, x, PA, NQKV_, NQKV_, H, B, st)) return rc;
         } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_Q], PA, NQKV_, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_K], PA + NQ, NQKV_, B, st)) return rc;
@@ -1029,6 +1088,8 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             o_svh = (const uint16_t *)L.ex[VMX_L_O].svh.p;
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_O], attn, PB, H, B, st)) return rc;
+        } else if (dn) {
+            if (int rc = dense_forward(m, L.dn[1].p, attn, PB, H, H, NQ, B, st)) return rc;
         } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_O], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.o, attn, PB, B, st)) return rc;
@@ -1072,6 +1133,8 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_GATE], x, PA, 2 * I, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_UP], x, PA + I, 2 * I, B, st)) return rc;
+        } else if (dn) {
+            if (int rc = dense_forward(m, L.dn[2].p, x, PA, 2 * I, 2 * I, H, B, st)) return rc;
         } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_GATE], PA, 2 * I, B, st)) return rc;
             if (int rc = iq_forward(m, L.iq[VMX_L_UP], PA + I, 2 * I, B, st)) return rc;
@@ -1089,6 +1152,8 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             continue;
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_DOWN], act, PB, H, B, st)) return rc;
+        } else if (dn) {
+            if (int rc = dense_forward(m, L.dn[3].p, act, PB, H, H, I, B, st)) return rc;
         } else if (iq) {
             if (int rc = iq_forward(m, L.iq[VMX_L_DOWN], PB, H, B, st)) return rc;
         } else if (int rc = run_linear(m, L.down, act, PB, B, st)) return rc;

@@ -129,6 +129,13 @@ class QuantizedQwen3ForCausalLM:
         check(lib.vmx_qwen3_load_iq_linear(self._h, layer, slot, ggml_type, blocks.data_ptr(), blocks.numel(), self._stream()))
         torch.cuda.current_stream().synchronize()
 
+    def load_dense_linear(self, layer: int, slot: int, weight: torch.Tensor) -> None:
+        """weight: bf16 [out, in] (device or host): one projection of an unquantized checkpoint."""
+        assert weight.dtype == torch.bfloat16 and weight.dim() == 2
+        weight = weight.contiguous()
+        check(lib.vmx_qwen3_load_dense_linear(self._h, layer, slot, weight.data_ptr(), weight.numel() * 2, self._stream()))
+        torch.cuda.current_stream().synchronize()
+
     def load_exl3_linear(self, layer: int, slot: int, trellis: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor, codebook: int = 0) -> None:
         """trellis: int16 [in/16, out/16, 16 * bits]; suh f16 [in]; svh f16 [out]  (the tensors of an EXL3 checkpoint entry)."""
         assert trellis.dtype == torch.int16 and trellis.dim() == 3 and suh.dtype == torch.float16 and svh.dtype == torch.float16
@@ -211,6 +218,20 @@ class QuantizedQwen3ForCausalLM:
                 self.load_iq_linear(li, slot, t, raw.reshape(-1))
                 if keep_host_copy:
                     ck[f"{li}.{slot}.iq"] = (t, raw.reshape(-1).cpu())
+        return ck
+
+    def load_synthetic_bf16(self, seed: int = 0, keep_host_copy: bool = False):
+        """Seeded random-init UNQUANTIZED checkpoint of the architecture: every projection a bf16 [out, in] matrix with
+        ~1/sqrt(in) entries, bf16 norms and embeddings as load_synthetic."""
+        s = self.spec
+        ck = self._load_synthetic_dense(seed, keep_host_copy)
+        g = torch.Generator(device=self.device).manual_seed(seed + 2)
+        for li in range(s.num_layers):
+            for slot, (K, N) in self.linear_shapes().items():
+                w = (torch.randn((N, K), device=self.device, generator=g) * (1.0 / math.sqrt(K))).to(torch.bfloat16)
+                self.load_dense_linear(li, slot, w)
+                if keep_host_copy:
+                    ck[f"{li}.{slot}.dense"] = w.cpu()
         return ck
 
     def load_synthetic_exl3(self, bits: int = 4, codebook: int = 0, seed: int = 0, keep_host_copy: bool = False):
