@@ -379,6 +379,62 @@ def batch_sweep_secondary(prompt, steps, warmup, batches=(1, 4, 8, 16)):
     return {"metric": "aggregate decode tok/s at B concurrent sequences, Qwen3-8B AWQ, TP=1", "prompt": prompt, "steps": steps, "by_batch": out}
 
 
+def context_sweep_secondary(steps, warmup, contexts=(1024, 8192)):
+    """Decode tok/s of the headline model (Qwen3-8B AWQ, batch 1) at longer contexts: the prompt goes through the native
+    prompt pass in chunks of 2048 tokens, then `steps` timed tokens from one hipGraph.  Up to 8192 tokens the attention of a
+    five-launch layer is the split kernel (8 workgroups per KV head, merged by o_proj)."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    chunk = 2048
+    top = max(contexts) + warmup + steps + 8
+    n_blocks = (top + 15) // 16 + 1
+    spec = Qwen3Spec.qwen3_8b(max_position=top + 1, num_blocks=n_blocks, max_batch=1, max_seq_len=top + 1, max_prefill_tokens=chunk)
+    model = QuantizedQwen3ForCausalLM(spec)
+    model.load_synthetic(seed=4321)
+    dev = model.device
+    out = {}
+    bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).reshape(1, n_blocks).contiguous()
+    side = torch.cuda.Stream(device=dev)
+    for ctx in contexts:
+        total = ctx + warmup + steps + 8
+        g7 = torch.Generator(device=dev).manual_seed(ctx)
+        ids = torch.empty(1, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(side):
+            t_pre = time.perf_counter()
+            for c0 in range(0, ctx, chunk):
+                n = min(chunk, ctx - c0)
+                pids = torch.randint(0, spec.vocab_size, (n,), dtype=torch.int32, device=dev, generator=g7)
+                model.prefill(pids, c0, bt[0], out_id=ids)
+            torch.cuda.synchronize()
+            t_pre = time.perf_counter() - t_pre
+            pos = torch.full((1,), ctx, dtype=torch.int32, device=dev)
+            slots = (bt[:, ctx // 16] * 16 + ctx % 16).to(torch.int32).contiguous()
+            sl = torch.full((1,), ctx + 1, dtype=torch.int32, device=dev)
+            o = torch.empty(1, dtype=torch.int32, device=dev)
+
+            def step():
+                model.forward_decode_batch(ids, pos, slots, bt, sl, max_seq_len=total + 1, out_ids=o)
+                model.advance(ids, o, pos, slots, sl, bt)
+            step()
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                step()
+            for _ in range(warmup):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            del g
+        kv_bytes = 2 * spec.num_layers * ctx * spec.num_kv_heads * spec.head_dim * 2
+        out[str(ctx)] = {"tok_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "kv_bytes_read_per_token": kv_bytes,
+                         "prefill_tok_s": round(ctx / t_pre, 1)}
+    model.close()
+    return {"metric": "decode tok/s at longer contexts, Qwen3-8B AWQ, batch 1, bf16 KV, TP=1", "steps": steps, "by_context": out}
+
+
 def mixtral_secondary(prompt, steps, warmup):
     """BASELINE.json configs[4] on one GPU: decode tok/s of a Mixtral-8x7B-shaped model (AWQ attention projections, 8 GPTQ
     int4 experts top-2 per layer behind a dense router) through the executor's device-side fused MoE path."""
@@ -591,6 +647,7 @@ def main():
     secondary_moe = None
     secondary_exl3 = None
     batch_sweep = None
+    context_sweep = None
     if rank == 0 and not dist_on and not args.no_secondary and not args.layers and not exl3:
         model.close()
         del model, graph
@@ -609,6 +666,8 @@ def main():
                 secondary_exl3["cpu_baseline"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         batch_sweep = batch_sweep_secondary(args.prompt, 32, 4)
+        torch.cuda.empty_cache()
+        context_sweep = context_sweep_secondary(32, 4)
 
     if rank == 0:
         tok_s = (1 if use_tp else world) * B * K_steps / elapsed
@@ -633,6 +692,7 @@ def main():
             "secondary_moe": secondary_moe,
             "secondary_exl3": secondary_exl3,
             "batch_sweep": batch_sweep,
+            "context_sweep": context_sweep,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

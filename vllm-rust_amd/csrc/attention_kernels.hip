@@ -1090,8 +1090,7 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
 }
 
 // ---- decode attention spread over P workgroups per KV head, merged by the consumer (split_decode_attn_kernel)
-// Partition count for a context bound, 0 = not covered.  VMX_SPLIT_ATTN_P overrides the count for contexts up to 1024
-// tokens (measurement), VMX_NO_SPLIT_ATTN=1 switches the path off.
+// Partition count for a context bound, 0 = not covered.  VMX_SPLIT_ATTN_P overrides the count (measurement), VMX_NO_SPLIT_ATTN=1 switches the path off.
 int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
     static const bool off = getenv("VMX_NO_SPLIT_ATTN") && atoi(getenv("VMX_NO_SPLIT_ATTN"));
     static const int p_env = getenv("VMX_SPLIT_ATTN_P") ? atoi(getenv("VMX_SPLIT_ATTN_P")) : 0;
@@ -1099,9 +1098,11 @@ int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max
     const int half = rot_dim / 2;
     if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return 0;
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
-    if (ctx <= 0 || ctx > 8192) return 0;
-    if (ctx <= 1024) return p_env >= 1 && p_env <= 8 ? p_env : 4;
-    return 8;
+    // Measured on MI355X (Qwen3-8B, batch 1): up to 1024 tokens 4 workgroups per KV head beat both the one-workgroup kernel
+    // and the three-launch path (560 vs 530 tok/s at 300 tokens); beyond that the three-launch path with its 64 partitions
+    // per sequence wins (2048 tokens: 478 vs 460 tok/s with 8 workgroups here), because the consumer's merge grows with P.
+    if (ctx <= 0 || ctx > 1024) return 0;
+    return p_env >= 1 && p_env <= 8 ? p_env : 4;
 }
 
 size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim) {
