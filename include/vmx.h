@@ -556,6 +556,50 @@ int vmx_gemma4_debug_kv(vmx_gemma4 *m, int layer, int which, int write, void *bu
 
 /* ------------------------------------------------------------------ GGUF container (host only) */
 
+/* ---- quantization detection and the safetensors container (host only) ----------------------------------------------
+ * Replaces crates/core/src/quantization/detection.rs:82-314 (detect_from_directory / detect_from_config_json /
+ * detect_from_quantize_config): config.json's "quantization_config" wins (quant_method, bits, group_size, desc_act,
+ * activation_scheme), then quantize_config.json (GPTQ form: bits + group_size, "gptq_marlin" -> Marlin; AWQ form: w_bit,
+ * q_group_size), then *.gguf files in the directory.  Fields the files do not state are -1 / "". */
+#define VMX_QM_NONE 0
+#define VMX_QM_AWQ 1
+#define VMX_QM_GPTQ 2
+#define VMX_QM_MARLIN 3        /* gptq_marlin */
+#define VMX_QM_AWQ_MARLIN 4
+#define VMX_QM_EXL3 5
+#define VMX_QM_FP8 6
+#define VMX_QM_GGUF 7
+#define VMX_QM_OTHER 8         /* a method the reference names that has no kernels here (method_name says which) */
+typedef struct vmx_quant_info {
+    int method;                /* VMX_QM_* */
+    int bits, group_size;      /* -1 when absent */
+    int desc_act;              /* -1 absent, 0 false, 1 true */
+    char method_name[32];      /* the quant_method string as found ("awq", "gptq_marlin", ...) */
+    char activation_scheme[32];
+} vmx_quant_info;
+/* Either text may be NULL (file absent); unparsable text counts as absent, as in the reference. */
+int vmx_quant_detect_json(const char *config_json, const char *quantize_config_json, vmx_quant_info *out);
+int vmx_quant_detect_dir(const char *model_dir, vmx_quant_info *out);
+
+/* The safetensors file the reference's weight loader reads "<prefix>.qweight / .qzeros / .scales / .trellis ..." from
+ * (crates/core/src/quantization/weight_loader.rs:470-559,597-714): u64 LE header length, JSON header, tensor bytes.
+ * Header lengths, offsets and shape x dtype sizes are validated against the file; tensor_info strings stay valid until
+ * close.  read_tensor copies one tensor's bytes to host memory (the caller uploads them with the executor's load calls). */
+typedef struct vmx_safetensors vmx_safetensors;
+typedef struct vmx_safetensors_tensor {
+    const char *name, *dtype;  /* dtype as spelled in the file: "I32", "F16", "BF16", "U8", ... */
+    int element_bytes, n_dims;
+    int64_t shape[8];
+    uint64_t file_offset, n_bytes;
+} vmx_safetensors_tensor;
+int vmx_safetensors_open(const char *path, vmx_safetensors **out);
+void vmx_safetensors_close(vmx_safetensors *h);
+int vmx_safetensors_tensor_count(const vmx_safetensors *h);
+int vmx_safetensors_find(const vmx_safetensors *h, const char *name);              /* index in header order, -1 if absent */
+int vmx_safetensors_tensor_info(const vmx_safetensors *h, int index, vmx_safetensors_tensor *out);
+int vmx_safetensors_read_tensor(const vmx_safetensors *h, int index, void *dst_host, size_t dst_bytes);
+const char *vmx_safetensors_metadata(const vmx_safetensors *h, const char *key);   /* "__metadata__" string entry or NULL */
+
 /* Replaces GgufHeader::read / read_tensor_bytes (crates/core/src/quantization/gguf/header.rs:221-321) and the HF ->
  * llama.cpp name map of the GGUF weight loader (gguf/mod.rs:1416-1479).  GGUF v1-3; tensor shapes come back in the logical
  * orientation (on-disk dims reversed: a 2-D weight is [out, in]); n_bytes = elements / block * type_size; tensor data

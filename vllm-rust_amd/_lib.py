@@ -114,6 +114,15 @@ _SIGS = {
     "vmx_qwen3_linears_select": (_i, [_p, _i]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
     "vmx_prefill_attention_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "vmx_quant_detect_json": (_i, [C.c_char_p, C.c_char_p, _p]),
+    "vmx_quant_detect_dir": (_i, [C.c_char_p, _p]),
+    "vmx_safetensors_open": (_i, [C.c_char_p, _p]),
+    "vmx_safetensors_close": (None, [_p]),
+    "vmx_safetensors_tensor_count": (_i, [_p]),
+    "vmx_safetensors_find": (_i, [_p, C.c_char_p]),
+    "vmx_safetensors_tensor_info": (_i, [_p, _i, _p]),
+    "vmx_safetensors_read_tensor": (_i, [_p, _i, _p, _sz]),
+    "vmx_safetensors_metadata": (C.c_char_p, [_p, C.c_char_p]),
     "vmx_gguf_open": (_i, [C.c_char_p, _p]),
     "vmx_gguf_parse": (_i, [_p, _sz, _p]),
     "vmx_gguf_close": (None, [_p]),
