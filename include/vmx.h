@@ -547,6 +547,13 @@ int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *po
 /* Measurement aid: launches and summed algorithmic bytes (weights + q8_1 activations + f32 outputs) of the MMVQ calls of one step,
  * and a pass that runs only those launches on the model's own buffers. */
 int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_bytes);
+/* ModelForward::forward for one sequence (engine/model_forward.rs:22-64; models/gemma4_quantized.rs forward): q_len prompt
+ * tokens at positions seqlen_offset .. seqlen_offset + q_len - 1 in passes of 16 rows; slot_mapping i32 [q_len], block_table
+ * i32 [blocks of the sequence] (device).  K/V rows go to the paged cache, attention is causal over the cache (sliding layers
+ * inside their window); only the last row goes through the lm_head: out_id_last (i32 [1]) / logits_last (bf16 [vocab]), either
+ * may be NULL. */
+int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int seqlen_offset, const int32_t *slot_mapping,
+                       const int32_t *block_table, int q_len, int32_t *out_id_last, uint16_t *logits_last, void *stream);
 int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream);
 /* Parity aid: 0 = residual stream h, 1 = final normed x (bf16 [batch, hidden]). */
 int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, void *stream);

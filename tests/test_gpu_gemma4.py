@@ -64,6 +64,86 @@ def test_gemma4_decode_k_eq_v_q3k_embedding_bf16_kv():
     _run(spec, steps=4, B=1, slot_types={0: 17, 1: 22, 2: 18, 3: 21, 4: 23, 5: 18, 6: 21})
 
 
+@pytest.mark.parametrize("kv_dtype,k_eq_v", [(0, False), (1, False), (0, True)])
+def test_gemma4_native_prefill_matches_token_by_token_oracle(kv_dtype, k_eq_v):
+    """vmx_gemma4_prefill on a 37-token prompt (passes of 16, 16 and 5 rows; sliding window 8 < prompt, so windowed causal
+    attention inside and across passes) followed by decode steps: last-token logits and every decoded step against the CPU
+    oracle, which walks the same tokens one at a time.  Also a second prefill call that continues at seqlen_offset > 0."""
+    import torch
+    import vllm_rust_amd as vmx
+    from oracle import oracle as orc
+    from tests.model_oracle import OracleGemma4
+    from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
+    vmx.init(0)
+    spec = Gemma4Spec(256, 3, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=8, full_every=3, k_eq_v_on_full=k_eq_v, max_position=128, kv_cache_dtype=kv_dtype, num_blocks=8,
+                      max_batch=1, max_seq_len=96)
+    model = QuantizedGemma4ForCausalLM(spec)
+    try:
+        ck = model.load_synthetic(seed=5, keep_host_copy=True)
+        # Gemma attends with scale 1 on RMS-normed q and k: with norm weights near 1 the logits have a standard deviation of
+        # sqrt(head_dim) = 8..11 and the softmax over a few dozen tokens is close to one-hot, so a one-ulp difference between
+        # two near-tied tokens moves the whole output (measured: 1.2 % relative error at 5 tokens, 13 % at 37, with the same
+        # kernels).  Norm weights of head_dim^-1/4 give logits of order 1, as trained checkpoints have; the error is then the
+        # same ~2 % (q8_1 noise of a 256-wide model) at every prompt length.
+        from vllm_rust_amd.gemma4 import T_K_NORM, T_Q_NORM
+        gq = torch.Generator(device="cuda").manual_seed(9)
+        for li in range(spec.num_layers):
+            hd = spec.head_dim_full if (li + 1) % 3 == 0 else spec.head_dim_sliding
+            for which, name in ((T_Q_NORM, "q_norm"), (T_K_NORM, "k_norm")):
+                w = ((1.0 + 0.1 * torch.randn(hd, device="cuda", generator=gq)) * (1.0 / (hd ** 0.25))).to(torch.bfloat16)
+                model.load_tensor(which, li, w)
+                ck[f"{li}.{name}"] = w.cpu()
+        ref = OracleGemma4(spec, ck, model.cos_sin_sliding, model.cos_sin_full)
+        bs = spec.block_size
+        bt = np.asarray([[5, 2, 7, 0, 3, 1]], np.int32)
+        P1, P2 = 37, 9
+        prompt = np.random.default_rng(1).integers(0, spec.vocab_size, P1 + P2).astype(np.int32)
+        bar = 3.5e-2 if kv_dtype == 0 else 5e-2   # measured 0.022-0.030 (bf16 KV), 0.028-0.033 (FP8 KV)
+
+        def slot(p):
+            return np.asarray([bt[0, p // bs] * bs + p % bs], np.int32)
+
+        def oracle_walk(p0, p1):
+            lg = None
+            for p in range(p0, p1):
+                lg, _, _ = ref.decode(prompt[p:p + 1], np.asarray([p], np.int32), slot(p), bt, np.asarray([p + 1], np.int32))
+            return orc.bf16_to_f32(lg)[0]
+
+        def rel(a, b):
+            return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+
+        bt_t = torch.from_numpy(bt).cuda()
+        lg = torch.empty(spec.vocab_size, dtype=torch.bfloat16, device="cuda")
+        nxt = model.prefill(torch.from_numpy(prompt[:P1]).cuda(), 0, bt_t[0], logits_last=lg)
+        torch.cuda.synchronize()
+        exp = oracle_walk(0, P1)
+        got = orc.bf16_to_f32(lg.cpu().view(torch.int16).numpy().view(np.uint16))
+        r1 = rel(got, exp)
+        assert np.isfinite(got).all() and r1 <= bar, r1
+        assert exp[int(nxt.item())] >= exp.max() - abs(exp.max()) * 2 ** -6
+        # continue the same sequence with a second chunk at an offset, then two decode steps
+        model.prefill(torch.from_numpy(prompt[P1:]).cuda(), P1, bt_t[0], logits_last=lg)
+        torch.cuda.synchronize()
+        exp = oracle_walk(P1, P1 + P2)
+        r2 = rel(orc.bf16_to_f32(lg.cpu().view(torch.int16).numpy().view(np.uint16)), exp)
+        assert r2 <= bar, r2
+        ids = np.asarray([int(np.argmax(exp))], np.int32)
+        for step in range(2):
+            p = P1 + P2 + step
+            lgb = torch.empty((1, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+            out = model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, np.asarray([p], np.int32), slot(p), bt,
+                                                                                   np.asarray([p + 1], np.int32))), logits=lgb)
+            torch.cuda.synchronize()
+            e, _, _ = ref.decode(ids, np.asarray([p], np.int32), slot(p), bt, np.asarray([p + 1], np.int32))
+            r3 = rel(orc.bf16_to_f32(lgb.cpu().view(torch.int16).numpy().view(np.uint16)), orc.bf16_to_f32(e))
+            assert r3 <= bar, (step, r3)
+            ids = out.cpu().numpy().astype(np.int32)
+        print(f"prefill rel-L2 {r1:.4f} / {r2:.4f}")
+    finally:
+        model.close()
+
+
 def test_gemma4_rejects_bad_config():
     import ctypes as C
     from vllm_rust_amd._lib import Gemma4Config, lib

@@ -145,6 +145,7 @@ _SIGS = {
     "vmx_gemma4_load_iq_linear": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "vmx_gemma4_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "vmx_gemma4_mmvq_info": (_i, [_p, _i, _p, _p]),
+    "vmx_gemma4_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "vmx_gemma4_mmvq_only": (_i, [_p, _i, _p]),
     "vmx_gemma4_debug_read": (_i, [_p, _i, _p, _sz, _p]),
     "vmx_gemma4_debug_kv": (_i, [_p, _i, _i, _i, _p, _sz, _p]),

@@ -296,7 +296,7 @@ struct vmx_gemma4 {
     vmx_gemma4_config cfg;
     std::vector<G4Layer> layers;
     Buf embed, final_norm, cos_sin_s, cos_sin_f;
-    Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8;
+    Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8, positions;
     float embed_scale = 1.f;
 };
 
@@ -419,22 +419,24 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
                 rc = VMX_ELAUNCH;
         }
     }
-    TRY(m->h.alloc((size_t)B * H * 2));
-    TRY(m->x.alloc((size_t)B * H * 2));
-    TRY(m->q.alloc((size_t)B * max_nq * 2));
-    TRY(m->attn.alloc((size_t)B * max_nq * 2));
-    TRY(m->act.alloc((size_t)B * I * 2));
-    TRY(m->proj.alloc((size_t)B * max_proj * 4));
-    TRY(m->out.alloc((size_t)B * H * 4));
+    const int R = B > 16 ? B : 16;   // activation rows: a decode batch, or one 16-row pass of the prompt path
+    TRY(m->positions.alloc((size_t)R * 4));
+    TRY(m->h.alloc((size_t)R * H * 2));
+    TRY(m->x.alloc((size_t)R * H * 2));
+    TRY(m->q.alloc((size_t)R * max_nq * 2));
+    TRY(m->attn.alloc((size_t)R * max_nq * 2));
+    TRY(m->act.alloc((size_t)R * I * 2));
+    TRY(m->proj.alloc((size_t)R * max_proj * 4));
+    TRY(m->out.alloc((size_t)R * H * 4));
     TRY(m->logits.alloc((size_t)B * c.vocab_size * 2));
     if (c.embed_ggml_type != 0) {
         TRY(m->logits_f32.alloc((size_t)B * c.vocab_size * 4));
-        TRY(m->x_f32.alloc((size_t)B * H * 4));
+        TRY(m->x_f32.alloc((size_t)R * H * 4));
     }
     {
         size_t kmax = (size_t)(H > I ? H : I);
         kmax = (size_t)max_nq > kmax ? (size_t)max_nq : kmax;
-        TRY(m->q8.alloc(B * kmax + 256 + B * (kmax / 32) * 4));
+        TRY(m->q8.alloc(R * kmax + 256 + R * (kmax / 32) * 4));
     }
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, max_hd, c.max_seq_len)));
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
@@ -455,7 +457,7 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
                        &L.kv_scales})
             b->release();
     }
-    for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
+    for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
                    &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8})
         b->release();
     delete m;
@@ -510,17 +512,21 @@ extern "C" int vmx_gemma4_load_iq_linear(vmx_gemma4 *m, int layer, int slot, int
     return VMX_OK;
 }
 
-extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
-                                 const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq, int max_seq_len,
-                                 int32_t *out_ids, uint16_t *logits_out, void *stream) {
-    VMX_REQUIRE(m && input_ids && positions && slot_mapping && block_tables && seq_lens, "gemma4_decode: null pointer");
+namespace {
+__global__ void g4_iota_kernel(int32_t *pos, int offset, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[i] = offset + i;
+}
+
+// The layer stack on `rows` token rows, up to and including the final norm (m->x).  prefill_offset < 0: every row is one
+// sequence's new token (paged decode attention over block_tables [rows, max_blocks_per_seq] / seq_lens); >= 0: the rows
+// are consecutive tokens of ONE sequence at positions prefill_offset + i (causal attention over the cache, block_tables =
+// that sequence's block table).
+int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+                  const int32_t *block_tables, const int32_t *seq_lens, int rows, int max_blocks_per_seq, int max_seq_len, int prefill_offset,
+                  hipStream_t st) {
     const vmx_gemma4_config &c = m->cfg;
-    VMX_REQUIRE(batch >= 1 && batch <= c.max_batch, "gemma4_decode: batch %d exceeds max_batch %d", batch, c.max_batch);
-    VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "gemma4_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
-                c.max_seq_len);
-    for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_decode: weights not fully loaded");
-    hipStream_t st = vmx_stream(stream);
-    const int H = c.hidden_size, I = c.intermediate_size, B = batch, Hq = c.num_heads;
+    const int H = c.hidden_size, I = c.intermediate_size, B = rows, Hq = c.num_heads;
     uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p, *attn = (uint16_t *)m->attn.p,
              *act = (uint16_t *)m->act.p;
     float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
@@ -548,7 +554,7 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
         }
         const float *ks = (const float *)L.kv_scales.p;
         // short contexts: per-head norms + RoPE + KV write + attention + merge in one launch (not for K == V layers)
-        const bool fused_attn = !L.k_eq_v && vmx_fused_decode_attention_ok(hd, Hq / Hkv, L.rot, max_seq_len, L.window);
+        const bool fused_attn = prefill_offset < 0 && !L.k_eq_v && vmx_fused_decode_attention_ok(hd, Hq / Hkv, L.rot, max_seq_len, L.window);
         if (fused_attn) {
             if (int rc = vmx_fused_decode_attention(attn, proj, 1, L.k_cache.p, L.v_cache.p, (const uint16_t *)L.q_norm.p,
                                                     (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
@@ -557,15 +563,23 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
                                                     L.window, c.kv_cache_dtype, ks, ks + 1, aq_of(m), ad_of(m, B, NQ), 1, st))
                 return rc;
         } else {
-        hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, L.k_cache.p, L.v_cache.p,
-                           (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
-                           (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping, Hq, Hkv, hd, L.rot,
-                           L.k_eq_v ? 1 : 0, fp8, ks, ks + 1);
-        VmxAttnParts ap;
-        if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, 1.0f, B, Hq, Hkv, max_blocks_per_seq,
-                                               max_seq_len, hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, m->attn_ws.p, &ap, st))
-            return rc;
-        if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
+            hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, L.k_cache.p, L.v_cache.p,
+                               (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
+                               (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping, Hq, Hkv, hd, L.rot,
+                               L.k_eq_v ? 1 : 0, fp8, ks, ks + 1);
+            if (prefill_offset >= 0) {   // the rows' K/V are in the cache: causal (windowed) attention over it, then q8_1 for o_proj
+                if (int rc = vmx_prefill_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, 1.0f, Hq, Hkv, hd,
+                                                        c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, st))
+                    return rc;
+                if (int rc = vmx_quantize_q8_1_bf16(attn, aq_of(m), ad_of(m, B, NQ), (int64_t)B * (NQ / 32), st)) return rc;
+            } else {
+                VmxAttnParts ap;
+                if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, 1.0f, B, Hq, Hkv, max_blocks_per_seq,
+                                                       max_seq_len, hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, m->attn_ws.p, &ap,
+                                                       st))
+                    return rc;
+                if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
+            }
         }
         if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, B, st)) return rc;
         // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
@@ -585,7 +599,15 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
         pending_scalar = (const uint16_t *)L.scalar.p;
     }
     launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr);
-    VMX_CHECK_LAUNCH("gemma4_decode");
+    VMX_CHECK_LAUNCH("gemma4 layers");
+    return VMX_OK;
+}
+
+// tied lm_head (+ soft-cap, greedy ids) on `rows` rows of normed activations starting at x
+int g4_run_head(vmx_gemma4 *m, const uint16_t *x, int rows, int32_t *out_ids, uint16_t *logits_out, void *stream) {
+    const vmx_gemma4_config &c = m->cfg;
+    hipStream_t st = vmx_stream(stream);
+    const int H = c.hidden_size, B = rows;
     uint16_t *logits = logits_out ? logits_out : (uint16_t *)m->logits.p;
     const int64_t nlog = (int64_t)B * c.vocab_size;
     const float cap = c.final_logit_softcap;
@@ -614,10 +636,52 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
         hipLaunchKernelGGL(g4_logits_kernel, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, st, logits, (const float *)lf, nlog, inv_cap,
                            cap);
     }
-    VMX_CHECK_LAUNCH("gemma4_decode(lm_head)");
+    VMX_CHECK_LAUNCH("gemma4(lm_head)");
     if (out_ids)
         if (int rc = vmx_argmax_bf16(out_ids, logits, B, c.vocab_size, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
     return VMX_OK;
+}
+}  // namespace
+
+extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positions, const int32_t *slot_mapping,
+                                 const int32_t *block_tables, const int32_t *seq_lens, int batch, int max_blocks_per_seq, int max_seq_len,
+                                 int32_t *out_ids, uint16_t *logits_out, void *stream) {
+    VMX_REQUIRE(m && input_ids && positions && slot_mapping && block_tables && seq_lens, "gemma4_decode: null pointer");
+    const vmx_gemma4_config &c = m->cfg;
+    VMX_REQUIRE(batch >= 1 && batch <= c.max_batch, "gemma4_decode: batch %d exceeds max_batch %d", batch, c.max_batch);
+    VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "gemma4_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
+                c.max_seq_len);
+    for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_decode: weights not fully loaded");
+    if (int rc = g4_run_layers(m, input_ids, positions, slot_mapping, block_tables, seq_lens, batch, max_blocks_per_seq, max_seq_len, -1,
+                               vmx_stream(stream)))
+        return rc;
+    return g4_run_head(m, (const uint16_t *)m->x.p, batch, out_ids, logits_out, stream);
+}
+
+// ModelForward::forward for one sequence (crates/core/src/engine/model_forward.rs:22-64; QuantizedGemma4ForCausalLM::forward,
+// models/gemma4_quantized.rs): q_len prompt tokens at positions seqlen_offset .. seqlen_offset + q_len - 1, in passes of 16
+// rows (the row limit of the q8_1 MMVQ, IQ_GEMV_MAX_M: the weights are streamed once per pass).  Every pass writes its K/V
+// rows to the paged cache and attends causally over the cache (sliding layers inside their window); only the last row of the
+// last pass goes through the lm_head.  Pure launch sequence.
+extern "C" int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int seqlen_offset, const int32_t *slot_mapping,
+                                  const int32_t *block_table, int q_len, int32_t *out_id_last, uint16_t *logits_last, void *stream) {
+    VMX_REQUIRE(m && input_ids && slot_mapping && block_table, "gemma4_prefill: null pointer");
+    const vmx_gemma4_config &c = m->cfg;
+    VMX_REQUIRE(q_len >= 1, "gemma4_prefill: q_len %d", q_len);
+    VMX_REQUIRE(seqlen_offset >= 0 && seqlen_offset + q_len <= c.max_position && seqlen_offset + q_len <= c.max_seq_len,
+                "gemma4_prefill: positions %d..%d exceed max_position %d / max_seq_len %d", seqlen_offset, seqlen_offset + q_len - 1,
+                c.max_position, c.max_seq_len);
+    for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_prefill: weights not fully loaded");
+    hipStream_t st = vmx_stream(stream);
+    int32_t *pos = (int32_t *)m->positions.p;
+    int last_rows = 0;
+    for (int r0 = 0; r0 < q_len; r0 += 16) {
+        const int rows = q_len - r0 < 16 ? q_len - r0 : 16;
+        hipLaunchKernelGGL(g4_iota_kernel, dim3(1), dim3(64), 0, st, pos, seqlen_offset + r0, rows);
+        if (int rc = g4_run_layers(m, input_ids + r0, pos, slot_mapping + r0, block_table, nullptr, rows, 0, 0, seqlen_offset + r0, st)) return rc;
+        last_rows = rows;
+    }
+    return g4_run_head(m, (const uint16_t *)m->x.p + (size_t)(last_rows - 1) * c.hidden_size, 1, out_id_last, logits_last, stream);
 }
 
 extern "C" int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_bytes) {

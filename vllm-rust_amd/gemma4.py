@@ -300,6 +300,20 @@ class QuantizedGemma4ForCausalLM:
                                      seq_lens.data_ptr(), block_tables.data_ptr(), input_ids.numel(), block_tables.shape[1],
                                      self.spec.block_size, self._stream()))
 
+    def prefill(self, input_ids, seqlen_offset: int, block_table, out_id=None, logits_last=None):
+        """Native prompt path (vmx_gemma4_prefill): all of input_ids in passes of 16 rows; returns the greedy id after the last
+        prompt token (int32 [1]); logits_last: optional bf16 [vocab] for that row."""
+        s = self.spec
+        S = input_ids.numel()
+        bt = block_table.reshape(-1).to(torch.int32).contiguous()
+        pos = torch.arange(seqlen_offset, seqlen_offset + S, dtype=torch.int64, device=self.device)
+        slots = (bt[(pos // s.block_size)].to(torch.int64) * s.block_size + pos % s.block_size).to(torch.int32).contiguous()
+        if out_id is None:
+            out_id = torch.empty(1, dtype=torch.int32, device=self.device)
+        check(lib.vmx_gemma4_prefill(self._h, input_ids.contiguous().data_ptr(), int(seqlen_offset), slots.data_ptr(), bt.data_ptr(), S,
+                                     out_id.data_ptr(), None if logits_last is None else logits_last.data_ptr(), self._stream()))
+        return out_id
+
     def mmvq_only(self, batch: int = 1) -> None:
         check(lib.vmx_gemma4_mmvq_only(self._h, batch, self._stream()))
 
