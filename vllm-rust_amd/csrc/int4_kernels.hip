@@ -529,7 +529,7 @@ __device__ unsigned long long vmx_wide_stamp_buf[8192 * 8];
 #define WIDE_STAMP(i) do { } while (0)
 #endif
 
-template <int NWV, int UPW, int NTW, bool GLU, int MR>
+template <int NWV, int UPW, int NTW, bool GLU, int MR, bool DOT2 = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 1 ? WIDE_WAVES_PER_EU : 4))) void int4_gemm_wide_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                                    const uint16_t *__restrict__ hres, const uint16_t *__restrict__ norm_w,
                                                                    float eps, const float *__restrict__ ssq, float *__restrict__ partial,
@@ -614,8 +614,17 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
             pk[e] = (uint32_t)vmx_f32_to_bf16(hv[2 * e] * iv * wv[2 * e]) | ((uint32_t)vmx_f32_to_bf16(hv[2 * e + 1] * iv * wv[2 * e + 1]) << 16);
         const uint4 xn = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = xn;
-        const float sm = chunk_sum16(xn);   // 16 consecutive chunks = one (row, k-block)
-        if (live && (tid & 15) == 0) sumx[(cc >> 4) * 4 + m] = sm;
+        if constexpr (DOT2) {   // one row: sums over the chunks h, 4 + h, 8 + h, 12 + h of a k-block (what lane group h multiplies)
+            float f8[8];
+            bf16x8_to_f32(xn, f8);
+            float sh = ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
+            sh += __shfl_xor(sh, 4, 64);
+            sh += __shfl_xor(sh, 8, 64);
+            if (live && (tid & 15) < 4) sumx[(cc >> 4) * 4 + (tid & 3)] = sh;
+        } else {
+            const float sm = chunk_sum16(xn);   // 16 consecutive chunks = one (row, k-block)
+            if (live && (tid & 15) == 0) sumx[(cc >> 4) * 4 + m] = sm;
+        }
     }
 #pragma unroll
     for (int j = 0; j < SZW; j++)
@@ -623,10 +632,51 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
     __syncthreads();
     WIDE_STAMP(3);
 
+    if constexpr (DOT2) {
+        // The same sum on the vector ALU: lane (column nl, group hh) multiplies its 32 weights of a unit with v_dot2c_f32_bf16
+        // (two bf16 products per instruction, f32 accumulate); the four groups of a column are added at the end.
+        static_assert(MR == 1, "the v_dot2 form is for one activation row");
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const uint16_t *xr = xs + 8 * hh;
+        float fsum[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; t++) fsum[t] = 0.f;
+#pragma unroll
+        for (int u = 0; u < UPW; u++) {
+            const int kbl = wave * UPW + u;
+            uint4 xa[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) xa[i] = *reinterpret_cast<const uint4 *>(xr + kbl * KB + 32 * i);
+            const float sxh = sumx[kbl * 4 + hh];
+#pragma unroll
+            for (int t = 0; t < NTW; t++) {
+                float acc = 0.f;
+                const uint32_t w4[4] = {wreg[t][u].x, wreg[t][u].y, wreg[t][u].z, wreg[t][u].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t xw[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t b = ((w4[i] >> (4 * q)) & 0x000F000Fu) | 0x43004300u;   // weights 2q, 2q + 1 as bf16 128 + nib
+                        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xw[q]), __builtin_bit_cast(bf16x2_t, b), acc, false);
+                    }
+                }
+                const uint32_t szw = szs[(t * KBS + kbl) * 16 + nl];
+                fsum[t] += __uint_as_float(szw << 16) * (acc - __uint_as_float(szw & 0xFFFF0000u) * sxh);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            fsum[t] += __shfl_xor(fsum[t], 16, 64);
+            fsum[t] += __shfl_xor(fsum[t], 32, 64);
+            if (hh == 0) red[((t * NWV + wave) * 16 + nl) * 4] = fsum[t];
+        }
+    }
     const uint16_t *xrow = xs + min(nl, M - 1) * XROW + 8 * hh;
     vmx_f32x4 fin[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; t++) fin[t] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!DOT2) {
 #pragma unroll
     for (int u = 0; u < UPW; u++) {
         const int kbl = wave * UPW + u;
@@ -657,12 +707,13 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
             fin[t][3] += sc * (acc[3] - zo * sx.w);
         }
     }
-    WIDE_STAMP(4);
     if (hh == 0) {   // rows 0..3 of the MFMA tile (M <= 2)
 #pragma unroll
         for (int t = 0; t < NTW; t++)
             *reinterpret_cast<float4 *>(red + ((t * NWV + wave) * 16 + nl) * 4) = make_float4(fin[t][0], fin[t][1], fin[t][2], fin[t][3]);
     }
+    }
+    WIDE_STAMP(4);
     __syncthreads();
     // thread = (tile t, row m, column c): sum over the waves in wave order
     for (int i = tid; i < NTW * 32; i += TH) {
@@ -1242,6 +1293,16 @@ int launch_wide_m(const WidePlan &p, const uint4 *W, const uint32_t *SZ, const u
     if (lds > 64 * 1024)
         VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
+    // VMX_INT4_DOT2=1: the one-row kernel with v_dot2c_f32_bf16 on the vector ALU instead of the matrix cores (A/B measurement)
+    static const bool dot2 = getenv("VMX_INT4_DOT2") && atoi(getenv("VMX_INT4_DOT2"));
+    if constexpr (MR == 1 && NTW == 1 && NWV == 4) {
+        if (dot2) {
+            hipLaunchKernelGGL((int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR, true>), dim3((unsigned)((N / NT) / NTW * p.splits)), dim3(64 * NWV), lds,
+                               st, W, SZ, h, norm_w, eps, ssq, partial, act, N, K, group);
+            VMX_CHECK_LAUNCH("int4_gemm(wide, dot2)");
+            return VMX_OK;
+        }
+    }
     hipLaunchKernelGGL((int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR>), dim3((unsigned)((N / NT) / NTW * p.splits)), dim3(64 * NWV), lds, st, W, SZ,
                        h, norm_w, eps, ssq, partial, act, N, K, group);
     VMX_CHECK_LAUNCH("int4_gemm(wide)");
