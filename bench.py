@@ -536,16 +536,20 @@ def main():
         spec.num_layers = args.layers
     use_tp = args.tp and dist_on
     comm = None
+    full_spec = spec
     if use_tp:
         from vllm_rust_amd.parallel import Communicator, shard_spec
-        spec = shard_spec(spec, rank, world)   # this rank's heads / MLP columns / lm_head rows (random-init shards)
+        spec = shard_spec(spec, rank, world)   # this rank's heads / MLP columns / lm_head rows
         comm = Communicator(rank, world)
     model = QuantizedQwen3ForCausalLM(spec, device=local_rank)
     exl3 = args.weights == "exl3"
     if exl3:
         model.load_synthetic_exl3(bits=4, codebook=0, seed=1234 + rank)
     else:
-        model.load_synthetic(seed=1234 + rank)
+        if use_tp:   # every rank slices the SAME seeded checkpoint: the TP job computes the model of the single-GPU run
+            model.load_synthetic_tp(full_spec, seed=1234)
+        else:
+            model.load_synthetic(seed=1234 + rank)
     if comm is not None:
         model.set_comm(comm)
 

@@ -54,3 +54,29 @@ def test_awq_safetensors_directory_round_trip(tmp_path):
     finally:
         a.close()
         b.close()
+
+
+def test_seeded_tp_checkpoint_at_world_1_is_the_single_gpu_checkpoint():
+    """load_synthetic_tp draws the full seeded checkpoint and keeps this rank's slice; with one rank the slice is everything, so
+    the model must be bit-identical to load_synthetic with the same seed (the property that makes a TP run checkable)."""
+    import torch
+    import vllm_rust_amd as vmx
+    from vllm_rust_amd.parallel import shard_spec
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
+    vmx.init(0)
+    spec = Qwen3Spec(512, 2, 4, 2, 128, 1024, 2048, max_position=128, num_blocks=8, max_batch=1, max_seq_len=64)
+    a = QuantizedQwen3ForCausalLM(spec)
+    b = QuantizedQwen3ForCausalLM(shard_spec(spec, 0, 1))
+    try:
+        a.load_synthetic(seed=5)
+        b.load_synthetic_tp(spec, seed=5)
+        args = [torch.tensor(v, dtype=torch.int32, device="cuda") for v in ([9], [0], [0], [[0, 1]], [1])]
+        la = torch.empty((1, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        lb = torch.empty_like(la)
+        a.forward_decode_batch(*args, logits=la)
+        b.forward_decode_batch(*args, logits=lb)
+        torch.cuda.synchronize()
+        assert torch.equal(la.view(torch.int16), lb.view(torch.int16))
+    finally:
+        a.close()
+        b.close()

@@ -104,3 +104,22 @@ def test_shard_spec_rejects_bad_divisors():
         shard_spec(Qwen3Spec.qwen3_8b(), 0, 3)
     with pytest.raises(ValueError):
         shard_spec(Qwen3Spec.qwen3_8b(), 0, 16)         # 8 KV heads
+
+
+def test_one_seeded_checkpoint_shards_reassemble():
+    """The slicing rules load_synthetic_tp applies to one seeded checkpoint (columns for q/k/v/gate/up, whole-group rows for
+    o/down): the ranks' shards put back together are the full tensors, for 2 and 4 ranks."""
+    import torch
+    from vllm_rust_amd.parallel import shard_awq_column, shard_awq_row
+    g = torch.Generator().manual_seed(0)
+    K, N, group = 512, 256, 128
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, generator=g)
+    qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // group, N // 8), dtype=torch.int32, generator=g)
+    sc = torch.rand((K // group, N), generator=g).to(torch.float16)
+    for world in (2, 4):
+        cols = [shard_awq_column(qw, qz, sc, r, world) for r in range(world)]
+        assert torch.equal(torch.cat([c[0] for c in cols], 1), qw) and torch.equal(torch.cat([c[1] for c in cols], 1), qz)
+        assert torch.equal(torch.cat([c[2] for c in cols], 1), sc)
+        rows = [shard_awq_row(qw, qz, sc, r, world, group) for r in range(world)]
+        assert torch.equal(torch.cat([c[0] for c in rows], 0), qw) and torch.equal(torch.cat([c[1] for c in rows], 0), qz)
+        assert torch.equal(torch.cat([c[2] for c in rows], 0), sc)

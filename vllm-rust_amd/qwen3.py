@@ -220,6 +220,42 @@ class QuantizedQwen3ForCausalLM:
                     ck[f"{li}.{slot}.iq"] = (t, raw.reshape(-1).cpu())
         return ck
 
+    def load_synthetic_tp(self, full_spec, seed: int = 0):
+        """This rank's shard of ONE seeded AWQ checkpoint of `full_spec` (self.spec = shard_spec(full_spec, rank, world)): every
+        rank draws the same full tensors from the same generator and keeps its slice -- q/k/v/gate/up by output columns, o/down
+        by input rows (whole quantisation groups), lm_head by vocabulary rows; embedding and norms whole -- so a TP run computes
+        the same model as the single-GPU run with this seed (load_synthetic(seed)), up to the bf16 all-reduce."""
+        from .parallel import shard_awq_column, shard_awq_row
+        s, f = self.spec, full_spec
+        r, w = s.tp_rank, s.tp_size
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        emb = (torch.randn((f.vocab_size, f.hidden_size), device=self.device, generator=g) * 0.5).to(torch.bfloat16)
+        self.load_tensor(T_EMBED, 0, emb)
+        if not f.tie_word_embeddings:
+            head = (torch.randn((f.vocab_size, f.hidden_size), device=self.device, generator=g) * 0.05).to(torch.bfloat16)
+            rows = f.vocab_size // w
+            self.load_tensor(T_LM_HEAD, 0, head[r * rows:(r + 1) * rows].contiguous())
+            del head
+        del emb
+        self.load_tensor(T_FINAL_NORM, 0, (1.0 + 0.1 * torch.randn(f.hidden_size, device=self.device, generator=g)).to(torch.bfloat16))
+        for li in range(f.num_layers):
+            for which, n in ((T_INPUT_LN, f.hidden_size), (T_POST_LN, f.hidden_size), (T_Q_NORM, f.head_dim), (T_K_NORM, f.head_dim)):
+                self.load_tensor(which, li, (1.0 + 0.1 * torch.randn(n, device=self.device, generator=g)).to(torch.bfloat16))
+        g = torch.Generator(device=self.device).manual_seed(seed + 1)
+        H, I = f.hidden_size, f.intermediate_size
+        nq, nkv = f.num_heads * f.head_dim, f.num_kv_heads * f.head_dim
+        full_shapes = {0: (H, nq), 1: (H, nkv), 2: (H, nkv), 3: (nq, H), 4: (H, I), 5: (H, I), 6: (I, H)}
+        for li in range(f.num_layers):
+            for slot, (K, N) in full_shapes.items():
+                qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=self.device, generator=g)
+                qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // f.group_size, N // 8), dtype=torch.int32, device=self.device, generator=g)
+                sc = ((torch.rand((K // f.group_size, N), device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (6.5 * math.sqrt(K)))).to(torch.float16)
+                if slot in (3, 6):
+                    qw, qz, sc = shard_awq_row(qw, qz, sc, r, w, f.group_size)
+                else:
+                    qw, qz, sc = shard_awq_column(qw, qz, sc, r, w)
+                self.load_awq_linear(li, slot, qw, qz, sc)
+
     def load_synthetic_bf16(self, seed: int = 0, keep_host_copy: bool = False):
         """Seeded random-init UNQUANTIZED checkpoint of the architecture: every projection a bf16 [out, in] matrix with
         ~1/sqrt(in) entries, bf16 norms and embeddings as load_synthetic."""
