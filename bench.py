@@ -541,6 +541,13 @@ def main():
         from vllm_rust_amd.parallel import Communicator, shard_spec
         spec = shard_spec(spec, rank, world)   # this rank's heads / MLP columns / lm_head rows
         comm = Communicator(rank, world)
+        allreduce_path = "RCCL ring"
+        if os.environ.get("VMX_NO_P2P_ALLREDUCE", "0") in ("", "0"):
+            try:   # the 8 KiB row-parallel sums go over peer-mapped memory in one step; RCCL keeps the larger messages
+                comm.enable_p2p(64 * 1024)
+                allreduce_path = "one-shot over peer-mapped memory (xGMI) for the row-parallel sums, RCCL for the rest"
+            except Exception as e:
+                allreduce_path = f"RCCL ring (peer-mapped path unavailable: {e})"
     model = QuantizedQwen3ForCausalLM(spec, device=local_rank)
     exl3 = args.weights == "exl3"
     if exl3:
@@ -694,7 +701,7 @@ def main():
             "config": {"workload": (f"Qwen3-8B EXL3 4.0 bpw greedy decode, batch=1, {args.prompt}-token prompt then timed tokens, bf16 KV" if exl3 else
                                     f"Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, {args.prompt}-token prompt (native prefill) then timed tokens, bf16 KV"),
                        "layers": spec.num_layers, "hidden": spec.hidden_size, "vocab": spec.vocab_size,
-                       "parallelism": "tp1" if world == 1 else (f"tp{world} (RCCL all-reduce)" if use_tp else f"dp{world} replicas (tp1 each)"),
+                       "parallelism": "tp1" if world == 1 else (f"tp{world} ({allreduce_path})" if use_tp else f"dp{world} replicas (tp1 each)"),
                        "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
                        "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
             "prefill": {"tokens": args.prompt, "ms": round(prefill_s * 1e3, 3), "tok_s": round(args.prompt / prefill_s, 1),

@@ -338,6 +338,18 @@ int vmx_comm_world(const vmx_comm *c);
 /* all_reduce(Sum) of row-parallel linear outputs (parallel_layers.rs:296) and all_reduce(Max) of argmax keys. */
 int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t count, void *stream);
 int vmx_comm_all_reduce_max_u64(vmx_comm *c, unsigned long long *buf, size_t count, void *stream);
+/* One-shot all-reduce over peer-mapped memory for the decode-sized messages (design reference: the one-shot kernel of
+ * crates/core/kernels/custom_allreduce.cu:264-484; SURVEY's target for the 8 KiB x 72 per token row-parallel sums).  Set-up,
+ * once per communicator and on every rank: vmx_comm_p2p_export allocates this rank's staging slots (2 x max_bytes, max_bytes
+ * <= 256 KiB) and flag words and returns two hipIpc handles (128 bytes); the caller all-gathers them in rank order;
+ * vmx_comm_p2p_import maps the peers.  From then on vmx_comm_all_reduce_sum_bf16 takes this path for messages of at most
+ * max_bytes (count % 8 == 0, 16-byte aligned): one kernel, ranks added in rank order (identical bits everywhere), hipGraph-
+ * replayable (call counters live in device memory).  Larger messages keep using RCCL.  A flag wait gives up after ~2 s and is
+ * counted (vmx_comm_p2p_timeouts) instead of hanging.  vmx_comm_create_local makes a communicator without RCCL (at most 8 ranks). */
+int vmx_comm_create_local(int rank, int world, vmx_comm **out);
+int vmx_comm_p2p_export(vmx_comm *c, size_t max_bytes, void *handles_out128);
+int vmx_comm_p2p_import(vmx_comm *c, const void *all_handles);
+int vmx_comm_p2p_timeouts(vmx_comm *c, int *out);
 
 /* ------------------------------------------------------- whole-token decoder */
 

@@ -92,6 +92,10 @@ _SIGS = {
     "vmx_comm_world": (_i, [_p]),
     "vmx_comm_all_reduce_sum_bf16": (_i, [_p, _p, _sz, _p]),
     "vmx_comm_all_reduce_max_u64": (_i, [_p, _p, _sz, _p]),
+    "vmx_comm_create_local": (_i, [_i, _i, _p]),
+    "vmx_comm_p2p_export": (_i, [_p, _sz, _p]),
+    "vmx_comm_p2p_import": (_i, [_p, _p]),
+    "vmx_comm_p2p_timeouts": (_i, [_p, _p]),
     "vmx_qwen3_set_comm": (_i, [_p, _p]),
     "vmx_qwen3_create": (_i, [_p, _p]),
     "vmx_qwen3_destroy": (None, [_p]),

@@ -40,6 +40,25 @@ class Communicator:
         check(lib.vmx_comm_create(raw, rank, world, C.byref(self.handle)))
         self.rank, self.world = rank, world
 
+    def enable_p2p(self, max_bytes: int = 64 * 1024, group=None) -> None:
+        """Set up the one-shot peer-mapped all-reduce for messages of at most max_bytes: every rank exports its staging buffer
+        and flag words as hipIpc handles, the handles are all-gathered through torch.distributed, every rank maps its peers."""
+        import torch.distributed as dist
+        mine = (C.c_uint8 * 128)()
+        check(lib.vmx_comm_p2p_export(self.handle, int(max_bytes), mine))
+        gathered = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(gathered, bytes(mine), group=group)
+        else:
+            gathered = [bytes(mine)]
+        allh = (C.c_uint8 * (128 * self.world))(*b"".join(gathered))
+        check(lib.vmx_comm_p2p_import(self.handle, allh))
+
+    def p2p_timeouts(self) -> int:
+        n = C.c_int()
+        check(lib.vmx_comm_p2p_timeouts(self.handle, C.byref(n)))
+        return n.value
+
     def all_reduce_sum_bf16(self, t: torch.Tensor) -> None:
         assert t.dtype == torch.bfloat16 and t.is_contiguous()
         check(lib.vmx_comm_all_reduce_sum_bf16(self.handle, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
@@ -48,6 +67,21 @@ class Communicator:
         if self.handle:
             lib.vmx_comm_destroy(self.handle)
             self.handle = C.c_void_p()
+
+
+class LocalCommunicator(Communicator):
+    """A communicator without RCCL (vmx_comm_create_local): only the peer-mapped one-shot all-reduce, with the handle
+    exchange left to the caller (`exchange(my_128_bytes) -> list of every rank's bytes in rank order`)."""
+
+    def __init__(self, rank: int, world: int, exchange, max_bytes: int = 64 * 1024):
+        self.handle = C.c_void_p()
+        check(lib.vmx_comm_create_local(rank, world, C.byref(self.handle)))
+        self.rank, self.world = rank, world
+        mine = (C.c_uint8 * 128)()
+        check(lib.vmx_comm_p2p_export(self.handle, int(max_bytes), mine))
+        gathered = exchange(bytes(mine))
+        allh = (C.c_uint8 * (128 * world))(*b"".join(gathered))
+        check(lib.vmx_comm_p2p_import(self.handle, allh))
 
 
 def shard_spec(spec, tp_rank: int, tp_size: int):
