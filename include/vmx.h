@@ -532,6 +532,11 @@ typedef struct vmx_gemma4 vmx_gemma4;
 /* layer_flags[i]: bit 0 = sliding-attention layer, bit 1 = V reuses the K projection (attention_k_eq_v, :863-870) */
 #define VMX_G4_SLIDING 1
 #define VMX_G4_K_EQ_V 2
+/* KV-shared layer (gemma4_quantized.rs:441-469, :805-826, :1332-1337): no k/v projections, q only; attention reads the cache
+ * of the last earlier non-shared layer of the same attention type.  Only a suffix of the stack may carry it. */
+#define VMX_G4_KV_SHARED 4
+/* this layer's MLP is twice intermediate_size wide (use_double_wide_mlp on KV-shared layers, gemma4_quantized.rs:514-525) */
+#define VMX_G4_DOUBLE_WIDE_MLP 8
 
 /* tensor ids for vmx_gemma4_load_tensor */
 #define VMX_G4T_EMBED 0          /* bf16 [vocab, hidden] or raw GGML blocks of token_embd */

@@ -184,16 +184,23 @@ class OracleGemma4:
             hd, kvh, rot, window, keqv = s.layer_geom(li)
             sliding = s.sliding(li)
             x = orc.rms_norm_bf16(h, self.ck[f"{li}.input_ln"], s.rms_norm_eps)
-            q, k = self.linear(li, 0, x), self.linear(li, 1, x)
-            v = k if keqv else self.linear(li, 2, x)
-            ones = orc.f32_to_bf16(np.ones(hd, np.float32))
+            q = self.linear(li, 0, x)
             q = orc.rms_norm_bf16(q.reshape(B * s.num_heads, hd), self.ck[f"{li}.q_norm"], s.rms_norm_eps).reshape(B, -1)
-            v = orc.rms_norm_bf16(v.reshape(B * kvh, hd), ones, s.rms_norm_eps).reshape(B, -1)
-            k = orc.rms_norm_bf16(k.reshape(B * kvh, hd), self.ck[f"{li}.k_norm"], s.rms_norm_eps).reshape(B, -1)
-            q, k = orc.rope_neox_bf16(positions, q, k, self.cs[0 if sliding else 1], rot, hd, s.num_heads, kvh)
-            orc.reshape_and_cache(k, v, self.k_cache[li], self.v_cache[li], slots, kvh, hd, s.block_size, s.kv_cache_dtype, 1.0, 1.0)
+            cl = s.kv_target(li)      # a KV-shared layer rotates q only and reads its target's cache (:1332-1337, :1718)
+            if cl is None:
+                cl = li
+                k = self.linear(li, 1, x)
+                v = k if keqv else self.linear(li, 2, x)
+                ones = orc.f32_to_bf16(np.ones(hd, np.float32))
+                v = orc.rms_norm_bf16(v.reshape(B * kvh, hd), ones, s.rms_norm_eps).reshape(B, -1)
+                k = orc.rms_norm_bf16(k.reshape(B * kvh, hd), self.ck[f"{li}.k_norm"], s.rms_norm_eps).reshape(B, -1)
+                q, k = orc.rope_neox_bf16(positions, q, k, self.cs[0 if sliding else 1], rot, hd, s.num_heads, kvh)
+                orc.reshape_and_cache(k, v, self.k_cache[li], self.v_cache[li], slots, kvh, hd, s.block_size, s.kv_cache_dtype, 1.0, 1.0)
+            else:
+                q, _ = orc.rope_neox_bf16(positions, q, np.zeros((B, kvh * hd), np.uint16), self.cs[0 if sliding else 1], rot, hd,
+                                          s.num_heads, kvh)
             psize = 64 if int(seq_lens.max()) <= 4096 else 256
-            attn = orc.paged_attention_v2(q, self.k_cache[li], self.v_cache[li], block_tables, seq_lens, 1.0, s.num_heads, kvh, hd,
+            attn = orc.paged_attention_v2(q, self.k_cache[cl], self.v_cache[cl], block_tables, seq_lens, 1.0, s.num_heads, kvh, hd,
                                           s.block_size, psize, window, s.kv_cache_dtype, 1.0, 1.0)
             o = self.linear(li, 3, attn)
             h = add_bf16(orc.rms_norm_bf16(o, self.ck[f"{li}.post_attn_ln"], s.rms_norm_eps), h)

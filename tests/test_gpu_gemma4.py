@@ -64,8 +64,31 @@ def test_gemma4_decode_k_eq_v_q3k_embedding_bf16_kv():
     _run(spec, steps=4, B=1, slot_types={0: 17, 1: 22, 2: 18, 3: 21, 4: 23, 5: 18, 6: 21})
 
 
-@pytest.mark.parametrize("kv_dtype,k_eq_v", [(0, False), (1, False), (0, True)])
-def test_gemma4_native_prefill_matches_token_by_token_oracle(kv_dtype, k_eq_v):
+def test_gemma4_kv_shared_layers_double_wide_mlp():
+    """6 layers (s, s, f, s, s, f), the last three KV-shared: layers 3 and 4 read layer 1's cache, layer 5 reads layer 2's, none
+    of them has k/v projections, and their MLPs are twice as wide (num_kv_shared_layers + use_double_wide_mlp)."""
+    from vllm_rust_amd.gemma4 import Gemma4Spec
+    spec = Gemma4Spec(256, 6, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=4, full_every=3, num_kv_shared_layers=3, use_double_wide_mlp=True, max_position=64,
+                      kv_cache_dtype=1, num_blocks=8, max_batch=2, max_seq_len=32)
+    assert [spec.kv_target(i) for i in range(6)] == [None, None, None, 1, 1, 2]
+    assert sorted(spec.linear_shapes(4)) == [0, 3, 4, 5, 6] and spec.linear_shapes(4)[6] == (1024, 256)
+    _run(spec, steps=7, B=2)
+
+
+def test_gemma4_kv_shared_flags_must_be_a_suffix_with_a_target():
+    import ctypes as C
+    from vllm_rust_amd._lib import Gemma4Config, lib
+    cfg = Gemma4Config(256, 3, 4, 512, 100, 1e-6, 64, 128, 2, 1, 4, 64, 32, 64, 0, 16, 4, 1, 32, 0.0, 0)
+    h = C.c_void_p()
+    assert lib.vmx_gemma4_create(C.byref(cfg), (C.c_int * 3)(1, 1 | 4, 1), C.byref(h)) == -1     # shared layer in the middle
+    assert b"KV-shared" in lib.vmx_last_error()
+    assert lib.vmx_gemma4_create(C.byref(cfg), (C.c_int * 3)(1, 1, 0 | 4), C.byref(h)) == -1     # full-attention, no earlier full layer
+    assert b"no earlier" in lib.vmx_last_error()
+
+
+@pytest.mark.parametrize("kv_dtype,k_eq_v,shared", [(0, False, 0), (1, False, 0), (0, True, 0), (0, False, 1)])
+def test_gemma4_native_prefill_matches_token_by_token_oracle(kv_dtype, k_eq_v, shared):
     """vmx_gemma4_prefill on a 37-token prompt (passes of 16, 16 and 5 rows; sliding window 8 < prompt, so windowed causal
     attention inside and across passes) followed by decode steps: last-token logits and every decoded step against the CPU
     oracle, which walks the same tokens one at a time.  Also a second prefill call that continues at seqlen_offset > 0."""
@@ -75,9 +98,9 @@ def test_gemma4_native_prefill_matches_token_by_token_oracle(kv_dtype, k_eq_v):
     from tests.model_oracle import OracleGemma4
     from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
     vmx.init(0)
-    spec = Gemma4Spec(256, 3, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
-                      sliding_window=8, full_every=3, k_eq_v_on_full=k_eq_v, max_position=128, kv_cache_dtype=kv_dtype, num_blocks=8,
-                      max_batch=1, max_seq_len=96)
+    spec = Gemma4Spec(256, 3 + shared, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=8, full_every=3, k_eq_v_on_full=k_eq_v, num_kv_shared_layers=shared, max_position=128,
+                      kv_cache_dtype=kv_dtype, num_blocks=8, max_batch=1, max_seq_len=96)
     model = QuantizedGemma4ForCausalLM(spec)
     try:
         ck = model.load_synthetic(seed=5, keep_host_copy=True)

@@ -278,12 +278,17 @@ struct IqLin {
 
 struct G4Layer {
     bool sliding = false, k_eq_v = false;
+    // KV-shared layer (gemma4_quantized.rs:805-826, :1332-1337): no k/v projections or norms, q only; attention reads the
+    // cache of layer kv_target, the last earlier non-shared layer of the same attention type (:441-469)
+    bool kv_shared = false;
+    int kv_target = -1;
     int hd = 0, kvh = 0, rot = 0, window = 0;
+    int inter = 0;   // MLP width: twice the base on a double-wide layer (:514-525)
     IqLin lin[7];
     Buf input_ln, post_attn_ln, pre_ffn_ln, post_ffn_ln, q_norm, k_norm, scalar, k_cache, v_cache, kv_scales;
     bool ready() const {
         for (int s = 0; s < 7; s++)
-            if (!lin[s].loaded && !(s == VMX_L_V && k_eq_v)) return false;
+            if (!lin[s].loaded && !(s == VMX_L_V && k_eq_v) && !((s == VMX_L_K || s == VMX_L_V) && kv_shared)) return false;
         return true;
     }
     int nq(int heads) const { return heads * hd; }
@@ -381,11 +386,31 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     TRY(m->final_norm.alloc((size_t)H * 2));
     TRY(m->cos_sin_s.alloc((size_t)c.max_position * c.rot_dim_sliding * 4));
     TRY(m->cos_sin_f.alloc((size_t)c.max_position * c.rot_dim_full * 4));
-    int max_nq = 0, max_proj = 2 * I, max_hd = 0;
+    int max_nq = 0, max_proj = 2 * I, max_hd = 0, max_inter = I;
+    int first_shared = c.num_layers;
+    for (int li = c.num_layers - 1; li >= 0 && (layer_flags[li] & VMX_G4_KV_SHARED); li--) first_shared = li;
     for (int li = 0; li < c.num_layers; li++) {
         G4Layer &L = m->layers[li];
         L.sliding = (layer_flags[li] & VMX_G4_SLIDING) != 0;
         L.k_eq_v = (layer_flags[li] & VMX_G4_K_EQ_V) != 0;
+        L.kv_shared = (layer_flags[li] & VMX_G4_KV_SHARED) != 0;
+        L.inter = (layer_flags[li] & VMX_G4_DOUBLE_WIDE_MLP) ? 2 * I : I;
+        max_inter = L.inter > max_inter ? L.inter : max_inter;
+        if (L.kv_shared) {
+            if (li < first_shared) {
+                vmx_set_error("gemma4_create: layer %d is KV-shared but layer %d after it is not (shared layers are the last ones)", li,
+                              first_shared - 1);
+                rc = rc ? rc : VMX_EINVAL;
+            }
+            for (int cand = first_shared - 1; cand >= 0 && L.kv_target < 0; cand--)
+                if (((layer_flags[cand] & VMX_G4_SLIDING) != 0) == L.sliding) L.kv_target = cand;
+            if (L.kv_target < 0) {
+                vmx_set_error("gemma4_create: KV-shared layer %d has no earlier %s layer to share a cache with", li,
+                              L.sliding ? "sliding" : "full-attention");
+                rc = rc ? rc : VMX_EINVAL;
+            }
+            L.k_eq_v = false;
+        }
         L.hd = L.sliding ? c.head_dim_sliding : c.head_dim_full;
         L.kvh = L.sliding ? c.kv_heads_sliding : c.kv_heads_full;
         L.rot = L.sliding ? c.rot_dim_sliding : c.rot_dim_full;
@@ -395,10 +420,11 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
             vmx_set_error("gemma4_create: num_heads * head_dim (%d) must be a multiple of 256 (o_proj input)", NQ);
             rc = rc ? rc : VMX_EINVAL;
         }
-        const int in_f[7] = {H, H, H, NQ, H, H, I}, out_f[7] = {NQ, NKV, NKV, H, I, I, H};
+        const int in_f[7] = {H, H, H, NQ, H, H, L.inter}, out_f[7] = {NQ, NKV, NKV, H, L.inter, L.inter, H};
         for (int s = 0; s < 7; s++) { L.lin[s].in_features = in_f[s]; L.lin[s].out_features = out_f[s]; }
         max_nq = NQ > max_nq ? NQ : max_nq;
         max_proj = NQ + 2 * NKV > max_proj ? NQ + 2 * NKV : max_proj;
+        max_proj = 2 * L.inter > max_proj ? 2 * L.inter : max_proj;
         max_hd = L.hd > max_hd ? L.hd : max_hd;
         TRY(L.input_ln.alloc((size_t)H * 2));
         TRY(L.post_attn_ln.alloc((size_t)H * 2));
@@ -408,8 +434,10 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         TRY(L.k_norm.alloc((size_t)L.hd * 2));
         TRY(L.scalar.alloc(2));
         const size_t kvb = (size_t)c.num_blocks * c.block_size * L.kvh * L.hd * kv_elem;
-        TRY(L.k_cache.alloc(kvb));
-        TRY(L.v_cache.alloc(kvb));
+        if (!L.kv_shared) {
+            TRY(L.k_cache.alloc(kvb));
+            TRY(L.v_cache.alloc(kvb));
+        }
         TRY(L.kv_scales.alloc(8));
         if (!rc) {
             const float ones[2] = {1.0f, 1.0f};
@@ -425,7 +453,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     TRY(m->x.alloc((size_t)R * H * 2));
     TRY(m->q.alloc((size_t)R * max_nq * 2));
     TRY(m->attn.alloc((size_t)R * max_nq * 2));
-    TRY(m->act.alloc((size_t)R * I * 2));
+    TRY(m->act.alloc((size_t)R * max_inter * 2));
     TRY(m->proj.alloc((size_t)R * max_proj * 4));
     TRY(m->out.alloc((size_t)R * H * 4));
     TRY(m->logits.alloc((size_t)B * c.vocab_size * 2));
@@ -434,7 +462,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         TRY(m->x_f32.alloc((size_t)R * H * 4));
     }
     {
-        size_t kmax = (size_t)(H > I ? H : I);
+        size_t kmax = (size_t)(H > max_inter ? H : max_inter);
         kmax = (size_t)max_nq > kmax ? (size_t)max_nq : kmax;
         TRY(m->q8.alloc(R * kmax + 256 + R * (kmax / 32) * 4));
     }
@@ -494,6 +522,8 @@ extern "C" int vmx_gemma4_load_iq_linear(vmx_gemma4 *m, int layer, int slot, int
     VMX_REQUIRE(ts > 0, "gemma4_load_iq_linear: ggml type %d is not a supported I-quant", ggml_type);
     G4Layer &L = m->layers[layer];
     VMX_REQUIRE(!(slot == VMX_L_V && L.k_eq_v), "gemma4_load_iq_linear: layer %d reuses K as V and has no v_proj", layer);
+    VMX_REQUIRE(!((slot == VMX_L_K || slot == VMX_L_V) && L.kv_shared),
+                "gemma4_load_iq_linear: layer %d shares layer %d's KV cache and has no k_proj / v_proj", layer, L.kv_target);
     IqLin &l = L.lin[slot];
     VMX_REQUIRE(l.in_features % 256 == 0, "gemma4_load_iq_linear: in_features %d not a multiple of 256", l.in_features);
     const size_t need = (size_t)l.out_features * (l.in_features / 256) * ts;
@@ -526,7 +556,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
                   const int32_t *block_tables, const int32_t *seq_lens, int rows, int max_blocks_per_seq, int max_seq_len, int prefill_offset,
                   hipStream_t st) {
     const vmx_gemma4_config &c = m->cfg;
-    const int H = c.hidden_size, I = c.intermediate_size, B = rows, Hq = c.num_heads;
+    const int H = c.hidden_size, B = rows, Hq = c.num_heads;
     uint16_t *h = (uint16_t *)m->h.p, *x = (uint16_t *)m->x.p, *q = (uint16_t *)m->q.p, *attn = (uint16_t *)m->attn.p,
              *act = (uint16_t *)m->act.p;
     float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
@@ -542,19 +572,22 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
     const float *pending = nullptr;
     const uint16_t *pending_w = nullptr, *pending_scalar = nullptr;
     for (const G4Layer &L : m->layers) {
-        const int hd = L.hd, Hkv = L.kvh, NQ = Hq * hd, NKV = Hkv * hd;
-        const int ntot = NQ + (L.k_eq_v ? 1 : 2) * NKV;
+        const G4Layer &KV = L.kv_shared ? m->layers[L.kv_target] : L;   // whose paged cache this layer's attention reads
+        const int hd = L.hd, Hkv = L.kvh, NQ = Hq * hd, NKV = Hkv * hd, I = L.inter;
+        const int nseg = L.kv_shared ? 1 : (L.k_eq_v ? 2 : 3);
+        const int ntot = NQ + (nseg - 1) * NKV;
         // (previous layer's tail) + input_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H, aq_of(m),
                     ad_of(m, B, H));
         {
             const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
             const int offs[3] = {0, NQ, NQ + NKV};
-            if (int rc = mmvq_group(m, qkv, offs, L.k_eq_v ? 2 : 3, proj, ntot, B, st)) return rc;
+            if (int rc = mmvq_group(m, qkv, offs, nseg, proj, ntot, B, st)) return rc;
         }
-        const float *ks = (const float *)L.kv_scales.p;
-        // short contexts: per-head norms + RoPE + KV write + attention + merge in one launch (not for K == V layers)
-        const bool fused_attn = prefill_offset < 0 && !L.k_eq_v && vmx_fused_decode_attention_ok(hd, Hq / Hkv, L.rot, max_seq_len, L.window);
+        const float *ks = (const float *)KV.kv_scales.p;
+        // short contexts: per-head norms + RoPE + KV write + attention + merge in one launch (not for K == V or KV-shared layers)
+        const bool fused_attn = prefill_offset < 0 && !L.k_eq_v && !L.kv_shared &&
+                                vmx_fused_decode_attention_ok(hd, Hq / Hkv, L.rot, max_seq_len, L.window);
         if (fused_attn) {
             if (int rc = vmx_fused_decode_attention(attn, proj, 1, L.k_cache.p, L.v_cache.p, (const uint16_t *)L.q_norm.p,
                                                     (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
@@ -563,20 +596,21 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
                                                     L.window, c.kv_cache_dtype, ks, ks + 1, aq_of(m), ad_of(m, B, NQ), 1, st))
                 return rc;
         } else {
-            hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, L.k_cache.p, L.v_cache.p,
-                               (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
+            // a KV-shared layer launches the query heads only: its K/V for these tokens were written by the target layer
+            hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(L.kv_shared ? Hq : Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, KV.k_cache.p,
+                               KV.v_cache.p, (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
                                (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping, Hq, Hkv, hd, L.rot,
                                L.k_eq_v ? 1 : 0, fp8, ks, ks + 1);
             if (prefill_offset >= 0) {   // the rows' K/V are in the cache: causal (windowed) attention over it, then q8_1 for o_proj
-                if (int rc = vmx_prefill_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, 1.0f, Hq, Hkv, hd,
-                                                        c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, st))
+                if (int rc = vmx_prefill_attention_bf16(attn, q, KV.k_cache.p, KV.v_cache.p, block_tables, B, prefill_offset, 1.0f, Hq, Hkv,
+                                                        hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, st))
                     return rc;
                 if (int rc = vmx_quantize_q8_1_bf16(attn, aq_of(m), ad_of(m, B, NQ), (int64_t)B * (NQ / 32), st)) return rc;
             } else {
                 VmxAttnParts ap;
-                if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, 1.0f, B, Hq, Hkv, max_blocks_per_seq,
-                                                       max_seq_len, hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, m->attn_ws.p, &ap,
-                                                       st))
+                if (int rc = vmx_paged_attention_parts(q, KV.k_cache.p, KV.v_cache.p, block_tables, seq_lens, 1.0f, B, Hq, Hkv,
+                                                       max_blocks_per_seq, max_seq_len, hd, c.block_size, L.window, c.kv_cache_dtype, ks,
+                                                       ks + 1, m->attn_ws.p, &ap, st))
                     return rc;
                 if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
             }
@@ -691,10 +725,10 @@ extern "C" int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, dou
     const bool multi = batch == 1 && m->cfg.hidden_size <= 4096;   // q|k|v and gate|up go out as one launch each
     for (const G4Layer &L : m->layers) {
         for (int s = 0; s < 7; s++) {
-            if (s == VMX_L_V && L.k_eq_v) continue;
+            if ((s == VMX_L_V && L.k_eq_v) || ((s == VMX_L_K || s == VMX_L_V) && L.kv_shared)) continue;
             by += L.lin[s].alg_bytes(batch);
         }
-        n += multi ? 4 : (L.k_eq_v ? 6 : 7);
+        n += multi ? 4 : (L.kv_shared ? 5 : (L.k_eq_v ? 6 : 7));
     }
     *launches = n;
     *alg_bytes = by;
@@ -707,12 +741,13 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
     hipStream_t st = vmx_stream(stream);
     const vmx_gemma4_config &c = m->cfg;
     float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
-    const int I = c.intermediate_size, H = c.hidden_size;
+    const int H = c.hidden_size;
     for (const G4Layer &L : m->layers) {
-        const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd, ntot = NQ + (L.k_eq_v ? 1 : 2) * NKV;
+        const int nseg = L.kv_shared ? 1 : (L.k_eq_v ? 2 : 3), I = L.inter;
+        const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd, ntot = NQ + (nseg - 1) * NKV;
         const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
         const int qoffs[3] = {0, NQ, NQ + NKV};
-        if (int rc = mmvq_group(m, qkv, qoffs, L.k_eq_v ? 2 : 3, proj, ntot, batch, st)) return rc;
+        if (int rc = mmvq_group(m, qkv, qoffs, nseg, proj, ntot, batch, st)) return rc;
         if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
         const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
         const int goffs[2] = {0, I};
@@ -726,6 +761,8 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
 extern "C" int vmx_gemma4_debug_kv(vmx_gemma4 *m, int layer, int which, int write, void *buf, size_t bytes, void *stream) {
     VMX_REQUIRE(m && buf, "gemma4_debug_kv: null pointer");
     VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && (which == 0 || which == 1), "gemma4_debug_kv: layer %d / which %d", layer, which);
+    const G4Layer &L = m->layers[layer];
+    VMX_REQUIRE(!L.kv_shared, "gemma4_debug_kv: layer %d owns no cache (it reads layer %d's)", layer, L.kv_target);
     Buf &c = which == 0 ? m->layers[layer].k_cache : m->layers[layer].v_cache;
     VMX_REQUIRE(bytes == c.bytes, "gemma4_debug_kv: the cache holds %zu bytes, got %zu", c.bytes, bytes);
     VMX_CHECK_HIP(write ? hipMemcpyAsync(c.p, buf, bytes, hipMemcpyDefault, vmx_stream(stream))

@@ -21,7 +21,7 @@ from .qwen3 import rope_cos_sin_cache
 (T_EMBED, T_FINAL_NORM, T_COS_SIN_SLIDING, T_COS_SIN_FULL, T_INPUT_LN, T_POST_ATTN_LN, T_PRE_FFN_LN, T_POST_FFN_LN, T_Q_NORM,
  T_K_NORM, T_LAYER_SCALAR, T_KV_SCALES) = range(12)
 L_Q, L_K, L_V, L_O, L_GATE, L_UP, L_DOWN = range(7)
-G4_SLIDING, G4_K_EQ_V = 1, 2
+G4_SLIDING, G4_K_EQ_V, G4_KV_SHARED, G4_DOUBLE_WIDE_MLP = 1, 2, 4, 8
 
 IQ_TYPE_SIZE = {17: 74, 22: 82, 18: 98, 21: 110, 23: 136}
 GGML_TYPE_SIZE = {2: (18, 32), 3: (20, 32), 6: (22, 32), 7: (24, 32), 8: (34, 32), 10: (84, 256), 11: (110, 256), 12: (144, 256), 13: (176, 256), 14: (210, 256)}
@@ -44,6 +44,8 @@ class Gemma4Spec:
     full_every: int = 6                      # layer i is a full-attention layer when (i + 1) % full_every == 0
     layer_is_sliding: Optional[List[bool]] = None
     k_eq_v_on_full: bool = False
+    num_kv_shared_layers: int = 0            # the last n layers read an earlier layer's KV cache (gemma4_quantized.rs:441-469)
+    use_double_wide_mlp: bool = False        # KV-shared layers carry a twice-as-wide MLP (gemma4_quantized.rs:514-525)
     rope_theta_sliding: float = 10000.0
     rope_theta_full: float = 1e6
     partial_rotary_factor_full: float = 0.25
@@ -66,8 +68,33 @@ class Gemma4Spec:
             return bool(self.layer_is_sliding[i])
         return (i + 1) % self.full_every != 0
 
+    def kv_shared(self, i: int) -> bool:
+        return self.num_kv_shared_layers > 0 and i >= max(self.num_layers - self.num_kv_shared_layers, 0)
+
+    def kv_target(self, i: int) -> Optional[int]:
+        """Layer whose cache layer i attends over: the last layer before the shared suffix with i's attention type
+        (kv_sharing_target_layer, gemma4_quantized.rs:441-469); None for a layer that owns its cache."""
+        if not self.kv_shared(i):
+            return None
+        first_shared = max(self.num_layers - self.num_kv_shared_layers, 0)
+        for cand in range(first_shared - 1, -1, -1):
+            if self.sliding(cand) == self.sliding(i):
+                return cand
+        return None
+
+    def layer_intermediate(self, i: int) -> int:
+        return self.intermediate_size * (2 if self.use_double_wide_mlp and self.kv_shared(i) else 1)
+
     def layer_flags(self) -> List[int]:
-        return [(G4_SLIDING if self.sliding(i) else (G4_K_EQ_V if self.k_eq_v_on_full else 0)) for i in range(self.num_layers)]
+        out = []
+        for i in range(self.num_layers):
+            f = G4_SLIDING if self.sliding(i) else 0
+            if self.kv_shared(i):
+                f |= G4_KV_SHARED | (G4_DOUBLE_WIDE_MLP if self.use_double_wide_mlp else 0)
+            elif not self.sliding(i) and self.k_eq_v_on_full:
+                f |= G4_K_EQ_V
+            out.append(f)
+        return out
 
     def rot_dim_full(self) -> int:
         r = int(self.head_dim_full * self.partial_rotary_factor_full)
@@ -77,14 +104,16 @@ class Gemma4Spec:
         """(head_dim, kv_heads, rot_dim, window, k_eq_v) of layer i."""
         if self.sliding(i):
             return self.head_dim_sliding, self.kv_heads_sliding, self.head_dim_sliding, self.sliding_window, False
-        return self.head_dim_full, self.kv_heads_full, self.rot_dim_full(), 0, self.k_eq_v_on_full
+        return self.head_dim_full, self.kv_heads_full, self.rot_dim_full(), 0, self.k_eq_v_on_full and not self.kv_shared(i)
 
     def linear_shapes(self, i: int):
         hd, kvh, _, _, keqv = self.layer_geom(i)
-        H, I, nq, nkv = self.hidden_size, self.intermediate_size, self.num_heads * hd, kvh * hd
+        H, I, nq, nkv = self.hidden_size, self.layer_intermediate(i), self.num_heads * hd, kvh * hd
         sh = {L_Q: (H, nq), L_K: (H, nkv), L_V: (H, nkv), L_O: (nq, H), L_GATE: (H, I), L_UP: (H, I), L_DOWN: (I, H)}
-        if keqv:
+        if keqv or self.kv_shared(i):
             del sh[L_V]
+        if self.kv_shared(i):
+            del sh[L_K]
         return sh
 
 
