@@ -399,6 +399,11 @@ typedef struct vmx_qwen3 vmx_qwen3;
 #define VMX_L_GATE 4
 #define VMX_L_UP 5
 #define VMX_L_DOWN 6
+/* Gemma 4 per-layer-input linears: per layer the gate [P, hidden] and projection [hidden, P]; once per model
+ * per_layer_model_projection [layers * P, hidden] (its `layer` argument is ignored) */
+#define VMX_L_PLE_GATE 7
+#define VMX_L_PLE_PROJ 8
+#define VMX_L_PLE_MODEL_PROJ 9
 
 int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out);
 void vmx_qwen3_destroy(vmx_qwen3 *m);
@@ -525,6 +530,10 @@ typedef struct vmx_gemma4_config {
     int max_batch, max_seq_len;
     float final_logit_softcap;                /* 0 = off */
     int embed_ggml_type;                      /* 0 = bf16 table, else the GGML type id of token_embd (11 Q3_K, 14 Q6_K, ...) */
+    /* per-layer inputs of the E2B / E4B variants (gemma4_quantized.rs:1663-1683, :2143-2192); 0 = the model has none */
+    int hidden_size_per_layer_input;          /* P: 0 or a multiple of 256, at most 1024 */
+    int vocab_size_per_layer_input;           /* rows of embed_tokens_per_layer [vocab_pl, num_layers * P] */
+    int ple_embed_ggml_type;                  /* 0 = bf16 table, else a GGML legacy / K-quant type id */
 } vmx_gemma4_config;
 
 typedef struct vmx_gemma4 vmx_gemma4;
@@ -551,6 +560,9 @@ typedef struct vmx_gemma4 vmx_gemma4;
 #define VMX_G4T_K_NORM 9
 #define VMX_G4T_LAYER_SCALAR 10  /* bf16 [1] */
 #define VMX_G4T_KV_SCALES 11     /* f32 [2] = {k_scale, v_scale} */
+#define VMX_G4T_PLE_EMBED 12     /* embed_tokens_per_layer: bf16 [vocab_pl, layers * P] or raw GGML blocks */
+#define VMX_G4T_PLE_PROJ_NORM 13 /* per_layer_projection_norm, bf16 [P] */
+#define VMX_G4T_POST_PLE_NORM 14 /* per layer: post_per_layer_input_norm, bf16 [hidden] */
 
 int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_flags, vmx_gemma4 **out);
 void vmx_gemma4_destroy(vmx_gemma4 *m);

@@ -174,12 +174,32 @@ class OracleGemma4:
         n_out = raw.size // (n_in // 256 * orc.IQ_TYPE_SIZE[t])
         return orc.f32_to_bf16(orc.iq_matmul(t, raw, x, n_out, n_in))
 
+    def per_layer_inputs(self, ids, h0):
+        """compute_per_layer_inputs (gemma4_quantized.rs:2143-2192): bf16 [B, layers, P], or None without per-layer inputs."""
+        s = self.s
+        P, L, B = s.hidden_size_per_layer_input, s.num_layers, len(ids)
+        if P == 0:
+            return None
+
+        def scalar(v, shape):
+            return np.broadcast_to(orc.f32_to_bf16(np.float32(v)), shape)
+
+        if s.ple_embed_ggml_type == 0:
+            table = orc.bf16_to_f32(self.ck["ple_embed"]).reshape(s.vocab_size_per_layer_input, L * P)
+        else:
+            table = orc.ggml_dequant(s.ple_embed_ggml_type, self.ck["ple_embed"]).reshape(s.vocab_size_per_layer_input, L * P)
+        emb = mul_bf16(orc.f32_to_bf16(np.ascontiguousarray(table[ids])), scalar(np.sqrt(np.float64(P)), (B, L * P)))
+        proj = mul_bf16(self.linear(0, 9, h0), scalar(np.float64(s.hidden_size) ** -0.5, (B, L * P)))
+        normed = orc.rms_norm_bf16(proj.reshape(B * L, P), self.ck["ple_proj_norm"], s.rms_norm_eps).reshape(B, L * P)
+        return mul_bf16(add_bf16(normed, emb), scalar(np.float64(2.0) ** -0.5, (B, L * P))).reshape(B, L, P)
+
     def decode(self, ids, positions, slots, block_tables, seq_lens):
         from scipy.special import erf
         s = self.s
         B = len(ids)
         norm_bf16 = orc.f32_to_bf16(np.float32(np.sqrt(np.float32(s.hidden_size))))        # affine factor rounded to bf16
         h = mul_bf16(orc.f32_to_bf16(self.embed_f32[ids]), np.broadcast_to(norm_bf16, (B, s.hidden_size)))
+        pli = self.per_layer_inputs(ids, h)
         for li in range(s.num_layers):
             hd, kvh, rot, window, keqv = s.layer_geom(li)
             sliding = s.sliding(li)
@@ -210,6 +230,11 @@ class OracleGemma4:
             a = mul_bf16(ge, self.linear(li, 5, x))
             d = self.linear(li, 6, a)
             h = add_bf16(orc.rms_norm_bf16(d, self.ck[f"{li}.post_ffn_ln"], s.rms_norm_eps), h)
+            if pli is not None:     # apply_ple (gemma4_quantized.rs:1663-1683); gelu_tanh in f32, one rounding (parity unpinned)
+                g = orc.bf16_to_f32(self.linear(li, 7, h)).astype(np.float64)
+                ge = orc.f32_to_bf16((0.5 * g * (1.0 + np.tanh(0.7978845608028654 * g * (1.0 + 0.044715 * g * g)))).astype(np.float32))
+                contrib = self.linear(li, 8, mul_bf16(ge, np.ascontiguousarray(pli[:, li, :])))
+                h = add_bf16(h, orc.rms_norm_bf16(contrib, self.ck[f"{li}.post_ple_norm"], s.rms_norm_eps))
             h = mul_bf16(h, np.broadcast_to(self.ck[f"{li}.scalar"].reshape(1, 1), h.shape))
         x = orc.rms_norm_bf16(h, self.ck["final_norm"], s.rms_norm_eps)
         logits = (orc.bf16_to_f32(x).astype(np.float64) @ self.embed_f32.astype(np.float64).T).astype(np.float32)

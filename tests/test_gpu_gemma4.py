@@ -76,6 +76,18 @@ def test_gemma4_kv_shared_layers_double_wide_mlp():
     _run(spec, steps=7, B=2)
 
 
+@pytest.mark.parametrize("ple_type", [0, 14])
+def test_gemma4_per_layer_inputs(ple_type):
+    """Per-layer inputs (E2B / E4B variants): embed_tokens_per_layer (bf16 or Q6_K) + per_layer_model_projection + norm once per
+    step, and per layer the gelu_tanh gate, projection and post norm before the layer scalar; with a KV-shared last layer."""
+    from vllm_rust_amd.gemma4 import Gemma4Spec
+    spec = Gemma4Spec(256, 4, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=4, full_every=3, num_kv_shared_layers=1, hidden_size_per_layer_input=256,
+                      vocab_size_per_layer_input=1000, ple_embed_ggml_type=ple_type, max_position=64, kv_cache_dtype=0, num_blocks=8,
+                      max_batch=2, max_seq_len=32)
+    _run(spec, steps=5, B=2)
+
+
 def test_gemma4_kv_shared_flags_must_be_a_suffix_with_a_target():
     import ctypes as C
     from vllm_rust_amd._lib import Gemma4Config, lib

@@ -180,7 +180,7 @@ class Gemma4Config(C.Structure):
         ("rms_norm_eps", _f), ("head_dim_sliding", _i), ("head_dim_full", _i), ("kv_heads_sliding", _i), ("kv_heads_full", _i),
         ("sliding_window", _i), ("rot_dim_sliding", _i), ("rot_dim_full", _i), ("max_position", _i), ("kv_cache_dtype", _i),
         ("block_size", _i), ("num_blocks", _i), ("max_batch", _i), ("max_seq_len", _i), ("final_logit_softcap", _f),
-        ("embed_ggml_type", _i),
+        ("embed_ggml_type", _i), ("hidden_size_per_layer_input", _i), ("vocab_size_per_layer_input", _i), ("ple_embed_ggml_type", _i),
     ]
 
 

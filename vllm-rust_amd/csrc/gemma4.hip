@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void g4_embed_kernel(uint16_t *__restrict__ ou
 // One workgroup per token; thread t owns the 8-element chunks t, t+256, ... (CH of them) in registers.
 //   o given:  o_r = bf16(o);  n = bf16(o_r * rsqrt(mean(o_r^2) + eps) * w_post);  h = bf16(n + h);
 //             scalar given: h = bf16(h * scalar)                       (post-norm, residual add, layer_scalar)
-//   always:   x = bf16(h * rsqrt(mean(h^2) + eps) * w_next)  (+ its q8_1 form)   (the next sub-block's pre-norm)
+//   always:   x = bf16(h * rsqrt(mean(h^2) + eps) * w_next)  (+ its q8_1 form)   (the next sub-block's pre-norm);
+//             w_next == nullptr: x = h (the per-layer-input gate projects the residual stream itself)
 template <int CH>
 __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x, const float *__restrict__ o,
                                                        const uint16_t *__restrict__ w_post, const uint16_t *__restrict__ scalar,
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, 
             wp[c] = *reinterpret_cast<const uint4 *>(w_post + 8 * ci);
         }
         hraw[c] = *reinterpret_cast<const uint4 *>(h + row + 8 * ci);
-        wn[c] = *reinterpret_cast<const uint4 *>(w_next + 8 * ci);
+        wn[c] = w_next ? *reinterpret_cast<const uint4 *>(w_next + 8 * ci) : make_uint4(0, 0, 0, 0);
     }
     const float sc = scalar ? vmx_bf16_to_f32(scalar[0]) : 1.0f;
     float hv[CH][8];
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, 
             float wv[8], out[8];
             unpack8(wn[c], wv);
 #pragma unroll
-            for (int j = 0; j < 8; j++) out[j] = hv[c][j] * inv2 * wv[j];
+            for (int j = 0; j < 8; j++) out[j] = w_next ? hv[c][j] * inv2 * wv[j] : hv[c][j];
             const uint4 packed = pack8(out);
             *reinterpret_cast<uint4 *>(x + row + 8 * ci) = packed;
             if (aq) {
@@ -231,6 +232,50 @@ __global__ __launch_bounds__(256) void g4_geglu_kernel(const float *__restrict__
     }
 }
 
+// Per-layer inputs (compute_per_layer_inputs, gemma4_quantized.rs:2143-2192), grid (layers, tokens), block 64:
+//   a = bf16(bf16(proj) * bf16(hidden^-1/2));  n = bf16(a * rsqrt(mean(a^2) + eps) * w);     (per (token, layer) slice of width P)
+//   pli = bf16(bf16(n + e) * bf16(2^-1/2))     with e = bf16(embed_per_layer[id] * bf16(sqrt(P))) gathered beforehand
+__global__ __launch_bounds__(64) void g4_ple_inputs_kernel(const float *__restrict__ proj, const uint16_t *__restrict__ emb,
+                                                            const uint16_t *__restrict__ w, uint16_t *__restrict__ pli, int P, float eps,
+                                                            float proj_scale, float input_scale) {
+    __shared__ float vals[1024];
+    const int64_t base = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * P;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < P; i += 64) {
+        const float a = rbf(rbf(proj[base + i]) * proj_scale);
+        vals[i] = a;
+        ss += a * a;
+    }
+    ss = vmx_wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)P + eps);
+    for (int i = threadIdx.x; i < P; i += 64) {
+        const float n = rbf(vals[i] * inv * vmx_bf16_to_f32(w[i]));
+        pli[base + i] = vmx_f32_to_bf16(rbf(n + vmx_bf16_to_f32(emb[base + i])) * input_scale);
+    }
+}
+
+// apply_ple's gate (gemma4_quantized.rs:1674-1676): gated = bf16(bf16(gelu_tanh(bf16(gate))) * pli[token][layer]) and its q8_1
+// form for per_layer_projection.  One thread per 8 values, P % 32 == 0; pli row stride = pli_stride elements.
+__global__ __launch_bounds__(256) void g4_ple_gate_kernel(const float *__restrict__ gate, const uint16_t *__restrict__ pli, int64_t pli_stride,
+                                                           int tokens, int P, int8_t *__restrict__ aq, float *__restrict__ ad) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, chunks = (int64_t)tokens * P / 8;
+    if (c >= chunks) return;
+    const int cpr = P / 8;
+    const int64_t t = c / cpr, col = (c % cpr) * 8;
+    float r[8], pv[8];
+    unpack8(*reinterpret_cast<const uint4 *>(pli + t * pli_stride + col), pv);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float g = rbf(gate[t * P + col + j]);
+        const float ge = rbf(0.5f * g * (1.0f + tanhf(0.7978845608028654f * g * (1.0f + 0.044715f * g * g))));
+        r[j] = ge * pv[j];
+    }
+    const uint4 packed = pack8(r);
+    float rr[8];
+    unpack8(packed, rr);
+    vmx_q8_1_emit8(rr, aq + c * 8, ad + (c >> 2), (c & 3) == 0);
+}
+
 __global__ __launch_bounds__(256) void g4_bf16_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = vmx_bf16_to_f32(in[i]);
@@ -284,11 +329,13 @@ struct G4Layer {
     int kv_target = -1;
     int hd = 0, kvh = 0, rot = 0, window = 0;
     int inter = 0;   // MLP width: twice the base on a double-wide layer (:514-525)
-    IqLin lin[7];
-    Buf input_ln, post_attn_ln, pre_ffn_ln, post_ffn_ln, q_norm, k_norm, scalar, k_cache, v_cache, kv_scales;
+    IqLin lin[9];   // VMX_L_Q .. VMX_L_DOWN, VMX_L_PLE_GATE, VMX_L_PLE_PROJ
+    bool ple = false;
+    Buf input_ln, post_attn_ln, pre_ffn_ln, post_ffn_ln, q_norm, k_norm, scalar, k_cache, v_cache, kv_scales, post_ple_norm;
     bool ready() const {
         for (int s = 0; s < 7; s++)
             if (!lin[s].loaded && !(s == VMX_L_V && k_eq_v) && !((s == VMX_L_K || s == VMX_L_V) && kv_shared)) return false;
+        if (ple && (!lin[VMX_L_PLE_GATE].loaded || !lin[VMX_L_PLE_PROJ].loaded)) return false;
         return true;
     }
     int nq(int heads) const { return heads * hd; }
@@ -303,6 +350,11 @@ struct vmx_gemma4 {
     Buf embed, final_norm, cos_sin_s, cos_sin_f;
     Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8, positions;
     float embed_scale = 1.f;
+    // per-layer inputs (hidden_size_per_layer_input > 0): embed_tokens_per_layer, per_layer_model_projection and its norm, and the
+    // step's buffers [rows][layers * P]: gathered embedding rows, projection output, combined inputs
+    IqLin ple_model_proj;
+    Buf ple_embed, ple_proj_norm, ple_e, ple_p, pli;
+    float ple_embed_scale = 1.f, ple_proj_scale = 1.f, ple_input_scale = 1.f;
 };
 
 namespace {
@@ -365,17 +417,33 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     VMX_REQUIRE(c.embed_ggml_type == 0 || (vmx_ggml_type_size(c.embed_ggml_type) > 0 && vmx_iq_type_size(c.embed_ggml_type) < 0),
                 "gemma4_create: token_embd type %d unsupported (bf16 or a GGML legacy/K-quant type)", c.embed_ggml_type);
     VMX_REQUIRE(c.embed_ggml_type == 0 || c.hidden_size % vmx_ggml_block_elems(c.embed_ggml_type) == 0, "gemma4_create: hidden_size vs embed block");
+    VMX_REQUIRE(c.hidden_size_per_layer_input >= 0 && c.hidden_size_per_layer_input % 256 == 0 && c.hidden_size_per_layer_input <= 1024,
+                "gemma4_create: hidden_size_per_layer_input (%d) must be 0 or a multiple of 256, at most 1024", c.hidden_size_per_layer_input);
+    VMX_REQUIRE(c.hidden_size_per_layer_input == 0 || c.vocab_size_per_layer_input > 0,
+                "gemma4_create: vocab_size_per_layer_input must be positive with per-layer inputs");
+    VMX_REQUIRE(c.hidden_size_per_layer_input == 0 || c.ple_embed_ggml_type == 0 ||
+                    (vmx_ggml_type_size(c.ple_embed_ggml_type) > 0 && vmx_iq_type_size(c.ple_embed_ggml_type) < 0),
+                "gemma4_create: per-layer embedding type %d unsupported (bf16 or a GGML legacy/K-quant type)", c.ple_embed_ggml_type);
     vmx_gemma4 *m = new (std::nothrow) vmx_gemma4();
     VMX_REQUIRE(m, "gemma4_create: out of host memory");
     m->cfg = c;
     m->layers.resize(c.num_layers);
     // embed_tokens.forward(ids) * sqrt(hidden) is a bf16 affine: the factor is rounded to bf16 first
-    {
-        const float s = sqrtf((float)c.hidden_size);
+    auto to_bf16 = [](double v) {
+        const float s = (float)v;
         uint32_t u;
         memcpy(&u, &s, 4);
         u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-        memcpy(&m->embed_scale, &u, 4);
+        float r;
+        memcpy(&r, &u, 4);
+        return r;
+    };
+    m->embed_scale = to_bf16(sqrt((double)c.hidden_size));
+    const int P = c.hidden_size_per_layer_input, LP = P * c.num_layers;
+    if (P > 0) {   // the three affine factors of compute_per_layer_inputs, each a bf16 scalar (gemma4_quantized.rs:2159-2161)
+        m->ple_embed_scale = to_bf16(sqrt((double)P));
+        m->ple_proj_scale = to_bf16(pow((double)c.hidden_size, -0.5));
+        m->ple_input_scale = to_bf16(pow(2.0, -0.5));
     }
     const int H = c.hidden_size, I = c.intermediate_size, B = c.max_batch;
     const size_t kv_elem = c.kv_cache_dtype == VMX_KV_FP8_E4M3 ? 1 : 2;
@@ -422,6 +490,14 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         }
         const int in_f[7] = {H, H, H, NQ, H, H, L.inter}, out_f[7] = {NQ, NKV, NKV, H, L.inter, L.inter, H};
         for (int s = 0; s < 7; s++) { L.lin[s].in_features = in_f[s]; L.lin[s].out_features = out_f[s]; }
+        if (P > 0) {   // per_layer_input_gate [P, hidden], per_layer_projection [hidden, P], post_per_layer_input_norm [hidden] (:1605-1625)
+            L.ple = true;
+            L.lin[VMX_L_PLE_GATE].in_features = H;
+            L.lin[VMX_L_PLE_GATE].out_features = P;
+            L.lin[VMX_L_PLE_PROJ].in_features = P;
+            L.lin[VMX_L_PLE_PROJ].out_features = H;
+            TRY(L.post_ple_norm.alloc((size_t)H * 2));
+        }
         max_nq = NQ > max_nq ? NQ : max_nq;
         max_proj = NQ + 2 * NKV > max_proj ? NQ + 2 * NKV : max_proj;
         max_proj = 2 * L.inter > max_proj ? 2 * L.inter : max_proj;
@@ -448,6 +524,24 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         }
     }
     const int R = B > 16 ? B : 16;   // activation rows: a decode batch, or one 16-row pass of the prompt path
+    if (P > 0) {
+        if (c.ple_embed_ggml_type != 0 && LP % vmx_ggml_block_elems(c.ple_embed_ggml_type) != 0) {
+            vmx_set_error("gemma4_create: layers * hidden_size_per_layer_input (%d) vs the per-layer embedding's block size", LP);
+            rc = rc ? rc : VMX_EINVAL;
+        } else if (c.ple_embed_ggml_type == 0) {
+            TRY(m->ple_embed.alloc((size_t)c.vocab_size_per_layer_input * LP * 2));
+        } else {
+            TRY(m->ple_embed.alloc((size_t)c.vocab_size_per_layer_input * (LP / vmx_ggml_block_elems(c.ple_embed_ggml_type)) *
+                                   vmx_ggml_type_size(c.ple_embed_ggml_type)));
+        }
+        m->ple_model_proj.in_features = H;
+        m->ple_model_proj.out_features = LP;
+        TRY(m->ple_proj_norm.alloc((size_t)P * 2));
+        TRY(m->ple_e.alloc((size_t)R * LP * 2));
+        TRY(m->ple_p.alloc((size_t)R * LP * 4));
+        TRY(m->pli.alloc((size_t)R * LP * 2));
+        max_proj = P > max_proj ? P : max_proj;
+    }
     TRY(m->positions.alloc((size_t)R * 4));
     TRY(m->h.alloc((size_t)R * H * 2));
     TRY(m->x.alloc((size_t)R * H * 2));
@@ -464,6 +558,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     {
         size_t kmax = (size_t)(H > max_inter ? H : max_inter);
         kmax = (size_t)max_nq > kmax ? (size_t)max_nq : kmax;
+        kmax = (size_t)P > kmax ? (size_t)P : kmax;
         TRY(m->q8.alloc(R * kmax + 256 + R * (kmax / 32) * 4));
     }
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, max_hd, c.max_seq_len)));
@@ -482,9 +577,12 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     for (G4Layer &L : m->layers) {
         for (IqLin &l : L.lin) { l.raw.release(); l.packed.release(); }
         for (Buf *b : {&L.input_ln, &L.post_attn_ln, &L.pre_ffn_ln, &L.post_ffn_ln, &L.q_norm, &L.k_norm, &L.scalar, &L.k_cache, &L.v_cache,
-                       &L.kv_scales})
+                       &L.kv_scales, &L.post_ple_norm})
             b->release();
     }
+    m->ple_model_proj.raw.release();
+    m->ple_model_proj.packed.release();
+    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli}) b->release();
     for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
                    &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8})
         b->release();
@@ -499,7 +597,13 @@ extern "C" int vmx_gemma4_load_tensor(vmx_gemma4 *m, int which, int layer, const
         case VMX_G4T_FINAL_NORM: dst = &m->final_norm; break;
         case VMX_G4T_COS_SIN_SLIDING: dst = &m->cos_sin_s; break;
         case VMX_G4T_COS_SIN_FULL: dst = &m->cos_sin_f; break;
+        case VMX_G4T_PLE_EMBED: dst = m->ple_embed.p ? &m->ple_embed : nullptr; break;
+        case VMX_G4T_PLE_PROJ_NORM: dst = m->ple_proj_norm.p ? &m->ple_proj_norm : nullptr; break;
         default: break;
+    }
+    if (which == VMX_G4T_POST_PLE_NORM) {
+        VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "gemma4_load_tensor: layer %d out of range", layer);
+        dst = m->layers[layer].ple ? &m->layers[layer].post_ple_norm : nullptr;
     }
     if (!dst && which >= VMX_G4T_INPUT_LN && which <= VMX_G4T_KV_SCALES) {
         VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "gemma4_load_tensor: layer %d out of range", layer);
@@ -516,15 +620,18 @@ extern "C" int vmx_gemma4_load_tensor(vmx_gemma4 *m, int which, int layer, const
 extern "C" int vmx_gemma4_load_iq_linear(vmx_gemma4 *m, int layer, int slot, int ggml_type, const void *blocks, size_t bytes,
                                          void *stream) {
     VMX_REQUIRE(m && blocks, "gemma4_load_iq_linear: null pointer");
-    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && slot >= VMX_L_Q && slot <= VMX_L_DOWN,
+    const bool model_level = slot == VMX_L_PLE_MODEL_PROJ;
+    VMX_REQUIRE(model_level || (layer >= 0 && layer < (int)m->layers.size() && slot >= VMX_L_Q && slot <= VMX_L_PLE_PROJ),
                 "gemma4_load_iq_linear: layer %d / slot %d out of range", layer, slot);
     const int ts = vmx_iq_type_size(ggml_type);
     VMX_REQUIRE(ts > 0, "gemma4_load_iq_linear: ggml type %d is not a supported I-quant", ggml_type);
-    G4Layer &L = m->layers[layer];
+    VMX_REQUIRE(slot < VMX_L_PLE_GATE || m->cfg.hidden_size_per_layer_input > 0,
+                "gemma4_load_iq_linear: slot %d needs hidden_size_per_layer_input > 0", slot);
+    G4Layer &L = m->layers[model_level ? 0 : layer];
     VMX_REQUIRE(!(slot == VMX_L_V && L.k_eq_v), "gemma4_load_iq_linear: layer %d reuses K as V and has no v_proj", layer);
     VMX_REQUIRE(!((slot == VMX_L_K || slot == VMX_L_V) && L.kv_shared),
                 "gemma4_load_iq_linear: layer %d shares layer %d's KV cache and has no k_proj / v_proj", layer, L.kv_target);
-    IqLin &l = L.lin[slot];
+    IqLin &l = model_level ? m->ple_model_proj : L.lin[slot];
     VMX_REQUIRE(l.in_features % 256 == 0, "gemma4_load_iq_linear: in_features %d not a multiple of 256", l.in_features);
     const size_t need = (size_t)l.out_features * (l.in_features / 256) * ts;
     VMX_REQUIRE(bytes == need, "gemma4_load_iq_linear: expected %zu bytes for [%d, %d] of type %d, got %zu", need, l.out_features,
@@ -568,10 +675,28 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
     } else if (int rc = vmx_kquant_gather_scaled_bf16(c.embed_ggml_type, m->embed.p, input_ids, h, B, H, c.vocab_size, m->embed_scale, st)) {
         return rc;
     }
-    // pending: the previous layer's MLP output still to be post-normed, added, scaled
+    const int P = c.hidden_size_per_layer_input, LP = P * c.num_layers;
+    if (P > 0) {   // per-layer inputs of this step, [rows][layers][P] (compute_per_layer_inputs, :2143-2192)
+        uint16_t *pe = (uint16_t *)m->ple_e.p;
+        if (c.ple_embed_ggml_type == 0) {
+            hipLaunchKernelGGL(g4_embed_kernel, dim3(B), dim3(256), 0, st, pe, (const uint16_t *)m->ple_embed.p, input_ids, LP,
+                               c.vocab_size_per_layer_input, m->ple_embed_scale);
+        } else if (int rc = vmx_kquant_gather_scaled_bf16(c.ple_embed_ggml_type, m->ple_embed.p, input_ids, pe, B, LP,
+                                                          c.vocab_size_per_layer_input, m->ple_embed_scale, st)) {
+            return rc;
+        }
+        if (int rc = vmx_quantize_q8_1_bf16(h, aq_of(m), ad_of(m, B, H), (int64_t)B * (H / 32), st)) return rc;
+        if (int rc = mmvq(m, m->ple_model_proj, (float *)m->ple_p.p, LP, B, st)) return rc;
+        hipLaunchKernelGGL(g4_ple_inputs_kernel, dim3(c.num_layers, B), dim3(64), 0, st, (const float *)m->ple_p.p, pe,
+                           (const uint16_t *)m->ple_proj_norm.p, (uint16_t *)m->pli.p, P, c.rms_norm_eps, m->ple_proj_scale,
+                           m->ple_input_scale);
+    }
+    // pending: the previous layer's last linear output still to be post-normed, added, scaled
     const float *pending = nullptr;
     const uint16_t *pending_w = nullptr, *pending_scalar = nullptr;
+    int li = -1;
     for (const G4Layer &L : m->layers) {
+        li++;
         const G4Layer &KV = L.kv_shared ? m->layers[L.kv_target] : L;   // whose paged cache this layer's attention reads
         const int hd = L.hd, Hkv = L.kvh, NQ = Hq * hd, NKV = Hkv * hd, I = L.inter;
         const int nseg = L.kv_shared ? 1 : (L.k_eq_v ? 2 : 3);
@@ -631,6 +756,14 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         pending = out;
         pending_w = (const uint16_t *)L.post_ffn_ln.p;
         pending_scalar = (const uint16_t *)L.scalar.p;
+        if (L.ple) {   // apply_ple (:1663-1683): h += norm(per_layer_projection(gelu_tanh(gate(h)) * pli[layer])), before the scalar
+            launch_norm(st, B, h, x, pending, pending_w, nullptr, nullptr, c.rms_norm_eps, H, aq_of(m), ad_of(m, B, H));
+            if (int rc = mmvq(m, L.lin[VMX_L_PLE_GATE], proj, P, B, st)) return rc;
+            hipLaunchKernelGGL(g4_ple_gate_kernel, dim3((unsigned)(((int64_t)B * P / 8 + 255) / 256)), dim3(256), 0, st, proj,
+                               (const uint16_t *)m->pli.p + (size_t)li * P, (int64_t)LP, B, P, aq_of(m), ad_of(m, B, P));
+            if (int rc = mmvq(m, L.lin[VMX_L_PLE_PROJ], out, H, B, st)) return rc;
+            pending_w = (const uint16_t *)L.post_ple_norm.p;
+        }
     }
     launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr);
     VMX_CHECK_LAUNCH("gemma4 layers");
@@ -686,6 +819,7 @@ extern "C" int vmx_gemma4_decode(vmx_gemma4 *m, const int32_t *input_ids, const 
     VMX_REQUIRE(max_seq_len >= 1 && max_seq_len <= c.max_seq_len, "gemma4_decode: max_seq_len %d exceeds the model's %d", max_seq_len,
                 c.max_seq_len);
     for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_decode: weights not fully loaded");
+    VMX_REQUIRE(m->cfg.hidden_size_per_layer_input == 0 || m->ple_model_proj.loaded, "gemma4_decode: per_layer_model_projection not loaded");
     if (int rc = g4_run_layers(m, input_ids, positions, slot_mapping, block_tables, seq_lens, batch, max_blocks_per_seq, max_seq_len, -1,
                                vmx_stream(stream)))
         return rc;
@@ -706,6 +840,7 @@ extern "C" int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int s
                 "gemma4_prefill: positions %d..%d exceed max_position %d / max_seq_len %d", seqlen_offset, seqlen_offset + q_len - 1,
                 c.max_position, c.max_seq_len);
     for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_prefill: weights not fully loaded");
+    VMX_REQUIRE(m->cfg.hidden_size_per_layer_input == 0 || m->ple_model_proj.loaded, "gemma4_prefill: per_layer_model_projection not loaded");
     hipStream_t st = vmx_stream(stream);
     int32_t *pos = (int32_t *)m->positions.p;
     int last_rows = 0;
@@ -738,6 +873,7 @@ extern "C" int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, dou
 extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
     VMX_REQUIRE(m && batch >= 1 && batch <= m->cfg.max_batch, "gemma4_mmvq_only: bad arguments");
     for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_mmvq_only: weights not fully loaded");
+    VMX_REQUIRE(m->cfg.hidden_size_per_layer_input == 0 || m->ple_model_proj.loaded, "gemma4_mmvq_only: per_layer_model_projection not loaded");
     hipStream_t st = vmx_stream(stream);
     const vmx_gemma4_config &c = m->cfg;
     float *proj = (float *)m->proj.p, *out = (float *)m->out.p;

@@ -19,8 +19,8 @@ from ._lib import Gemma4Config, check, lib
 from .qwen3 import rope_cos_sin_cache
 
 (T_EMBED, T_FINAL_NORM, T_COS_SIN_SLIDING, T_COS_SIN_FULL, T_INPUT_LN, T_POST_ATTN_LN, T_PRE_FFN_LN, T_POST_FFN_LN, T_Q_NORM,
- T_K_NORM, T_LAYER_SCALAR, T_KV_SCALES) = range(12)
-L_Q, L_K, L_V, L_O, L_GATE, L_UP, L_DOWN = range(7)
+ T_K_NORM, T_LAYER_SCALAR, T_KV_SCALES, T_PLE_EMBED, T_PLE_PROJ_NORM, T_POST_PLE_NORM) = range(15)
+L_Q, L_K, L_V, L_O, L_GATE, L_UP, L_DOWN, L_PLE_GATE, L_PLE_PROJ, L_PLE_MODEL_PROJ = range(10)
 G4_SLIDING, G4_K_EQ_V, G4_KV_SHARED, G4_DOUBLE_WIDE_MLP = 1, 2, 4, 8
 
 IQ_TYPE_SIZE = {17: 74, 22: 82, 18: 98, 21: 110, 23: 136}
@@ -58,6 +58,9 @@ class Gemma4Spec:
     max_seq_len: int = 1024
     final_logit_softcap: float = 30.0
     embed_ggml_type: int = 0                 # 0 bf16, 11 Q3_K (the 12B file), 14 Q6_K
+    hidden_size_per_layer_input: int = 0     # P of the per-layer inputs (E2B / E4B variants), 0 = none
+    vocab_size_per_layer_input: int = 0
+    ple_embed_ggml_type: int = 0             # embed_tokens_per_layer: 0 bf16, else a K-quant type id
 
     @staticmethod
     def gemma4_12b(**kw):
@@ -114,6 +117,9 @@ class Gemma4Spec:
             del sh[L_V]
         if self.kv_shared(i):
             del sh[L_K]
+        if self.hidden_size_per_layer_input > 0:
+            sh[L_PLE_GATE] = (H, self.hidden_size_per_layer_input)
+            sh[L_PLE_PROJ] = (self.hidden_size_per_layer_input, H)
         return sh
 
 
@@ -141,7 +147,8 @@ class QuantizedGemma4ForCausalLM:
         cfg = Gemma4Config(s.hidden_size, s.num_layers, s.num_heads, s.intermediate_size, s.vocab_size, s.rms_norm_eps,
                            s.head_dim_sliding, s.head_dim_full, s.kv_heads_sliding, s.kv_heads_full, s.sliding_window,
                            s.head_dim_sliding, s.rot_dim_full(), s.max_position, s.kv_cache_dtype, s.block_size, s.num_blocks,
-                           s.max_batch, s.max_seq_len, s.final_logit_softcap, s.embed_ggml_type)
+                           s.max_batch, s.max_seq_len, s.final_logit_softcap, s.embed_ggml_type, s.hidden_size_per_layer_input,
+                           s.vocab_size_per_layer_input, s.ple_embed_ggml_type)
         flags = (C.c_int * s.num_layers)(*s.layer_flags())
         self._h = C.c_void_p()
         check(lib.vmx_gemma4_create(C.byref(cfg), flags, C.byref(self._h)))
@@ -188,20 +195,37 @@ class QuantizedGemma4ForCausalLM:
             if keep_host_copy:
                 ck[name] = t.cpu() if isinstance(t, torch.Tensor) else t
 
+        def random_kquant_table(ggml_type, rows, cols):
+            ts, qk = GGML_TYPE_SIZE[ggml_type]
+            nb = rows * (cols // qk)
+            tab = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=self.device, generator=g)
+            # valid small f16 super-scale(s): positions of the f16 fields per type (d; Q4_K also dmin)
+            dpos = {2: [0], 8: [0], 11: [108], 12: [0, 2], 14: [208]}[ggml_type]
+            mag = {2: 0.01, 8: 0.0006, 11: 0.0008, 12: 0.0001, 14: 0.00004}[ggml_type]
+            for pos in dpos:
+                d = ((torch.rand(nb, device=self.device, generator=g) * 0.5 + 0.75) * mag).to(torch.float16).view(torch.int16)
+                tab[:, pos] = (d & 0xFF).to(torch.uint8)
+                tab[:, pos + 1] = ((d >> 8) & 0xFF).to(torch.uint8)
+            return tab.reshape(-1)
+
+        def random_iq_linear(li, slot, K, N, gain=1.0):
+            t = slot_types.get(slot, 18)
+            ts = IQ_TYPE_SIZE[t]
+            nb = N * (K // 256)
+            raw = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=self.device, generator=g)
+            d = (torch.rand(nb, device=self.device, generator=g) * 0.5 + 0.75) * (gain / (120.0 * math.sqrt(K)))
+            if t == 23:
+                d = d * 6.0
+            dbits = d.to(torch.float16).view(torch.int16)
+            raw[:, 0] = (dbits & 0xFF).to(torch.uint8)
+            raw[:, 1] = ((dbits >> 8) & 0xFF).to(torch.uint8)
+            self.load_iq_linear(li, slot, t, raw.reshape(-1))
+            keep(f"{li}.{slot}.iq", (t, raw.reshape(-1).cpu()) if keep_host_copy else None)
+
         if s.embed_ggml_type == 0:
             emb = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.05).to(torch.bfloat16)
         else:
-            ts, qk = GGML_TYPE_SIZE[s.embed_ggml_type]
-            nb = s.vocab_size * (s.hidden_size // qk)
-            emb = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=self.device, generator=g)
-            # valid small f16 super-scale(s): positions of the f16 fields per type (d; Q4_K also dmin)
-            dpos = {2: [0], 8: [0], 11: [108], 12: [0, 2], 14: [208]}[s.embed_ggml_type]
-            mag = {2: 0.01, 8: 0.0006, 11: 0.0008, 12: 0.0001, 14: 0.00004}[s.embed_ggml_type]
-            for pos in dpos:
-                d = ((torch.rand(nb, device=self.device, generator=g) * 0.5 + 0.75) * mag).to(torch.float16).view(torch.int16)
-                emb[:, pos] = (d & 0xFF).to(torch.uint8)
-                emb[:, pos + 1] = ((d >> 8) & 0xFF).to(torch.uint8)
-            emb = emb.reshape(-1)
+            emb = random_kquant_table(s.embed_ggml_type, s.vocab_size, s.hidden_size)
         self.load_tensor(T_EMBED, 0, emb); keep("embed", emb)
         del emb
         fn = (1.0 + 0.1 * torch.randn(s.hidden_size, device=self.device, generator=g)).to(torch.bfloat16)
@@ -215,19 +239,21 @@ class QuantizedGemma4ForCausalLM:
                 self.load_tensor(which, li, w); keep(f"{li}.{name}", w)
             sc = (0.75 + 0.5 * torch.rand(1, device=self.device, generator=g)).to(torch.bfloat16)
             self.load_tensor(T_LAYER_SCALAR, li, sc); keep(f"{li}.scalar", sc)
+            if s.hidden_size_per_layer_input > 0:
+                w = (1.0 + 0.1 * torch.randn(s.hidden_size, device=self.device, generator=g)).to(torch.bfloat16)
+                self.load_tensor(T_POST_PLE_NORM, li, w); keep(f"{li}.post_ple_norm", w)
             for slot, (K, N) in s.linear_shapes(li).items():
-                t = slot_types[slot]
-                ts = IQ_TYPE_SIZE[t]
-                nb = N * (K // 256)
-                raw = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=self.device, generator=g)
-                d = (torch.rand(nb, device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (120.0 * math.sqrt(K)))
-                if t == 23:
-                    d = d * 6.0
-                dbits = d.to(torch.float16).view(torch.int16)
-                raw[:, 0] = (dbits & 0xFF).to(torch.uint8)
-                raw[:, 1] = ((dbits >> 8) & 0xFF).to(torch.uint8)
-                self.load_iq_linear(li, slot, t, raw.reshape(-1))
-                keep(f"{li}.{slot}.iq", (t, raw.reshape(-1).cpu()) if keep_host_copy else None)
+                random_iq_linear(li, slot, K, N)
+        if s.hidden_size_per_layer_input > 0:
+            P, LP = s.hidden_size_per_layer_input, s.hidden_size_per_layer_input * s.num_layers
+            random_iq_linear(0, L_PLE_MODEL_PROJ, s.hidden_size, LP, gain=math.sqrt(s.hidden_size))
+            w = (1.0 + 0.1 * torch.randn(P, device=self.device, generator=g)).to(torch.bfloat16)
+            self.load_tensor(T_PLE_PROJ_NORM, 0, w); keep("ple_proj_norm", w)
+            if s.ple_embed_ggml_type == 0:
+                pe = (torch.randn((s.vocab_size_per_layer_input, LP), device=self.device, generator=g) * (1.0 / math.sqrt(P))).to(torch.bfloat16)
+            else:
+                pe = random_kquant_table(s.ple_embed_ggml_type, s.vocab_size_per_layer_input, LP)
+            self.load_tensor(T_PLE_EMBED, 0, pe); keep("ple_embed", pe)
         return ck
 
     GGUF_SLOT_NAMES = {L_Q: "self_attn.q_proj", L_K: "self_attn.k_proj", L_V: "self_attn.v_proj", L_O: "self_attn.o_proj",
@@ -243,6 +269,8 @@ class QuantizedGemma4ForCausalLM:
         HF -> llama.cpp map in priority order (gguf/mod.rs:1416-1479).  Returns the number of tensors loaded."""
         from ._lib import GgufTensor
         s = self.spec
+        if s.hidden_size_per_layer_input > 0:
+            raise NotImplementedError("per-layer-input tensors have no GGUF name map here: load them with load_iq_linear / load_tensor")
         h = C.c_void_p()
         check(lib.vmx_gguf_open(str(path).encode(), C.byref(h)))
         try:
