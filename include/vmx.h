@@ -242,6 +242,17 @@ int vmx_softmax_to_probs(float *probs, const void *logits, int logits_dtype, int
 int vmx_top_k_top_p_sample(int32_t *out_ids, const float *probs, const float *rand_vals, const int32_t *top_k_per_seq,
                            const float *top_p_per_seq, int top_k, float top_p, int rows, int vocab, void *stream);
 
+/* KVScales (kv_cache/quantization.rs:80-277) as device-resident state of vmx_kv_scales_state_bytes() = 32 bytes whose first two
+ * f32 are k_scale and v_scale, so `state` and `(float *)state + 1` are the k_scale / v_scale arguments of every entry point here.
+ * vmx_kv_scales_init = KVScales::new (1, 1, calibrated = 0), from_values / set (calibrated = 1) and reset.
+ * vmx_kv_scales_calibrate_if_needed = KVScales::calibrate_if_needed (:200-213) on the bf16 K / V about to be written: a no-op once
+ * calibrated, else scale = max(absmax * headroom / 448, 1e-12) (compute_scale_with_headroom :272-277; the reference's default
+ * headroom is 1.5, :108) and calibrated = 1.  Runs on the stream, no host round trip; headroom must be positive and finite. */
+size_t vmx_kv_scales_state_bytes(void);
+int vmx_kv_scales_init(void *state, float k_scale, float v_scale, int calibrated, void *stream);
+int vmx_kv_scales_calibrate_if_needed(void *state, const uint16_t *k, int64_t nk, const uint16_t *v, int64_t nv, float headroom,
+                                      void *stream);
+
 /* Replaces reshape_and_cache_bf16 and the FP8 quantise branch of CacheEngine::write_batch
  * (crates/core/kernels/cache_ops.cu:28-62; kv_cache/cache_engine.rs:196-247):
  * caches [blocks, block_size, kv_heads, head_dim]; kv_dtype VMX_KV_AUTO (bf16 copy) or
@@ -587,6 +598,13 @@ int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream);
 /* Parity aid: 0 = residual stream h, 1 = final normed x (bf16 [batch, hidden]). */
 int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, void *stream);
 /* Parity aid: as vmx_qwen3_debug_kv, for a layer's cache in its own geometry (sliding or full). */
+/* KVScales::reset on every layer's FP8 cache (kv_cache/quantization.rs:231-239): scales back to 1, not calibrated; the next K/V
+ * write of each layer (a decode step, or a prompt chunk of at most 16 tokens) pins them from the bf16 K / V it writes with
+ * `headroom` (the reference's default is 1.5), as KVScales::calibrate_if_needed does.  After vmx_gemma4_create the scales are 1
+ * and count as calibrated; VMX_G4T_KV_SCALES loads explicit (calibrated) scales. */
+int vmx_gemma4_kv_scales_reset(vmx_gemma4 *m, float headroom, void *stream);
+/* the scales layer `layer` attends with (its target's for a KV-shared layer) and whether they are pinned; waits for the stream */
+int vmx_gemma4_kv_scales_get(vmx_gemma4 *m, int layer, float *k_scale, float *v_scale, int *calibrated, void *stream);
 int vmx_gemma4_debug_kv(vmx_gemma4 *m, int layer, int which, int write, void *buf, size_t bytes, void *stream);
 
 

@@ -287,6 +287,36 @@ def fp8_e4m3_encode_trunc(v: float) -> int:
     return int(_lib.orc_fp8_e4m3_encode_trunc(v))
 
 
+class KVScales:
+    """KVScales of the reference (crates/core/src/kv_cache/quantization.rs:80-240): identity scales until the first write pins
+    scale = max(absmax * headroom / 448, 1e-12) per tensor (compute_scale_with_headroom :272-277; candle's `x / 448.0` on an f32
+    tensor is the affine multiply by f32(1 / 448)); pinned scales never change until reset()."""
+
+    def __init__(self, k_scale: float = 1.0, v_scale: float = 1.0, calibrated: bool = False, headroom: float = 1.5):
+        self.k_scale, self.v_scale, self.calibrated, self.headroom = np.float32(k_scale), np.float32(v_scale), calibrated, headroom
+
+    def set_headroom_factor(self, factor: float) -> None:
+        if not np.isfinite(factor) or factor <= 0.0:
+            raise ValueError(f"KV scale headroom factor must be a positive finite value, got {factor}")
+        self.headroom = factor
+
+    @staticmethod
+    def _scale(x_bf16, headroom: float) -> np.float32:
+        amax = np.float32(np.abs(bf16_to_f32(_c(x_bf16, np.uint16))).max()) if np.size(x_bf16) else np.float32(0.0)
+        return np.maximum(np.float32(amax * np.float32(headroom)) * np.float32(1.0 / 448.0), np.float32(1e-12))
+
+    def calibrate_if_needed(self, k_bf16, v_bf16) -> None:
+        if self.calibrated:
+            return
+        self.k_scale, self.v_scale, self.calibrated = self._scale(k_bf16, self.headroom), self._scale(v_bf16, self.headroom), True
+
+    def set(self, k_scale: float, v_scale: float) -> None:
+        self.k_scale, self.v_scale, self.calibrated = np.float32(k_scale), np.float32(v_scale), True
+
+    def reset(self) -> None:
+        self.k_scale, self.v_scale, self.calibrated = np.float32(1.0), np.float32(1.0), False
+
+
 def reshape_and_cache(key_bf16, value_bf16, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int,
                       kv_dtype: int = 0, k_scale: float = 1.0, v_scale: float = 1.0) -> None:
     key = _c(key_bf16, np.uint16)

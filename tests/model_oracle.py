@@ -161,6 +161,8 @@ class OracleGemma4:
             hd, kvh, _, _, _ = s.layer_geom(li)
             self.k_cache.append(np.zeros((s.num_blocks, s.block_size, kvh, hd), kv_np))
             self.v_cache.append(np.zeros((s.num_blocks, s.block_size, kvh, hd), kv_np))
+        # per-layer KVScales: identity and pinned unless reset_kv_scales() arms the first-write calibration
+        self.kvs = [orc.KVScales(calibrated=True) for _ in range(s.num_layers)]
         if s.embed_ggml_type == 0:
             self.embed_f32 = orc.bf16_to_f32(self.ck["embed"])
         else:   # dequantised table (QuantizedEmbedding / QMatMul over the same blocks)
@@ -173,6 +175,11 @@ class OracleGemma4:
         n_in = x.shape[1]
         n_out = raw.size // (n_in // 256 * orc.IQ_TYPE_SIZE[t])
         return orc.f32_to_bf16(orc.iq_matmul(t, raw, x, n_out, n_in))
+
+    def reset_kv_scales(self, headroom=1.5):
+        for kv in self.kvs:
+            kv.reset()
+            kv.set_headroom_factor(headroom)
 
     def per_layer_inputs(self, ids, h0):
         """compute_per_layer_inputs (gemma4_quantized.rs:2143-2192): bf16 [B, layers, P], or None without per-layer inputs."""
@@ -215,13 +222,17 @@ class OracleGemma4:
                 v = orc.rms_norm_bf16(v.reshape(B * kvh, hd), ones, s.rms_norm_eps).reshape(B, -1)
                 k = orc.rms_norm_bf16(k.reshape(B * kvh, hd), self.ck[f"{li}.k_norm"], s.rms_norm_eps).reshape(B, -1)
                 q, k = orc.rope_neox_bf16(positions, q, k, self.cs[0 if sliding else 1], rot, hd, s.num_heads, kvh)
-                orc.reshape_and_cache(k, v, self.k_cache[li], self.v_cache[li], slots, kvh, hd, s.block_size, s.kv_cache_dtype, 1.0, 1.0)
+                if s.kv_cache_dtype == 1:
+                    self.kvs[li].calibrate_if_needed(k, v)      # cache_engine write: first write pins the scales
+                orc.reshape_and_cache(k, v, self.k_cache[li], self.v_cache[li], slots, kvh, hd, s.block_size, s.kv_cache_dtype,
+                                      float(self.kvs[li].k_scale), float(self.kvs[li].v_scale))
             else:
                 q, _ = orc.rope_neox_bf16(positions, q, np.zeros((B, kvh * hd), np.uint16), self.cs[0 if sliding else 1], rot, hd,
                                           s.num_heads, kvh)
             psize = 64 if int(seq_lens.max()) <= 4096 else 256
             attn = orc.paged_attention_v2(q, self.k_cache[cl], self.v_cache[cl], block_tables, seq_lens, 1.0, s.num_heads, kvh, hd,
-                                          s.block_size, psize, window, s.kv_cache_dtype, 1.0, 1.0)
+                                          s.block_size, psize, window, s.kv_cache_dtype, float(self.kvs[cl].k_scale),
+                                          float(self.kvs[cl].v_scale))
             o = self.linear(li, 3, attn)
             h = add_bf16(orc.rms_norm_bf16(o, self.ck[f"{li}.post_attn_ln"], s.rms_norm_eps), h)
             x = orc.rms_norm_bf16(h, self.ck[f"{li}.pre_ffn_ln"], s.rms_norm_eps)

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(spec, steps, B, slot_types=None, seed=3):
+def _run(spec, steps, B, slot_types=None, seed=3, calibrate_headroom=None):
     import torch
     import vllm_rust_amd as vmx
     from oracle import oracle as orc
@@ -16,6 +16,10 @@ def _run(spec, steps, B, slot_types=None, seed=3):
     model = QuantizedGemma4ForCausalLM(spec)
     ck = model.load_synthetic(slot_types=slot_types, seed=seed, keep_host_copy=True)
     ref = OracleGemma4(spec, ck, model.cos_sin_sliding, model.cos_sin_full)
+    if calibrate_headroom is not None:      # FP8 scales pinned by the first write, on both sides
+        model.kv_scales_reset(calibrate_headroom)
+        ref.reset_kv_scales(calibrate_headroom)
+        assert model.kv_scales(0) == (1.0, 1.0, False)
     nblk = spec.num_blocks // B
     bt = np.arange(B * nblk, dtype=np.int32).reshape(B, nblk)
     ids = np.array([7, 123, 55, 900][:B], np.int32)
@@ -38,6 +42,11 @@ def _run(spec, steps, B, slot_types=None, seed=3):
         assert relh <= 2e-2, f"step {p}: residual stream differs from the CPU oracle (rel L2 {relh})"
         assert rel <= 2e-2, f"step {p}: logits differ from the CPU oracle (rel L2 {rel})"
         worst = max(worst, rel)
+        if calibrate_headroom is not None:
+            for li in range(spec.num_layers):      # pinned at step 0 from that step's K / V; never moved afterwards
+                ks, vs, cal = model.kv_scales(li)
+                cl = spec.kv_target(li) if spec.kv_target(li) is not None else li
+                assert cal and abs(ks / float(ref.kvs[cl].k_scale) - 1) < 0.03 and abs(vs / float(ref.kvs[cl].v_scale) - 1) < 0.03, (p, li, ks, vs)
         # greedy id: the oracle's argmax, or a logit within one bf16 step of the oracle's maximum
         o = out.cpu().numpy()
         for b in range(B):
@@ -86,6 +95,31 @@ def test_gemma4_per_layer_inputs(ple_type):
                       vocab_size_per_layer_input=1000, ple_embed_ggml_type=ple_type, max_position=64, kv_cache_dtype=0, num_blocks=8,
                       max_batch=2, max_seq_len=32)
     _run(spec, steps=5, B=2)
+
+
+def test_gemma4_fp8_kv_first_write_calibration():
+    """FP8 KV scales start unpinned; the first decode step's K / V pin them at absmax * 1.5 / 448 per layer and tensor
+    (KVScales::calibrate_if_needed), later steps reuse them; logits and residual stream against the oracle doing the same.
+    An uncalibrated cache refuses a prompt chunk of more than one 16-row pass."""
+    import torch
+    from vllm_rust_amd._lib import VmxError
+    from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
+    spec = Gemma4Spec(256, 4, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=4, full_every=3, num_kv_shared_layers=1, max_position=64, kv_cache_dtype=1, num_blocks=8,
+                      max_batch=2, max_seq_len=32)
+    _run(spec, steps=6, B=2, calibrate_headroom=1.5)
+    model = QuantizedGemma4ForCausalLM(spec)
+    try:
+        model.load_synthetic(seed=1)
+        model.kv_scales_reset()
+        bt = torch.arange(2, dtype=torch.int32, device="cuda")
+        with pytest.raises(VmxError, match="not calibrated"):
+            model.prefill(torch.arange(17, dtype=torch.int32, device="cuda"), 0, bt)
+        model.prefill(torch.arange(16, dtype=torch.int32, device="cuda"), 0, bt)        # one pass: calibrates
+        assert model.kv_scales(0)[2] and model.kv_scales(0)[0] != 1.0
+        model.prefill(torch.arange(1, dtype=torch.int32, device="cuda") + 16, 16, bt)
+    finally:
+        model.close()
 
 
 def test_gemma4_kv_shared_flags_must_be_a_suffix_with_a_target():

@@ -113,6 +113,57 @@ def test_reshape_and_cache(gpu, kv_dtype):
     assert np.array_equal(vc.cpu().numpy().view(dt), vc_ref)
 
 
+def test_kv_scales_first_write_calibration(gpu):
+    """KVScales::calibrate_if_needed on the device: first call pins max(absmax * 1.5 / 448, 1e-12) bit-exactly, later calls and
+    larger inputs do not move it, reset() re-arms it, explicit scales count as calibrated; the FP8 cache written through the
+    calibrated state equals the oracle's bytes.  Edge cases: all-zero tensors (the 1e-12 floor), bad headroom."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    from vllm_rust_amd._lib import VmxError
+    from vllm_rust_amd.ops import KVScales
+    rng = np.random.default_rng(11)
+    KVH, D, BS, NB, T = 4, 64, 16, 4, 37
+    k = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32) * 0.3)
+    v = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32) * 3.0)
+    ref = orc.KVScales()
+    st = KVScales()
+    assert not st.is_calibrated and st.k_scale.item() == 1.0
+    ref.calibrate_if_needed(k, v)
+    st.calibrate_if_needed(_bf(torch, k), _bf(torch, v))
+    got = st.state[:2].cpu().numpy()
+    assert st.is_calibrated
+    assert got[0].view(np.uint32) == ref.k_scale.view(np.uint32) and got[1].view(np.uint32) == ref.v_scale.view(np.uint32), (got, ref.k_scale)
+    # the cache bytes written with the device-resident scales
+    slots = rng.permutation(NB * BS)[:T].astype(np.int32)
+    kc_ref = np.zeros((NB, BS, KVH, D), np.uint8); vc_ref = np.zeros_like(kc_ref)
+    orc.reshape_and_cache(k, v, kc_ref, vc_ref, slots, KVH, D, BS, 1, float(ref.k_scale), float(ref.v_scale))
+    kc = torch.zeros((NB, BS, KVH, D), dtype=torch.uint8, device="cuda"); vc = torch.zeros_like(kc)
+    vmx.reshape_and_cache(_bf(torch, k), _bf(torch, v), kc, vc, torch.from_numpy(slots).cuda(), KVH, D, BS, 1, st.k_scale, st.v_scale)
+    assert np.array_equal(kc.cpu().numpy(), kc_ref) and np.array_equal(vc.cpu().numpy(), vc_ref)
+    # pinned: a louder second batch does not move the scales
+    k2 = orc.f32_to_bf16(orc.bf16_to_f32(k) * 8)
+    st.calibrate_if_needed(_bf(torch, k2), _bf(torch, v))
+    assert np.array_equal(st.state[:2].cpu().numpy(), got)
+    # reset re-arms; headroom 1.0; zero tensors hit the floor
+    st.reset(); ref.reset()
+    st.headroom = 1.0; ref.set_headroom_factor(1.0)
+    z = np.zeros((3, 8), np.uint16)
+    ref.calibrate_if_needed(k2, z)
+    st.calibrate_if_needed(_bf(torch, k2), _bf(torch, z))
+    got = st.state[:2].cpu().numpy()
+    assert got[0].view(np.uint32) == ref.k_scale.view(np.uint32) and got[1] == np.float32(1e-12) == ref.v_scale
+    # explicit scales are calibrated scales
+    st.set(0.25, 0.5)
+    st.calibrate_if_needed(_bf(torch, k), _bf(torch, v))
+    assert st.state[:2].cpu().numpy().tolist() == [0.25, 0.5]
+    st.reset()
+    st.headroom = float("nan")
+    with pytest.raises(VmxError, match="headroom"):
+        st.calibrate_if_needed(_bf(torch, k), _bf(torch, v))
+    with pytest.raises(ValueError):
+        ref.set_headroom_factor(0.0)
+
+
 # (40, 8) = 5, (28, 4) = 7, (24, 8) = 3, (12, 1) = 12 query heads per KV head: ratios between the compiled capacities
 @pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (16, 1, 512), (4, 4, 64), (40, 8, 128), (28, 4, 128), (24, 8, 64),
                                      (12, 1, 256)])

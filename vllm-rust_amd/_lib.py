@@ -78,6 +78,9 @@ _SIGS = {
     "vmx_silu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "vmx_argmax_workspace_bytes": (_sz, [_i, _i]),
     "vmx_argmax_bf16": (_i, [_p, _p, _i, _i, _p, _sz, _p]),
+    "vmx_kv_scales_state_bytes": (_sz, []),
+    "vmx_kv_scales_init": (_i, [_p, _f, _f, _i, _p]),
+    "vmx_kv_scales_calibrate_if_needed": (_i, [_p, _p, _i64, _p, _i64, _f, _p]),
     "vmx_reshape_and_cache": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vmx_paged_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vmx_paged_attention_bf16": (_i, [_p] * 6 + [_f] + [_i] * 9 + [_p, _p, _p, _sz, _p]),
@@ -152,6 +155,8 @@ _SIGS = {
     "vmx_gemma4_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "vmx_gemma4_mmvq_only": (_i, [_p, _i, _p]),
     "vmx_gemma4_debug_read": (_i, [_p, _i, _p, _sz, _p]),
+    "vmx_gemma4_kv_scales_reset": (_i, [_p, _f, _p]),
+    "vmx_gemma4_kv_scales_get": (_i, [_p, _i, _p, _p, _p, _p]),
     "vmx_gemma4_debug_kv": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
 }
 

@@ -146,14 +146,15 @@ __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, 
 // grid (Hq + 2*Hkv, tokens), block 64.  proj: f32 [tokens][ntot] = q | k | (v) projections.  Per head: bf16 round,
 // per-head RMSNorm (q, k weighted; v unweighted), NeoX RoPE on the first rot_dim dims of q and k, bf16 rounds after
 // each; q -> q_out, k and v -> the layer's paged cache (bf16 or FP8 e4m3).  v_from_k: V is the K projection
-// (before K's norm and rotation) put through the unweighted norm.
+// (before K's norm and rotation) put through the unweighted norm.  stage != nullptr: K and V go to that bf16 buffer instead of the cache.
 __global__ __launch_bounds__(64) void g4_qkv_post_kernel(const float *__restrict__ proj, int ntot, uint16_t *__restrict__ q_out,
                                                           void *__restrict__ k_cache, void *__restrict__ v_cache,
                                                           const uint16_t *__restrict__ q_norm_w, const uint16_t *__restrict__ k_norm_w,
                                                           float eps, const float *__restrict__ cos_sin,
                                                           const int32_t *__restrict__ positions, const int32_t *__restrict__ slots, int Hq,
                                                           int Hkv, int hd, int rot_dim, int v_from_k, int fp8,
-                                                          const float *__restrict__ k_scale, const float *__restrict__ v_scale) {
+                                                          const float *__restrict__ k_scale, const float *__restrict__ v_scale,
+                                                          uint16_t *__restrict__ stage) {
     __shared__ float vals[512];
     const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
     const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
@@ -185,9 +186,14 @@ __global__ __launch_bounds__(64) void g4_qkv_post_kernel(const float *__restrict
         for (int i = lane; i < hd; i += 64) q_out[((int64_t)t * Hq + head) * hd + i] = vmx_f32_to_bf16(vals[i]);
         return;
     }
+    const int kvh = is_k ? head - Hq : head - Hq - Hkv;
+    if (stage) {   // first write of an uncalibrated FP8 cache: bf16 K | V rows [tokens][Hkv * hd] each, scaled and scattered afterwards
+        uint16_t *dst_row = stage + ((int64_t)(is_k ? 0 : gridDim.y) + t) * Hkv * hd + (int64_t)kvh * hd;
+        for (int i = lane; i < hd; i += 64) dst_row[i] = vmx_f32_to_bf16(vals[i]);
+        return;
+    }
     const int slot = slots[t];
     if (slot < 0) return;
-    const int kvh = is_k ? head - Hq : head - Hq - Hkv;
     const int64_t dst = ((int64_t)slot * Hkv + kvh) * hd;
     void *cache = is_k ? k_cache : v_cache;
     if (!fp8) {
@@ -327,6 +333,7 @@ struct G4Layer {
     // cache of layer kv_target, the last earlier non-shared layer of the same attention type (:441-469)
     bool kv_shared = false;
     int kv_target = -1;
+    bool kv_calibrated = true;   // false: the next K/V write first pins the FP8 scales from what it writes (KVScales::calibrate_if_needed)
     int hd = 0, kvh = 0, rot = 0, window = 0;
     int inter = 0;   // MLP width: twice the base on a double-wide layer (:514-525)
     IqLin lin[9];   // VMX_L_Q .. VMX_L_DOWN, VMX_L_PLE_GATE, VMX_L_PLE_PROJ
@@ -352,6 +359,8 @@ struct vmx_gemma4 {
     float embed_scale = 1.f;
     // per-layer inputs (hidden_size_per_layer_input > 0): embed_tokens_per_layer, per_layer_model_projection and its norm, and the
     // step's buffers [rows][layers * P]: gathered embedding rows, projection output, combined inputs
+    float kv_headroom = 1.5f;   // DEFAULT_KV_HEADROOM_FACTOR (kv_cache/quantization.rs:108)
+    Buf kv_stage;               // bf16 K | V rows of one pass, used by an FP8 cache's first (calibrating) write
     IqLin ple_model_proj;
     Buf ple_embed, ple_proj_norm, ple_e, ple_p, pli;
     float ple_embed_scale = 1.f, ple_proj_scale = 1.f, ple_input_scale = 1.f;
@@ -454,7 +463,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     TRY(m->final_norm.alloc((size_t)H * 2));
     TRY(m->cos_sin_s.alloc((size_t)c.max_position * c.rot_dim_sliding * 4));
     TRY(m->cos_sin_f.alloc((size_t)c.max_position * c.rot_dim_full * 4));
-    int max_nq = 0, max_proj = 2 * I, max_hd = 0, max_inter = I;
+    int max_nq = 0, max_proj = 2 * I, max_hd = 0, max_inter = I, max_nkv = 0;
     int first_shared = c.num_layers;
     for (int li = c.num_layers - 1; li >= 0 && (layer_flags[li] & VMX_G4_KV_SHARED); li--) first_shared = li;
     for (int li = 0; li < c.num_layers; li++) {
@@ -499,6 +508,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
             TRY(L.post_ple_norm.alloc((size_t)H * 2));
         }
         max_nq = NQ > max_nq ? NQ : max_nq;
+        max_nkv = NKV > max_nkv ? NKV : max_nkv;
         max_proj = NQ + 2 * NKV > max_proj ? NQ + 2 * NKV : max_proj;
         max_proj = 2 * L.inter > max_proj ? 2 * L.inter : max_proj;
         max_hd = L.hd > max_hd ? L.hd : max_hd;
@@ -514,11 +524,10 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
             TRY(L.k_cache.alloc(kvb));
             TRY(L.v_cache.alloc(kvb));
         }
-        TRY(L.kv_scales.alloc(8));
+        TRY(L.kv_scales.alloc(vmx_kv_scales_state_bytes()));
         if (!rc) {
-            const float ones[2] = {1.0f, 1.0f};
             const uint16_t one_bf16 = 0x3F80;
-            if (hipMemcpy(L.kv_scales.p, ones, 8, hipMemcpyHostToDevice) != hipSuccess ||
+            if (vmx_kv_scales_init(L.kv_scales.p, 1.0f, 1.0f, 1, nullptr) != VMX_OK ||
                 hipMemcpy(L.scalar.p, &one_bf16, 2, hipMemcpyHostToDevice) != hipSuccess)
                 rc = VMX_ELAUNCH;
         }
@@ -543,6 +552,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         max_proj = P > max_proj ? P : max_proj;
     }
     TRY(m->positions.alloc((size_t)R * 4));
+    TRY(m->kv_stage.alloc((size_t)R * 2 * max_nkv * 2));
     TRY(m->h.alloc((size_t)R * H * 2));
     TRY(m->x.alloc((size_t)R * H * 2));
     TRY(m->q.alloc((size_t)R * max_nq * 2));
@@ -582,7 +592,7 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     }
     m->ple_model_proj.raw.release();
     m->ple_model_proj.packed.release();
-    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli}) b->release();
+    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage}) b->release();
     for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
                    &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8})
         b->release();
@@ -612,6 +622,13 @@ extern "C" int vmx_gemma4_load_tensor(vmx_gemma4 *m, int which, int layer, const
         dst = tab[which - VMX_G4T_INPUT_LN];
     }
     VMX_REQUIRE(dst, "gemma4_load_tensor: unknown tensor id %d", which);
+    if (which == VMX_G4T_KV_SCALES) {   // explicit scales are calibrated scales (KVScales::set, kv_cache/quantization.rs:218-224)
+        VMX_REQUIRE(bytes == 8, "gemma4_load_tensor: KV scales are two f32, got %zu bytes", bytes);
+        float ks[2];
+        VMX_CHECK_HIP(hipMemcpy(ks, src, 8, hipMemcpyDefault));
+        m->layers[layer].kv_calibrated = true;
+        return vmx_kv_scales_init(dst->p, ks[0], ks[1], 1, stream);
+    }
     VMX_REQUIRE(bytes == dst->bytes, "gemma4_load_tensor: tensor %d expects %zu bytes, got %zu", which, dst->bytes, bytes);
     VMX_CHECK_HIP(hipMemcpyAsync(dst->p, src, bytes, hipMemcpyDefault, vmx_stream(stream)));
     return VMX_OK;
@@ -711,7 +728,10 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         }
         const float *ks = (const float *)KV.kv_scales.p;
         // short contexts: per-head norms + RoPE + KV write + attention + merge in one launch (not for K == V or KV-shared layers)
-        const bool fused_attn = prefill_offset < 0 && !L.k_eq_v && !L.kv_shared &&
+        // an FP8 cache whose scales are not pinned yet: this write goes through a bf16 staging buffer, calibrates, then scatters
+        const bool first_write = fp8 && !L.kv_shared && !L.kv_calibrated;
+        uint16_t *stage = (uint16_t *)m->kv_stage.p;
+        const bool fused_attn = prefill_offset < 0 && !L.k_eq_v && !L.kv_shared && !first_write &&
                                 vmx_fused_decode_attention_ok(hd, Hq / Hkv, L.rot, max_seq_len, L.window);
         if (fused_attn) {
             if (int rc = vmx_fused_decode_attention(attn, proj, 1, L.k_cache.p, L.v_cache.p, (const uint16_t *)L.q_norm.p,
@@ -725,7 +745,14 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
             hipLaunchKernelGGL(g4_qkv_post_kernel, dim3(L.kv_shared ? Hq : Hq + 2 * Hkv, B), dim3(64), 0, st, proj, ntot, q, KV.k_cache.p,
                                KV.v_cache.p, (const uint16_t *)L.q_norm.p, (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
                                (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping, Hq, Hkv, hd, L.rot,
-                               L.k_eq_v ? 1 : 0, fp8, ks, ks + 1);
+                               L.k_eq_v ? 1 : 0, fp8, ks, ks + 1, first_write ? stage : nullptr);
+            if (first_write) {
+                const int64_t n = (int64_t)B * NKV;
+                if (int rc = vmx_kv_scales_calibrate_if_needed(L.kv_scales.p, stage, n, stage + n, n, m->kv_headroom, st)) return rc;
+                if (int rc = vmx_reshape_and_cache(stage, stage + n, L.k_cache.p, L.v_cache.p, slot_mapping, B, Hkv, hd, c.block_size,
+                                                   c.kv_cache_dtype, ks, ks + 1, st))
+                    return rc;
+            }
             if (prefill_offset >= 0) {   // the rows' K/V are in the cache: causal (windowed) attention over it, then q8_1 for o_proj
                 if (int rc = vmx_prefill_attention_bf16(attn, q, KV.k_cache.p, KV.v_cache.p, block_tables, B, prefill_offset, 1.0f, Hq, Hkv,
                                                         hd, c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, st))
@@ -767,6 +794,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
     }
     launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr);
     VMX_CHECK_LAUNCH("gemma4 layers");
+    for (G4Layer &L : m->layers) L.kv_calibrated = true;   // every cache has had its first write
     return VMX_OK;
 }
 
@@ -841,6 +869,13 @@ extern "C" int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int s
                 c.max_position, c.max_seq_len);
     for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_prefill: weights not fully loaded");
     VMX_REQUIRE(m->cfg.hidden_size_per_layer_input == 0 || m->ple_model_proj.loaded, "gemma4_prefill: per_layer_model_projection not loaded");
+    // The prompt path walks 16 rows at a time through all layers, so a calibrating first write sees 16 rows; the reference's
+    // first write sees the whole chunk.  Identical scales need the chunk to fit one pass.
+    if (c.kv_cache_dtype == VMX_KV_FP8_E4M3 && q_len > 16)
+        for (const G4Layer &L : m->layers)
+            VMX_REQUIRE(L.kv_shared || L.kv_calibrated,
+                        "gemma4_prefill: FP8 KV scales are not calibrated yet; first-write calibration takes a chunk of at most 16 tokens "
+                        "(got %d): prefill the first 16 tokens separately or load explicit scales", q_len);
     hipStream_t st = vmx_stream(stream);
     int32_t *pos = (int32_t *)m->positions.p;
     int last_rows = 0;
@@ -851,6 +886,31 @@ extern "C" int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int s
         last_rows = rows;
     }
     return g4_run_head(m, (const uint16_t *)m->x.p + (size_t)(last_rows - 1) * c.hidden_size, 1, out_id_last, logits_last, stream);
+}
+
+// KVScales::reset for every layer (kv_cache/quantization.rs:231-239) with the headroom of the next first-write calibration
+extern "C" int vmx_gemma4_kv_scales_reset(vmx_gemma4 *m, float headroom, void *stream) {
+    VMX_REQUIRE(m, "gemma4_kv_scales_reset: null pointer");
+    VMX_REQUIRE(isfinite(headroom) && headroom > 0.f, "KV scale headroom factor must be a positive finite value, got %g", (double)headroom);
+    m->kv_headroom = headroom;
+    for (G4Layer &L : m->layers) {
+        if (int rc = vmx_kv_scales_init(L.kv_scales.p, 1.0f, 1.0f, 0, stream)) return rc;
+        L.kv_calibrated = false;
+    }
+    return VMX_OK;
+}
+
+extern "C" int vmx_gemma4_kv_scales_get(vmx_gemma4 *m, int layer, float *k_scale, float *v_scale, int *calibrated, void *stream) {
+    VMX_REQUIRE(m && k_scale && v_scale && calibrated, "gemma4_kv_scales_get: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "gemma4_kv_scales_get: layer %d out of range", layer);
+    const G4Layer &L = m->layers[layer].kv_shared ? m->layers[m->layers[layer].kv_target] : m->layers[layer];
+    uint32_t w[3];
+    VMX_CHECK_HIP(hipMemcpyAsync(w, L.kv_scales.p, 12, hipMemcpyDeviceToHost, vmx_stream(stream)));
+    VMX_CHECK_HIP(hipStreamSynchronize(vmx_stream(stream)));
+    memcpy(k_scale, &w[0], 4);
+    memcpy(v_scale, &w[1], 4);
+    *calibrated = (int)w[2];
+    return VMX_OK;
 }
 
 extern "C" int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_bytes) {

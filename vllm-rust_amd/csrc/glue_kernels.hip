@@ -4,6 +4,7 @@
 // activations.cu:33-35,148-164, sampling.cu:47-94, cache_ops.cu:28-62} and the FP8 branch of
 // crates/core/src/kv_cache/cache_engine.rs:196-247.  All are HBM/launch-bound: 16-byte
 // vector accesses, one pass over the data, wave64 butterflies for the reductions.
+#include <cmath>
 #include "vmx_kernels.h"
 #include <float.h>
 
@@ -279,6 +280,77 @@ extern "C" int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value,
     hipLaunchKernelGGL(reshape_and_cache_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), key, value, k_cache, v_cache,
                        slot_mapping, kv_heads * head_dim, kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0, k_scale, v_scale);
     VMX_CHECK_LAUNCH("reshape_and_cache");
+    return VMX_OK;
+}
+
+// ---- KVScales: first-write calibration of the FP8 KV cache's per-tensor scales (kv_cache/quantization.rs:80-277) ----
+// Device-resident state, 32 bytes: f32 k_scale, f32 v_scale, u32 calibrated, u32 amax bits of K and V (scratch, zero between
+// calls), 3 words of padding.  The first two words are what every kernel here takes as k_scale / v_scale pointers.
+namespace {
+struct KvScalesState {
+    float k_scale, v_scale;
+    uint32_t calibrated, amax_k, amax_v, pad[3];
+};
+
+__global__ __launch_bounds__(256) void kv_scales_amax_kernel(KvScalesState *__restrict__ st, const uint16_t *__restrict__ k, int64_t nk,
+                                                              const uint16_t *__restrict__ v, int64_t nv) {
+    __shared__ float red[4];
+    if (st->calibrated) return;   // pinned scales never move again (calibrate_if_needed, :200-203)
+    const bool is_v = blockIdx.y == 1;
+    const uint16_t *x = is_v ? v : k;
+    const int64_t n = is_v ? nv : nk;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = fmaxf(m, fabsf(vmx_bf16_to_f32(x[i])));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(is_v ? &st->amax_v : &st->amax_k, __float_as_uint(m));   // non-negative floats order as their bit patterns
+    }
+}
+
+// scale = max(amax * headroom / 448, 1e-12) in f32, the division as the multiply by f32(1/448) the reference's affine op does
+// (compute_scale_with_headroom, :272-277)
+__global__ void kv_scales_finish_kernel(KvScalesState *st, float headroom) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!st->calibrated) {
+        const float inv_max = (float)(1.0 / 448.0);
+        st->k_scale = fmaxf((__uint_as_float(st->amax_k) * headroom) * inv_max, 1e-12f);
+        st->v_scale = fmaxf((__uint_as_float(st->amax_v) * headroom) * inv_max, 1e-12f);
+        st->calibrated = 1u;
+    }
+    st->amax_k = 0u;
+    st->amax_v = 0u;
+}
+}  // namespace
+
+extern "C" size_t vmx_kv_scales_state_bytes(void) { return sizeof(KvScalesState); }
+
+extern "C" int vmx_kv_scales_init(void *state, float k_scale, float v_scale, int calibrated, void *stream) {
+    VMX_REQUIRE(state, "kv_scales_init: null pointer");
+    VMX_REQUIRE(std::isfinite(k_scale) && std::isfinite(v_scale) && k_scale > 0.f && v_scale > 0.f,
+                "kv_scales_init: scales must be positive and finite (got %g, %g)", (double)k_scale, (double)v_scale);
+    KvScalesState h = {k_scale, v_scale, calibrated ? 1u : 0u, 0u, 0u, {0u, 0u, 0u}};
+    // the source is this stack frame: wait for the copy before returning
+    VMX_CHECK_HIP(hipMemcpyAsync(state, &h, sizeof(h), hipMemcpyHostToDevice, vmx_stream(stream)));
+    VMX_CHECK_HIP(hipStreamSynchronize(vmx_stream(stream)));
+    return VMX_OK;
+}
+
+extern "C" int vmx_kv_scales_calibrate_if_needed(void *state, const uint16_t *k, int64_t nk, const uint16_t *v, int64_t nv, float headroom,
+                                                 void *stream) {
+    VMX_REQUIRE(state && k && v, "kv_scales_calibrate_if_needed: null pointer");
+    VMX_REQUIRE(nk >= 0 && nv >= 0, "kv_scales_calibrate_if_needed: negative element count");
+    VMX_REQUIRE(std::isfinite(headroom) && headroom > 0.f,
+                "KV scale headroom factor must be a positive finite value, got %g", (double)headroom);   // set_headroom_factor, :143-151
+    const int64_t n = nk > nv ? nk : nv;
+    int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(kv_scales_amax_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, vmx_stream(stream), (KvScalesState *)state, k, nk, v, nv);
+    hipLaunchKernelGGL(kv_scales_finish_kernel, dim3(1), dim3(64), 0, vmx_stream(stream), (KvScalesState *)state, headroom);
+    VMX_CHECK_LAUNCH("kv_scales_calibrate_if_needed");
     return VMX_OK;
 }
 

@@ -379,6 +379,16 @@ class QuantizedGemma4ForCausalLM:
         check(lib.vmx_gemma4_mmvq_info(self._h, batch, C.byref(n), C.byref(by)))
         return n.value, by.value
 
+    def kv_scales_reset(self, headroom: float = 1.5) -> None:
+        """KVScales::reset on every layer: the next K/V write of each layer pins its FP8 scales from what it writes."""
+        check(lib.vmx_gemma4_kv_scales_reset(self._h, headroom, self._stream()))
+
+    def kv_scales(self, layer: int):
+        """(k_scale, v_scale, calibrated) that layer `layer` attends with."""
+        k, v, cal = C.c_float(), C.c_float(), C.c_int()
+        check(lib.vmx_gemma4_kv_scales_get(self._h, layer, C.byref(k), C.byref(v), C.byref(cal), self._stream()))
+        return k.value, v.value, bool(cal.value)
+
     def debug_kv(self, layer: int, which: int, t: torch.Tensor, write: bool) -> None:
         """Parity aid: copy a layer's whole K (which = 0) / V (1) cache into `t` or from it (contiguous CUDA tensor of the cache's size)."""
         check(lib.vmx_gemma4_debug_kv(self._h, layer, which, int(write), t.data_ptr(), t.numel() * t.element_size(), self._stream()))

@@ -13,7 +13,7 @@ from ._lib import check, lib
 __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_subdots_packed",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
-    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
+    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant",
     "topk_softmax", "moe_align_block_size", "moe_int4_forward",
 ]
@@ -163,6 +163,39 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     out = torch.empty(rows, dtype=torch.int32, device=logits.device)
     check(lib.vmx_argmax_bf16(_ptr(out), _ptr(logits), rows, vocab, _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+class KVScales:
+    """Device-resident per-tensor FP8 KV scales with the reference's first-write calibration (KVScales,
+    crates/core/src/kv_cache/quantization.rs:80-240).  `k_scale` / `v_scale` are one-element f32 views into the state that the
+    cache-write and attention entry points take as their scale pointers."""
+    DEFAULT_HEADROOM = 1.5          # DEFAULT_KV_HEADROOM_FACTOR, :108
+
+    def __init__(self, device="cuda", k_scale: float = 1.0, v_scale: float = 1.0, calibrated: bool = False):
+        self.state = torch.zeros(lib.vmx_kv_scales_state_bytes() // 4, dtype=torch.float32, device=device)
+        self.headroom = self.DEFAULT_HEADROOM
+        self.set(k_scale, v_scale, calibrated)
+
+    def set(self, k_scale: float, v_scale: float, calibrated: bool = True) -> None:
+        check(lib.vmx_kv_scales_init(_ptr(self.state), k_scale, v_scale, int(calibrated), _stream()))
+
+    def reset(self) -> None:
+        self.set(1.0, 1.0, False)
+
+    def calibrate_if_needed(self, k: torch.Tensor, v: torch.Tensor) -> None:
+        check(lib.vmx_kv_scales_calibrate_if_needed(_ptr(self.state), _ptr(k), k.numel(), _ptr(v), v.numel(), self.headroom, _stream()))
+
+    @property
+    def k_scale(self) -> torch.Tensor:
+        return self.state[0:1]
+
+    @property
+    def v_scale(self) -> torch.Tensor:
+        return self.state[1:2]
+
+    @property
+    def is_calibrated(self) -> bool:
+        return bool(self.state[2:3].view(torch.int32).item())
 
 
 def reshape_and_cache(key, value, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int,
