@@ -179,7 +179,8 @@ int vmx_exl3_gemm_f16(uint16_t *y, const uint16_t *x, const void *trellis, const
 
 /* Replaces fp8_gemm_bf16_{naive,tiled,with_bias} (crates/core/kernels/fp8_gemm.cu:38-218; launcher
  * fp8_cuda.rs:519-727) for small M: y[m,n] = bf16(sum_k x[m,k] * (e4m3(W[n,k]) * scale) + bias[n]);
- * W u8 [N, K] OCP e4m3fn, scale f32 [1] or [N] (per_channel_scale), 1 <= M <= 16, K % 16 == 0. */
+ * W u8 [N, K] OCP e4m3fn, scale f32 [1] or [N] (per_channel_scale), M >= 1, K % 16 == 0.  Up to 16 rows stream the weights once
+ * through a dot-product kernel; more rows run on the bf16 matrix cores over weights converted fp8 -> bf16 in registers. */
 int vmx_fp8_gemm_bf16(uint16_t *y, const uint16_t *x, const void *weight, const float *scale, const uint16_t *bias,
                       int M, int N, int K, int per_channel_scale, void *stream);
 
@@ -194,6 +195,29 @@ int vmx_fp8_dequant_bf16(uint16_t *out, const void *in, const float *scale, int6
  * scales_out; otherwise scale_in[token] (per_token_scale) or scale_in[0]. */
 int vmx_fp8_quant_bf16(void *out, float *scales_out, const uint16_t *in, const float *scale_in, int tokens, int hidden,
                        int dynamic_per_token, int per_token_scale, void *stream);
+
+/* Replaces fp8_scaled_mm_bf16 / fp8_scaled_mm_f32 (crates/core/kernels/fp8_gemm.cu:332-466), the W8A8 GEMM:
+ * out[m,n] = sum_k (e4m3(A[m,k]) * a_scale) * (e4m3(B[n,k]) * b_scale) + bias[n]; A u8 [M, K], B u8 [N, K];
+ * a_scale_mode 0: a_scale[0], 1: a_scale[m]; b_scale_mode 0: b_scale[0], 1: b_scale[n]; bias bf16 [N] or null (bf16 output only);
+ * out bf16 [M, N], or f32 when out_f32.  Runs on v_mfma_f32_16x16x32_fp8_fp8 with the scales applied to the f32 sum. K % 16 == 0. */
+int vmx_fp8_scaled_mm(void *out, int out_f32, const void *a, const void *b, const float *a_scale, const float *b_scale,
+                      const uint16_t *bias, int M, int N, int K, int a_scale_mode, int b_scale_mode, void *stream);
+
+/* Block-scaled FP8 weights (Fp8Linear::dequantize_block_weights and the block-quantized branch of forward,
+ * crates/core/src/quantization/fp8.rs:305-342, :417-425), with the semantics that function documents:
+ * W_bf16[n,k] = bf16(e4m3(W[n,k]) * scale[n / block_n][k / block_k]), scale f32 [ceil(N/block_n), ceil(K/block_k)];
+ * y = bf16(bf16(x @ W_bf16^T) + bias).  vmx_fp8_block_gemm_bf16 dequantises into `workspace` (bf16 [N, K]) and runs the bf16
+ * matrix-core GEMM; K % 16 == 0. */
+int vmx_fp8_dequant_block_bf16(uint16_t *out, const void *in, const float *scale, int64_t rows, int64_t cols, int block_n, int block_k,
+                               void *stream);
+int vmx_fp8_block_gemm_bf16(uint16_t *y, const uint16_t *x, const void *weight, const float *block_scale, const uint16_t *bias, int M,
+                            int N, int K, int block_n, int block_k, uint16_t *workspace, void *stream);
+
+/* Replaces fused_rmsnorm_fp8 (crates/core/kernels/layernorm_quant.cu:33-134): per row, normed = x * rsqrt(mean(x^2) + eps) * w in
+ * f32, scales[row] = max(absmax(normed) / 448, 1e-12), out = e4m3(normed / scale) saturating: the activation operand and a_scale
+ * (mode 1) of vmx_fp8_scaled_mm. */
+int vmx_fused_rmsnorm_fp8(void *out, float *scales, const uint16_t *input, const uint16_t *weight, int rows, int hidden, float eps,
+                          void *stream);
 
 /* ----------------------------------------------------------- glue operators */
 

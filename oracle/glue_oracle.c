@@ -350,6 +350,61 @@ void orc_fp8_dequant_bf16(const uint8_t *in, const float *scale, int64_t rows, i
             out[r * cols + c] = orc_f32_to_bf16(orc_fp8_e4m3_decode(in[r * cols + c]) * (per_row ? scale[r] : scale[0]));
 }
 
+/* fp8_scaled_mm_{bf16,f32} (crates/core/kernels/fp8_gemm.cu:332-466): both operands e4m3, each element multiplied by its scale
+ * before the product, f32 accumulate in k order, + bias, -> bf16 (or f32).  a_mode / b_mode: 0 one scale, 1 per row / column. */
+void orc_fp8_scaled_mm(const uint8_t *A, const uint8_t *B, const float *a_scale, const float *b_scale, const uint16_t *bias, int64_t M,
+                       int64_t N, int64_t K, int a_mode, int b_mode, int out_f32, void *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; n++) {
+        const float sb = b_mode ? b_scale[n] : b_scale[0];
+        for (int64_t m = 0; m < M; m++) {
+            const float sa = a_mode ? a_scale[m] : a_scale[0];
+            float acc = 0.0f;
+            for (int64_t k = 0; k < K; k++) acc += (orc_fp8_e4m3_decode(A[m * K + k]) * sa) * (orc_fp8_e4m3_decode(B[n * K + k]) * sb);
+            if (bias) acc += orc_bf16_to_f32(bias[n]);
+            if (out_f32) ((float *)out)[m * N + n] = acc;
+            else ((uint16_t *)out)[m * N + n] = orc_f32_to_bf16(acc);
+        }
+    }
+}
+
+/* Block-scaled weights as the reference documents them (crates/core/src/quantization/fp8.rs:305-342):
+ * W_bf16[i][j] = bf16(e4m3(w[i][j]) * scale[i / block_n][j / block_k]). */
+void orc_fp8_dequant_block_bf16(const uint8_t *in, const float *scale, int64_t rows, int64_t cols, int64_t block_n, int64_t block_k,
+                                uint16_t *out) {
+    const int64_t sc = (cols + block_k - 1) / block_k;
+    for (int64_t r = 0; r < rows; r++)
+        for (int64_t c = 0; c < cols; c++)
+            out[r * cols + c] = orc_f32_to_bf16(orc_fp8_e4m3_decode(in[r * cols + c]) * scale[(r / block_n) * sc + c / block_k]);
+}
+
+/* fused_rmsnorm_fp8 (crates/core/kernels/layernorm_quant.cu:33-134): normed = x * rsqrt(mean(x^2) + eps) * w in f32 (never rounded
+ * to bf16), per-row scale = max(absmax(normed) / 448, 1e-12), out = e4m3_satfinite_rne(normed * (1 / scale)). */
+void orc_fused_rmsnorm_fp8(const uint16_t *in, const uint16_t *w, int64_t rows, int64_t hidden, float eps, uint8_t *out, float *scales) {
+    for (int64_t r = 0; r < rows; r++) {
+        /* the kernel sums 256 strided per-thread partials and then a tree, all in f32; a double sum rounded once sits within that
+         * order's noise (a sequential f32 sum does not: its error grows with the row length) */
+        double ssd = 0.0;
+        for (int64_t i = 0; i < hidden; i++) {
+            const float v = orc_bf16_to_f32(in[r * hidden + i]);
+            ssd += (double)(v * v);
+        }
+        const float ss = (float)ssd;
+        const float rms = 1.0f / sqrtf(ss / (float)hidden + eps);
+        float mx = 0.0f;
+        for (int64_t i = 0; i < hidden; i++) {
+            const float v = fabsf(orc_bf16_to_f32(in[r * hidden + i]) * rms * orc_bf16_to_f32(w[i]));
+            if (v > mx) mx = v;
+        }
+        float sc = mx / 448.0f;
+        if (sc < 1e-12f) sc = 1e-12f;
+        scales[r] = sc;
+        const float inv = 1.0f / sc;
+        for (int64_t i = 0; i < hidden; i++)
+            out[r * hidden + i] = orc_fp8_e4m3_encode_rne(orc_bf16_to_f32(in[r * hidden + i]) * rms * orc_bf16_to_f32(w[i]) * inv);
+    }
+}
+
 /* Dense bf16 linear without bias, one row at a time: y[m,n] = bf16(sum_k x[m,k] * W[n,k]), f32 sequential accumulate
  * over k.  This is the arithmetic of the reference's unquantized Linear on the decode path (candle matmul of bf16
  * operands with f32 accumulation, result cast to bf16): the lm_head of the quantized models

@@ -86,6 +86,9 @@ for _name, _res, _args in [
     ("orc_exl3_gemm", C.c_int, [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4),
     ("orc_fp8_gemm_bf16", None, [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_void_p]),
     ("orc_fp8_quant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("orc_fp8_scaled_mm", None, [C.c_void_p] * 5 + [C.c_int64] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    ("orc_fp8_dequant_block_bf16", None, [C.c_void_p, C.c_void_p] + [C.c_int64] * 4 + [C.c_void_p]),
+    ("orc_fused_rmsnorm_fp8", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     ("orc_fp8_dequant_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     ("orc_dense_gemv_bf16", None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
 ]:
@@ -385,6 +388,32 @@ def fp8_quant_bf16(x_bf16, scale=None, dynamic: bool = True, per_token: bool = F
     scales = np.zeros(T, np.float32)
     sc = _c(scale, np.float32) if scale is not None else None
     _lib.orc_fp8_quant_bf16(_p(x), _p(sc) if sc is not None else None, T, H, int(dynamic), int(per_token), _p(out), _p(scales))
+    return out, scales
+
+
+def fp8_scaled_mm(a_u8, b_u8, a_scale, b_scale, bias_bf16=None, a_per_row: bool = False, b_per_col: bool = False,
+                  out_f32: bool = False) -> np.ndarray:
+    A, B = _c(a_u8, np.uint8), _c(b_u8, np.uint8)
+    sa, sb = _c(a_scale, np.float32).reshape(-1), _c(b_scale, np.float32).reshape(-1)
+    b = _c(bias_bf16, np.uint16) if bias_bf16 is not None else None
+    (M, K), N = A.shape, B.shape[0]
+    out = np.zeros((M, N), np.float32 if out_f32 else np.uint16)
+    _lib.orc_fp8_scaled_mm(_p(A), _p(B), _p(sa), _p(sb), _p(b) if b is not None else None, M, N, K, int(a_per_row), int(b_per_col),
+                           int(out_f32), _p(out))
+    return out
+
+
+def fp8_dequant_block_bf16(q_u8, block_scale, block_n: int, block_k: int) -> np.ndarray:
+    q, sc = _c(q_u8, np.uint8), _c(block_scale, np.float32)
+    out = np.zeros(q.shape, np.uint16)
+    _lib.orc_fp8_dequant_block_bf16(_p(q), _p(sc), q.shape[0], q.shape[1], block_n, block_k, _p(out))
+    return out
+
+
+def fused_rmsnorm_fp8(x_bf16, w_bf16, eps: float):
+    x, w = _c(x_bf16, np.uint16), _c(w_bf16, np.uint16)
+    out, scales = np.zeros(x.shape, np.uint8), np.zeros(x.shape[0], np.float32)
+    _lib.orc_fused_rmsnorm_fp8(_p(x), _p(w), x.shape[0], x.shape[1], eps, _p(out), _p(scales))
     return out, scales
 
 

@@ -130,3 +130,37 @@ def test_legacy_ggml_blocks_against_numpy_formulas():
             exp = np.concatenate([lo.astype(np.float32) * d[:, None] + m[:, None], hi.astype(np.float32) * d[:, None] + m[:, None]], axis=1)
         got = orc.ggml_dequant(t, b.reshape(-1)).reshape(nb, 32)
         assert np.array_equal(got, exp.astype(np.float32)), t
+
+
+def test_fp8_w8a8_block_and_fused_norm_restatements_against_numpy():
+    """The FP8 restatements checked against independent float64 numpy forms on small cases: scaled_mm (all scale modes, bias),
+    block-scaled dequant (ragged blocks), fused rmsnorm + dynamic quant (scale and decoded values), KVScales first-write rule."""
+    rng = np.random.default_rng(0)
+    dec = np.array([orc.fp8_e4m3_decode(i) for i in range(256)], np.float64)
+    M, N, K = 3, 5, 48
+    A = rng.integers(0, 0x60, (M, K)).astype(np.uint8); B = rng.integers(0, 0x60, (N, K)).astype(np.uint8)
+    sa = rng.random(M).astype(np.float32) + 0.5; sb = rng.random(N).astype(np.float32) + 0.5
+    bias = orc.f32_to_bf16(rng.standard_normal(N).astype(np.float32))
+    exact = (dec[A] * sa[:, None]) @ (dec[B] * sb[:, None]).T + orc.bf16_to_f32(bias)[None, :]
+    got = orc.fp8_scaled_mm(A, B, sa, sb, bias, True, True, True)
+    assert np.allclose(got, exact, rtol=1e-5)
+    got1 = orc.fp8_scaled_mm(A, B, sa[:1], sb[:1], None, False, False, False)
+    exact1 = (dec[A] * sa[0]) @ (dec[B] * sb[0]).T
+    assert np.allclose(orc.bf16_to_f32(got1), exact1, rtol=2 ** -7)
+    W = rng.integers(0, 0x78, (5, 12)).astype(np.uint8)
+    sc = (rng.random((3, 2)).astype(np.float32) + 0.5)
+    exp = dec[W] * np.repeat(np.repeat(sc, 2, axis=0), 8, axis=1)[:5, :12]
+    assert np.array_equal(orc.fp8_dequant_block_bf16(W, sc, 2, 8), orc.f32_to_bf16(exp.astype(np.float32)))
+    x = orc.f32_to_bf16(rng.standard_normal((2, 64)).astype(np.float32)); w = orc.f32_to_bf16(np.ones(64, np.float32) * 1.5)
+    q, s = orc.fused_rmsnorm_fp8(x, w, 1e-6)
+    xf = orc.bf16_to_f32(x).astype(np.float64)
+    normed = xf / np.sqrt((xf ** 2).mean(axis=1, keepdims=True) + 1e-6) * 1.5
+    assert np.allclose(s, np.abs(normed).max(axis=1) / 448.0, rtol=1e-6)
+    assert np.abs(dec[q] * s[:, None] - normed).max() <= np.abs(normed).max() * 2 ** -4     # e4m3: 3 mantissa bits
+    assert (np.abs(dec[q]).max(axis=1) == 448.0).all()                                       # the row maximum lands on +-448
+    kv = orc.KVScales()
+    k = orc.f32_to_bf16(np.array([0.5, -2.0, 1.0], np.float32)); v = orc.f32_to_bf16(np.zeros(3, np.float32))
+    kv.calibrate_if_needed(k, v)
+    assert kv.calibrated and kv.k_scale == np.float32(np.float32(2.0 * 1.5) * np.float32(1 / 448)) and kv.v_scale == np.float32(1e-12)
+    kv.calibrate_if_needed(orc.f32_to_bf16(np.array([100.0], np.float32)), v)
+    assert kv.k_scale == np.float32(np.float32(3.0) * np.float32(1 / 448))

@@ -63,6 +63,10 @@ _SIGS = {
     "vmx_fp8_gemm_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vmx_fp8_dequant_bf16": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),
     "vmx_fp8_quant_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vmx_fp8_scaled_mm": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vmx_fp8_dequant_block_bf16": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _p]),
+    "vmx_fp8_block_gemm_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "vmx_fused_rmsnorm_fp8": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "vmx_topk_softmax": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vmx_moe_align_block_size": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vmx_moe_int4_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -14,7 +14,7 @@ __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_subdots_packed",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
-    "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant",
+    "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
     "topk_softmax", "moe_align_block_size", "moe_int4_forward",
 ]
 
@@ -255,6 +255,44 @@ def fp8_gemm(x: torch.Tensor, W_u8: torch.Tensor, scale: torch.Tensor, bias=None
     y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     check(lib.vmx_fp8_gemm_bf16(_ptr(y), _ptr(x), _ptr(W_u8), _ptr(scale), _ptr(bias), M, N, K, int(scale.numel() > 1), _stream()))
     return y
+
+
+def fp8_scaled_mm(a_u8: torch.Tensor, b_u8: torch.Tensor, a_scale: torch.Tensor, b_scale: torch.Tensor, bias=None,
+                  out_dtype=torch.bfloat16) -> torch.Tensor:
+    """W8A8: a e4m3 bytes [M, K], b e4m3 bytes [N, K]; a_scale f32 [1] or [M], b_scale f32 [1] or [N]; -> bf16 or f32 [M, N]."""
+    M, K = a_u8.shape
+    N = b_u8.shape[0]
+    out = torch.empty((M, N), dtype=out_dtype, device=a_u8.device)
+    check(lib.vmx_fp8_scaled_mm(_ptr(out), int(out_dtype == torch.float32), _ptr(a_u8), _ptr(b_u8), _ptr(a_scale), _ptr(b_scale), _ptr(bias),
+                                M, N, K, int(a_scale.numel() > 1), int(b_scale.numel() > 1), _stream()))
+    return out
+
+
+def fp8_dequant_block(q_u8: torch.Tensor, block_scale: torch.Tensor, block_n: int, block_k: int) -> torch.Tensor:
+    rows, cols = q_u8.shape
+    out = torch.empty((rows, cols), dtype=torch.bfloat16, device=q_u8.device)
+    check(lib.vmx_fp8_dequant_block_bf16(_ptr(out), _ptr(q_u8), _ptr(block_scale), rows, cols, block_n, block_k, _stream()))
+    return out
+
+
+def fp8_block_gemm(x: torch.Tensor, W_u8: torch.Tensor, block_scale: torch.Tensor, block_n: int, block_k: int, bias=None) -> torch.Tensor:
+    """Block-scaled FP8 linear: x bf16 [M, K], W e4m3 bytes [N, K], block_scale f32 [ceil(N/block_n), ceil(K/block_k)]."""
+    M, K = x.shape
+    N = W_u8.shape[0]
+    ws = torch.empty((N, K), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(lib.vmx_fp8_block_gemm_bf16(_ptr(y), _ptr(x), _ptr(W_u8), _ptr(block_scale), _ptr(bias), M, N, K, block_n, block_k, _ptr(ws),
+                                      _stream()))
+    return y
+
+
+def fused_rmsnorm_fp8(x: torch.Tensor, weight: torch.Tensor, eps: float):
+    """(e4m3 bytes [rows, hidden], f32 scales [rows]) of rms_norm(x) * weight with a dynamic per-row scale."""
+    rows, hidden = x.shape
+    out = torch.empty((rows, hidden), dtype=torch.uint8, device=x.device)
+    scales = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.vmx_fused_rmsnorm_fp8(_ptr(out), _ptr(scales), _ptr(x), _ptr(weight), rows, hidden, eps, _stream()))
+    return out, scales
 
 
 def fp8_dequant(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
