@@ -1,0 +1,114 @@
+"""Two tensor-parallel ranks of the whole-token executor as two processes on the one GPU of the test box, joined by the peer-mapped
+one-shot all-reduce (no RCCL): each rank loads its shard of ONE seeded checkpoint, rank 0 also runs the unsharded model in the same
+process, and every decode step's greedy ids and logits are compared.  Dense Qwen3: column / row-parallel linears, vocab-parallel
+argmax.  Mixtral: tensor-parallel attention + expert-parallel MLP (each rank holds half of the experts; one all-reduce combines
+them, which for two experts per token is the same single bf16 addition as on one GPU)."""
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _spec(moe):
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    kw = dict(hidden_size=256, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64, intermediate_size=512, vocab_size=1024,
+              group_size=128, max_position=64, num_blocks=8, block_size=16, max_batch=2, max_seq_len=64)
+    if moe:
+        kw.update(num_experts=4, experts_per_tok=2, qk_norm=False)
+    return Qwen3Spec(**kw)
+
+
+def _worker(rank, world, moe, conns, result_q):
+    try:
+        import torch
+        import vllm_rust_amd as vmx
+        from vllm_rust_amd.parallel import LocalCommunicator, shard_spec
+        from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
+        vmx.init(0)
+
+        def exchange(mine):
+            for c in conns[rank]:
+                c.send((rank, mine))
+            got = {rank: mine}
+            for c in conns[rank]:
+                r, b = c.recv()
+                got[r] = b
+            return [got[r] for r in range(world)]
+
+        full = _spec(moe)
+        comm = LocalCommunicator(rank, world, exchange, max_bytes=64 * 1024)
+        shard = QuantizedQwen3ForCausalLM(shard_spec(full, rank, world))
+        shard.load_synthetic_tp(full, seed=7)
+        shard.set_comm(comm)
+        ref = None
+        if rank == 0:
+            ref = QuantizedQwen3ForCausalLM(full)
+            (ref.load_synthetic_moe if moe else ref.load_synthetic)(seed=7)
+        B, V, VL = 2, full.vocab_size, full.vocab_size // world
+        nblk = full.num_blocks // B
+        bt = torch.arange(B * nblk, dtype=torch.int32, device="cuda").reshape(B, nblk)
+        ids = torch.tensor([5, 900], dtype=torch.int32, device="cuda")
+        ref_ids = ids.clone()
+        report = []
+        for p in range(6):
+            pos = torch.full((B,), p, dtype=torch.int32, device="cuda")
+            slots = (bt[:, p // full.block_size] * full.block_size + p % full.block_size).to(torch.int32)
+            sl = pos + 1
+            lg = torch.empty((B, VL), dtype=torch.bfloat16, device="cuda")
+            out = shard.forward_decode_batch(ids, pos, slots, bt, sl, logits=lg)
+            torch.cuda.synchronize()
+            if ref is not None:
+                lr = torch.empty((B, V), dtype=torch.bfloat16, device="cuda")
+                out_ref = ref.forward_decode_batch(ref_ids, pos, slots, bt, sl, logits=lr)
+                torch.cuda.synchronize()
+                a, b = lg.float().cpu().numpy(), lr[:, :VL].float().cpu().numpy()
+                rel = float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+                full_row = lr.float().cpu().numpy()
+                picked = out.cpu().numpy()
+                near_max = all(full_row[i, picked[i]] >= full_row[i].max() - abs(full_row[i].max()) * 2 ** -5 for i in range(B))
+                report.append((p, rel, near_max, picked.tolist(), out_ref.cpu().numpy().tolist()))
+                ref_ids = out.clone()       # both models walk the sharded run's tokens, so every step is comparable
+            ids = out.clone()
+        result_q.put((rank, report, ids.cpu().numpy().tolist(), comm.p2p_timeouts()))
+        shard.close()
+        if ref is not None:
+            ref.close()
+        comm.close()
+    except Exception as e:   # report instead of hanging the parent
+        import traceback
+        result_q.put((rank, [("exception", repr(e), traceback.format_exc())], None, -1))
+
+
+@pytest.mark.parametrize("moe", [False, True])
+def test_two_rank_executor_matches_single_gpu(moe):
+    world = 2
+    ctx = mp.get_context("spawn")
+    a, b = ctx.Pipe()
+    conns = {0: [a], 1: [b]}
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, moe, conns, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            r, report, last_ids, timeouts = q.get(timeout=150)
+            results[r] = (report, last_ids, timeouts)
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    assert set(results) == {0, 1}
+    for r, (report, _, timeouts) in results.items():
+        assert not (report and report[0][0] == "exception"), report[0][1:]
+        assert timeouts == 0, f"rank {r}: {timeouts} flag waits timed out"
+    assert results[0][1] == results[1][1]                     # the vocab-parallel argmax gives both ranks the same tokens
+    report = results[0][0]
+    assert len(report) == 6
+    for p, rel, near_max, picked, ref_picked in report:
+        # the row-parallel o / down outputs are rounded to bf16 per rank before the sum: a bf16-ulp-level difference per layer
+        assert rel <= 2e-2, (p, rel)
+        assert near_max, (p, picked, ref_picked)

@@ -123,3 +123,22 @@ def test_one_seeded_checkpoint_shards_reassemble():
         rows = [shard_awq_row(qw, qz, sc, r, world, group) for r in range(world)]
         assert torch.equal(torch.cat([c[0] for c in rows], 0), qw) and torch.equal(torch.cat([c[1] for c in rows], 0), qz)
         assert torch.equal(torch.cat([c[2] for c in rows], 0), sc)
+
+
+def test_expert_parallel_spec_and_ownership():
+    """Mixture-of-experts under tensor parallelism: attention dims divide, experts stay whole and full width, each rank owns a
+    contiguous block of them (ExpertPlacement::Linear), together every expert exactly once."""
+    sys.path.insert(0, str(ROOT))
+    from vllm_rust_amd.parallel import local_experts, shard_spec
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    full = Qwen3Spec.mixtral_8x7b()
+    for world in (2, 4, 8):
+        owned = []
+        for rank in range(world):
+            s = shard_spec(full, rank, world)
+            assert (s.num_heads, s.num_kv_heads, s.intermediate_size, s.num_experts) == (32 // world, 8 // world, 14336, 8)
+            owned += list(local_experts(full.num_experts, rank, world))
+        assert owned == list(range(8))
+    assert list(local_experts(8, 1, 2)) == [4, 5, 6, 7]          # expert_map.rs: rank 1 of 2 holds [4, 8)
+    with pytest.raises(ValueError):
+        shard_spec(full, 0, 3)

@@ -78,7 +78,9 @@ struct P2PArgs {
     int64_t slot_elems;
 };
 
-__global__ __launch_bounds__(256) void p2p_all_reduce_bf16_kernel(P2PArgs a, uint16_t *__restrict__ buf, int count) {
+// OP 0: bf16 sum of `count` elements (count % 8 == 0); OP 1: u64 max of `count` elements (the vocab-parallel argmax keys)
+template <int OP>
+__global__ __launch_bounds__(256) void p2p_all_reduce_kernel(P2PArgs a, void *__restrict__ buf_v, int count) {
     __shared__ uint32_t epoch_s;
     const int tid = threadIdx.x, wg = blockIdx.x;
     if (tid == 0) {   // this workgroup's call number: the same on every rank, because every rank makes the same calls
@@ -89,11 +91,21 @@ __global__ __launch_bounds__(256) void p2p_all_reduce_bf16_kernel(P2PArgs a, uin
     __syncthreads();
     const uint32_t epoch = epoch_s;
     const int par = (int)(epoch & 1u);
-    const int64_t idx = ((int64_t)wg * 256 + tid) * 8;
-    const bool live = idx < count;   // count % 8 == 0
+    // 16-byte chunk of this thread: 8 bf16 or 2 u64; idx = its offset in 2-byte units (the staging buffer's element type)
+    const int64_t chunk = (int64_t)wg * 256 + tid;
+    const int64_t idx = chunk * 8;
+    const int64_t nchunks = OP == 0 ? count / 8 : (count + 1) / 2;
+    const bool live = chunk < nchunks;
+    const bool odd_tail = OP == 1 && live && 2 * chunk + 1 >= count;   // odd u64 count: the last chunk holds one element
+    uint16_t *buf = static_cast<uint16_t *>(buf_v);
     uint4 mine = make_uint4(0, 0, 0, 0);
     if (live) {
-        mine = *reinterpret_cast<const uint4 *>(buf + idx);
+        if (odd_tail) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(buf + idx);
+            mine = make_uint4(lo.x, lo.y, 0, 0);
+        } else {
+            mine = *reinterpret_cast<const uint4 *>(buf + idx);
+        }
         *reinterpret_cast<uint4 *>(a.stage[a.rank] + par * a.slot_elems + idx) = mine;
     }
     __threadfence_system();   // the slice is in memory before any flag says so
@@ -115,7 +127,8 @@ __global__ __launch_bounds__(256) void p2p_all_reduce_bf16_kernel(P2PArgs a, uin
     }
     __syncthreads();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (system scope by default in HIP device code) peers' slices are read afresh
-    if (live) {
+    if (!live) return;
+    if (OP == 0) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < a.world; r++) {   // rank order: identical bits on every rank
             const uint4 v = r == a.rank ? mine : *reinterpret_cast<const uint4 *>(a.stage[r] + par * a.slot_elems + idx);
@@ -130,6 +143,17 @@ __global__ __launch_bounds__(256) void p2p_all_reduce_bf16_kernel(P2PArgs a, uin
 #pragma unroll
         for (int j = 0; j < 4; j++) o[j] = (uint32_t)vmx_f32_to_bf16(acc[2 * j]) | ((uint32_t)vmx_f32_to_bf16(acc[2 * j + 1]) << 16);
         *reinterpret_cast<uint4 *>(buf + idx) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        unsigned long long m0 = ((unsigned long long)mine.y << 32) | mine.x, m1 = ((unsigned long long)mine.w << 32) | mine.z;
+        for (int r = 0; r < a.world; r++) {
+            if (r == a.rank) continue;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.stage[r] + par * a.slot_elems + idx);
+            const unsigned long long v0 = ((unsigned long long)v.y << 32) | v.x, v1 = ((unsigned long long)v.w << 32) | v.z;
+            m0 = v0 > m0 ? v0 : m0;
+            m1 = v1 > m1 ? v1 : m1;
+        }
+        if (odd_tail) *reinterpret_cast<uint2 *>(buf + idx) = make_uint2((uint32_t)m0, (uint32_t)(m0 >> 32));
+        else *reinterpret_cast<uint4 *>(buf + idx) = make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32));
     }
 }
 
@@ -285,7 +309,7 @@ extern "C" int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t c
     static const bool p2p_off = getenv("VMX_NO_P2P_ALLREDUCE") && atoi(getenv("VMX_NO_P2P_ALLREDUCE"));
     if (c->p2p.ready && (!p2p_off || !c->comm) && count > 0 && count % 8 == 0 && count * 2 <= c->p2p.max_bytes && ((uintptr_t)buf & 15) == 0) {
         const int grid = (int)((count + P2P_WG_ELEMS - 1) / P2P_WG_ELEMS);
-        hipLaunchKernelGGL(p2p_all_reduce_bf16_kernel, dim3(grid), dim3(256), 0, vmx_stream(stream), c->p2p.args, buf, (int)count);
+        hipLaunchKernelGGL(p2p_all_reduce_kernel<0>, dim3(grid), dim3(256), 0, vmx_stream(stream), c->p2p.args, (void *)buf, (int)count);
         VMX_CHECK_LAUNCH("p2p_all_reduce");
         return VMX_OK;
     }
@@ -295,5 +319,15 @@ extern "C" int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t c
 
 extern "C" int vmx_comm_all_reduce_max_u64(vmx_comm *c, unsigned long long *buf, size_t count, void *stream) {
     VMX_REQUIRE(c && buf, "comm_all_reduce: null pointer");
+    if (c->world == 1 && !c->comm) return VMX_OK;
+    static const bool p2p_off = getenv("VMX_NO_P2P_ALLREDUCE") && atoi(getenv("VMX_NO_P2P_ALLREDUCE"));
+    if (c->p2p.ready && (!p2p_off || !c->comm) && count > 0 && count * 8 <= c->p2p.max_bytes && count <= (size_t)P2P_MAX_WG * 512 &&
+        ((uintptr_t)buf & 7) == 0) {
+        const int grid = (int)(((count + 1) / 2 + 255) / 256);
+        hipLaunchKernelGGL(p2p_all_reduce_kernel<1>, dim3(grid), dim3(256), 0, vmx_stream(stream), c->p2p.args, (void *)buf, (int)count);
+        VMX_CHECK_LAUNCH("p2p_all_reduce(max)");
+        return VMX_OK;
+    }
+    VMX_REQUIRE(c->comm, "comm_all_reduce: %zu keys do not fit the peer-mapped path and this communicator has no RCCL side", count);
     return check_rccl(rccl().AllReduce(buf, buf, count, NCCL_UINT64, NCCL_MAX, c->comm, vmx_stream(stream)), "ncclAllReduce(u64,max)");
 }

@@ -575,7 +575,10 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
                 "qwen3_create: tp_rank %d / tp_size %d invalid (vocab_size must divide by tp_size)", c.tp_rank, c.tp_size);
     VMX_REQUIRE(c.num_experts >= 0 && c.num_experts <= 256 && (c.num_experts == 0 || (c.experts_per_tok >= 1 && c.experts_per_tok <= c.num_experts)),
                 "qwen3_create: num_experts %d / experts_per_tok %d invalid", c.num_experts, c.experts_per_tok);
-    VMX_REQUIRE(c.num_experts == 0 || c.tp_size <= 1, "qwen3_create: mixture-of-experts layers are not tensor-parallel here");
+    // tensor-parallel attention + expert-parallel MLP: rank r owns experts [r * E / tp, (r + 1) * E / tp) (ExpertPlacement::Linear,
+    // crates/core/src/moe/expert_map.rs:100-109); the decode batch is replicated, so the combine is one all-reduce, no all-to-all
+    VMX_REQUIRE(c.num_experts == 0 || c.tp_size <= 1 || c.num_experts % c.tp_size == 0,
+                "qwen3_create: num_experts (%d) must divide by tp_size (%d)", c.num_experts, c.tp_size);
     vmx_qwen3 *m = new (std::nothrow) vmx_qwen3();
     VMX_REQUIRE(m, "qwen3_create: out of host memory");
     m->cfg = c;
@@ -610,6 +613,10 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
             TRY(L.router.alloc((size_t)c.num_experts * H * 2));
             TRY(L.w13_table.alloc((size_t)c.num_experts * sizeof(void *)));
             TRY(L.w2_table.alloc((size_t)c.num_experts * sizeof(void *)));
+            // a null entry = an expert another rank owns: its (token, slot) pairs are skipped here
+            if (!rc && (hipMemset(L.w13_table.p, 0, (size_t)c.num_experts * sizeof(void *)) != hipSuccess ||
+                        hipMemset(L.w2_table.p, 0, (size_t)c.num_experts * sizeof(void *)) != hipSuccess))
+                rc = VMX_ELAUNCH;
             L.w13.resize(c.num_experts);
             L.w2.resize(c.num_experts);
         }
@@ -779,6 +786,11 @@ extern "C" int vmx_qwen3_load_gptq_expert(vmx_qwen3 *m, int layer, int expert, c
     VMX_REQUIRE(c.num_experts > 0, "qwen3_load_gptq_expert: the model has no experts");
     VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size() && expert >= 0 && expert < c.num_experts,
                 "qwen3_load_gptq_expert: layer %d / expert %d out of range", layer, expert);
+    if (c.tp_size > 1) {
+        const int per = c.num_experts / c.tp_size;
+        VMX_REQUIRE(expert / per == c.tp_rank, "qwen3_load_gptq_expert: expert %d belongs to rank %d, this is rank %d of %d", expert,
+                    expert / per, c.tp_rank, c.tp_size);
+    }
     hipStream_t st = vmx_stream(stream);
     Layer &L = m->layers[layer];
     const int H = c.hidden_size, I = c.intermediate_size, g = c.group_size;
@@ -944,7 +956,7 @@ namespace {
 // A mixture-of-experts model runs int4 attention projections plus the expert tables; a dense one needs all seven
 // projections in ONE of the three formats.
 bool layer_ready(const vmx_qwen3 *m, const Layer &L) {
-    if (m->cfg.num_experts > 0) return L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts);
+    if (m->cfg.num_experts > 0) return L.int4_attn_ready() && L.moe_ready(m->cfg.num_experts / (m->cfg.tp_size > 1 ? m->cfg.tp_size : 1));
     return L.int4_ready() || L.iq_ready() || L.exl3_ready() || L.dense_ready();
 }
 
@@ -1118,6 +1130,8 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                                                   c.num_experts, H, I, c.group_size, m->moe_ws.p, m->moe_ws.bytes,
                                                   vmx_int4_glu_fusable(2 * I, H) ? 1 : 0, st))
                 return rc;
+            if (tp)   // every rank holds the weighted sum over its own experts: the sum over ranks is the layer's output
+                if (int rc = vmx_comm_all_reduce_sum_bf16(m->comm, (uint16_t *)m->moe_out.p, (size_t)B * H, st)) return rc;
             pending = (const float *)m->moe_out.p;
             pending_splits = -1;
             continue;

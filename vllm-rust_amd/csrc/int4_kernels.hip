@@ -1034,6 +1034,7 @@ __global__ __launch_bounds__(256) void int4_gemm_grouped_kernel(const void *cons
     int e = expert_ids[p];
     e = e < 0 ? 0 : (e >= num_experts ? num_experts - 1 : e);  // ids come from top-k over num_experts
     const char *packed = static_cast<const char *>(packed_table[e]);
+    if (!packed) return;   // expert held by another rank (expert parallelism): the combine step skips this pair
     const uint4 *W = reinterpret_cast<const uint4 *>(packed);
     const uint32_t *SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
     int4_gemm_body<UPW, TAIL>(W, SZ, x + (int64_t)(p / x_row_div) * K, nullptr, nullptr, partial + (int64_t)p * N, (int64_t)pairs * N, 1,
@@ -1050,6 +1051,7 @@ __global__ __launch_bounds__(256) void int4_gemm_grouped_glu_kernel(const void *
     int e = expert_ids[p];
     e = e < 0 ? 0 : (e >= num_experts ? num_experts - 1 : e);
     const char *packed = static_cast<const char *>(packed_table[e]);
+    if (!packed) return;
     const uint4 *W = reinterpret_cast<const uint4 *>(packed);
     const uint32_t *SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
     int4_gemm_body<UPW, TAIL, true>(W, SZ, x + (int64_t)(p / x_row_div) * K, nullptr, act + (int64_t)p * (N / 2), nullptr, 0, 1, N, K, group,

@@ -113,13 +113,20 @@ __global__ __launch_bounds__(256) void moe_align_kernel(const int32_t *__restric
 
 // out[t, :] = sum over slots j (in slot order) of bf16( bf16(expert_out[t*k+j, :]) * bf16(w[t,j]) ), each partial
 // sum rounded to bf16: the reference's `token_output + expert_out * weight` chain on bf16 tensors.
+// Pairs whose expert has a null table entry (held by another rank) contribute nothing: with expert parallelism every rank
+// sums its own experts' terms and the ranks' sums are all-reduced.
 __global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t *__restrict__ out, const float *__restrict__ partial, int splits,
-                                                           int pairs, const float *__restrict__ w, int k, int hidden) {
+                                                           int pairs, const float *__restrict__ w, int k, int hidden,
+                                                           const void *const *__restrict__ w2_table, const int32_t *__restrict__ ids,
+                                                           int num_experts) {
     const int t = blockIdx.y;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hidden; i += gridDim.x * 256) {
         float acc = 0.f;
         for (int j = 0; j < k; j++) {
             const int p = t * k + j;
+            int e = ids[p];
+            e = e < 0 ? 0 : (e >= num_experts ? num_experts - 1 : e);
+            if (!w2_table[e]) continue;
             float o = 0.f;
             for (int s = 0; s < splits; s++) o += partial[((int64_t)s * pairs + p) * hidden + i];
             acc = rb(acc + rb(rb(o) * rb(w[p])));
@@ -221,7 +228,8 @@ int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk
     }
     // down projection; x row = pair
     if (int rc = vmx_int4_gemm_grouped(w2_packed, topk_ids, num_experts, act, 1, p2, pairs, hidden, inter, group, st)) return rc;
-    hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden + 255) / 256, tokens), dim3(256), 0, st, out, p2, s2, pairs, topk_weights, k, hidden);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden + 255) / 256, tokens), dim3(256), 0, st, out, p2, s2, pairs, topk_weights, k, hidden, w2_packed, topk_ids,
+                       num_experts);
     VMX_CHECK_LAUNCH("moe_combine");
     return VMX_OK;
 }

@@ -88,15 +88,24 @@ def shard_spec(spec, tp_rank: int, tp_size: int):
     """Per-rank model geometry: heads and MLP width divided, hidden and vocabulary global."""
     if tp_size == 1:
         return dataclasses.replace(spec, tp_size=1, tp_rank=0)
-    for name in ("num_heads", "num_kv_heads", "intermediate_size", "vocab_size"):
+    moe = getattr(spec, "num_experts", 0) > 0
+    for name in ("num_heads", "num_kv_heads", "num_experts" if moe else "intermediate_size", "vocab_size"):
         if getattr(spec, name) % tp_size:
             raise ValueError(f"{name}={getattr(spec, name)} is not divisible by tp_size={tp_size}")
-    if (spec.intermediate_size // tp_size) % max(spec.group_size, 128):
+    if not moe and (spec.intermediate_size // tp_size) % max(spec.group_size, 128):
         raise ValueError("row-parallel shard of the down projection must be a multiple of the group size (and of 128)")
     if (spec.num_heads // tp_size * spec.head_dim) % max(spec.group_size, 128):
         raise ValueError("row-parallel shard of the o projection must be a multiple of the group size (and of 128)")
+    # mixture-of-experts: attention is tensor-parallel, the MLP expert-parallel (whole experts of full width per rank)
+    inter = spec.intermediate_size if moe else spec.intermediate_size // tp_size
     return dataclasses.replace(spec, num_heads=spec.num_heads // tp_size, num_kv_heads=spec.num_kv_heads // tp_size,
-                               intermediate_size=spec.intermediate_size // tp_size, tp_size=tp_size, tp_rank=tp_rank)
+                               intermediate_size=inter, tp_size=tp_size, tp_rank=tp_rank)
+
+
+def local_experts(num_experts: int, tp_rank: int, tp_size: int) -> range:
+    """Experts rank `tp_rank` holds: a contiguous block (ExpertPlacement::Linear, crates/core/src/moe/expert_map.rs:100-109)."""
+    per = num_experts // max(tp_size, 1)
+    return range(tp_rank * per, (tp_rank + 1) * per)
 
 
 def shard_awq_column(qweight, qzeros, scales, tp_rank: int, tp_size: int):

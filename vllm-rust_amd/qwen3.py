@@ -225,7 +225,7 @@ class QuantizedQwen3ForCausalLM:
         rank draws the same full tensors from the same generator and keeps its slice -- q/k/v/gate/up by output columns, o/down
         by input rows (whole quantisation groups), lm_head by vocabulary rows; embedding and norms whole -- so a TP run computes
         the same model as the single-GPU run with this seed (load_synthetic(seed)), up to the bf16 all-reduce."""
-        from .parallel import shard_awq_column, shard_awq_row
+        from .parallel import local_experts, shard_awq_column, shard_awq_row
         s, f = self.spec, full_spec
         r, w = s.tp_rank, s.tp_size
         g = torch.Generator(device=self.device).manual_seed(seed)
@@ -245,6 +245,9 @@ class QuantizedQwen3ForCausalLM:
         H, I = f.hidden_size, f.intermediate_size
         nq, nkv = f.num_heads * f.head_dim, f.num_kv_heads * f.head_dim
         full_shapes = {0: (H, nq), 1: (H, nkv), 2: (H, nkv), 3: (nq, H), 4: (H, I), 5: (H, I), 6: (I, H)}
+        if f.num_experts > 0:   # the draw order of load_synthetic_moe: attention projections, router, then every expert
+            full_shapes = {k: v for k, v in full_shapes.items() if k <= 3}
+            mine = local_experts(f.num_experts, r, w)
         for li in range(f.num_layers):
             for slot, (K, N) in full_shapes.items():
                 qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=self.device, generator=g)
@@ -255,6 +258,17 @@ class QuantizedQwen3ForCausalLM:
                 else:
                     qw, qz, sc = shard_awq_column(qw, qz, sc, r, w)
                 self.load_awq_linear(li, slot, qw, qz, sc)
+            if f.num_experts > 0:
+                router = (torch.randn((f.num_experts, H), device=self.device, generator=g) * 0.3).to(torch.bfloat16)
+                self.load_tensor(T_ROUTER, li, router)
+                for e in range(f.num_experts):
+                    def mk(K, N):
+                        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), dtype=torch.int32, device=self.device, generator=g)
+                        sc = ((torch.rand((K // f.group_size, N), device=self.device, generator=g) * 0.5 + 0.75) * (1.0 / (4.6 * math.sqrt(K)))).to(torch.float16)
+                        return qw, sc
+                    w1, w3, w2 = mk(H, I), mk(H, I), mk(I, H)   # drawn on every rank to keep the stream aligned
+                    if e in mine:
+                        self.load_gptq_expert(li, e, w1, w3, w2)
 
     def load_synthetic_bf16(self, seed: int = 0, keep_host_copy: bool = False):
         """Seeded random-init UNQUANTIZED checkpoint of the architecture: every projection a bf16 [out, in] matrix with
