@@ -569,6 +569,12 @@ typedef struct vmx_gemma4_config {
     int hidden_size_per_layer_input;          /* P: 0 or a multiple of 256, at most 1024 */
     int vocab_size_per_layer_input;           /* rows of embed_tokens_per_layer [vocab_pl, num_layers * P] */
     int ple_embed_ggml_type;                  /* 0 = bf16 table, else a GGML legacy / K-quant type id */
+    /* tensor parallelism (0 or 1 = off).  With tp_size > 1, num_heads, kv_heads_sliding and intermediate_size are THIS RANK'S shares
+     * (q/k/v/gate/up split by output rows, o/down by input columns in whole 256-blocks); kv_heads_full is the rank's share, or the
+     * whole count when the model has fewer full-attention KV heads than ranks (those K/V projections are then replicated);
+     * hidden_size and vocab_size stay global, vocab_size % tp_size == 0 (the tied lm_head is vocabulary-parallel over the rank's
+     * rows of the full table); per-layer-input tensors are replicated.  Needs vmx_gemma4_set_comm before the first step. */
+    int tp_size, tp_rank;
 } vmx_gemma4_config;
 
 typedef struct vmx_gemma4 vmx_gemma4;
@@ -626,6 +632,10 @@ int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, voi
  * write of each layer (a decode step, or a prompt chunk of at most 16 tokens) pins them from the bf16 K / V it writes with
  * `headroom` (the reference's default is 1.5), as KVScales::calibrate_if_needed does.  After vmx_gemma4_create the scales are 1
  * and count as calibrated; VMX_G4T_KV_SCALES loads explicit (calibrated) scales. */
+/* Attach the tensor-parallel communicator (not owned; rank / world must match the config).  Row-parallel outputs (o_proj, down_proj)
+ * are rounded to bf16 per rank and all-reduced, greedy ids come from a vocabulary-parallel argmax; logits_out then holds this rank's
+ * [rows, vocab_size / tp_size] slice. */
+int vmx_gemma4_set_comm(vmx_gemma4 *m, vmx_comm *comm);
 int vmx_gemma4_kv_scales_reset(vmx_gemma4 *m, float headroom, void *stream);
 /* the scales layer `layer` attends with (its target's for a KV-shared layer) and whether they are pinned; waits for the stream */
 int vmx_gemma4_kv_scales_get(vmx_gemma4 *m, int layer, float *k_scale, float *v_scale, int *calibrated, void *stream);

@@ -2,7 +2,9 @@
 one-shot all-reduce (no RCCL): each rank loads its shard of ONE seeded checkpoint, rank 0 also runs the unsharded model in the same
 process, and every decode step's greedy ids and logits are compared.  Dense Qwen3: column / row-parallel linears, vocab-parallel
 argmax.  Mixtral: tensor-parallel attention + expert-parallel MLP (each rank holds half of the experts; one all-reduce combines
-them, which for two experts per token is the same single bf16 addition as on one GPU)."""
+them, which for two experts per token is the same single bf16 addition as on one GPU).  Gemma 4: I-quant projections split by
+output rows / 256-element input blocks, the one full-attention KV head replicated, a KV-shared last layer, vocabulary-parallel tied
+Q3_K lm_head."""
 import multiprocessing as mp
 
 import numpy as np
@@ -20,6 +22,14 @@ def _spec(moe):
     return Qwen3Spec(**kw)
 
 
+def _gemma_spec():
+    from vllm_rust_amd.gemma4 import Gemma4Spec
+    # (sliding, sliding, full) x 2 with the last layer KV-shared; the single full-attention KV head is replicated on both ranks
+    return Gemma4Spec(256, 6, 8, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1, sliding_window=4,
+                      full_every=3, num_kv_shared_layers=1, max_position=64, kv_cache_dtype=1, num_blocks=8, max_batch=2, max_seq_len=64,
+                      embed_ggml_type=11)
+
+
 def _worker(rank, world, moe, conns, result_q):
     try:
         import torch
@@ -27,6 +37,7 @@ def _worker(rank, world, moe, conns, result_q):
         from vllm_rust_amd.parallel import LocalCommunicator, shard_spec
         from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
         vmx.init(0)
+        gemma = moe == "gemma"
 
         def exchange(mine):
             for c in conns[rank]:
@@ -37,15 +48,36 @@ def _worker(rank, world, moe, conns, result_q):
                 got[r] = b
             return [got[r] for r in range(world)]
 
-        full = _spec(moe)
         comm = LocalCommunicator(rank, world, exchange, max_bytes=64 * 1024)
-        shard = QuantizedQwen3ForCausalLM(shard_spec(full, rank, world))
-        shard.load_synthetic_tp(full, seed=7)
-        shard.set_comm(comm)
         ref = None
-        if rank == 0:
-            ref = QuantizedQwen3ForCausalLM(full)
-            (ref.load_synthetic_moe if moe else ref.load_synthetic)(seed=7)
+        if gemma:
+            from vllm_rust_amd.gemma4 import QuantizedGemma4ForCausalLM, shard_gemma4_spec
+            full = _gemma_spec()
+            shard = QuantizedGemma4ForCausalLM(shard_gemma4_spec(full, rank, world))
+            shard.load_synthetic(seed=7, full_spec=full)
+            if rank == 0:
+                ref = QuantizedGemma4ForCausalLM(full)
+                ref.load_synthetic(seed=7)
+            # Gemma attends with scale 1 on RMS-normed q and k: norm weights near 1 give logits of order sqrt(head_dim) and a
+            # near one-hot softmax that turns a one-ulp difference into a different token's V row; weights of head_dim^-1/4
+            # give logits of order 1, as trained checkpoints have
+            from vllm_rust_amd.gemma4 import T_K_NORM, T_Q_NORM
+            gq = torch.Generator().manual_seed(9)
+            for li in range(full.num_layers):
+                hd = full.layer_geom(li)[0]
+                for which in (T_Q_NORM, T_K_NORM):
+                    w = ((1.0 + 0.1 * torch.randn(hd, generator=gq)) * (1.0 / (hd ** 0.25))).to(torch.bfloat16).cuda()
+                    for mdl in (shard, ref):
+                        if mdl is not None:
+                            mdl.load_tensor(which, li, w)
+        else:
+            full = _spec(moe)
+            shard = QuantizedQwen3ForCausalLM(shard_spec(full, rank, world))
+            shard.load_synthetic_tp(full, seed=7)
+            if rank == 0:
+                ref = QuantizedQwen3ForCausalLM(full)
+                (ref.load_synthetic_moe if moe else ref.load_synthetic)(seed=7)
+        shard.set_comm(comm)
         B, V, VL = 2, full.vocab_size, full.vocab_size // world
         nblk = full.num_blocks // B
         bt = torch.arange(B * nblk, dtype=torch.int32, device="cuda").reshape(B, nblk)
@@ -81,7 +113,7 @@ def _worker(rank, world, moe, conns, result_q):
         result_q.put((rank, [("exception", repr(e), traceback.format_exc())], None, -1))
 
 
-@pytest.mark.parametrize("moe", [False, True])
+@pytest.mark.parametrize("moe", [False, True, "gemma"])
 def test_two_rank_executor_matches_single_gpu(moe):
     world = 2
     ctx = mp.get_context("spawn")
@@ -109,6 +141,8 @@ def test_two_rank_executor_matches_single_gpu(moe):
     report = results[0][0]
     assert len(report) == 6
     for p, rel, near_max, picked, ref_picked in report:
-        # the row-parallel o / down outputs are rounded to bf16 per rank before the sum: a bf16-ulp-level difference per layer
-        assert rel <= 2e-2, (p, rel)
+        # the row-parallel o / down outputs are rounded to bf16 per rank before the sum: a bf16-ulp-level difference per layer.
+        # On the 256-wide Gemma model that difference re-rolls the q8_1 activation rounding of every later projection: each run
+        # sits about 2 % from the CPU oracle (tests/test_gpu_gemma4.py), so two runs sit about 3 % from each other.
+        assert rel <= (6e-2 if moe == "gemma" else 2e-2), [(q, round(r, 4)) for q, r, *_ in report]
         assert near_max, (p, picked, ref_picked)

@@ -142,3 +142,24 @@ def test_expert_parallel_spec_and_ownership():
     assert list(local_experts(8, 1, 2)) == [4, 5, 6, 7]          # expert_map.rs: rank 1 of 2 holds [4, 8)
     with pytest.raises(ValueError):
         shard_spec(full, 0, 3)
+
+
+def test_gemma4_shard_spec_and_iq_block_slices():
+    """Gemma 4 under tensor parallelism: the 12B geometry divides for 2 and 4 ranks (8 would split down_proj inside a 256-block),
+    the single full-attention KV head stays whole; I-quant block slices of a column- and a row-parallel weight reassemble."""
+    sys.path.insert(0, str(ROOT))
+    import torch
+    from vllm_rust_amd.gemma4 import Gemma4Spec, L_DOWN, L_GATE, shard_gemma4_spec, shard_iq_blocks
+    full = Gemma4Spec.gemma4_12b()
+    for world in (2, 4):
+        s = shard_gemma4_spec(full, 1, world)
+        assert (s.num_heads, s.kv_heads_sliding, s.kv_heads_full, s.intermediate_size, s.vocab_size) == \
+            (16 // world, 8 // world, 1, 15360 // world, 262144)
+    with pytest.raises(ValueError, match="256-element"):
+        shard_gemma4_spec(full, 0, 8)
+    N, K, ts = 8, 1024, 98
+    raw = torch.arange(N * (K // 256) * ts, dtype=torch.int32).to(torch.uint8)
+    cols = [shard_iq_blocks(raw, L_GATE, N, K, ts, r, 2).reshape(N // 2, K // 256, ts) for r in range(2)]
+    assert torch.equal(torch.cat(cols, 0).reshape(-1), raw)
+    rows = [shard_iq_blocks(raw, L_DOWN, N, K, ts, r, 2).reshape(N, K // 512, ts) for r in range(2)]
+    assert torch.equal(torch.cat(rows, 1).reshape(-1), raw)

@@ -159,6 +159,7 @@ _SIGS = {
     "vmx_gemma4_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "vmx_gemma4_mmvq_only": (_i, [_p, _i, _p]),
     "vmx_gemma4_debug_read": (_i, [_p, _i, _p, _sz, _p]),
+    "vmx_gemma4_set_comm": (_i, [_p, _p]),
     "vmx_gemma4_kv_scales_reset": (_i, [_p, _f, _p]),
     "vmx_gemma4_kv_scales_get": (_i, [_p, _i, _p, _p, _p, _p]),
     "vmx_gemma4_debug_kv": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
@@ -189,7 +190,7 @@ class Gemma4Config(C.Structure):
         ("rms_norm_eps", _f), ("head_dim_sliding", _i), ("head_dim_full", _i), ("kv_heads_sliding", _i), ("kv_heads_full", _i),
         ("sliding_window", _i), ("rot_dim_sliding", _i), ("rot_dim_full", _i), ("max_position", _i), ("kv_cache_dtype", _i),
         ("block_size", _i), ("num_blocks", _i), ("max_batch", _i), ("max_seq_len", _i), ("final_logit_softcap", _f),
-        ("embed_ggml_type", _i), ("hidden_size_per_layer_input", _i), ("vocab_size_per_layer_input", _i), ("ple_embed_ggml_type", _i),
+        ("embed_ggml_type", _i), ("hidden_size_per_layer_input", _i), ("vocab_size_per_layer_input", _i), ("ple_embed_ggml_type", _i), ("tp_size", _i), ("tp_rank", _i),
     ]
 
 

@@ -282,6 +282,11 @@ __global__ __launch_bounds__(256) void g4_ple_gate_kernel(const float *__restric
     vmx_q8_1_emit8(rr, aq + c * 8, ad + (c >> 2), (c & 3) == 0);
 }
 
+__global__ __launch_bounds__(256) void g4_f32_to_bf16_kernel(const float *__restrict__ in, uint16_t *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = vmx_f32_to_bf16(in[i]);
+}
+
 __global__ __launch_bounds__(256) void g4_bf16_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = vmx_bf16_to_f32(in[i]);
@@ -359,6 +364,9 @@ struct vmx_gemma4 {
     float embed_scale = 1.f;
     // per-layer inputs (hidden_size_per_layer_input > 0): embed_tokens_per_layer, per_layer_model_projection and its norm, and the
     // step's buffers [rows][layers * P]: gathered embedding rows, projection output, combined inputs
+    vmx_comm *comm = nullptr;   // tensor-parallel group (not owned)
+    Buf red_bf16, keys;         // row-parallel outputs on their way through the all-reduce; argmax keys of the vocabulary-parallel head
+    int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     float kv_headroom = 1.5f;   // DEFAULT_KV_HEADROOM_FACTOR (kv_cache/quantization.rs:108)
     Buf kv_stage;               // bf16 K | V rows of one pass, used by an FP8 cache's first (calibrating) write
     IqLin ple_model_proj;
@@ -390,6 +398,16 @@ int mmvq(vmx_gemma4 *m, const IqLin &l, float *y, int ldy, int tokens, hipStream
         if (vmx_iq_packed_preferred(&pk, 1, l.in_features, tokens)) return mmvq_group(m, one, off, 1, y, ldy, tokens, st);
     }
     return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq_of(m), ad_of(m, tokens, l.in_features), y, l.out_features, l.in_features, tokens, ldy, st);
+}
+
+// Row-parallel linear under tensor parallelism: each rank's f32 output is rounded to bf16 (the reference's local matmul result),
+// summed over the ranks, and handed on as f32 again for the post-norm that follows.
+int g4_tp_reduce(vmx_gemma4 *m, float *out, int tokens, int hidden, hipStream_t st) {
+    const int64_t n = (int64_t)tokens * hidden;
+    hipLaunchKernelGGL(g4_f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, (uint16_t *)m->red_bf16.p, n);
+    if (int rc = vmx_comm_all_reduce_sum_bf16(m->comm, (uint16_t *)m->red_bf16.p, (size_t)n, st)) return rc;
+    hipLaunchKernelGGL(g4_bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint16_t *)m->red_bf16.p, out, n);
+    return VMX_OK;
 }
 
 void launch_norm(hipStream_t st, int tokens, uint16_t *h, uint16_t *x, const float *o, const uint16_t *w_post, const uint16_t *scalar,
@@ -426,6 +444,8 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     VMX_REQUIRE(c.embed_ggml_type == 0 || (vmx_ggml_type_size(c.embed_ggml_type) > 0 && vmx_iq_type_size(c.embed_ggml_type) < 0),
                 "gemma4_create: token_embd type %d unsupported (bf16 or a GGML legacy/K-quant type)", c.embed_ggml_type);
     VMX_REQUIRE(c.embed_ggml_type == 0 || c.hidden_size % vmx_ggml_block_elems(c.embed_ggml_type) == 0, "gemma4_create: hidden_size vs embed block");
+    VMX_REQUIRE(c.tp_size >= 0 && c.tp_rank >= 0 && (c.tp_size <= 1 || (c.tp_rank < c.tp_size && c.vocab_size % c.tp_size == 0)),
+                "gemma4_create: tp_rank %d / tp_size %d invalid (vocab_size must divide by tp_size)", c.tp_rank, c.tp_size);
     VMX_REQUIRE(c.hidden_size_per_layer_input >= 0 && c.hidden_size_per_layer_input % 256 == 0 && c.hidden_size_per_layer_input <= 1024,
                 "gemma4_create: hidden_size_per_layer_input (%d) must be 0 or a multiple of 256, at most 1024", c.hidden_size_per_layer_input);
     VMX_REQUIRE(c.hidden_size_per_layer_input == 0 || c.vocab_size_per_layer_input > 0,
@@ -551,6 +571,8 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         TRY(m->pli.alloc((size_t)R * LP * 2));
         max_proj = P > max_proj ? P : max_proj;
     }
+    TRY(m->red_bf16.alloc((size_t)R * H * 2));
+    TRY(m->keys.alloc((size_t)R * 8));
     TRY(m->positions.alloc((size_t)R * 4));
     TRY(m->kv_stage.alloc((size_t)R * 2 * max_nkv * 2));
     TRY(m->h.alloc((size_t)R * H * 2));
@@ -592,7 +614,7 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     }
     m->ple_model_proj.raw.release();
     m->ple_model_proj.packed.release();
-    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage}) b->release();
+    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage, &m->red_bf16, &m->keys}) b->release();
     for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
                    &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8})
         b->release();
@@ -685,6 +707,8 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
              *act = (uint16_t *)m->act.p;
     float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
     const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
+    const bool tp = c.tp_size > 1 || m->comm != nullptr;   // a 1-rank communicator still exercises the collective path
+    VMX_REQUIRE(!tp || m->comm, "gemma4: tp_size %d but no communicator attached (vmx_gemma4_set_comm)", c.tp_size);
 
     if (c.embed_ggml_type == 0) {
         hipLaunchKernelGGL(g4_embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size,
@@ -768,6 +792,8 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
             }
         }
         if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, B, st)) return rc;
+        if (tp)
+            if (int rc = g4_tp_reduce(m, out, B, H, st)) return rc;
         // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, out, (const uint16_t *)L.post_attn_ln.p, nullptr, (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, H,
                     aq_of(m), ad_of(m, B, H));
@@ -780,6 +806,8 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         hipLaunchKernelGGL(g4_geglu_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, proj, B, act, I, aq_of(m),
                            ad_of(m, B, I));
         if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, B, st)) return rc;
+        if (tp)
+            if (int rc = g4_tp_reduce(m, out, B, H, st)) return rc;
         pending = out;
         pending_w = (const uint16_t *)L.post_ffn_ln.p;
         pending_scalar = (const uint16_t *)L.scalar.p;
@@ -804,7 +832,10 @@ int g4_run_head(vmx_gemma4 *m, const uint16_t *x, int rows, int32_t *out_ids, ui
     hipStream_t st = vmx_stream(stream);
     const int H = c.hidden_size, B = rows;
     uint16_t *logits = logits_out ? logits_out : (uint16_t *)m->logits.p;
-    const int64_t nlog = (int64_t)B * c.vocab_size;
+    const bool tp = c.tp_size > 1 || m->comm != nullptr;
+    const int VL = m->vocab_local();                                // this rank's rows of the tied table
+    const int64_t v0 = tp ? (int64_t)c.tp_rank * VL : 0;
+    const int64_t nlog = (int64_t)B * VL;
     const float cap = c.final_logit_softcap;
     float inv_cap = 0.f;
     if (cap > 0.f) {   // xs / cap is a bf16 multiply by bf16(1 / cap)
@@ -815,7 +846,7 @@ int g4_run_head(vmx_gemma4 *m, const uint16_t *x, int rows, int32_t *out_ids, ui
         memcpy(&inv_cap, &u, 4);
     }
     if (c.embed_ggml_type == 0) {
-        if (int rc = vmx_dense_gemv_launch(logits, x, (const uint16_t *)m->embed.p, nullptr, B, c.vocab_size, H, st)) return rc;
+        if (int rc = vmx_dense_gemv_launch(logits, x, (const uint16_t *)m->embed.p + v0 * H, nullptr, B, VL, H, st)) return rc;
         if (cap > 0.f)
             hipLaunchKernelGGL(g4_logits_kernel, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, st, logits, (const float *)nullptr, nlog,
                                inv_cap, cap);
@@ -824,16 +855,25 @@ int g4_run_head(vmx_gemma4 *m, const uint16_t *x, int rows, int32_t *out_ids, ui
         hipLaunchKernelGGL(g4_bf16_to_f32_kernel, dim3((unsigned)(((int64_t)B * H + 255) / 256)), dim3(256), 0, st, x, xf, (int64_t)B * H);
         for (int b0 = 0; b0 < B; b0 += 8) {
             const int mb = B - b0 < 8 ? B - b0 : 8;
-            if (int rc = vmx_kquant_gemv_f32(c.embed_ggml_type, m->embed.p, xf + (int64_t)b0 * H, lf + (int64_t)b0 * c.vocab_size,
-                                             c.vocab_size, H, mb, stream))
+            const size_t row_bytes = (size_t)(H / vmx_ggml_block_elems(c.embed_ggml_type)) * vmx_ggml_type_size(c.embed_ggml_type);
+            if (int rc = vmx_kquant_gemv_f32(c.embed_ggml_type, (const char *)m->embed.p + (size_t)v0 * row_bytes, xf + (int64_t)b0 * H,
+                                             lf + (int64_t)b0 * VL, VL, H, mb, stream))
                 return rc;
         }
         hipLaunchKernelGGL(g4_logits_kernel, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, st, logits, (const float *)lf, nlog, inv_cap,
                            cap);
     }
     VMX_CHECK_LAUNCH("gemma4(lm_head)");
-    if (out_ids)
-        if (int rc = vmx_argmax_bf16(out_ids, logits, B, c.vocab_size, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
+    if (out_ids) {
+        if (!tp) {
+            if (int rc = vmx_argmax_bf16(out_ids, logits, B, VL, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
+        } else {   // vocabulary-parallel: best (value, global index) key per rank, max over the ranks
+            unsigned long long *keys = (unsigned long long *)m->keys.p;
+            if (int rc = vmx_argmax_keys(keys, logits, B, VL, (uint32_t)v0, m->argmax_ws.p, st)) return rc;
+            if (int rc = vmx_comm_all_reduce_max_u64(m->comm, keys, B, stream)) return rc;
+            if (int rc = vmx_argmax_keys_to_ids(keys, out_ids, B, st)) return rc;
+        }
+    }
     return VMX_OK;
 }
 }  // namespace
@@ -886,6 +926,14 @@ extern "C" int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int s
         last_rows = rows;
     }
     return g4_run_head(m, (const uint16_t *)m->x.p + (size_t)(last_rows - 1) * c.hidden_size, 1, out_id_last, logits_last, stream);
+}
+
+extern "C" int vmx_gemma4_set_comm(vmx_gemma4 *m, vmx_comm *comm) {
+    VMX_REQUIRE(m, "gemma4_set_comm: null model");
+    VMX_REQUIRE(!comm || (vmx_comm_world(comm) == (m->cfg.tp_size > 1 ? m->cfg.tp_size : 1) && vmx_comm_rank(comm) == m->cfg.tp_rank),
+                "gemma4_set_comm: communicator rank/world do not match the model's tp_rank/tp_size");
+    m->comm = comm;
+    return VMX_OK;
 }
 
 // KVScales::reset for every layer (kv_cache/quantization.rs:231-239) with the headroom of the next first-write calibration

@@ -61,6 +61,8 @@ class Gemma4Spec:
     hidden_size_per_layer_input: int = 0     # P of the per-layer inputs (E2B / E4B variants), 0 = none
     vocab_size_per_layer_input: int = 0
     ple_embed_ggml_type: int = 0             # embed_tokens_per_layer: 0 bf16, else a K-quant type id
+    tp_size: int = 1                         # with tp_size > 1 the head counts and intermediate_size are this rank's shares
+    tp_rank: int = 0
 
     @staticmethod
     def gemma4_12b(**kw):
@@ -123,6 +125,40 @@ class Gemma4Spec:
         return sh
 
 
+def shard_gemma4_spec(spec: Gemma4Spec, tp_rank: int, tp_size: int) -> Gemma4Spec:
+    """Per-rank geometry: query heads, sliding KV heads and the MLP width divide; a full-attention layer with fewer KV heads than
+    ranks keeps them all (its K/V projections are replicated); hidden size and vocabulary stay global.  Row-parallel inputs
+    (o_proj, down_proj) must be whole 256-element blocks per rank."""
+    if tp_size == 1:
+        return dataclasses.replace(spec, tp_size=1, tp_rank=0)
+    for name in ("num_heads", "kv_heads_sliding", "intermediate_size", "vocab_size"):
+        if getattr(spec, name) % tp_size:
+            raise ValueError(f"{name}={getattr(spec, name)} is not divisible by tp_size={tp_size}")
+    if spec.kv_heads_full >= tp_size and spec.kv_heads_full % tp_size:
+        raise ValueError(f"kv_heads_full={spec.kv_heads_full} is not divisible by tp_size={tp_size}")
+    for k in (spec.num_heads // tp_size * spec.head_dim_sliding, spec.num_heads // tp_size * spec.head_dim_full,
+              spec.intermediate_size // tp_size):
+        if k % 256:
+            raise ValueError(f"a row-parallel shard of {k} inputs is not a whole number of 256-element blocks")
+    kvf = spec.kv_heads_full // tp_size if spec.kv_heads_full >= tp_size else spec.kv_heads_full
+    return dataclasses.replace(spec, num_heads=spec.num_heads // tp_size, kv_heads_sliding=spec.kv_heads_sliding // tp_size,
+                               kv_heads_full=kvf, intermediate_size=spec.intermediate_size // tp_size, tp_size=tp_size, tp_rank=tp_rank)
+
+
+def shard_iq_blocks(raw: torch.Tensor, slot: int, n_out: int, n_in: int, type_size: int, tp_rank: int, tp_size: int,
+                    replicate: bool = False) -> torch.Tensor:
+    """This rank's part of an I-quant weight stored as [n_out][n_in / 256] blocks of type_size bytes: output rows for
+    q/k/v/gate/up (column-parallel), 256-element input blocks for o/down (row-parallel); `replicate`: the whole tensor."""
+    if replicate or tp_size == 1:
+        return raw
+    blocks = raw.reshape(n_out, n_in // 256, type_size)
+    if slot in (L_O, L_DOWN):
+        per = (n_in // 256) // tp_size
+        return blocks[:, tp_rank * per:(tp_rank + 1) * per].contiguous().reshape(-1)
+    per = n_out // tp_size
+    return blocks[tp_rank * per:(tp_rank + 1) * per].contiguous().reshape(-1)
+
+
 def proportional_cos_sin_cache(head_dim: int, rot_dim: int, max_position: int, theta: float) -> np.ndarray:
     """cos|sin table of RotaryEmbedding::new_gemma4_proportional (crates/core/src/layers/rotary.rs:128-174): the exponent's
     denominator is the full head_dim, only rot_dim leading dims rotate; values rounded to bf16 (model dtype)."""
@@ -148,7 +184,8 @@ class QuantizedGemma4ForCausalLM:
                            s.head_dim_sliding, s.head_dim_full, s.kv_heads_sliding, s.kv_heads_full, s.sliding_window,
                            s.head_dim_sliding, s.rot_dim_full(), s.max_position, s.kv_cache_dtype, s.block_size, s.num_blocks,
                            s.max_batch, s.max_seq_len, s.final_logit_softcap, s.embed_ggml_type, s.hidden_size_per_layer_input,
-                           s.vocab_size_per_layer_input, s.ple_embed_ggml_type)
+                           s.vocab_size_per_layer_input, s.ple_embed_ggml_type, s.tp_size if s.tp_size > 1 else 0, s.tp_rank)
+        self._comm = None
         flags = (C.c_int * s.num_layers)(*s.layer_flags())
         self._h = C.c_void_p()
         check(lib.vmx_gemma4_create(C.byref(cfg), flags, C.byref(self._h)))
@@ -182,11 +219,19 @@ class QuantizedGemma4ForCausalLM:
         check(lib.vmx_gemma4_load_iq_linear(self._h, layer, slot, ggml_type, blocks.data_ptr(), blocks.numel(), self._stream()))
         torch.cuda.current_stream().synchronize()
 
-    def load_synthetic(self, slot_types=None, seed: int = 0, keep_host_copy: bool = False):
+    def set_comm(self, comm) -> None:
+        """Attach a vllm_rust_amd.parallel.Communicator (kept alive by the model)."""
+        self._comm = comm
+        check(lib.vmx_gemma4_set_comm(self._h, comm.handle if comm is not None else None))
+
+    def load_synthetic(self, slot_types=None, seed: int = 0, keep_host_copy: bool = False, full_spec: Optional[Gemma4Spec] = None):
         """Seeded random-init weights of the architecture: valid random I-quant blocks per projection (slot_types: ggml type
         per slot, default the 12B UD-IQ3_XXS mix), bf16 norms and layer scalars, bf16 or K-quant token embedding.
         Super-block scales are sized so activations stay O(1).  Returns the host copy when keep_host_copy (tiny models)."""
-        s = self.spec
+        # full_spec: this model is one tensor-parallel rank of it (self.spec = shard_gemma4_spec(full_spec, rank, world)); every
+        # rank draws the full tensors from the same generator and keeps its part, so the ranks together hold the single-GPU model
+        s = full_spec if full_spec is not None else self.spec
+        rank, world = (self.spec.tp_rank, self.spec.tp_size) if full_spec is not None else (0, 1)
         slot_types = slot_types or GEMMA4_12B_IQ3_MIX
         g = torch.Generator(device=self.device).manual_seed(seed)
         ck = {}
@@ -219,7 +264,10 @@ class QuantizedGemma4ForCausalLM:
             dbits = d.to(torch.float16).view(torch.int16)
             raw[:, 0] = (dbits & 0xFF).to(torch.uint8)
             raw[:, 1] = ((dbits >> 8) & 0xFF).to(torch.uint8)
-            self.load_iq_linear(li, slot, t, raw.reshape(-1))
+            # replicated under tensor parallelism: the per-layer-input linears, and K/V of layers with fewer KV heads than ranks
+            whole = slot >= L_PLE_GATE or (slot in (L_K, L_V) and s.layer_geom(li)[1] < world)
+            mine = shard_iq_blocks(raw.reshape(-1), slot, N, K, ts, rank, world, replicate=whole)
+            self.load_iq_linear(li, slot, t, mine)
             keep(f"{li}.{slot}.iq", (t, raw.reshape(-1).cpu()) if keep_host_copy else None)
 
         if s.embed_ggml_type == 0:
