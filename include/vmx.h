@@ -61,6 +61,14 @@ int vmx_iq_type_size(int ggml_type);
  * n_blocks super-blocks -> n_blocks*256 f32. */
 int vmx_iq_dequantize_f32(int ggml_type, const void *blocks, float *out, int64_t n_blocks, void *stream);
 
+/* IqLinear::forward for more than IQ_GEMV_MAX_M = 16 rows (crates/core/src/quantization/gguf/mod.rs:358-365): the weight is
+ * dequantised to dense f32 once and multiplied with the UNQUANTISED activations, y[m, n] = sum_k x[m,k] * w[n,k] in f32.
+ * x bf16 [m, n_in], y f32 [m, n_out]; workspace of vmx_iq_gemm_workspace_bytes(n_out, n_in) bytes.  The f32 weight runs on the bf16
+ * matrix cores as an exact two-term split (w = hi + lo), so the result differs from an f32 GEMM only by summation order. */
+size_t vmx_iq_gemm_workspace_bytes(int n_out, int n_in);
+int vmx_iq_gemm_f32(int ggml_type, const void *blocks, const uint16_t *x, float *y, int m, int n_out, int n_in, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
 /* Replaces quantize_q8_1_rows (iq_dequant.cu:253-267; launcher iq/mod.rs:797-817):
  * x f32 [total_blocks*32] -> aq int8 [total_blocks*32], ad f32 [total_blocks]. */
 int vmx_quantize_q8_1_rows(const float *x, int8_t *aq, float *ad, int64_t total_blocks, void *stream);
@@ -575,6 +583,10 @@ typedef struct vmx_gemma4_config {
      * hidden_size and vocab_size stay global, vocab_size % tp_size == 0 (the tied lm_head is vocabulary-parallel over the rank's
      * rows of the full table); per-layer-input tensors are replicated.  Needs vmx_gemma4_set_comm before the first step. */
     int tp_size, tp_rank;
+    /* rows per pass of vmx_gemma4_prefill.  0 (or <= 16): passes of 16 rows through the q8_1 MMVQ.  More: every pass of more than
+     * 16 rows runs the reference's large-M linear (weight dequantised once per pass, unquantised activations, IqLinear::forward_inner
+     * gguf/mod.rs:358-365) on the matrix cores; costs activation buffers for that many rows plus one dequantised projection. */
+    int max_prefill_tokens;
 } vmx_gemma4_config;
 
 typedef struct vmx_gemma4 vmx_gemma4;

@@ -169,11 +169,16 @@ class OracleGemma4:
             self.embed_f32 = orc.ggml_dequant(s.embed_ggml_type, self.ck["embed"]).reshape(s.vocab_size, s.hidden_size)
 
     def linear(self, li, slot, x_u16):
+        """IqLinear::forward_inner (gguf/mod.rs:329-377): q8_1 MMVQ up to 16 rows; beyond that the weight is dequantised to dense
+        f32 and multiplied with the unquantised activations (float64 accumulate here: summation order is the only freedom)."""
         t, raw = self.ck[f"{li}.{slot}.iq"]
         raw = raw.numpy() if hasattr(raw, "numpy") else raw
         x = orc.bf16_to_f32(x_u16)
         n_in = x.shape[1]
         n_out = raw.size // (n_in // 256 * orc.IQ_TYPE_SIZE[t])
+        if x.shape[0] > 16:
+            w = orc.iq_dequant(t, raw).reshape(n_out, n_in).astype(np.float64)
+            return orc.f32_to_bf16((x.astype(np.float64) @ w.T).astype(np.float32))
         return orc.f32_to_bf16(orc.iq_matmul(t, raw, x, n_out, n_in))
 
     def reset_kv_scales(self, headroom=1.5):

@@ -213,6 +213,73 @@ def test_gemma4_native_prefill_matches_token_by_token_oracle(kv_dtype, k_eq_v, s
         model.close()
 
 
+@pytest.mark.parametrize("kv_dtype", [0, 1])
+def test_gemma4_prefill_large_pass_dense_linears(kv_dtype):
+    """max_prefill_tokens = 64: a 37-token chunk and a 20-token continuation each run as ONE pass whose linears take the reference's
+    large-M form (weight dequantised to f32, unquantised activations) instead of the q8_1 MMVQ; with FP8 KV the first write
+    calibrates the scales on the whole chunk, as the reference's cache engine does.  Oracle: the same chunk as one batch of rows
+    of one sequence (all K/V rows written, then each row attends up to its own position), linears dense beyond 16 rows."""
+    import torch
+    import vllm_rust_amd as vmx
+    from oracle import oracle as orc
+    from tests.model_oracle import OracleGemma4
+    from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM, T_K_NORM, T_Q_NORM
+    vmx.init(0)
+    spec = Gemma4Spec(256, 4, 4, 512, 1000, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
+                      sliding_window=8, full_every=3, num_kv_shared_layers=1, max_position=128, kv_cache_dtype=kv_dtype, num_blocks=8,
+                      max_batch=1, max_seq_len=96, max_prefill_tokens=64)
+    model = QuantizedGemma4ForCausalLM(spec)
+    try:
+        ck = model.load_synthetic(seed=5, keep_host_copy=True)
+        gq = torch.Generator(device="cuda").manual_seed(9)      # q/k norm weights of head_dim^-1/4: logits of order 1 (see above)
+        for li in range(spec.num_layers):
+            hd = spec.layer_geom(li)[0]
+            for which, name in ((T_Q_NORM, "q_norm"), (T_K_NORM, "k_norm")):
+                w = ((1.0 + 0.1 * torch.randn(hd, device="cuda", generator=gq)) * (1.0 / (hd ** 0.25))).to(torch.bfloat16)
+                model.load_tensor(which, li, w)
+                ck[f"{li}.{name}"] = w.cpu()
+        ref = OracleGemma4(spec, ck, model.cos_sin_sliding, model.cos_sin_full)
+        if kv_dtype == 1:
+            model.kv_scales_reset(1.5)
+            ref.reset_kv_scales(1.5)
+        bs = spec.block_size
+        bt = np.asarray([[5, 2, 7, 0, 3, 1]], np.int32)
+        P1, P2 = 37, 20
+        prompt = np.random.default_rng(1).integers(0, spec.vocab_size, P1 + P2).astype(np.int32)
+
+        def chunk(p0, p1):
+            pos = np.arange(p0, p1, dtype=np.int32)
+            slots = (bt[0, pos // bs] * bs + pos % bs).astype(np.int32)
+            lg, _, _ = ref.decode(prompt[p0:p1], pos, slots, np.repeat(bt, p1 - p0, axis=0), pos + 1)
+            return orc.bf16_to_f32(lg)[-1]
+
+        def rel(a, b):
+            return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+
+        bt_t = torch.from_numpy(bt).cuda()
+        lg = torch.empty(spec.vocab_size, dtype=torch.bfloat16, device="cuda")
+        nxt = model.prefill(torch.from_numpy(prompt[:P1]).cuda(), 0, bt_t[0], logits_last=lg)
+        torch.cuda.synchronize()
+        exp = chunk(0, P1)
+        r1 = rel(orc.bf16_to_f32(lg.cpu().view(torch.int16).numpy().view(np.uint16)), exp)
+        bar = 2e-2 if kv_dtype == 0 else 4e-2     # measured 0.012 / 0.015 (bf16 KV); FP8 KV adds its e4m3 rounding of every K / V
+        assert r1 <= bar, r1
+        assert exp[int(nxt.item())] >= exp.max() - abs(exp.max()) * 2 ** -6
+        if kv_dtype == 1:      # pinned from the whole 37-row chunk on both sides
+            for li in range(spec.num_layers):
+                ks, vs, cal = model.kv_scales(li)
+                cl = spec.kv_target(li) if spec.kv_target(li) is not None else li
+                assert cal and abs(ks / float(ref.kvs[cl].k_scale) - 1) < 0.02 and abs(vs / float(ref.kvs[cl].v_scale) - 1) < 0.02
+        model.prefill(torch.from_numpy(prompt[P1:]).cuda(), P1, bt_t[0], logits_last=lg)
+        torch.cuda.synchronize()
+        exp = chunk(P1, P1 + P2)
+        r2 = rel(orc.bf16_to_f32(lg.cpu().view(torch.int16).numpy().view(np.uint16)), exp)
+        assert r2 <= bar, r2
+        print(f"dense-linear prefill rel-L2 {r1:.4f} / {r2:.4f}")
+    finally:
+        model.close()
+
+
 def test_gemma4_rejects_bad_config():
     import ctypes as C
     from vllm_rust_amd._lib import Gemma4Config, lib

@@ -210,3 +210,24 @@ def test_packed_rejects_types_without_packed_form(gpu):
     assert lib.vmx_iq_packed_bytes(17, 8, 256) == 0 and lib.vmx_iq_packed_bytes(18, 9, 512) == 16 * 2 * 98
     assert lib.vmx_iq_pack(23, 1, 1, 8, 256, None) == -1
     assert b"packed form" in lib.vmx_last_error()
+
+
+@pytest.mark.parametrize("name", IQ_NAMES)
+@pytest.mark.parametrize("m,n_out,n_in", [(17, 203, 3840), (64, 512, 256), (130, 300, 1024)])
+def test_iq_gemm_prompt_sized_rows(gpu, name, m, n_out, n_in):
+    """More than 16 rows: the reference dequantises the weight to dense f32 and multiplies the unquantised activations
+    (gguf/mod.rs:358-365).  Checked against the oracle's dequantised weight times the bf16 activations in float64: the only
+    differences left are the 2^-17 split of the weight and f32 summation order (1e-3 is the stated bar; measured ~1e-6)."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    tid = orc.IQ_TYPES[name]; ts = orc.IQ_TYPE_SIZE[tid]
+    rng = np.random.default_rng(7 * m + n_out)
+    w_raw = random_iq_blocks(rng, ts, n_out * n_in // 256)
+    x = orc.f32_to_bf16(rng.standard_normal((m, n_in)).astype(np.float32))
+    xt = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16)
+    got = vmx.iq_gemm(tid, _dev(torch, w_raw), xt, n_out).cpu().numpy()
+    w = orc.iq_dequant(tid, w_raw).reshape(n_out, n_in).astype(np.float64)
+    ref = orc.bf16_to_f32(x).astype(np.float64) @ w.T
+    assert np.isfinite(got).all()
+    assert rel_l2(got, ref) <= 2e-5
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()

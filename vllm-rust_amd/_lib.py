@@ -34,6 +34,8 @@ _SIGS = {
     "vmx_last_error": (C.c_char_p, []),
     "vmx_iq_type_size": (_i, [_i]),
     "vmx_iq_dequantize_f32": (_i, [_i, _p, _p, _i64, _p]),
+    "vmx_iq_gemm_workspace_bytes": (_sz, [_i, _i]),
+    "vmx_iq_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vmx_quantize_q8_1_rows": (_i, [_p, _p, _p, _i64, _p]),
     "vmx_iq_mmvq_f32": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vmx_iq_matmul_workspace_bytes": (_sz, [_i, _i]),
@@ -190,7 +192,7 @@ class Gemma4Config(C.Structure):
         ("rms_norm_eps", _f), ("head_dim_sliding", _i), ("head_dim_full", _i), ("kv_heads_sliding", _i), ("kv_heads_full", _i),
         ("sliding_window", _i), ("rot_dim_sliding", _i), ("rot_dim_full", _i), ("max_position", _i), ("kv_cache_dtype", _i),
         ("block_size", _i), ("num_blocks", _i), ("max_batch", _i), ("max_seq_len", _i), ("final_logit_softcap", _f),
-        ("embed_ggml_type", _i), ("hidden_size_per_layer_input", _i), ("vocab_size_per_layer_input", _i), ("ple_embed_ggml_type", _i), ("tp_size", _i), ("tp_rank", _i),
+        ("embed_ggml_type", _i), ("hidden_size_per_layer_input", _i), ("vocab_size_per_layer_input", _i), ("ple_embed_ggml_type", _i), ("tp_size", _i), ("tp_rank", _i), ("max_prefill_tokens", _i),
     ]
 
 

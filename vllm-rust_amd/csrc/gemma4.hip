@@ -263,7 +263,8 @@ __global__ __launch_bounds__(64) void g4_ple_inputs_kernel(const float *__restri
 // apply_ple's gate (gemma4_quantized.rs:1674-1676): gated = bf16(bf16(gelu_tanh(bf16(gate))) * pli[token][layer]) and its q8_1
 // form for per_layer_projection.  One thread per 8 values, P % 32 == 0; pli row stride = pli_stride elements.
 __global__ __launch_bounds__(256) void g4_ple_gate_kernel(const float *__restrict__ gate, const uint16_t *__restrict__ pli, int64_t pli_stride,
-                                                           int tokens, int P, int8_t *__restrict__ aq, float *__restrict__ ad) {
+                                                           int tokens, int P, uint16_t *__restrict__ gated, int8_t *__restrict__ aq,
+                                                           float *__restrict__ ad) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, chunks = (int64_t)tokens * P / 8;
     if (c >= chunks) return;
     const int cpr = P / 8;
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(256) void g4_ple_gate_kernel(const float *__restric
         r[j] = ge * pv[j];
     }
     const uint4 packed = pack8(r);
+    *reinterpret_cast<uint4 *>(gated + c * 8) = packed;
     float rr[8];
     unpack8(packed, rr);
     vmx_q8_1_emit8(rr, aq + c * 8, ad + (c >> 2), (c & 3) == 0);
@@ -368,6 +370,7 @@ struct vmx_gemma4 {
     Buf red_bf16, keys;         // row-parallel outputs on their way through the all-reduce; argmax keys of the vocabulary-parallel head
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     float kv_headroom = 1.5f;   // DEFAULT_KV_HEADROOM_FACTOR (kv_cache/quantization.rs:108)
+    Buf gemm_ws;                // dequantised weight of one projection (f32 + bf16 halves) for passes of more than 16 rows
     Buf kv_stage;               // bf16 K | V rows of one pass, used by an FP8 cache's first (calibrating) write
     IqLin ple_model_proj;
     Buf ple_embed, ple_proj_norm, ple_e, ple_p, pli;
@@ -398,6 +401,28 @@ int mmvq(vmx_gemma4 *m, const IqLin &l, float *y, int ldy, int tokens, hipStream
         if (vmx_iq_packed_preferred(&pk, 1, l.in_features, tokens)) return mmvq_group(m, one, off, 1, y, ldy, tokens, st);
     }
     return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq_of(m), ad_of(m, tokens, l.in_features), y, l.out_features, l.in_features, tokens, ldy, st);
+}
+
+// A linear on `rows` token rows: the q8_1 MMVQ up to IQ_GEMV_MAX_M = 16 rows (activations already quantised in m->q8), beyond that
+// the reference's large-M form (gguf/mod.rs:358-365): dequantise the weight once, multiply the unquantised bf16 rows `a`.
+int g4_linears(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, const uint16_t *a, float *y, int ldy, int rows,
+               hipStream_t st) {
+    if (rows <= 16) {
+        if (n == 1 && offs[0] == 0) return mmvq(m, *lins[0], y, ldy, rows, st);
+        return mmvq_group(m, lins, offs, n, y, ldy, rows, st);
+    }
+    for (int i = 0; i < n; i++) {
+        const IqLin &l = *lins[i];
+        if (int rc = vmx_iq_dequant_split(l.ggml_type, l.raw.p, m->gemm_ws.p, l.out_features, l.in_features, st)) return rc;
+        if (int rc = vmx_split_gemm_f32(a, m->gemm_ws.p, y + offs[i], rows, l.out_features, l.in_features, ldy, st)) return rc;
+    }
+    return VMX_OK;
+}
+
+int g4_linear(vmx_gemma4 *m, const IqLin &l, const uint16_t *a, float *y, int ldy, int rows, hipStream_t st) {
+    const IqLin *one[1] = {&l};
+    const int off[1] = {0};
+    return g4_linears(m, one, off, 1, a, y, ldy, rows, st);
 }
 
 // Row-parallel linear under tensor parallelism: each rank's f32 output is rounded to bf16 (the reference's local matmul result),
@@ -444,6 +469,8 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
     VMX_REQUIRE(c.embed_ggml_type == 0 || (vmx_ggml_type_size(c.embed_ggml_type) > 0 && vmx_iq_type_size(c.embed_ggml_type) < 0),
                 "gemma4_create: token_embd type %d unsupported (bf16 or a GGML legacy/K-quant type)", c.embed_ggml_type);
     VMX_REQUIRE(c.embed_ggml_type == 0 || c.hidden_size % vmx_ggml_block_elems(c.embed_ggml_type) == 0, "gemma4_create: hidden_size vs embed block");
+    VMX_REQUIRE(c.max_prefill_tokens >= 0 && c.max_prefill_tokens <= 8192, "gemma4_create: max_prefill_tokens (%d) must be in 0..8192",
+                c.max_prefill_tokens);
     VMX_REQUIRE(c.tp_size >= 0 && c.tp_rank >= 0 && (c.tp_size <= 1 || (c.tp_rank < c.tp_size && c.vocab_size % c.tp_size == 0)),
                 "gemma4_create: tp_rank %d / tp_size %d invalid (vocab_size must divide by tp_size)", c.tp_rank, c.tp_size);
     VMX_REQUIRE(c.hidden_size_per_layer_input >= 0 && c.hidden_size_per_layer_input % 256 == 0 && c.hidden_size_per_layer_input <= 1024,
@@ -552,7 +579,8 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
                 rc = VMX_ELAUNCH;
         }
     }
-    const int R = B > 16 ? B : 16;   // activation rows: a decode batch, or one 16-row pass of the prompt path
+    int R = B > 16 ? B : 16;   // activation rows: a decode batch, or one pass of the prompt path (16 rows, or max_prefill_tokens)
+    R = c.max_prefill_tokens > R ? c.max_prefill_tokens : R;
     if (P > 0) {
         if (c.ple_embed_ggml_type != 0 && LP % vmx_ggml_block_elems(c.ple_embed_ggml_type) != 0) {
             vmx_set_error("gemma4_create: layers * hidden_size_per_layer_input (%d) vs the per-layer embedding's block size", LP);
@@ -570,6 +598,19 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         TRY(m->ple_p.alloc((size_t)R * LP * 4));
         TRY(m->pli.alloc((size_t)R * LP * 2));
         max_proj = P > max_proj ? P : max_proj;
+    }
+    if (c.max_prefill_tokens > 16) {   // the largest projection's dequantised form
+        size_t wmax = 0;
+        for (const G4Layer &L : m->layers)
+            for (const IqLin &l : L.lin) {
+                const size_t w = vmx_iq_gemm_workspace(l.out_features, l.in_features);
+                wmax = w > wmax ? w : wmax;
+            }
+        if (P > 0) {
+            const size_t w = vmx_iq_gemm_workspace(LP, H);
+            wmax = w > wmax ? w : wmax;
+        }
+        TRY(m->gemm_ws.alloc(wmax));
     }
     TRY(m->red_bf16.alloc((size_t)R * H * 2));
     TRY(m->keys.alloc((size_t)R * 8));
@@ -614,7 +655,7 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     }
     m->ple_model_proj.raw.release();
     m->ple_model_proj.packed.release();
-    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage, &m->red_bf16, &m->keys}) b->release();
+    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage, &m->red_bf16, &m->keys, &m->gemm_ws}) b->release();
     for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
                    &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8})
         b->release();
@@ -727,7 +768,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
             return rc;
         }
         if (int rc = vmx_quantize_q8_1_bf16(h, aq_of(m), ad_of(m, B, H), (int64_t)B * (H / 32), st)) return rc;
-        if (int rc = mmvq(m, m->ple_model_proj, (float *)m->ple_p.p, LP, B, st)) return rc;
+        if (int rc = g4_linear(m, m->ple_model_proj, h, (float *)m->ple_p.p, LP, B, st)) return rc;
         hipLaunchKernelGGL(g4_ple_inputs_kernel, dim3(c.num_layers, B), dim3(64), 0, st, (const float *)m->ple_p.p, pe,
                            (const uint16_t *)m->ple_proj_norm.p, (uint16_t *)m->pli.p, P, c.rms_norm_eps, m->ple_proj_scale,
                            m->ple_input_scale);
@@ -748,7 +789,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         {
             const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
             const int offs[3] = {0, NQ, NQ + NKV};
-            if (int rc = mmvq_group(m, qkv, offs, nseg, proj, ntot, B, st)) return rc;
+            if (int rc = g4_linears(m, qkv, offs, nseg, x, proj, ntot, B, st)) return rc;
         }
         const float *ks = (const float *)KV.kv_scales.p;
         // short contexts: per-head norms + RoPE + KV write + attention + merge in one launch (not for K == V or KV-shared layers)
@@ -791,7 +832,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
                 if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
             }
         }
-        if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, B, st)) return rc;
+        if (int rc = g4_linear(m, L.lin[VMX_L_O], attn, out, H, B, st)) return rc;
         if (tp)
             if (int rc = g4_tp_reduce(m, out, B, H, st)) return rc;
         // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
@@ -800,12 +841,12 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         {
             const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
             const int offs[2] = {0, I};
-            if (int rc = mmvq_group(m, gu, offs, 2, proj, 2 * I, B, st)) return rc;
+            if (int rc = g4_linears(m, gu, offs, 2, x, proj, 2 * I, B, st)) return rc;
         }
         int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
         hipLaunchKernelGGL(g4_geglu_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, proj, B, act, I, aq_of(m),
                            ad_of(m, B, I));
-        if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, B, st)) return rc;
+        if (int rc = g4_linear(m, L.lin[VMX_L_DOWN], act, out, H, B, st)) return rc;
         if (tp)
             if (int rc = g4_tp_reduce(m, out, B, H, st)) return rc;
         pending = out;
@@ -813,10 +854,10 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         pending_scalar = (const uint16_t *)L.scalar.p;
         if (L.ple) {   // apply_ple (:1663-1683): h += norm(per_layer_projection(gelu_tanh(gate(h)) * pli[layer])), before the scalar
             launch_norm(st, B, h, x, pending, pending_w, nullptr, nullptr, c.rms_norm_eps, H, aq_of(m), ad_of(m, B, H));
-            if (int rc = mmvq(m, L.lin[VMX_L_PLE_GATE], proj, P, B, st)) return rc;
+            if (int rc = g4_linear(m, L.lin[VMX_L_PLE_GATE], x, proj, P, B, st)) return rc;
             hipLaunchKernelGGL(g4_ple_gate_kernel, dim3((unsigned)(((int64_t)B * P / 8 + 255) / 256)), dim3(256), 0, st, proj,
-                               (const uint16_t *)m->pli.p + (size_t)li * P, (int64_t)LP, B, P, aq_of(m), ad_of(m, B, P));
-            if (int rc = mmvq(m, L.lin[VMX_L_PLE_PROJ], out, H, B, st)) return rc;
+                               (const uint16_t *)m->pli.p + (size_t)li * P, (int64_t)LP, B, P, act, aq_of(m), ad_of(m, B, P));
+            if (int rc = g4_linear(m, L.lin[VMX_L_PLE_PROJ], act, out, H, B, st)) return rc;
             pending_w = (const uint16_t *)L.post_ple_norm.p;
         }
     }
@@ -909,19 +950,21 @@ extern "C" int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int s
                 c.max_position, c.max_seq_len);
     for (const G4Layer &L : m->layers) VMX_REQUIRE(L.ready(), "gemma4_prefill: weights not fully loaded");
     VMX_REQUIRE(m->cfg.hidden_size_per_layer_input == 0 || m->ple_model_proj.loaded, "gemma4_prefill: per_layer_model_projection not loaded");
-    // The prompt path walks 16 rows at a time through all layers, so a calibrating first write sees 16 rows; the reference's
-    // first write sees the whole chunk.  Identical scales need the chunk to fit one pass.
-    if (c.kv_cache_dtype == VMX_KV_FP8_E4M3 && q_len > 16)
+    // The prompt path walks one pass of rows at a time through all layers (16 rows, or max_prefill_tokens when that is larger), so
+    // a calibrating first write sees one pass; the reference's first write sees the whole chunk.  Identical scales need the chunk
+    // to fit one pass.
+    const int pass = c.max_prefill_tokens > 16 ? c.max_prefill_tokens : 16;
+    if (c.kv_cache_dtype == VMX_KV_FP8_E4M3 && q_len > pass)
         for (const G4Layer &L : m->layers)
             VMX_REQUIRE(L.kv_shared || L.kv_calibrated,
-                        "gemma4_prefill: FP8 KV scales are not calibrated yet; first-write calibration takes a chunk of at most 16 tokens "
-                        "(got %d): prefill the first 16 tokens separately or load explicit scales", q_len);
+                        "gemma4_prefill: FP8 KV scales are not calibrated yet; first-write calibration takes a chunk of at most %d tokens "
+                        "(one pass; got %d): prefill the first pass separately or load explicit scales", pass, q_len);
     hipStream_t st = vmx_stream(stream);
     int32_t *pos = (int32_t *)m->positions.p;
     int last_rows = 0;
-    for (int r0 = 0; r0 < q_len; r0 += 16) {
-        const int rows = q_len - r0 < 16 ? q_len - r0 : 16;
-        hipLaunchKernelGGL(g4_iota_kernel, dim3(1), dim3(64), 0, st, pos, seqlen_offset + r0, rows);
+    for (int r0 = 0; r0 < q_len; r0 += pass) {
+        const int rows = q_len - r0 < pass ? q_len - r0 : pass;
+        hipLaunchKernelGGL(g4_iota_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, pos, seqlen_offset + r0, rows);
         if (int rc = g4_run_layers(m, input_ids + r0, pos, slot_mapping + r0, block_table, nullptr, rows, 0, 0, seqlen_offset + r0, st)) return rc;
         last_rows = rows;
     }

@@ -55,6 +55,77 @@ __global__ __launch_bounds__(256) void iq_dequant_kernel(const uint8_t *__restri
     }
 }
 
+// Dequantise straight into the two bf16 halves of the prompt-sized GEMM (hi = bf16(w), lo = bf16(w - hi)): one thread per
+// 32-weight sub-block as above, but the 64 + 64 bytes a thread produces go through LDS so that the workgroup's 16 KiB of each
+// half leave as whole 16-byte-per-lane contiguous stores (a thread-per-sub-block store pattern touches 64 cache lines per
+// instruction).
+template <int T>
+__global__ __launch_bounds__(256) void iq_dequant_split_kernel(const uint8_t *__restrict__ blocks, uint16_t *__restrict__ hi,
+                                                                uint16_t *__restrict__ lo, int64_t n_blocks) {
+    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
+    __shared__ uint2 sg[SignLut<T>::N];
+    __shared__ __align__(16) uint16_t stage[2][256 * 32];
+    load_tables<T>(cb, sg);
+    const int64_t total = n_blocks * 8;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {   // uniform per workgroup
+        const int64_t s = base + threadIdx.x;
+        if (s < total) {
+            const int64_t blk = s >> 3;
+            const int ib = (int)(s & 7);
+            const uint8_t *b = blocks + blk * IqTraits<T>::TS;
+            const float d = vmx_f16_to_f32((uint16_t)ld16(b));
+            int q[8];
+            SubScale sc;
+            decode_sub<T>(b, ib, cb, sg, q, sc);
+            float db0, db1;
+            if constexpr (T == 17 || T == 22) {
+                db0 = d * (0.5f + (float)sc.ls0) * 0.25f;
+                db1 = d * (0.5f + (float)sc.ls1) * 0.25f;
+            } else if constexpr (T == 18) {
+                db0 = db1 = d * (0.5f + (float)sc.ls0) * 0.5f;
+            } else if constexpr (T == 21) {
+                db0 = db1 = d * (float)(1 + 2 * sc.ls0);
+            } else {
+                db0 = db1 = d * (float)(sc.ls0 - 32);
+            }
+            uint32_t h[16], l[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float db = k < 4 ? db0 : db1;
+                const int w = q[k];
+                uint16_t hh[4], ll[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float v = db * (float)(int8_t)((w >> (8 * j)) & 0xFF);
+                    hh[j] = vmx_f32_to_bf16(v);
+                    ll[j] = vmx_f32_to_bf16(v - vmx_bf16_to_f32(hh[j]));
+                }
+                h[2 * k] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+                h[2 * k + 1] = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+                l[2 * k] = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
+                l[2 * k + 1] = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+            }
+            uint4 *dh = reinterpret_cast<uint4 *>(stage[0] + threadIdx.x * 32), *dl = reinterpret_cast<uint4 *>(stage[1] + threadIdx.x * 32);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                dh[r] = make_uint4(h[4 * r], h[4 * r + 1], h[4 * r + 2], h[4 * r + 3]);
+                dl[r] = make_uint4(l[4 * r], l[4 * r + 1], l[4 * r + 2], l[4 * r + 3]);
+            }
+        }
+        __syncthreads();
+        const int64_t live = (total - base < 256 ? total - base : 256) * 4;   // 16-byte pieces of this chunk per half
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = r * 256 + threadIdx.x;
+            if (i < live) {
+                reinterpret_cast<uint4 *>(hi + base * 32)[i] = reinterpret_cast<const uint4 *>(stage[0])[i];
+                reinterpret_cast<uint4 *>(lo + base * 32)[i] = reinterpret_cast<const uint4 *>(stage[1])[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ q8_1
 // 8 lanes per 32-value block: one float4 load, one packed int8x4 store per lane.
 __global__ __launch_bounds__(256) void quantize_q8_1_kernel(const float *__restrict__ x, int8_t *__restrict__ aq,
@@ -515,6 +586,16 @@ extern "C" int vmx_iq_dequantize_f32(int ggml_type, const void *blocks, float *o
     IQ_DISPATCH(ggml_type, CALL)
 #undef CALL
     VMX_CHECK_LAUNCH("iq_dequantize");
+    return VMX_OK;
+}
+
+int vmx_iq_dequantize_split_bf16(int ggml_type, const void *blocks, uint16_t *hi, uint16_t *lo, int64_t n_blocks, hipStream_t st) {
+    if (n_blocks <= 0) return VMX_OK;
+    const int grid = grid_for(n_blocks * 8, 256, 16384);
+#define CALL(T) hipLaunchKernelGGL((iq_dequant_split_kernel<T>), dim3(grid), dim3(256), 0, st, (const uint8_t *)blocks, hi, lo, n_blocks)
+    IQ_DISPATCH(ggml_type, CALL)
+#undef CALL
+    VMX_CHECK_LAUNCH("iq_dequantize_split");
     return VMX_OK;
 }
 

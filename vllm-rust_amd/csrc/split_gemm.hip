@@ -1,0 +1,106 @@
+// Prompt-sized linears over GGUF I-quant weights.  Beyond IQ_GEMV_MAX_M = 16 rows the reference dequantises the whole weight to
+// dense f32 and runs one f32 GEMM on the f32 activations (IqLinear::forward_inner, crates/core/src/quantization/gguf/mod.rs:346-365):
+// no q8_1 rounding of the activations on that path.  gfx950 has no fast f32 matrix instruction, but the activations are bf16 values
+// and a dequantised weight w = d * scale * grid needs at most ~16 mantissa bits, so w is split as hi = bf16(w), lo = bf16(w - hi) and
+// the product is two bf16 MFMA passes into one f32 accumulator: x * hi and x * lo are exact in f32, and hi + lo reproduces w to
+// 2^-17 relative -- below the f32 summation noise of a dot over thousands of terms.
+#include "vmx_internal.h"
+#include "vmx_kernels.h"
+
+namespace {
+
+typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
+
+// C[m, n] (f32, row stride ldc) = sum_k A[m,k] * (Bhi[n,k] + Blo[n,k]);  A [M, K] bf16, Bhi / Blo [N, K] bf16, K % 32 == 0.
+// Workgroup = 4 waves side by side on a 64 x 256 tile of C; a wave owns 64 rows x 64 columns = 4 x 4 accumulators of
+// v_mfma_f32_16x16x32_bf16.  Lane (i = lane & 15, g = lane >> 4) feeds row i of a 16-row block with the 8 values k0 + 8 g .. + 7,
+// read straight from global memory as one 16-byte load per operand block (the four waves of a workgroup re-read the A rows
+// through the vector L1).  No LDS, no barriers: out-of-range rows and columns read a clamped address and are not stored.
+template <bool LO>
+__global__ __launch_bounds__(256) void split_gemm_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Bhi,
+                                                          const uint16_t *__restrict__ Blo, float *__restrict__ C, int M, int N, int K,
+                                                          int ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 256 + wave * 64;
+    if (n0 >= N) return;
+    int64_t arow[4], brow[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        arow[b] = (int64_t)min(m0 + b * 16 + i, M - 1) * K + 8 * g;
+        brow[b] = (int64_t)min(n0 + b * 16 + i, N - 1) * K + 8 * g;
+    }
+    sg_f32x4 acc[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) acc[rb][cb] = sg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        uint4 a[4], bh[4], bl[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            a[b] = *reinterpret_cast<const uint4 *>(A + arow[b] + k0);
+            bh[b] = *reinterpret_cast<const uint4 *>(Bhi + brow[b] + k0);
+            if (LO) bl[b] = *reinterpret_cast<const uint4 *>(Blo + brow[b] + k0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, a[rb]), __builtin_bit_cast(vmx_bf16x8, bh[cb]),
+                                                                      acc[rb][cb], 0, 0, 0);
+                if (LO)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, a[rb]),
+                                                                          __builtin_bit_cast(vmx_bf16x8, bl[cb]), acc[rb][cb], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            const int col = n0 + cb * 16 + i;
+            if (col >= N) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = m0 + rb * 16 + 4 * g + j;
+                if (row < M) C[(int64_t)row * ldc + col] = acc[rb][cb][j];
+            }
+        }
+}
+
+}  // namespace
+
+size_t vmx_iq_gemm_workspace(int N, int K) { return (size_t)N * K * 4; }   // the two bf16 halves
+
+// workspace -> (hi bf16 [N*K], lo bf16 [N*K])
+int vmx_iq_dequant_split(int ggml_type, const void *blocks, void *workspace, int N, int K, hipStream_t st) {
+    const int64_t n = (int64_t)N * K;
+    uint16_t *hi = (uint16_t *)workspace, *lo = hi + n;
+    return vmx_iq_dequantize_split_bf16(ggml_type, blocks, hi, lo, n / 256, st);
+}
+
+// C[:, 0..N) (row stride ldc) = A @ (hi + lo)^T with the halves a previous vmx_iq_dequant_split left in `workspace`
+int vmx_split_gemm_f32(const uint16_t *A, const void *workspace, float *C, int M, int N, int K, int ldc, hipStream_t st) {
+    const int64_t n = (int64_t)N * K;
+    const uint16_t *hi = (const uint16_t *)workspace, *lo = hi + n;
+    hipLaunchKernelGGL(split_gemm_kernel<true>, dim3((N + 255) / 256, (M + 63) / 64), dim3(256), 0, st, A, hi, lo, C, M, N, K, ldc);
+    VMX_CHECK_LAUNCH("split_gemm");
+    return VMX_OK;
+}
+
+extern "C" size_t vmx_iq_gemm_workspace_bytes(int n_out, int n_in) {
+    return n_out > 0 && n_in > 0 ? vmx_iq_gemm_workspace(n_out, n_in) : 0;
+}
+
+extern "C" int vmx_iq_gemm_f32(int ggml_type, const void *blocks, const uint16_t *x, float *y, int m, int n_out, int n_in, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(blocks && x && y && workspace, "iq_gemm: null pointer");
+    VMX_REQUIRE(vmx_iq_type_size(ggml_type) > 0, "iq_gemm: ggml type %d is not a supported I-quant", ggml_type);
+    VMX_REQUIRE(m >= 0 && n_out > 0 && n_in > 0 && n_in % 256 == 0, "iq_gemm: n_in (%d) must be a positive multiple of 256", n_in);
+    VMX_REQUIRE(workspace_bytes >= vmx_iq_gemm_workspace(n_out, n_in), "iq_gemm: workspace of %zu bytes, need %zu", workspace_bytes,
+                vmx_iq_gemm_workspace(n_out, n_in));
+    if (m == 0) return VMX_OK;
+    hipStream_t st = vmx_stream(stream);
+    if (int rc = vmx_iq_dequant_split(ggml_type, blocks, workspace, n_out, n_in, st)) return rc;
+    return vmx_split_gemm_f32(x, workspace, y, m, n_out, n_in, n_out, st);
+}

@@ -102,4 +102,9 @@ int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_
                                   float scale, hipStream_t st);
 
 // dense_kernels.hip
+// split_gemm.hip: prompt-sized I-quant linear = dequantise once (bf16 hi/lo halves in `workspace`), then C = A @ W^T in f32
+size_t vmx_iq_gemm_workspace(int N, int K);
+int vmx_iq_dequantize_split_bf16(int ggml_type, const void *blocks, uint16_t *hi, uint16_t *lo, int64_t n_blocks, hipStream_t st);
+int vmx_iq_dequant_split(int ggml_type, const void *blocks, void *workspace, int N, int K, hipStream_t st);
+int vmx_split_gemm_f32(const uint16_t *A, const void *workspace, float *C, int M, int N, int K, int ldc, hipStream_t st);
 int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st);

@@ -61,6 +61,7 @@ class Gemma4Spec:
     hidden_size_per_layer_input: int = 0     # P of the per-layer inputs (E2B / E4B variants), 0 = none
     vocab_size_per_layer_input: int = 0
     ple_embed_ggml_type: int = 0             # embed_tokens_per_layer: 0 bf16, else a K-quant type id
+    max_prefill_tokens: int = 0              # rows per prefill pass; > 16 switches prompt passes to the dequant + GEMM linear
     tp_size: int = 1                         # with tp_size > 1 the head counts and intermediate_size are this rank's shares
     tp_rank: int = 0
 
@@ -184,7 +185,7 @@ class QuantizedGemma4ForCausalLM:
                            s.head_dim_sliding, s.head_dim_full, s.kv_heads_sliding, s.kv_heads_full, s.sliding_window,
                            s.head_dim_sliding, s.rot_dim_full(), s.max_position, s.kv_cache_dtype, s.block_size, s.num_blocks,
                            s.max_batch, s.max_seq_len, s.final_logit_softcap, s.embed_ggml_type, s.hidden_size_per_layer_input,
-                           s.vocab_size_per_layer_input, s.ple_embed_ggml_type, s.tp_size if s.tp_size > 1 else 0, s.tp_rank)
+                           s.vocab_size_per_layer_input, s.ple_embed_ggml_type, s.tp_size if s.tp_size > 1 else 0, s.tp_rank, s.max_prefill_tokens)
         self._comm = None
         flags = (C.c_int * s.num_layers)(*s.layer_flags())
         self._h = C.c_void_p()

@@ -11,7 +11,7 @@ import torch
 from ._lib import check, lib
 
 __all__ = [
-    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_subdots_packed",
+    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_subdots_packed",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
@@ -85,6 +85,16 @@ def iq_matmul(ggml_type: int, w: torch.Tensor, x: torch.Tensor, n_out: int, n_in
     ws = workspace if workspace is not None else torch.empty(max(need, 1), dtype=torch.uint8, device=w.device)
     y = torch.empty((m, n_out), dtype=torch.float32, device=w.device)
     check(lib.vmx_iq_matmul_f32(ggml_type, _ptr(w), _ptr(x), _ptr(y), n_out, n_in, m, _ptr(ws), ws.numel(), _stream()))
+    return y
+
+
+def iq_gemm(ggml_type: int, blocks: torch.Tensor, x: torch.Tensor, n_out: int) -> torch.Tensor:
+    """Prompt-sized I-quant linear (more than 16 rows): x bf16 [m, n_in] times the dequantised weight, f32 [m, n_out]."""
+    m, n_in = x.shape
+    need = lib.vmx_iq_gemm_workspace_bytes(n_out, n_in)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    y = torch.empty((m, n_out), dtype=torch.float32, device=x.device)
+    check(lib.vmx_iq_gemm_f32(ggml_type, _ptr(blocks), _ptr(x), _ptr(y), m, n_out, n_in, _ptr(ws), need, _stream()))
     return y
 
 
