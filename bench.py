@@ -193,26 +193,41 @@ def gemma4_secondary(prompt, steps, warmup):
             g.replay()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # roofline of the MMVQ kernel
-        launches, alg = model.mmvq_info(1)
-        model.mmvq_only(1)
-        lg = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(lg, stream=side):
+        # roofline of the MMVQ kernels: each kind of projection alone (and all four), replayed back to back from a graph between
+        # two HIP events on the stream they run on
+        def time_mmvq(mask):
+            model.mmvq_select(mask)
+            launches, alg = model.mmvq_info(1)
             model.mmvq_only(1)
-        reps = max(8, steps // 4)
-        lg.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(side)
-        for _ in range(reps):
+            lg = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(lg, stream=side):
+                model.mmvq_only(1)
+            reps = max(8, steps // 4)
             lg.replay()
-        e1.record(side)
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    achieved = alg / us / 1e3
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(reps):
+                lg.replay()
+            e1.record(side)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            del lg
+            return launches, alg, us
+
+        kinds = {}
+        for name, mask in (("qkv", 1), ("o_proj", 2), ("gate_up", 4), ("down_proj", 8), ("all", 15)):
+            launches, alg, us = time_mmvq(mask)
+            kinds[name] = {"launches_per_step": launches, "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches),
+                           "GB_s": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_step": round(us, 1)}
+        model.mmvq_select(15)
+    dom = max(("qkv", "o_proj", "gate_up", "down_proj"), key=lambda k: kinds[k]["us_per_step"])
+    mmvq_kernel = {"qkv": "iq_mmvq_multi_kernel (q|k|v, three I-quant types in one launch)", "o_proj": "iq_mmvq_kernel (o_proj)",
+                   "gate_up": "iq_pk_mmvq_kernel (gate|up, packed 8-row units, codebook + sign tables in LDS)",
+                   "down_proj": "iq_mmvq_pipe_kernel (down_proj, rows split over 4 waves)"}
     traffic = None
-    try:   # HBM bytes per launch from the committed PMC passes of the same kernels on the same shapes (tools/pmc_mmvq.py)
-        traffic = json.loads((ROOT / "profiles" / "r01_pmc_traffic_iq_mmvq.json").read_text())["hbm_bytes_per_launch"]
+    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_mmvq.py), when one exists for it
+        traffic = json.loads((ROOT / "profiles" / "r02_pmc_traffic_iq_mmvq.json").read_text())[dom]["hbm_bytes_per_launch"]
     except Exception:
         pass
     wbytes = model.iq_weight_bytes()
@@ -232,9 +247,10 @@ def gemma4_secondary(prompt, steps, warmup):
                                    "token embedding), 48 layers (40 sliding 8x256 window 1024, 8 full 1x512), FP8 e4m3 KV, soft-cap 30",
                        "weights": "seeded random-init blocks of the architecture", "execution": "one hipGraph per step"},
             "weight_bytes_per_token": wbytes + embed_bytes,
-            "roofline": {"bound": "hbm", "kernel": "iq_pk_mmvq_kernel (packed, large one-row launches) / iq_mmvq_multi_kernel / iq_mmvq_pipe_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "launches_per_step": launches,
-                         "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches)}}
+            "roofline": {"bound": "hbm", "kernel": mmvq_kernel[dom], "achieved": kinds[dom]["GB_s"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kinds[dom]["frac"], "traffic": traffic,
+                         "launches_per_step": kinds[dom]["launches_per_step"], "avg_launch_us": kinds[dom]["avg_launch_us"],
+                         "alg_bytes_per_launch": kinds[dom]["alg_bytes_per_launch"], "mmvq": kinds}}
 
 
 def exl3_secondary(reps=8):
@@ -507,6 +523,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the GGUF I-quant (Gemma-4-12B-shaped) secondary measurement")
     ap.add_argument("--no-moe", action="store_true", help="skip the Mixtral-8x7B-shaped fused-MoE secondary measurement")
+    ap.add_argument("--workload", choices=["all", "qwen3", "gemma4", "mixtral", "exl3"], default="all",
+                    help="profiling aid: run ONE workload alone (qwen3 = the primary without secondaries; the others print only "
+                         "their own block), so that a kernel trace of the run holds that workload's launches only")
     ap.add_argument("--tp", action="store_true",
                     help="with --gpus N > 1: ONE model tensor-parallel over the N ranks (RCCL all-reduce after every row-parallel "
                          "linear, strong scaling) instead of N independent replicas")
@@ -527,6 +546,18 @@ def main():
     vmx.init(local_rank)
 
     K_steps, W_steps = args.steps, args.warmup
+    if args.workload in ("gemma4", "mixtral", "exl3"):   # one secondary alone (single GPU)
+        if args.workload == "gemma4":
+            blk = gemma4_secondary(args.prompt, max(16, K_steps // 2), W_steps)
+        elif args.workload == "mixtral":
+            blk = mixtral_secondary(args.prompt, max(16, K_steps // 2), W_steps)
+        else:
+            blk = exl3_decode_secondary(args.prompt, min(args.steps, 64), args.warmup)
+            blk["linears_only"] = exl3_secondary()
+        print(json.dumps(blk), flush=True)
+        return
+    if args.workload == "qwen3":
+        args.no_secondary = True
     total_tokens = args.prompt + W_steps + 2 * K_steps + 8
     block_size = 16
     n_blocks = (total_tokens + block_size - 1) // block_size + 1

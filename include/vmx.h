@@ -105,6 +105,13 @@ int vmx_iq_pack(int ggml_type, const void *raw, void *packed, int n_out, int n_i
 int vmx_iq_mmvq_packed_f32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, float *y, int n_out, int n_in,
                            void *stream);
 
+/* The MLP front half of a GGUF Gemma layer in one launch (gemma4_quantized.rs:1390-1400: gate_proj and up_proj through
+ * IqLinear::forward, then gelu(gate) * up): act[i] = bf16(bf16(gelu_erf(bf16(gate_i))) * bf16(up_i)) with gate = W_gate x and
+ * up = W_up x as vmx_iq_mmvq_packed_f32 computes them (same bits), plus q8_1(act) (act_q int8 [inter], act_d f32 [inter / 32])
+ * for the down projection.  Both weights packed, of the same type; n_in <= 4096, inter % 64 == 0; act_q / act_d must not alias aq / ad. */
+int vmx_iq_mmvq_packed_geglu_bf16(int ggml_type, const void *gate_packed, const void *up_packed, const int8_t *aq, const float *ad,
+                                  uint16_t *act, int8_t *act_q, float *act_d, int inter, int n_in, void *stream);
+
 /* Parity aid: the integer sub-dots of the packed kernel, out[o * (n_in/32) + g] (the layout of vmx_iq_subdots_i32 at m = 1). */
 int vmx_iq_subdots_packed_i32(int ggml_type, const void *packed, const int8_t *aq, int32_t *out, int n_out, int n_in, void *stream);
 
@@ -637,6 +644,9 @@ int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_by
 int vmx_gemma4_prefill(vmx_gemma4 *m, const int32_t *input_ids, int seqlen_offset, const int32_t *slot_mapping,
                        const int32_t *block_table, int q_len, int32_t *out_id_last, uint16_t *logits_last, void *stream);
 int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream);
+/* Measurement aid (no reference counterpart): which projections vmx_gemma4_mmvq_only launches and vmx_gemma4_mmvq_info counts
+ * (bit 0 q|k|v, 1 o_proj, 2 gate|up, 3 down_proj; default 15 = all), as vmx_qwen3_linears_select. */
+int vmx_gemma4_mmvq_select(vmx_gemma4 *m, int mask);
 /* Parity aid: 0 = residual stream h, 1 = final normed x (bf16 [batch, hidden]). */
 int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t bytes, void *stream);
 /* Parity aid: as vmx_qwen3_debug_kv, for a layer's cache in its own geometry (sliding or full). */

@@ -231,3 +231,45 @@ def test_iq_gemm_prompt_sized_rows(gpu, name, m, n_out, n_in):
     assert np.isfinite(got).all()
     assert rel_l2(got, ref) <= 2e-5
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name,tid,ts", PACKED_TYPES)
+@pytest.mark.parametrize("inter,n_in", [(64, 256), (192, 3840), (15360, 3840), (1024, 4096)])
+def test_packed_gate_up_geglu_fused_matches_separate_launches(gpu, name, tid, ts, inter, n_in):
+    """gate|up MMVQ + GeGLU + q8_1 in one launch: the activation bits are those of the two separate packed launches followed by
+    the GeGLU of Gemma's MLP (bf16 roundings as in gemma4_quantized.rs:1390-1400, restated in tests/model_oracle.py), and its
+    q8_1 form is bit for bit the oracle quantiser's on that activation (iq/mod.rs:663-682).  15360 x 3840 is the 12B layer."""
+    from oracle import oracle as orc
+    from scipy.special import erf
+    vmx, torch = gpu
+    rng = np.random.default_rng(inter + n_in + tid)
+    wg_raw = random_iq_blocks(rng, ts, inter * (n_in // 256))
+    wu_raw = random_iq_blocks(rng, ts, inter * (n_in // 256))
+    x = (rng.standard_normal((1, n_in)) * 0.02).astype(np.float32)   # gate values of order one, where gelu bends
+    aq, ad = orc.quantize_q8_1(x)
+    aqd, add = _dev(torch, aq), _dev(torch, ad)
+    pg = vmx.iq_pack(tid, _dev(torch, wg_raw), inter, n_in)
+    pu = vmx.iq_pack(tid, _dev(torch, wu_raw), inter, n_in)
+    gate = vmx.iq_mmvq_packed(tid, pg, aqd, add, inter, n_in).cpu().numpy().reshape(-1)
+    up = vmx.iq_mmvq_packed(tid, pu, aqd, add, inter, n_in).cpu().numpy().reshape(-1)
+    act, act_q, act_d = vmx.iq_mmvq_packed_geglu(tid, pg, pu, aqd, add, inter, n_in)
+    torch.cuda.synchronize()
+    act = act.cpu().numpy().view(np.uint16)
+    g = orc.bf16_to_f32(orc.f32_to_bf16(gate))
+    u = orc.bf16_to_f32(orc.f32_to_bf16(up))
+    # gelu_erf with f32 steps (1 + erf underflows to 0 below about -5.5, as in the kernel and in the reference's f32 erf)
+    e32 = erf((g * np.float32(0.70710678118654752)).astype(np.float64)).astype(np.float32)
+    ge = orc.bf16_to_f32(orc.f32_to_bf16((np.float32(0.5) * g) * (np.float32(1.0) + e32)))
+    want = orc.f32_to_bf16((ge * u).astype(np.float32))
+    # erff on the GPU against double erf: an absolute error of ~2e-7 in erf is 0.5 |g| 2e-7 in gelu (1 + erf cancels for
+    # negative g), on top of one bf16 ulp each for the gelu rounding and the product rounding
+    gd, ud = g.astype(np.float64), u.astype(np.float64)
+    got_f, want_f = orc.bf16_to_f32(act).astype(np.float64), orc.bf16_to_f32(want).astype(np.float64)
+    tol = np.abs(ud) * (2.0 ** -8 * np.abs(ge.astype(np.float64)) + np.abs(gd) * 2e-7) * 1.01 + 2.0 ** -8 * np.abs(want_f) + 1e-30
+    bad = np.abs(got_f - want_f) > tol
+    assert not bad.any(), (np.flatnonzero(bad)[:4], gd[bad][:4], ud[bad][:4], got_f[bad][:4], want_f[bad][:4])
+    assert (act != want).mean() <= 0.02
+    # q8_1 of exactly the activation the kernel wrote
+    wq, wd = orc.quantize_q8_1(orc.bf16_to_f32(act).reshape(1, inter))
+    assert np.array_equal(act_q.cpu().numpy().reshape(-1), wq.reshape(-1))
+    assert np.array_equal(act_d.cpu().numpy().reshape(-1), wd.reshape(-1))

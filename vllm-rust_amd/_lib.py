@@ -44,6 +44,7 @@ _SIGS = {
     "vmx_iq_packed_bytes": (_sz, [_i, _i, _i]),
     "vmx_iq_pack": (_i, [_i, _p, _p, _i, _i, _p]),
     "vmx_iq_mmvq_packed_f32": (_i, [_i, _p, _p, _p, _p, _i, _i, _p]),
+    "vmx_iq_mmvq_packed_geglu_bf16": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "vmx_debug_iq_packed_stamps": (_i, [_p]),
     "vmx_iq_subdots_packed_i32": (_i, [_i, _p, _p, _p, _i, _i, _p]),
     "vmx_gather_dequant_q6k_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -160,6 +161,7 @@ _SIGS = {
     "vmx_gemma4_mmvq_info": (_i, [_p, _i, _p, _p]),
     "vmx_gemma4_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "vmx_gemma4_mmvq_only": (_i, [_p, _i, _p]),
+    "vmx_gemma4_mmvq_select": (_i, [_p, _i]),
     "vmx_gemma4_debug_read": (_i, [_p, _i, _p, _sz, _p]),
     "vmx_gemma4_set_comm": (_i, [_p, _p]),
     "vmx_gemma4_kv_scales_reset": (_i, [_p, _f, _p]),

@@ -362,7 +362,8 @@ struct vmx_gemma4 {
     vmx_gemma4_config cfg;
     std::vector<G4Layer> layers;
     Buf embed, final_norm, cos_sin_s, cos_sin_f;
-    Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8, positions;
+    Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8, q8b, positions;
+    void *q8_alt = nullptr;   // non-null while a linear reads its q8_1 activations from q8b (written by the fused gate|up + GeGLU launch)
     float embed_scale = 1.f;
     // per-layer inputs (hidden_size_per_layer_input > 0): embed_tokens_per_layer, per_layer_model_projection and its norm, and the
     // step's buffers [rows][layers * P]: gathered embedding rows, projection output, combined inputs
@@ -372,14 +373,15 @@ struct vmx_gemma4 {
     float kv_headroom = 1.5f;   // DEFAULT_KV_HEADROOM_FACTOR (kv_cache/quantization.rs:108)
     Buf gemm_ws;                // dequantised weight of one projection (f32 + bf16 halves) for passes of more than 16 rows
     Buf kv_stage;               // bf16 K | V rows of one pass, used by an FP8 cache's first (calibrating) write
+    int mmvq_mask = 15;         // measurement: which projections vmx_gemma4_mmvq_only launches (1 q|k|v, 2 o, 4 gate|up, 8 down)
     IqLin ple_model_proj;
     Buf ple_embed, ple_proj_norm, ple_e, ple_p, pli;
     float ple_embed_scale = 1.f, ple_proj_scale = 1.f, ple_input_scale = 1.f;
 };
 
 namespace {
-int8_t *aq_of(vmx_gemma4 *m) { return (int8_t *)m->q8.p; }
-float *ad_of(vmx_gemma4 *m, int tokens, int k) { return (float *)((char *)m->q8.p + (((size_t)tokens * k + 255) & ~(size_t)255)); }
+int8_t *aq_of(vmx_gemma4 *m) { return (int8_t *)(m->q8_alt ? m->q8_alt : m->q8.p); }
+float *ad_of(vmx_gemma4 *m, int tokens, int k) { return (float *)((char *)aq_of(m) + (((size_t)tokens * k + 255) & ~(size_t)255)); }
 
 // Projections that share the q8_1 activations (1..3 of them: q|k|v, gate|up, or a single one), outputs at y + off[i]
 int mmvq_group(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, float *y, int ldy, int tokens, hipStream_t st) {
@@ -633,6 +635,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         kmax = (size_t)max_nq > kmax ? (size_t)max_nq : kmax;
         kmax = (size_t)P > kmax ? (size_t)P : kmax;
         TRY(m->q8.alloc(R * kmax + 256 + R * (kmax / 32) * 4));
+        TRY(m->q8b.alloc(kmax + 256 + (kmax / 32) * 4));   // one row: the fused gate|up launch reads q8 and writes this
     }
     TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, max_hd, c.max_seq_len)));
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
@@ -657,7 +660,7 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     m->ple_model_proj.packed.release();
     for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage, &m->red_bf16, &m->keys, &m->gemm_ws}) b->release();
     for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
-                   &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8})
+                   &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8, &m->q8b})
         b->release();
     delete m;
 }
@@ -838,15 +841,30 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, out, (const uint16_t *)L.post_attn_ln.p, nullptr, (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, H,
                     aq_of(m), ad_of(m, B, H));
-        {
+        const VmxMmvqSeg gate_pk = {L.lin[VMX_L_GATE].packed.p, L.lin[VMX_L_GATE].ggml_type, L.lin[VMX_L_GATE].out_features, 0};
+        const VmxMmvqSeg up_pk = {L.lin[VMX_L_UP].packed.p, L.lin[VMX_L_UP].ggml_type, L.lin[VMX_L_UP].out_features, 0};
+        if (B == 1 && vmx_iq_packed_geglu_ok(&gate_pk, &up_pk, H, B)) {
+            // one launch: both projections, the GeGLU and q8_1 of the result.  It reads q8_1(x) from q8 while other workgroups
+            // already write q8_1(act), so the result goes to q8b and the down projection reads it from there.
+            m->q8_alt = m->q8b.p;
+            const int rc_glu = vmx_iq_mmvq_packed_geglu(&gate_pk, &up_pk, (const int8_t *)m->q8.p,
+                                                        (const float *)((const char *)m->q8.p + (((size_t)H + 255) & ~(size_t)255)), act,
+                                                        aq_of(m), ad_of(m, B, I), H, st);
+            if (rc_glu) {
+                m->q8_alt = nullptr;
+                return rc_glu;
+            }
+        } else {
             const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
             const int offs[2] = {0, I};
             if (int rc = g4_linears(m, gu, offs, 2, x, proj, 2 * I, B, st)) return rc;
+            int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
+            hipLaunchKernelGGL(g4_geglu_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, proj, B, act, I, aq_of(m),
+                               ad_of(m, B, I));
         }
-        int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
-        hipLaunchKernelGGL(g4_geglu_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, proj, B, act, I, aq_of(m),
-                           ad_of(m, B, I));
-        if (int rc = g4_linear(m, L.lin[VMX_L_DOWN], act, out, H, B, st)) return rc;
+        const int rc_down = g4_linear(m, L.lin[VMX_L_DOWN], act, out, H, B, st);
+        m->q8_alt = nullptr;
+        if (rc_down) return rc_down;
         if (tp)
             if (int rc = g4_tp_reduce(m, out, B, H, st)) return rc;
         pending = out;
@@ -1004,17 +1022,29 @@ extern "C" int vmx_gemma4_kv_scales_get(vmx_gemma4 *m, int layer, float *k_scale
     return VMX_OK;
 }
 
+extern "C" int vmx_gemma4_mmvq_select(vmx_gemma4 *m, int mask) {
+    VMX_REQUIRE(m && mask >= 1 && mask <= 15, "gemma4_mmvq_select: mask must be 1..15");
+    m->mmvq_mask = mask;
+    return VMX_OK;
+}
+
 extern "C" int vmx_gemma4_mmvq_info(vmx_gemma4 *m, int batch, int *launches, double *alg_bytes) {
     VMX_REQUIRE(m && launches && alg_bytes, "gemma4_mmvq_info: null pointer");
     double by = 0.0;
     int n = 0;
     const bool multi = batch == 1 && m->cfg.hidden_size <= 4096;   // q|k|v and gate|up go out as one launch each
+    const int mask = m->mmvq_mask;
     for (const G4Layer &L : m->layers) {
         for (int s = 0; s < 7; s++) {
             if ((s == VMX_L_V && L.k_eq_v) || ((s == VMX_L_K || s == VMX_L_V) && L.kv_shared)) continue;
-            by += L.lin[s].alg_bytes(batch);
+            const int kind = s <= VMX_L_V ? 1 : (s == VMX_L_O ? 2 : (s == VMX_L_DOWN ? 8 : 4));
+            if (mask & kind) by += L.lin[s].alg_bytes(batch);
         }
-        n += multi ? 4 : (L.kv_shared ? 5 : (L.k_eq_v ? 6 : 7));
+        const int nqkv = L.kv_shared ? 1 : (L.k_eq_v ? 2 : 3);
+        if (mask & 1) n += multi ? 1 : nqkv;
+        if (mask & 2) n += 1;
+        if (mask & 4) n += multi ? 1 : 2;
+        if (mask & 8) n += 1;
     }
     *launches = n;
     *alg_bytes = by;
@@ -1028,18 +1058,22 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
     hipStream_t st = vmx_stream(stream);
     const vmx_gemma4_config &c = m->cfg;
     float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
-    const int H = c.hidden_size;
+    const int H = c.hidden_size, mask = m->mmvq_mask;
     for (const G4Layer &L : m->layers) {
         const int nseg = L.kv_shared ? 1 : (L.k_eq_v ? 2 : 3), I = L.inter;
         const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd, ntot = NQ + (nseg - 1) * NKV;
         const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
         const int qoffs[3] = {0, NQ, NQ + NKV};
-        if (int rc = mmvq_group(m, qkv, qoffs, nseg, proj, ntot, batch, st)) return rc;
-        if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
+        if (mask & 1)
+            if (int rc = mmvq_group(m, qkv, qoffs, nseg, proj, ntot, batch, st)) return rc;
+        if (mask & 2)
+            if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
         const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
         const int goffs[2] = {0, I};
-        if (int rc = mmvq_group(m, gu, goffs, 2, proj, 2 * I, batch, st)) return rc;
-        if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
+        if (mask & 4)
+            if (int rc = mmvq_group(m, gu, goffs, 2, proj, 2 * I, batch, st)) return rc;
+        if (mask & 8)
+            if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
     }
     return VMX_OK;
 }

@@ -325,12 +325,16 @@ struct PkSeg {
 struct PkArgs {
     PkSeg seg[3];
     int nseg;
+    // GeGLU epilogue (iq_pk_mmvq_kernel<.., GLU = true>): seg[0] = gate, seg[1] = up; outputs of the fused activation
+    uint16_t *glu_act;   // bf16 [inter]
+    int8_t *glu_aq;      // its q8_1 form for the down projection
+    float *glu_ad;
 };
 
 // One wave = one work item = PPW row pairs of one unit (rows 2 PPW c .. 2 PPW (c + 1) - 1 of row group g, K-slice s; item
 // index ((g * (4 / PPW) + c) * S + s).  Workgroup = W waves on consecutive items of one segment (W % S == 0, so the S slices
 // of a row set sit in one workgroup and are combined through LDS in slice order).
-template <int T, int PPW, bool DBG, int ABL = 0>
+template <int T, int PPW, bool DBG, int ABL = 0, bool GLU = false>
 __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const PkSeg &sg, int wg, const int8_t *__restrict__ aq,
                                         const float *__restrict__ ad, int n_in, int S, int32_t *__restrict__ dbg, int issue_barrier) {
     constexpr int TS = Pk<T>::TS, CPU_ = 4 / PPW, NR = 2 * PPW;   // chunks per unit, rows per item
@@ -349,7 +353,8 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
 #endif
     const int nsb = n_in >> 8;
     const int groups = (sg.n_out + PK_ROWS - 1) / PK_ROWS, items = groups * CPU_ * S;
-    const int item = wg * W + wave;
+    // GLU: 16 waves = 8 gate units (waves 0..7) and the 8 up units of the same rows (waves 8..15)
+    const int item = GLU ? wg * 8 + (wave & 7) : wg * W + wave;
     const bool valid = item < items;
     const int ic = valid ? item : items - 1;
     const int slice = ic % S, gc = ic / S, group = gc / CPU_, chunk = gc % CPU_;
@@ -449,7 +454,9 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
     if constexpr (DBG) return;
     int rsel;
     const float z = reduce_rows<NR>(acc, lane, rsel);
-    if (S == 1) {
+    if constexpr (GLU) {
+        if ((lane & 7) == 0) part[wave * 8 + rsel] = valid ? z : 0.f;   // [gate 64 | up 64] of the workgroup's 64 columns
+    } else if (S == 1) {
         const int row = group * PK_ROWS + chunk * NR + rsel;
         if ((lane & 7) == 0 && valid && row < sg.n_out) sg.y[row] = z;
     } else {
@@ -478,28 +485,56 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
     }
 }
 
-template <int PPW, bool DBG, int ABL = 0>
+template <int PPW, bool DBG, int ABL = 0, bool GLU = false>
 __global__ __launch_bounds__(1024) void iq_pk_mmvq_kernel(PkArgs a, const int8_t *__restrict__ aq, const float *__restrict__ ad, int n_in,
                                                            int S, int32_t *__restrict__ dbg, int lds_tables, int issue_barrier) {
     // the only LDS object of the kernel, so the tables start at LDS address 0 and a gather needs no base add
     extern __shared__ __align__(16) unsigned char pk_smem[];
     const int b = blockIdx.x;
-    const int si = (a.nseg > 2 && b >= a.seg[2].wg0) ? 2 : ((a.nseg > 1 && b >= a.seg[1].wg0) ? 1 : 0);
+    int si, wg;
+    if constexpr (GLU) {
+        si = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 9);   // wave-uniform: waves 8..15 work on the up projection
+        wg = b;
+    } else {
+        si = (a.nseg > 2 && b >= a.seg[2].wg0) ? 2 : ((a.nseg > 1 && b >= a.seg[1].wg0) ? 1 : 0);
+        wg = b - a.seg[si].wg0;
+    }
     const PkSeg &sg = a.seg[si];
-    const int wg = b - sg.wg0;
     float *part = reinterpret_cast<float *>(pk_smem + lds_tables);   // [waves][8] slice sums (512 B) behind the tables, then the compact table copy
-    switch (sg.type) {   // workgroup-uniform
-        case 18: pk_body<18, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
-        case 21: pk_body<21, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
-        default: pk_body<22, PPW, DBG, ABL>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
+    switch (GLU ? a.seg[0].type : sg.type) {   // workgroup-uniform (GLU: gate and up share a type)
+        case 18: pk_body<18, PPW, DBG, ABL, GLU>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
+        case 21: pk_body<21, PPW, DBG, ABL, GLU>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
+        default: pk_body<22, PPW, DBG, ABL, GLU>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
+    }
+    if constexpr (GLU) {
+        // act = bf16(bf16(gelu_erf(bf16(gate))) * bf16(up)) and its q8_1 form (two 32-wide blocks), as g4_geglu_kernel computes them
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < 64) {
+            const int col = b * 64 + t;
+            const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(part[t]));
+            const float ge = vmx_bf16_to_f32(vmx_f32_to_bf16(0.5f * gg * (1.0f + erff(gg * 0.70710678118654752f))));
+            const uint16_t rb = vmx_f32_to_bf16(ge * vmx_bf16_to_f32(vmx_f32_to_bf16(part[64 + t])));
+            const float r = vmx_bf16_to_f32(rb);
+            float amax = fabsf(r);
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            const float d = amax / 127.0f;
+            const int q = amax != 0.0f ? (int)roundf(r / d) : 0;
+            if (col < a.seg[0].n_out) {
+                a.glu_act[col] = rb;
+                a.glu_aq[col] = (int8_t)q;
+                if ((t & 31) == 0) a.glu_ad[col >> 5] = d;
+            }
+        }
     }
 }
 
-template <int PPW, bool DBG, int ABL = 0> int pk_launch_ppw(const PkArgs &a, int wgs, int W, int lds, const int8_t *aq, const float *ad, int n_in, int S,
+template <int PPW, bool DBG, int ABL = 0, bool GLU = false> int pk_launch_ppw(const PkArgs &a, int wgs, int W, int lds, const int8_t *aq, const float *ad, int n_in, int S,
                                                int32_t *dbg, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)iq_pk_mmvq_kernel<PPW, DBG, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512 + 8192);
+        hipError_t e = hipFuncSetAttribute((const void *)iq_pk_mmvq_kernel<PPW, DBG, ABL, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512 + 8192);
         if (e != hipSuccess) {
             vmx_set_error("iq_mmvq(packed): hipFuncSetAttribute: %s", hipGetErrorString(e));
             return VMX_ELAUNCH;
@@ -507,7 +542,7 @@ template <int PPW, bool DBG, int ABL = 0> int pk_launch_ppw(const PkArgs &a, int
         attr_set = true;
     }
     static const int issue_barrier = getenv("VMX_IQ_ISSUE_BARRIER") ? atoi(getenv("VMX_IQ_ISSUE_BARRIER")) : 1;
-    hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL>), dim3(wgs), dim3(64 * W), lds + 512 + 8192, st, a, aq, ad, n_in, S, dbg, lds, issue_barrier);
+    hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL, GLU>), dim3(wgs), dim3(64 * W), lds + 512 + 8192, st, a, aq, ad, n_in, S, dbg, lds, issue_barrier);
     VMX_CHECK_LAUNCH("iq_mmvq(packed)");
     return VMX_OK;
 }
@@ -639,6 +674,64 @@ int vmx_iq_mmvq_packed_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq,
             return VMX_EUNSUPPORTED;
         }
     return pk_launch(segs, nseg, aq, ad, y, n_in, nullptr, st);
+}
+
+// Whether the gate|up pair can go through the fused GeGLU launch: one activation row, both tensors packed in the same type,
+// whole rows in one K-slice, 64 columns per workgroup, and a launch large enough for the packed kernel to be the faster one.
+bool vmx_iq_packed_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, int n_in, int m) {
+    static const int off = getenv("VMX_IQ_NO_GEGLU_FUSION") ? atoi(getenv("VMX_IQ_NO_GEGLU_FUSION")) : 0;
+    if (off || gate->ggml_type != up->ggml_type || gate->n_out != up->n_out || gate->n_out % 64) return false;
+    const VmxMmvqSeg both[2] = {*gate, *up};
+    return vmx_iq_packed_preferred(both, 2, n_in, m);
+}
+
+// act[i] = bf16(bf16(gelu_erf(bf16(gate_i))) * bf16(up_i)) with gate = W_gate x, up = W_up x (the q8_1 MMVQ of both, then the
+// GeGLU of Gemma's MLP, gemma4_quantized.rs:1390-1400) and q8_1(act) for the down projection, in one launch.
+int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const int8_t *aq, const float *ad, uint16_t *act, int8_t *aq_out,
+                             float *ad_out, int n_in, hipStream_t st) {
+    if (!vmx_iq_packed_geglu_ok(gate, up, n_in, 1)) {
+        vmx_set_error("iq_mmvq(packed, GeGLU): gate/up pair not eligible (types %d/%d, n_out %d/%d, n_in %d)", gate->ggml_type, up->ggml_type,
+                      gate->n_out, up->n_out, n_in);
+        return VMX_EUNSUPPORTED;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_pk_tables_ready[dev]) {
+        vmx_set_error("iq_mmvq(packed): vmx_init(%d) has not run on this device (it builds the decode tables)", dev);
+        return VMX_EINVAL;
+    }
+    PkArgs a = {};
+    a.nseg = 2;
+    a.seg[0] = PkSeg{(const uint8_t *)gate->w, nullptr, gate->ggml_type, gate->n_out, 0};
+    a.seg[1] = PkSeg{(const uint8_t *)up->w, nullptr, up->ggml_type, up->n_out, 0};
+    a.glu_act = act;
+    a.glu_aq = aq_out;
+    a.glu_ad = ad_out;
+    return pk_launch_ppw<4, false, 0, true>(a, gate->n_out / 64, 16, pk_lds_bytes(gate->ggml_type), aq, ad, n_in, 1, nullptr, st);
+}
+
+extern "C" int vmx_iq_mmvq_packed_geglu_bf16(int ggml_type, const void *gate_packed, const void *up_packed, const int8_t *aq, const float *ad,
+                                             uint16_t *act, int8_t *act_q, float *act_d, int inter, int n_in, void *stream) {
+    VMX_REQUIRE(gate_packed && up_packed && aq && ad && act && act_q && act_d, "iq_mmvq(packed, GeGLU): null pointer");
+    VMX_REQUIRE(pk_supported(ggml_type), "iq_mmvq(packed): ggml type %d has no packed form (IQ3_XXS 18, IQ3_S 21, IQ2_S 22)", ggml_type);
+    VMX_REQUIRE(n_in > 0 && n_in % 256 == 0, "iq_matmul: n_in %d not a multiple of 256", n_in);
+    VMX_REQUIRE(n_in <= 4096, "iq_mmvq(packed, GeGLU): n_in %d beyond one K-slice (4096)", n_in);
+    VMX_REQUIRE(inter > 0 && inter % 64 == 0, "iq_mmvq(packed, GeGLU): intermediate size %d not a multiple of 64", inter);
+    VMX_REQUIRE(act_q != aq && act_d != ad, "iq_mmvq(packed, GeGLU): the q8_1 output must not alias the q8_1 input");
+    VMX_REQUIRE(((uintptr_t)gate_packed & 15) == 0 && ((uintptr_t)up_packed & 15) == 0 && ((uintptr_t)aq & 15) == 0 && ((uintptr_t)ad & 7) == 0,
+                "iq_mmvq(packed): misaligned pointer");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_pk_tables_ready[dev]) {
+        vmx_set_error("iq_mmvq(packed): vmx_init(%d) has not run on this device (it builds the decode tables)", dev);
+        return VMX_EINVAL;
+    }
+    PkArgs a = {};
+    a.nseg = 2;
+    a.seg[0] = PkSeg{(const uint8_t *)gate_packed, nullptr, ggml_type, inter, 0};
+    a.seg[1] = PkSeg{(const uint8_t *)up_packed, nullptr, ggml_type, inter, 0};
+    a.glu_act = act;
+    a.glu_aq = act_q;
+    a.glu_ad = act_d;
+    return pk_launch_ppw<4, false, 0, true>(a, inter / 64, 16, pk_lds_bytes(ggml_type), aq, ad, n_in, 1, nullptr, vmx_stream(stream));
 }
 
 extern "C" int vmx_iq_mmvq_packed_f32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, float *y, int n_out, int n_in,

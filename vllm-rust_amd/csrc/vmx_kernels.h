@@ -96,6 +96,10 @@ int vmx_iq_mmvq_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const 
 bool vmx_iq_packed_supported(int ggml_type);
 bool vmx_iq_packed_preferred(const VmxMmvqSeg *segs_packed, int nseg, int n_in, int m);   // segs[i].w = packed copy or NULL
 int vmx_iq_mmvq_packed_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, hipStream_t st);
+// gate|up MMVQ + GeGLU + q8_1 of the result in one launch (packed tensors of one type, one activation row)
+bool vmx_iq_packed_geglu_ok(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, int n_in, int m);
+int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, const int8_t *aq, const float *ad, uint16_t *act,
+                             int8_t *aq_out, float *ad_out, int n_in, hipStream_t st);
 
 // kquant_kernels.hip
 int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_t *ids, uint16_t *out, int tokens, int dim, int vocab,

@@ -423,6 +423,10 @@ class QuantizedGemma4ForCausalLM:
     def mmvq_only(self, batch: int = 1) -> None:
         check(lib.vmx_gemma4_mmvq_only(self._h, batch, self._stream()))
 
+    def mmvq_select(self, mask: int = 15) -> None:
+        """Which projections mmvq_only launches and mmvq_info counts: 1 q|k|v, 2 o_proj, 4 gate|up, 8 down_proj."""
+        check(lib.vmx_gemma4_mmvq_select(self._h, int(mask)))
+
     def mmvq_info(self, batch: int = 1):
         n, by = C.c_int(), C.c_double()
         check(lib.vmx_gemma4_mmvq_info(self._h, batch, C.byref(n), C.byref(by)))

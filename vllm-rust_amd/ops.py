@@ -11,7 +11,7 @@ import torch
 from ._lib import check, lib
 
 __all__ = [
-    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_subdots_packed",
+    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_mmvq_packed_geglu", "iq_subdots_packed",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
@@ -71,6 +71,18 @@ def iq_mmvq_packed(ggml_type: int, packed: torch.Tensor, aq: torch.Tensor, ad: t
     y = out if out is not None else torch.empty((1, n_out), dtype=torch.float32, device=packed.device)
     check(lib.vmx_iq_mmvq_packed_f32(ggml_type, _ptr(packed), _ptr(aq), _ptr(ad), _ptr(y), n_out, n_in, _stream()))
     return y
+
+
+def iq_mmvq_packed_geglu(ggml_type: int, gate_packed: torch.Tensor, up_packed: torch.Tensor, aq: torch.Tensor, ad: torch.Tensor,
+                         inter: int, n_in: int):
+    """gate|up q8_1 MMVQ + GeGLU + q8_1 of the result in one launch -> (act bf16 bits [inter], act_q int8 [inter], act_d f32 [inter/32])."""
+    dev = gate_packed.device
+    act = torch.empty(inter, dtype=torch.int16, device=dev)
+    act_q = torch.empty(inter, dtype=torch.int8, device=dev)
+    act_d = torch.empty(inter // 32, dtype=torch.float32, device=dev)
+    check(lib.vmx_iq_mmvq_packed_geglu_bf16(ggml_type, _ptr(gate_packed), _ptr(up_packed), _ptr(aq), _ptr(ad), _ptr(act), _ptr(act_q),
+                                            _ptr(act_d), inter, n_in, _stream()))
+    return act, act_q, act_d
 
 
 def iq_subdots_packed(ggml_type: int, packed: torch.Tensor, aq: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
