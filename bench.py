@@ -148,7 +148,7 @@ def cpu_baseline_exl3(budget_s=8.0):
             "sample": f"oracle EXL3 linear [4096 -> 512] at 4.0 bpw x{reps} ({t * 1e3:.1f} ms), scaled by weight count to 36 layers x 7 projections"}
 
 
-def gemma4_secondary(prompt, steps, warmup):
+def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
     """BASELINE.json configs[2]: decode tok/s of a Gemma-4-12B-shaped GGUF model (UD-IQ3_XXS tensor-type mix, Q3_K tied token
     embedding, FP8 e4m3 KV cache with per-layer sliding/full geometry) through the Gemma 4 executor, plus the roofline of
     its dominant kernel (the q8_1 MMVQ): the step's MMVQ launches alone replayed back to back between two HIP events."""
@@ -236,7 +236,8 @@ def gemma4_secondary(prompt, steps, warmup):
     from vllm_rust_amd.gemma4 import GEMMA4_12B_IQ3_MIX
     cpu = None
     try:
-        cpu = cpu_baseline_mmvq(spec, GEMMA4_12B_IQ3_MIX)
+        if cpu_leg:
+            cpu = cpu_baseline_mmvq(spec, GEMMA4_12B_IQ3_MIX)
     except Exception as e:   # the CPU leg must not cost the GPU numbers
         cpu = {"error": repr(e)}
     return {"metric": "decode tok/s (greedy, batch=1), Gemma-4-12B GGUF UD-IQ3_XXS mix + FP8 KV", "cpu_baseline": cpu, "value": round(steps / dt, 2), "unit": "tok/s",
@@ -548,7 +549,7 @@ def main():
     K_steps, W_steps = args.steps, args.warmup
     if args.workload in ("gemma4", "mixtral", "exl3"):   # one secondary alone (single GPU)
         if args.workload == "gemma4":
-            blk = gemma4_secondary(args.prompt, max(16, K_steps // 2), W_steps)
+            blk = gemma4_secondary(args.prompt, max(16, K_steps // 2), W_steps, cpu_leg=not args.no_cpu_baseline)
         elif args.workload == "mixtral":
             blk = mixtral_secondary(args.prompt, max(16, K_steps // 2), W_steps)
         else:

@@ -304,7 +304,9 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
     const int seq_len = seq_lens[seq];
     if (seq_len == 0) return;
     const int eff = (window > 0 && seq_len > window) ? window : seq_len;
-    const int np = (eff + part_tokens - 1) / part_tokens;
+    // part_tokens == 0: the producer dealt the tiles to max_parts balanced ranges (split_decode_attn_kernel; a range without
+    // tokens carries sum 0 and weighs nothing)
+    const int np = part_tokens > 0 ? (eff + part_tokens - 1) / part_tokens : max_parts;
     const int64_t mo = ((int64_t)seq * num_heads + head) * max_parts;
     const float *tp = tmp_out + mo * head_dim;
     const int64_t obase = ((int64_t)seq * num_heads + head) * head_dim;
@@ -336,6 +338,60 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
         const uint16_t vb = vmx_f32_to_bf16(val);
         o[d] = vb;
         if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block (iq_dequant.cu:253-267)
+            const float v = vmx_bf16_to_f32(vb);
+            float amax = fabsf(v);
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            const float dq = amax / 127.0f;
+            aq[obase + d] = amax != 0.0f ? (int8_t)(int)roundf(v / dq) : (int8_t)0;
+            if ((d & 31) == 0) ad[(obase + d) >> 5] = dq;
+        }
+    }
+}
+
+// The same merge for the few balanced ranges of split_decode_attn_kernel (NP <= 8 partitions, every one of them written):
+// all addresses are known at entry, so the partition rows, maxima and sums are requested in one go instead of after the
+// weights (the kernel is a chain of memory round trips and little else).  grid (heads, seqs), block 128, EPT = head_dim / 128.
+template <int NP, int EPT>
+__global__ __launch_bounds__(128) void paged_attn_reduce_small_kernel(uint16_t *__restrict__ out, const float *__restrict__ tmp_out,
+                                                                       const float *__restrict__ exp_sums,
+                                                                       const float *__restrict__ max_logits,
+                                                                       const int32_t *__restrict__ seq_lens, int num_heads,
+                                                                       int8_t *__restrict__ aq, float *__restrict__ ad) {
+    constexpr int HD = 128 * EPT;
+    const int head = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
+    const int64_t mo = ((int64_t)seq * num_heads + head) * NP;
+    const float *tp = tmp_out + mo * HD;
+    float mx[NP], sm[NP], row[NP][EPT];
+    const int seq_len = seq_lens[seq];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        mx[p] = max_logits[mo + p];
+        sm[p] = exp_sums[mo + p];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) row[p][e] = tp[p * HD + tid + 128 * e];
+    }
+    if (seq_len == 0) return;
+    float gmax = -FLT_MAX;
+#pragma unroll
+    for (int p = 0; p < NP; p++) gmax = fmaxf(gmax, mx[p]);
+    float w[NP], gsum = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        w[p] = sm[p] * __expf(mx[p] - gmax);
+        gsum += w[p];
+    }
+    const float inv = 1.0f / (gsum + 1e-6f);
+    const int64_t obase = ((int64_t)seq * num_heads + head) * HD;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; p++) acc += row[p][e] * w[p];
+        const int d = tid + 128 * e;
+        const uint16_t vb = vmx_f32_to_bf16(NP == 1 ? row[0][e] : acc * inv);
+        out[obase + d] = vb;
+        if (aq) {
             const float v = vmx_bf16_to_f32(vb);
             float amax = fabsf(v);
 #pragma unroll
@@ -1033,8 +1089,18 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
 
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
                               int head_dim, int window, hipStream_t st, int8_t *aq, float *ad) {
-    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,
-                       parts->max_logits, seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad);
+    const dim3 grid(num_heads, num_seqs);
+#define SMALL(NP, EPT)                                                                                                                  \
+    hipLaunchKernelGGL((paged_attn_reduce_small_kernel<NP, EPT>), grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,          \
+                       parts->max_logits, seq_lens, num_heads, aq, ad)
+    if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 256) SMALL(4, 2);
+    else if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 128) SMALL(4, 1);
+    else if (parts->part_tokens == 0 && parts->max_parts == 2 && head_dim == 256) SMALL(2, 2);
+    else if (parts->part_tokens == 0 && parts->max_parts == 8 && head_dim == 256) SMALL(8, 2);
+    else
+        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
+                           seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad);
+#undef SMALL
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
 }
@@ -1091,10 +1157,11 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
 
 // ---- decode attention spread over P workgroups per KV head, merged by the consumer (split_decode_attn_kernel)
 // Partition count for a context bound, 0 = not covered.  VMX_SPLIT_ATTN_P overrides the count (measurement), VMX_NO_SPLIT_ATTN=1 switches the path off.
-int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
+static int split_parts_impl(int head_dim, int qpk, int rot_dim, int max_seq_len, int window, bool wide_heads) {
     static const bool off = getenv("VMX_NO_SPLIT_ATTN") && atoi(getenv("VMX_NO_SPLIT_ATTN"));
     static const int p_env = getenv("VMX_SPLIT_ATTN_P") ? atoi(getenv("VMX_SPLIT_ATTN_P")) : 0;
-    if (off || (head_dim != 64 && head_dim != 128) || qpk < 1 || qpk > 8) return 0;
+    const bool hd_ok = head_dim == 64 || head_dim == 128 || (wide_heads && head_dim == 256 && qpk <= 2);
+    if (off || !hd_ok || qpk < 1 || qpk > 8) return 0;
     const int half = rot_dim / 2;
     if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return 0;
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
@@ -1102,7 +1169,19 @@ int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max
     // and the three-launch path (560 vs 530 tok/s at 300 tokens); beyond that the three-launch path with its 64 partitions
     // per sequence wins (2048 tokens: 478 vs 460 tok/s with 8 workgroups here), because the consumer's merge grows with P.
     if (ctx <= 0 || ctx > 1024) return 0;
-    return p_env >= 1 && p_env <= 8 ? p_env : 4;
+    // 256-wide heads (Gemma 4 sliding layers, merged by paged_attn_reduce_small_kernel): 8 workgroups per KV head measured best
+    // (Gemma-4-12B shape, 300-400 tokens: 2 / 4 / 8 workgroups = 297 / 305 / 310 tok/s, three-launch path 295)
+    return p_env >= 1 && p_env <= 8 ? p_env : (head_dim == 256 ? 8 : 4);
+}
+
+int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
+    return split_parts_impl(head_dim, qpk, rot_dim, max_seq_len, window, false);
+}
+
+// As above, also covering 256-wide heads with one or two query heads per KV head (Gemma 4 sliding layers), for callers that
+// merge the partitions with vmx_paged_attention_merge rather than inside a linear's prologue.
+int vmx_split_decode_attention_parts_wide(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
+    return split_parts_impl(head_dim, qpk, rot_dim, max_seq_len, window, true);
 }
 
 size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim) {
@@ -1116,7 +1195,7 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
                                int max_blocks_per_seq, int max_seq_len, int block_size, int window, int kv_dtype, const float *k_scale,
                                const float *v_scale, int v_norm, hipStream_t st) {
     const int qpk = qpk_capacity(num_heads / num_kv_heads);
-    const int P = vmx_split_decode_attention_parts(head_dim, num_heads / num_kv_heads, rot_dim, max_seq_len, window);
+    const int P = split_parts_impl(head_dim, num_heads / num_kv_heads, rot_dim, max_seq_len, window, true);
     VMX_REQUIRE(P > 0 && workspace && out, "split_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head, context %d)",
                 head_dim, num_heads / num_kv_heads, max_seq_len);
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
@@ -1145,6 +1224,10 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
         default: break;                 \
     }
     if (head_dim == 64) { S_QPK(64) } else if (head_dim == 128) { S_QPK(128) }
+    else if (head_dim == 256 && !wide) {   // 8 waves only: the 16-wave form would spill at 128 registers per lane
+        if (qpk == 1) rc = fp8 ? launch_split<256, 1, true, 8>(SARGS) : launch_split<256, 1, false, 8>(SARGS);
+        else if (qpk == 2) rc = fp8 ? launch_split<256, 2, true, 8>(SARGS) : launch_split<256, 2, false, 8>(SARGS);
+    }
 #undef S_QPK
 #undef S_ONE
 #undef SARGS

@@ -637,7 +637,11 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         TRY(m->q8.alloc(R * kmax + 256 + R * (kmax / 32) * 4));
         TRY(m->q8b.alloc(kmax + 256 + (kmax / 32) * 4));   // one row: the fused gate|up launch reads q8 and writes this
     }
-    TRY(m->attn_ws.alloc(vmx_paged_attention_workspace_bytes(B, c.num_heads, max_hd, c.max_seq_len)));
+    {
+        const size_t a = vmx_paged_attention_workspace_bytes(B, c.num_heads, max_hd, c.max_seq_len);
+        const size_t b = vmx_split_decode_attention_workspace_bytes(B, c.num_heads, max_hd);
+        TRY(m->attn_ws.alloc(a > b ? a : b));
+    }
     TRY(m->argmax_ws.alloc(vmx_argmax_workspace_bytes(B, c.vocab_size)));
 #undef TRY
     if (rc) {
@@ -801,7 +805,20 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         uint16_t *stage = (uint16_t *)m->kv_stage.p;
         const bool fused_attn = prefill_offset < 0 && !L.k_eq_v && !L.kv_shared && !first_write &&
                                 vmx_fused_decode_attention_ok(hd, Hq / Hkv, L.rot, max_seq_len, L.window);
-        if (fused_attn) {
+        // sliding layers with 256-wide heads: per-head norms + RoPE + KV write inside the attention workgroups (4 per KV head),
+        // then the merge that also emits q8_1 for o_proj: two launches instead of three
+        const bool split_attn = !fused_attn && prefill_offset < 0 && !L.k_eq_v && !L.kv_shared && !first_write && hd == 256 &&
+                                vmx_split_decode_attention_parts_wide(hd, Hq / Hkv, L.rot, max_seq_len, L.window) > 0;
+        if (split_attn) {
+            VmxAttnParts ap;
+            if (int rc = vmx_split_decode_attention(&ap, m->attn_ws.p, proj, 1, L.k_cache.p, L.v_cache.p, (const uint16_t *)L.q_norm.p,
+                                                    (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
+                                                    (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping,
+                                                    block_tables, seq_lens, 1.0f, B, Hq, Hkv, hd, L.rot, max_blocks_per_seq, max_seq_len,
+                                                    c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, 1, st))
+                return rc;
+            if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
+        } else if (fused_attn) {
             if (int rc = vmx_fused_decode_attention(attn, proj, 1, L.k_cache.p, L.v_cache.p, (const uint16_t *)L.q_norm.p,
                                                     (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
                                                     (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping,

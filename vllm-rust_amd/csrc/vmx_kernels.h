@@ -65,6 +65,7 @@ int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const in
 // attention_kernels.hip: the same work as vmx_fused_decode_attention spread over P workgroups per KV head; the P partition
 // results stay in `workspace` (described by *out) for a consumer that merges them (vmx_int4_gemm_resid_attn)
 int vmx_split_decode_attention_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window);   // 0 = not covered
+int vmx_split_decode_attention_parts_wide(int head_dim, int qpk, int rot_dim, int max_seq_len, int window);   // + 256-wide heads, qpk <= 2
 size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim);
 int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
                                const uint16_t *q_norm_w, const uint16_t *k_norm_w, float eps, const float *cos_sin,
