@@ -148,6 +148,34 @@ def cpu_baseline_exl3(budget_s=8.0):
             "sample": f"oracle EXL3 linear [4096 -> 512] at 4.0 bpw x{reps} ({t * 1e3:.1f} ms), scaled by weight count to 36 layers x 7 projections"}
 
 
+def time_linear_kinds(model, side, B, reps):
+    """Each kind of linear launch of a decode step alone (and all four), captured into a graph on the model's own buffers and
+    replayed back to back between two HIP events on the stream the kernels run on: duration per launch = elapsed / launches."""
+    kinds = {}
+    for name, mask in (("qkv", 1), ("o_proj", 2), ("gate_up", 4), ("down_proj", 8), ("all", 15)):
+        model.linears_select(mask)
+        launches, alg = model.linears_info(B)
+        with torch.cuda.stream(side):
+            model.linears_only(B)
+            lg = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(lg, stream=side):
+                model.linears_only(B)
+            lg.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(reps):
+                lg.replay()
+            e1.record(side)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        del lg
+        kinds[name] = {"launches_per_step": launches, "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches),
+                       "GB_s": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_step": round(us, 1)}
+    model.linears_select(15)
+    return kinds
+
+
 def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
     """BASELINE.json configs[2]: decode tok/s of a Gemma-4-12B-shaped GGUF model (UD-IQ3_XXS tensor-type mix, Q3_K tied token
     embedding, FP8 e4m3 KV cache with per-layer sliding/full geometry) through the Gemma 4 executor, plus the roofline of
@@ -343,6 +371,9 @@ def exl3_decode_secondary(prompt, steps, warmup):
             g.replay()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    # the step's EXL3 linear launches alone, per kind (q|k|v and gate|up are one multi-tensor GEMM each, input Hadamard inside
+    # the GEMM workgroups, output Hadamard in the consumer except for q|k|v)
+    kinds = time_linear_kinds(model, side, 1, max(8, steps // 4))
     H, I = spec.hidden_size, spec.intermediate_size
     nq, nkv = spec.num_heads * spec.head_dim, spec.num_kv_heads * spec.head_dim
     ex = lambda K, N: K * N / 2 + 2 * K + 2 * N
@@ -352,7 +383,10 @@ def exl3_decode_secondary(prompt, steps, warmup):
             "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
             "config": {"workload": "Qwen3-8B-shaped: 36 layers, 252 EXL3 4.0 bpw projections (default codebook), bf16 lm_head and KV",
                        "weights": "seeded random trellis words and sign/scale vectors", "execution": "one hipGraph per step"},
-            "weight_bytes_per_token": int(per_tok), "GBps_weights_only": round(per_tok / (dt / steps) / 1e9, 1)}
+            "weight_bytes_per_token": int(per_tok), "GBps_weights_only": round(per_tok / (dt / steps) / 1e9, 1),
+            "roofline": {"bound": "valu (trellis decode: 7 vector-ALU slots per weight); shown against HBM", "kernel": "exl3_gemm_kernel<4 bpw>",
+                         "achieved": kinds["all"]["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kinds["all"]["frac"], "traffic": None,
+                         "linears": kinds}}
 
 
 def batch_sweep_secondary(prompt, steps, warmup, batches=(1, 4, 8, 16)):
@@ -651,33 +685,7 @@ def main():
     # one the step spends most time in (gate|up), `linears` lists all four and their launch-weighted total.
     roofline = None
     if rank == 0 and not exl3:
-        def time_linears(mask):
-            model.linears_select(mask)
-            launches, alg = model.linears_info(B)
-            with torch.cuda.stream(side):
-                model.linears_only(B)
-                lg = torch.cuda.CUDAGraph()
-                torch.cuda.synchronize()
-                with torch.cuda.graph(lg, stream=side):
-                    model.linears_only(B)
-                reps = max(8, K_steps // 4)
-                lg.replay()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(side)
-                for _ in range(reps):
-                    lg.replay()
-                e1.record(side)
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            del lg
-            return launches, alg, us
-
-        kinds = {}
-        for name, mask in (("qkv", 1), ("o_proj", 2), ("gate_up", 4), ("down_proj", 8), ("all", 15)):
-            launches, alg, us = time_linears(mask)
-            kinds[name] = {"launches_per_step": launches, "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches),
-                           "GB_s": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_step": round(us, 1)}
-        model.linears_select(15)
+        kinds = time_linear_kinds(model, side, B, max(8, K_steps // 4))
         dom = max(("qkv", "o_proj", "gate_up", "down_proj"), key=lambda k: kinds[k]["us_per_step"])
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 cannot run inside this process):
         # committed summary of `rocprofv3 --pmc ... -- python3 tools/pmc_linears.py`, same kernel, same shapes.

@@ -218,6 +218,16 @@ int vmx_fp8_quant_bf16(void *out, float *scales_out, const uint16_t *in, const f
 int vmx_fp8_scaled_mm(void *out, int out_f32, const void *a, const void *b, const float *a_scale, const float *b_scale,
                       const uint16_t *bias, int M, int N, int K, int a_scale_mode, int b_scale_mode, void *stream);
 
+/* GPTQ 8-bit checkpoints.  vmx_gptq_dequant_int8_bf16 replaces gptq_dequant_int8_bf16 (crates/core/kernels/gptq_dequant.cu:128-170):
+ * qweight u32 [K/4, N] (four k per word, low byte first), scales bf16 [groups, N], qzeros u32 [groups, ceil(N/4)];
+ * out[k][n] = bf16((q - z) * s), or out[n][k] with transposed != 0.  group_size <= 0: one group.
+ * vmx_gptq_int8_gemm_bf16 is gptq_gemm for such weights (quantization/gptq_cuda.rs:322-360): y = bf16(bf16(x @ W) + bias), through a
+ * caller-owned bf16 [N, K] workspace and the bf16 matrix-core GEMM; K % 16 == 0. */
+int vmx_gptq_dequant_int8_bf16(uint16_t *out, const uint32_t *qweight, const uint16_t *scales, const uint32_t *qzeros, int K, int N,
+                               int group_size, int transposed, void *stream);
+int vmx_gptq_int8_gemm_bf16(uint16_t *y, const uint16_t *x, const uint32_t *qweight, const uint16_t *scales, const uint32_t *qzeros,
+                            const uint16_t *bias, int M, int N, int K, int group_size, uint16_t *workspace, void *stream);
+
 /* Block-scaled FP8 weights (Fp8Linear::dequantize_block_weights and the block-quantized branch of forward,
  * crates/core/src/quantization/fp8.rs:305-342, :417-425), with the semantics that function documents:
  * W_bf16[n,k] = bf16(e4m3(W[n,k]) * scale[n / block_n][k / block_k]), scale f32 [ceil(N/block_n), ceil(K/block_k)];
@@ -245,6 +255,11 @@ int vmx_rms_norm_bf16(uint16_t *out, const uint16_t *x, uint16_t *residual, cons
 /* Replaces rotary_embedding_neox_bf16 (crates/core/kernels/rope.cu:94-114): in place on
  * q [tokens, heads*head_size], k [tokens, kv_heads*head_size] (k may be NULL). */
 int vmx_rope_neox_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin_cache,
+                       int tokens, int rot_dim, int head_size, int num_heads, int num_kv_heads, void *stream);
+
+/* Replaces rotary_embedding_gptj_bf16 (crates/core/kernels/rope.cu:119-141; pairing rule :34-38): as vmx_rope_neox_bf16 but
+ * the pair of angle i is elements (2i, 2i + 1) of a head (GPT-J, CodeGen); same cos|sin table.  q, k 4-byte aligned. */
+int vmx_rope_gptj_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin_cache,
                        int tokens, int rot_dim, int head_size, int num_heads, int num_kv_heads, void *stream);
 
 /* Replaces fused_qknorm_rope_bf16 (crates/core/kernels/qknorm_rope.cu:139-196): per-head RMSNorm (eps 1e-6) then NeoX
@@ -299,6 +314,16 @@ int vmx_kv_scales_calibrate_if_needed(void *state, const uint16_t *k, int64_t nk
 int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
                           const int32_t *slot_mapping, int tokens, int kv_heads, int head_dim, int block_size,
                           int kv_dtype, const float *k_scale, const float *v_scale, void *stream);
+
+/* Replaces reshape_and_cache_hnd_bf16 / _fp16 (crates/core/kernels/cache_ops.cu:106-176): the same scatter into caches laid
+ * out [blocks, kv_heads, block_size, head_dim] (16-bit elements of either type; head_dim % 8 == 0, 16-byte aligned pointers). */
+int vmx_reshape_and_cache_hnd(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
+                              const int32_t *slot_mapping, int tokens, int kv_heads, int head_dim, int block_size, void *stream);
+
+/* Replaces copy_blocks_bf16 (crates/core/kernels/cache_ops.cu:183-202; copy-on-write / preemption): for each pair
+ * (src, dst) = block_mapping[2i], block_mapping[2i + 1] (device i32) copy block src to block dst in both caches.
+ * bytes_per_block = block_size * kv_heads * head_dim * element bytes (any cache dtype or layout), a multiple of 16. */
+int vmx_copy_blocks(void *k_cache, void *v_cache, const int32_t *block_mapping, int num_pairs, int64_t bytes_per_block, void *stream);
 
 /* Replaces paged_attention_v2_* + paged_attention_v2_reduce_* (crates/core/kernels/paged_attention.cu:558-954;
  * launcher signature cuda_kernels.rs:641-658): decode attention for q [seqs, heads, head_dim] bf16 over the

@@ -136,3 +136,28 @@ void orc_f32_to_f16_array(const float *in, int64_t n, uint16_t *out) {
 void orc_f16_to_f32_array(const uint16_t *in, int64_t n, float *out) {
     for (int64_t i = 0; i < n; i++) out[i] = orc_f16_to_f32(in[i]);
 }
+
+/* GPTQ 8-bit dequantisation (crates/core/kernels/gptq_dequant.cu:128-170): qweight u32 [K/4][N] (k % 4 selects the byte, low
+ * first), scales bf16 [groups][N], qzeros u32 [groups][ceil(N/4)] (n % 4 selects the byte); out bf16 [K][N] = bf16((q - z) * s)
+ * with s read as bf16 -> f32.  group <= 0: a single group. */
+int orc_gptq_dequant_int8(const uint32_t *qweight, const uint16_t *scales, const uint32_t *qzeros, int64_t K, int64_t N,
+                          int64_t group, uint16_t *out) {
+    if (K % 4) return -1;
+    int64_t zpr = (N + 3) / 4;
+    for (int64_t k = 0; k < K; k++) {
+        int64_t g = group > 0 ? k / group : 0;
+        for (int64_t n = 0; n < N; n++) {
+            int q = (int)((qweight[(k / 4) * N + n] >> (8 * (k % 4))) & 0xFF);
+            int z = (int)((qzeros[g * zpr + n / 4] >> (8 * (n % 4))) & 0xFF);
+            uint32_t sb = (uint32_t)scales[g * N + n] << 16;
+            float sf;
+            memcpy(&sf, &sb, 4);
+            float w = (float)(q - z) * sf;
+            uint32_t u;
+            memcpy(&u, &w, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);   /* round to nearest even (finite values only here) */
+            out[k * N + n] = (uint16_t)(u >> 16);
+        }
+    }
+    return 0;
+}

@@ -168,6 +168,58 @@ uint8_t orc_kv_fp8_quant(uint16_t x_bf16, float scale) {
     return orc_fp8_e4m3_encode_rne(orc_round_bf16(v));
 }
 
+/* GPT-J RoPE (rope.cu:34-45,119-141): pair (2i, 2i + 1) turns by angle i; same cos|sin table layout as NeoX. */
+void orc_rope_gptj_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin,
+                        int64_t tokens, int rot_dim, int head_size, int n_heads, int n_kv_heads) {
+    int half = rot_dim / 2;
+    for (int64_t t = 0; t < tokens; t++) {
+        const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
+        for (int pass = 0; pass < 2; pass++) {
+            uint16_t *base = pass == 0 ? q : k;
+            int nh = pass == 0 ? n_heads : n_kv_heads;
+            if (!base) continue;
+            for (int h = 0; h < nh; h++) {
+                uint16_t *a = base + (t * nh + h) * head_size;
+                for (int i = 0; i < half; i++) {
+                    float xv = orc_bf16_to_f32(a[2 * i]), yv = orc_bf16_to_f32(a[2 * i + 1]);
+                    float c = cs[i], s = cs[half + i];
+                    a[2 * i] = orc_f32_to_bf16(xv * c - yv * s);
+                    a[2 * i + 1] = orc_f32_to_bf16(yv * c + xv * s);
+                }
+            }
+        }
+    }
+}
+
+/* reshape_and_cache_hnd_* (cache_ops.cu:106-176): cache [blocks, kv_heads, block_size, head_dim], 16-bit elements */
+void orc_reshape_and_cache_hnd(const uint16_t *key, const uint16_t *value, uint16_t *k_cache, uint16_t *v_cache,
+                               const int32_t *slots, int64_t tokens, int kv_heads, int head_dim, int block_size) {
+    for (int64_t t = 0; t < tokens; t++) {
+        int32_t slot = slots[t];
+        if (slot < 0) continue;
+        int64_t blk = slot / block_size, off = slot % block_size;
+        for (int h = 0; h < kv_heads; h++) {
+            int64_t src = (t * kv_heads + h) * head_dim;
+            int64_t dst = ((blk * kv_heads + h) * block_size + off) * head_dim;
+            for (int d = 0; d < head_dim; d++) {
+                k_cache[dst + d] = key[src + d];
+                v_cache[dst + d] = value[src + d];
+            }
+        }
+    }
+}
+
+/* copy_blocks_* (cache_ops.cu:183-202): pairs (src, dst) in order, whole blocks, both caches */
+void orc_copy_blocks(uint8_t *k_cache, uint8_t *v_cache, const int32_t *mapping, int64_t pairs, int64_t bytes_per_block) {
+    for (int64_t p = 0; p < pairs; p++) {
+        int64_t src = (int64_t)mapping[2 * p] * bytes_per_block, dst = (int64_t)mapping[2 * p + 1] * bytes_per_block;
+        for (int64_t i = 0; i < bytes_per_block; i++) {
+            k_cache[dst + i] = k_cache[src + i];
+            v_cache[dst + i] = v_cache[src + i];
+        }
+    }
+}
+
 /* Scatter K/V rows [tokens, kv_heads*head_dim] into the paged cache
  * [blocks, block_size, kv_heads, head_dim]; slot < 0 skips.  kv_dtype 0 = bf16
  * copy, 1 = FP8 e4m3 with per-tensor scales. */

@@ -51,6 +51,7 @@ for _name, _res, _args in [
     ("orc_awq_to_gptq_u32", C.c_uint32, [C.c_uint32]),
     ("orc_repack_awq_nibbles", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_awq_to_gptq_qweight", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    ("orc_gptq_dequant_int8", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     ("orc_int4_dequant", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     ("orc_int4_gemv_f32", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     ("orc_int4_gemv_bf16", C.c_int, [C.c_void_p] * 5 + [C.c_int64] * 4 + [C.c_void_p]),
@@ -67,6 +68,9 @@ for _name, _res, _args in [
     ("orc_fp8_e4m3_encode_rne", C.c_uint8, [C.c_float]),
     ("orc_fp8_e4m3_encode_trunc", C.c_uint8, [C.c_float]),
     ("orc_kv_fp8_quant", C.c_uint8, [C.c_uint16, C.c_float]),
+    ("orc_rope_gptj_bf16", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("orc_reshape_and_cache_hnd", None, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    ("orc_copy_blocks", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     ("orc_reshape_and_cache", None, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
     ("orc_paged_attention_v2", None, [C.c_void_p] * 5 + [C.c_float, C.c_int64] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
     ("orc_q6k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -262,6 +266,25 @@ def rope_neox_bf16(positions, q_bf16, k_bf16, cos_sin, rot_dim: int, head_size: 
     return q, k
 
 
+def gptq_dequant_int8(qweight, scales_bf16, qzeros, K: int, N: int, group: int) -> np.ndarray:
+    """GPTQ 8-bit weights -> bf16 bits [K, N] (gptq_dequant.cu:128-170)."""
+    qw, sc, qz = _c(qweight, np.uint32), _c(scales_bf16, np.uint16), _c(qzeros, np.uint32)
+    out = np.empty((K, N), np.uint16)
+    rc = _lib.orc_gptq_dequant_int8(_p(qw), _p(sc), _p(qz), K, N, group, _p(out))
+    assert rc == 0
+    return out
+
+
+def rope_gptj_bf16(positions, q_bf16, k_bf16, cos_sin, rot_dim: int, head_size: int, n_heads: int, n_kv_heads: int):
+    pos = _c(positions, np.int32)
+    q = _c(q_bf16, np.uint16).copy()
+    k = _c(k_bf16, np.uint16).copy() if k_bf16 is not None else None
+    cs = _c(cos_sin, np.float32)
+    _lib.orc_rope_gptj_bf16(_p(pos), _p(q), _p(k) if k is not None else None, _p(cs), pos.size, rot_dim, head_size,
+                            n_heads, n_kv_heads)
+    return q, k
+
+
 def silu_and_mul_bf16(gate_bf16, up_bf16) -> np.ndarray:
     g = _c(gate_bf16, np.uint16)
     u = _c(up_bf16, np.uint16)
@@ -318,6 +341,20 @@ class KVScales:
 
     def reset(self) -> None:
         self.k_scale, self.v_scale, self.calibrated = np.float32(1.0), np.float32(1.0), False
+
+
+def reshape_and_cache_hnd(key_u16, value_u16, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int) -> None:
+    """In place on uint16 caches [blocks, kv_heads, block_size, head_dim]."""
+    key, val, sl = _c(key_u16, np.uint16), _c(value_u16, np.uint16), _c(slots, np.int32)
+    assert k_cache.flags.c_contiguous and v_cache.flags.c_contiguous and k_cache.dtype == np.uint16
+    _lib.orc_reshape_and_cache_hnd(_p(key), _p(val), _p(k_cache), _p(v_cache), _p(sl), sl.size, kv_heads, head_dim, block_size)
+
+
+def copy_blocks(k_cache, v_cache, mapping, bytes_per_block: int) -> None:
+    """In place: block pairs (src, dst) of int32 [pairs, 2], applied in order."""
+    mp = _c(mapping, np.int32)
+    assert k_cache.flags.c_contiguous and v_cache.flags.c_contiguous
+    _lib.orc_copy_blocks(_p(k_cache), _p(v_cache), _p(mp), mp.size // 2, bytes_per_block)
 
 
 def reshape_and_cache(key_bf16, value_bf16, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int,

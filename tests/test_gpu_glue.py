@@ -240,3 +240,49 @@ def test_fused_qknorm_rope_add_gelu(gpu):
         check(lib.vmx_gelu_and_mul_bf16(out.data_ptr(), ta.data_ptr(), tb.data_ptr(), 5000, tanh_mode, st))
         g = orc.bf16_to_f32(_u16(torch, out)); exp = fn(af) * bf
         assert np.abs(g - exp).max() <= 2 ** -7 * np.abs(exp).max() + 1e-6
+
+
+def test_rope_gptj(gpu):
+    """rotary_embedding_gptj_bf16 (rope.cu:119-141): bit for bit the oracle, partial rotation, k optional."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(11)
+    T, H, KVH, D, R = 5, 8, 2, 128, 64
+    q = orc.f32_to_bf16(rng.standard_normal((T, H * D)).astype(np.float32))
+    k = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    pos = rng.integers(0, 64, T).astype(np.int32)
+    ang = np.arange(64)[:, None] * (1.0 / (10000.0 ** (np.arange(R // 2) * 2.0 / R)))[None, :]
+    cs = np.concatenate([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
+    qd, kd = _bf(torch, q), _bf(torch, k)
+    vmx.rope_gptj(torch.from_numpy(pos).cuda(), qd, kd, torch.from_numpy(cs).cuda(), R, D, H, KVH)
+    rq, rk = orc.rope_gptj_bf16(pos, q, k, cs, R, D, H, KVH)
+    assert np.array_equal(_u16(torch, qd).reshape(rq.shape), rq)
+    assert np.array_equal(_u16(torch, kd).reshape(rk.shape), rk)
+    qd2 = _bf(torch, q)
+    vmx.rope_gptj(torch.from_numpy(pos).cuda(), qd2, None, torch.from_numpy(cs).cuda(), R, D, H, KVH)
+    assert np.array_equal(_u16(torch, qd2).reshape(rq.shape), rq)
+
+
+def test_reshape_and_cache_hnd_and_copy_blocks(gpu):
+    """reshape_and_cache_hnd_* and copy_blocks_* (cache_ops.cu:106-202): byte for byte the oracle, skipped slots, 256-wide heads."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(12)
+    T, KVH, D, BS, NB = 9, 8, 256, 16, 12
+    k = rng.integers(0, 65536, (T, KVH * D)).astype(np.uint16)
+    v = rng.integers(0, 65536, (T, KVH * D)).astype(np.uint16)
+    slots = rng.permutation(NB * BS)[:T].astype(np.int32)
+    slots[3] = -1
+    kc_ref = rng.integers(0, 65536, (NB, KVH, BS, D)).astype(np.uint16)
+    vc_ref = rng.integers(0, 65536, (NB, KVH, BS, D)).astype(np.uint16)
+    kc, vc = torch.from_numpy(kc_ref.view(np.int16).copy()).cuda(), torch.from_numpy(vc_ref.view(np.int16).copy()).cuda()
+    orc.reshape_and_cache_hnd(k, v, kc_ref, vc_ref, slots, KVH, D, BS)
+    vmx.reshape_and_cache_hnd(torch.from_numpy(k.view(np.int16)).cuda(), torch.from_numpy(v.view(np.int16)).cuda(), kc, vc,
+                              torch.from_numpy(slots).cuda(), KVH, D, BS)
+    assert np.array_equal(kc.cpu().numpy().view(np.uint16), kc_ref) and np.array_equal(vc.cpu().numpy().view(np.uint16), vc_ref)
+    mapping = np.array([[0, 5], [7, 2], [11, 9]], np.int32)
+    bpb = KVH * BS * D * 2
+    orc.copy_blocks(kc_ref.view(np.uint8), vc_ref.view(np.uint8), mapping, bpb)
+    vmx.copy_blocks(kc, vc, torch.from_numpy(mapping).cuda(), bpb)
+    assert np.array_equal(kc.cpu().numpy().view(np.uint16), kc_ref) and np.array_equal(vc.cpu().numpy().view(np.uint16), vc_ref)
+    vmx.copy_blocks(kc, vc, torch.zeros((0, 2), dtype=torch.int32).cuda(), bpb)     # no pairs: nothing to do

@@ -144,3 +144,40 @@ def test_preconditions(gpu):
         vmx.int4_gemm(x[:1, :200].contiguous(), z, None, 128, 200, 128)
     with pytest.raises(VmxError, match="multiple of 16"):
         vmx.int4_gemm(x[:1], z, None, 120, 256, 128)
+
+
+@pytest.mark.parametrize("K,N,G,M", [(256, 128, 128, 1), (512, 200, 64, 5), (4096, 1024, 128, 16), (1024, 512, -1, 40)])
+def test_gptq_int8_dequant_and_gemm(gpu, K, N, G, M):
+    """GPTQ 8-bit: dequantised weights bit for bit the oracle's in both layouts (gptq_dequant.cu:128-170); y = x @ W + bias within a
+    bf16 ulp of the float64 product of the same bf16 operands (the reference multiplies the dequantised matrix with cuBLAS: parity
+    unpinned beyond that)."""
+    from oracle import oracle as orc
+    from vllm_rust_amd._lib import lib, check
+    vmx, torch = gpu
+    rng = np.random.default_rng(K + N + M)
+    groups = K // G if G > 0 else 1
+    qw = rng.integers(0, 2 ** 32, (K // 4, N), dtype=np.uint64).astype(np.uint32)
+    qz = rng.integers(0, 2 ** 32, (groups, (N + 3) // 4), dtype=np.uint64).astype(np.uint32)
+    sc = orc.f32_to_bf16((rng.random((groups, N)) * 0.01 + 0.0005).astype(np.float32))
+    ref_w = orc.gptq_dequant_int8(qw, sc, qz, K, N, G)
+    dq, dz, ds = (torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a.view(np.int16)).cuda() for a in (qw, qz, sc))
+    out = torch.empty((K, N), dtype=torch.int16, device="cuda")
+    check(lib.vmx_gptq_dequant_int8_bf16(out.data_ptr(), dq.data_ptr(), ds.data_ptr(), dz.data_ptr(), K, N, G, 0, None))
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), ref_w)
+    out_t = torch.empty((N, K), dtype=torch.int16, device="cuda")
+    check(lib.vmx_gptq_dequant_int8_bf16(out_t.data_ptr(), dq.data_ptr(), ds.data_ptr(), dz.data_ptr(), K, N, G, 1, None))
+    assert np.array_equal(out_t.cpu().numpy().view(np.uint16), ref_w.T)
+    x = orc.f32_to_bf16((rng.standard_normal((M, K)) * 0.5).astype(np.float32))
+    bias = orc.f32_to_bf16(rng.standard_normal(N).astype(np.float32))
+    y = torch.empty((M, N), dtype=torch.int16, device="cuda")
+    ws = torch.empty((N, K), dtype=torch.int16, device="cuda")
+    xd, bd = torch.from_numpy(x.view(np.int16)).cuda(), torch.from_numpy(bias.view(np.int16)).cuda()
+    check(lib.vmx_gptq_int8_gemm_bf16(y.data_ptr(), xd.data_ptr(), dq.data_ptr(), ds.data_ptr(), dz.data_ptr(), bd.data_ptr(), M, N, K, G,
+                                      ws.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = orc.bf16_to_f32(y.cpu().numpy().view(np.uint16)).astype(np.float64)
+    prod = orc.bf16_to_f32(x).astype(np.float64) @ orc.bf16_to_f32(ref_w).astype(np.float64)
+    want = orc.bf16_to_f32(orc.f32_to_bf16(prod.astype(np.float32))).astype(np.float64) + orc.bf16_to_f32(bias).astype(np.float64)
+    tol = 2.0 ** -7 * np.abs(want) + 2.0 ** -8 * np.abs(prod) + 1e-3 * np.abs(prod).mean() + 1e-6
+    assert (np.abs(got - want) <= tol).all()
+    assert lib.vmx_gptq_int8_gemm_bf16(y.data_ptr(), y.data_ptr(), dq.data_ptr(), ds.data_ptr(), dz.data_ptr(), None, 1, N, 6, G, ws.data_ptr(), None) != 0

@@ -60,3 +60,21 @@ def test_gptq_symmetric_zero_point():
     k, n = 5, 9
     nib = (int(qw[k // 8, n]) >> (4 * (k % 8))) & 0xF
     assert dense[k, n] == np.float32(nib - 8) * sc[0, n]        # marlin_gemm.cu:43-48
+
+
+def test_gptq_int8_dequant_formula():
+    """gptq_dequant.cu:128-170: (q - z) * s with byte k % 4 of word [k / 4][n] and byte n % 4 of the zero word; against numpy."""
+    rng = np.random.default_rng(3)
+    K, N, G = 64, 24, 32
+    q = rng.integers(0, 256, (K, N)).astype(np.uint32)
+    z = rng.integers(0, 256, (K // G, N)).astype(np.uint32)
+    s = orc.f32_to_bf16((rng.random((K // G, N)) * 0.02 + 0.001).astype(np.float32))
+    qw = np.zeros((K // 4, N), np.uint32)
+    for j in range(4):
+        qw |= q[j::4, :] << np.uint32(8 * j)
+    qz = np.zeros((K // G, N // 4), np.uint32)
+    for j in range(4):
+        qz |= z[:, j::4] << np.uint32(8 * j)
+    got = orc.bf16_to_f32(orc.gptq_dequant_int8(qw, s, qz, K, N, G))
+    want = (q.astype(np.int64) - np.repeat(z, G, axis=0).astype(np.int64)).astype(np.float32) * np.repeat(orc.bf16_to_f32(s), G, axis=0)
+    assert np.array_equal(got, orc.bf16_to_f32(orc.f32_to_bf16(want)))

@@ -164,3 +164,46 @@ def test_fp8_w8a8_block_and_fused_norm_restatements_against_numpy():
     assert kv.calibrated and kv.k_scale == np.float32(np.float32(2.0 * 1.5) * np.float32(1 / 448)) and kv.v_scale == np.float32(1e-12)
     kv.calibrate_if_needed(orc.f32_to_bf16(np.array([100.0], np.float32)), v)
     assert kv.k_scale == np.float32(np.float32(3.0) * np.float32(1 / 448))
+
+
+def test_rope_gptj_pairs_adjacent_elements_and_matches_float64():
+    """rope.cu:34-45: pair (2i, 2i + 1) rotates by angle i; against a float64 rotation, one bf16 rounding."""
+    rng = np.random.default_rng(5)
+    T, H, KVH, D, R = 3, 2, 1, 16, 8
+    q = orc.f32_to_bf16(rng.standard_normal((T, H * D)).astype(np.float32))
+    k = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    pos = np.array([0, 3, 7], np.int32)
+    ang = np.arange(8)[:, None] * (1.0 / (10000.0 ** (np.arange(R // 2) * 2.0 / R)))[None, :]
+    cs = np.concatenate([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
+    q2, k2 = orc.rope_gptj_bf16(pos, q, k, cs, R, D, H, KVH)
+    qf = orc.bf16_to_f32(q).reshape(T, H, D).astype(np.float64)
+    want = qf.copy()
+    for t in range(T):
+        c, s = cs[pos[t], : R // 2].astype(np.float64), cs[pos[t], R // 2:].astype(np.float64)
+        x, y = qf[t, :, 0:R:2], qf[t, :, 1:R:2]
+        want[t, :, 0:R:2] = x * c - y * s
+        want[t, :, 1:R:2] = y * c + x * s
+    got = orc.bf16_to_f32(q2).reshape(T, H, D)
+    assert np.abs(got - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6
+    assert np.array_equal(got[:, :, R:], qf[:, :, R:].astype(np.float32))     # dims past rot_dim untouched
+    assert np.array_equal(orc.bf16_to_f32(q2[0]), orc.bf16_to_f32(q[0]))       # position 0: identity
+    assert k2.shape == k.shape
+
+
+def test_reshape_and_cache_hnd_and_copy_blocks():
+    """cache_ops.cu:106-202: HND placement [blocks, kv_heads, block_size, head_dim]; copy_blocks copies whole blocks in both caches."""
+    rng = np.random.default_rng(6)
+    T, KVH, D, BS, NB = 3, 2, 8, 4, 5
+    k = rng.integers(0, 65536, (T, KVH * D)).astype(np.uint16)
+    v = rng.integers(0, 65536, (T, KVH * D)).astype(np.uint16)
+    kc = np.zeros((NB, KVH, BS, D), np.uint16)
+    vc = np.zeros_like(kc)
+    slots = np.array([6, -1, 17], np.int32)
+    orc.reshape_and_cache_hnd(k, v, kc, vc, slots, KVH, D, BS)
+    assert np.array_equal(kc[1, :, 2, :], k[0].reshape(KVH, D)) and np.array_equal(vc[4, :, 1, :], v[2].reshape(KVH, D))
+    assert kc.astype(np.int64).sum() == k[0].astype(np.int64).sum() + k[2].astype(np.int64).sum()     # the skipped row wrote nothing
+    mapping = np.array([[1, 0], [4, 3]], np.int32)
+    k_before = kc.copy()
+    orc.copy_blocks(kc.view(np.uint8), vc.view(np.uint8), mapping, KVH * BS * D * 2)
+    assert np.array_equal(kc[0], k_before[1]) and np.array_equal(kc[3], k_before[4]) and np.array_equal(kc[1], k_before[1])
+    assert np.array_equal(vc[3], vc[4])

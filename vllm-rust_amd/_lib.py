@@ -82,6 +82,11 @@ _SIGS = {
     "vmx_top_k_top_p_sample": (_i, [_p, _p, _p, _p, _p, _i, _f, _i, _i, _p]),
     "vmx_rms_norm_bf16": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _p]),
     "vmx_rope_neox_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vmx_rope_gptj_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vmx_reshape_and_cache_hnd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vmx_gptq_dequant_int8_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vmx_gptq_int8_gemm_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "vmx_copy_blocks": (_i, [_p, _p, _p, _i, C.c_int64, _p]),
     "vmx_silu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "vmx_argmax_workspace_bytes": (_sz, [_i, _i]),
     "vmx_argmax_bf16": (_i, [_p, _p, _i, _i, _p, _sz, _p]),

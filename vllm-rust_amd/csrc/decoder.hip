@@ -1295,7 +1295,8 @@ extern "C" int vmx_qwen3_debug_kv(vmx_qwen3 *m, int layer, int which, int write,
 // HIP events this gives the kernel's average launch duration on its own stream.
 extern "C" int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream) {
     VMX_REQUIRE(m && batch >= 1 && batch <= m->cfg.max_batch, "qwen3_linears_only: bad arguments");
-    for (const Layer &L : m->layers) VMX_REQUIRE(L.int4_ready(), "qwen3_linears_only: the model has no int4 linears loaded");
+    for (const Layer &L : m->layers)
+        VMX_REQUIRE(L.int4_ready() || L.exl3_ready(), "qwen3_linears_only: the model has neither int4 nor EXL3 linears loaded");
     hipStream_t st = vmx_stream(stream);
     const uint16_t *x = (const uint16_t *)m->x.p, *attn = (const uint16_t *)m->attn.p, *act = (const uint16_t *)m->act.p;
     float *PA = (float *)m->partial.p, *PB = (float *)m->partial_b.p;
@@ -1303,6 +1304,22 @@ extern "C" int vmx_qwen3_linears_only(vmx_qwen3 *m, int batch, void *stream) {
     const int H = c.hidden_size, I = c.intermediate_size, NQ = c.num_heads * c.head_dim, NQKV_ = m->qkv_n();
     uint16_t *h = (uint16_t *)m->h.p;
     for (const Layer &L : m->layers) {
+        if (!L.int4_ready()) {   // EXL3 layer: the launches a decode step of up to 4 rows makes for its seven projections
+            VMX_REQUIRE(batch <= 4 && !m->comm && H % 128 == 0 && I % 128 == 0 && L.ex_svh_gu.p && L.ex_svh_qkv.p,
+                        "qwen3_linears_only: EXL3 layers are covered for 1..4 rows on one GPU");
+            const int mk = m->lin_mask;
+            const float *src = nullptr;
+            int sp = 0;
+            if (mk & 1)
+                if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, PA, NQKV_, batch, st)) return rc;
+            if (mk & 2)
+                if (int rc = exl3_forward_group(m, L, {VMX_L_O}, L.ex[VMX_L_O].svh, attn, nullptr, H, batch, st, &src, &sp)) return rc;
+            if (mk & 4)
+                if (int rc = exl3_forward_group(m, L, {VMX_L_GATE, VMX_L_UP}, L.ex_svh_gu, x, nullptr, 2 * I, batch, st, &src, &sp)) return rc;
+            if (mk & 8)
+                if (int rc = exl3_forward_group(m, L, {VMX_L_DOWN}, L.ex[VMX_L_DOWN].svh, act, nullptr, H, batch, st, &src, &sp)) return rc;
+            continue;
+        }
         const bool fold = folded_layers_enabled() && !m->comm && c.tp_size <= 1 && c.num_experts == 0 && L.gate_up.glu &&
                           vmx_int4_norm_splits(batch, NQKV_, H, 0) > 0 && vmx_int4_norm_splits(batch, 2 * I, H, 1) == 1 &&
                           vmx_int4_resid_fusable(batch, H, NQ) && vmx_int4_resid_fusable(batch, H, I);
@@ -1350,6 +1367,17 @@ extern "C" int vmx_qwen3_linears_info(vmx_qwen3 *m, int batch, int *launches, do
     int n = 0;
     for (const Layer &L : m->layers) {
         int bit = 1;
+        if (!L.int4_ready() && L.exl3_ready()) {   // trellis words + fp16 sign/scale vectors + activations in (fp16) and out (f32 sums)
+            const int kind[7] = {1, 1, 1, 2, 4, 4, 8};
+            for (int s = 0; s < 7; s++) {
+                if (!(m->lin_mask & kind[s])) continue;
+                const Exl3Lin &e = L.ex[s];
+                by += (double)e.in_features * e.out_features * e.bits / 8.0 + 2.0 * e.in_features + 2.0 * e.out_features +
+                      (double)batch * (2.0 * e.in_features + 2.0 * e.out_features);
+            }
+            for (int b = 1; b <= 8; b <<= 1) n += (m->lin_mask & b) ? 1 : 0;
+            continue;
+        }
         for (const Int4Linear *l : {&L.qkv, &L.o, &L.gate_up, &L.down}) {
             if (m->lin_mask & bit) {
                 by += int4_alg_bytes(*l, batch);

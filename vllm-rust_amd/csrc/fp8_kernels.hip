@@ -282,6 +282,15 @@ __global__ __launch_bounds__(256) void fused_rmsnorm_fp8_kernel(uint8_t *__restr
 
 }  // namespace
 
+// y [M, N] = bf16(bf16(x [M, K] @ W [N, K]^T) + bias) on the bf16 matrix cores (the GEMM behind every "dequantise, then multiply"
+// linear of this library); K % 16 == 0.
+int vmx_bf16_gemm_nt(uint16_t *y, const uint16_t *x, const uint16_t *w, const uint16_t *bias, int M, int N, int K, hipStream_t st) {
+    Fp8MmEpilogue ep = {nullptr, nullptr, 0, 0, bias, 1, 0};
+    fp8_mm_launch<false, false>(y, x, w, M, N, K, ep, st);
+    VMX_CHECK_LAUNCH("bf16_gemm_nt");
+    return VMX_OK;
+}
+
 extern "C" int vmx_fp8_gemm_bf16(uint16_t *y, const uint16_t *x, const void *weight, const float *scale, const uint16_t *bias, int M,
                                  int N, int K, int per_channel_scale, void *stream) {
     VMX_REQUIRE(y && x && weight && scale, "fp8_gemm: null pointer");

@@ -85,6 +85,56 @@ __global__ __launch_bounds__(256) void rope_neox_kernel(const int32_t *__restric
     }
 }
 
+// GPT-J pairing: element pair (2i, 2i + 1) of the rotated part turns by angle i; the table row is cos[rot/2] | sin[rot/2] as for NeoX.
+__global__ __launch_bounds__(256) void rope_gptj_kernel(const int32_t *__restrict__ positions, uint16_t *__restrict__ q,
+                                                         uint16_t *__restrict__ k, const float *__restrict__ cos_sin, int rot_dim,
+                                                         int head_size, int num_heads, int num_kv_heads) {
+    const int t = blockIdx.x;
+    const int half = rot_dim >> 1;
+    const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
+    const int nq = num_heads * half, nk = k ? num_kv_heads * half : 0;
+    for (int i = threadIdx.x; i < nq + nk; i += 256) {
+        uint32_t *pair;   // the two bf16 values of a pair share an aligned dword (head_size is even)
+        int ri;
+        if (i < nq) { ri = i % half; pair = reinterpret_cast<uint32_t *>(q + ((int64_t)t * num_heads + i / half) * head_size) + ri; }
+        else { const int j = i - nq; ri = j % half; pair = reinterpret_cast<uint32_t *>(k + ((int64_t)t * num_kv_heads + j / half) * head_size) + ri; }
+        const float c = cs[ri], s = cs[half + ri];
+        const uint32_t w = *pair;
+        const float xv = vmx_bf16_to_f32((uint16_t)(w & 0xFFFFu)), yv = vmx_bf16_to_f32((uint16_t)(w >> 16));
+        *pair = (uint32_t)vmx_f32_to_bf16(xv * c - yv * s) | ((uint32_t)vmx_f32_to_bf16(yv * c + xv * s) << 16);
+    }
+}
+
+// K/V rows [tokens, kv_heads, head_dim] (16-bit elements) into a cache laid out [blocks, kv_heads, block_size, head_dim].
+// grid (tokens, kv_heads); 8 elements per thread step.
+__global__ __launch_bounds__(64) void reshape_and_cache_hnd_kernel(const uint16_t *__restrict__ key, const uint16_t *__restrict__ value,
+                                                                    uint16_t *__restrict__ k_cache, uint16_t *__restrict__ v_cache,
+                                                                    const int32_t *__restrict__ slots, int kv_heads, int head_dim,
+                                                                    int block_size) {
+    const int t = blockIdx.x, h = blockIdx.y;
+    const int slot = slots[t];
+    if (slot < 0) return;
+    const int64_t src = ((int64_t)t * kv_heads + h) * head_dim;
+    const int64_t dst = (((int64_t)(slot / block_size) * kv_heads + h) * block_size + slot % block_size) * head_dim;
+    for (int d = threadIdx.x * 8; d < head_dim; d += 64 * 8) {
+        *reinterpret_cast<uint4 *>(k_cache + dst + d) = *reinterpret_cast<const uint4 *>(key + src + d);
+        *reinterpret_cast<uint4 *>(v_cache + dst + d) = *reinterpret_cast<const uint4 *>(value + src + d);
+    }
+}
+
+// (src, dst) block pairs; grid (pairs, 2 caches x chunks); 16 bytes per thread step.  Pairs are independent unless the
+// caller lists a block both as a source and as a destination (the reference has the same rule: cache_ops.cu:183-202).
+__global__ __launch_bounds__(256) void copy_blocks_kernel(unsigned char *__restrict__ k_cache, unsigned char *__restrict__ v_cache,
+                                                           const int32_t *__restrict__ mapping, int64_t bytes_per_block) {
+    const int pair = blockIdx.x;
+    unsigned char *cache = (blockIdx.y & 1) ? v_cache : k_cache;
+    const int chunk = blockIdx.y >> 1, nchunk = gridDim.y >> 1;
+    const int64_t src = (int64_t)mapping[2 * pair] * bytes_per_block, dst = (int64_t)mapping[2 * pair + 1] * bytes_per_block;
+    const int64_t n16 = bytes_per_block >> 4;
+    for (int64_t i = (int64_t)chunk * 256 + threadIdx.x; i < n16; i += (int64_t)nchunk * 256)
+        reinterpret_cast<uint4 *>(cache + dst)[i] = reinterpret_cast<const uint4 *>(cache + src)[i];
+}
+
 __device__ __forceinline__ float silu(float g) { return g / (1.0f + expf(-g)); }
 
 __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ gate,
@@ -230,6 +280,48 @@ extern "C" int vmx_rope_neox_bf16(const int32_t *positions, uint16_t *q, uint16_
     hipLaunchKernelGGL(rope_neox_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), positions, q, k, cos_sin_cache, rot_dim,
                        head_size, num_heads, num_kv_heads);
     VMX_CHECK_LAUNCH("rope");
+    return VMX_OK;
+}
+
+extern "C" int vmx_rope_gptj_bf16(const int32_t *positions, uint16_t *q, uint16_t *k, const float *cos_sin_cache, int tokens,
+                                  int rot_dim, int head_size, int num_heads, int num_kv_heads, void *stream) {
+    VMX_REQUIRE(positions && q && cos_sin_cache, "rope: null pointer");
+    VMX_REQUIRE(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size && head_size % 2 == 0, "rope: rot_dim %d invalid for head_size %d",
+                rot_dim, head_size);
+    VMX_REQUIRE(((uintptr_t)q & 3) == 0 && ((uintptr_t)k & 3) == 0, "rope(gptj): q and k must be 4-byte aligned");
+    if (tokens <= 0) return VMX_OK;
+    hipLaunchKernelGGL(rope_gptj_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), positions, q, k, cos_sin_cache, rot_dim,
+                       head_size, num_heads, num_kv_heads);
+    VMX_CHECK_LAUNCH("rope(gptj)");
+    return VMX_OK;
+}
+
+extern "C" int vmx_reshape_and_cache_hnd(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
+                                         const int32_t *slot_mapping, int tokens, int kv_heads, int head_dim, int block_size, void *stream) {
+    VMX_REQUIRE(key && value && k_cache && v_cache && slot_mapping, "reshape_and_cache_hnd: null pointer");
+    VMX_REQUIRE(kv_heads > 0 && block_size > 0 && head_dim > 0 && head_dim % 8 == 0, "reshape_and_cache_hnd: head_dim %d not a multiple of 8",
+                head_dim);
+    VMX_REQUIRE((((uintptr_t)key | (uintptr_t)value | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15) == 0,
+                "reshape_and_cache_hnd: pointers must be 16-byte aligned");
+    if (tokens <= 0) return VMX_OK;
+    hipLaunchKernelGGL(reshape_and_cache_hnd_kernel, dim3(tokens, kv_heads), dim3(64), 0, vmx_stream(stream), key, value,
+                       (uint16_t *)k_cache, (uint16_t *)v_cache, slot_mapping, kv_heads, head_dim, block_size);
+    VMX_CHECK_LAUNCH("reshape_and_cache_hnd");
+    return VMX_OK;
+}
+
+extern "C" int vmx_copy_blocks(void *k_cache, void *v_cache, const int32_t *block_mapping, int num_pairs, int64_t bytes_per_block,
+                               void *stream) {
+    VMX_REQUIRE(k_cache && v_cache && (block_mapping || num_pairs == 0), "copy_blocks: null pointer");
+    VMX_REQUIRE(num_pairs >= 0 && bytes_per_block > 0 && bytes_per_block % 16 == 0, "copy_blocks: bytes_per_block %lld not a multiple of 16",
+                (long long)bytes_per_block);
+    VMX_REQUIRE((((uintptr_t)k_cache | (uintptr_t)v_cache) & 15) == 0, "copy_blocks: caches must be 16-byte aligned");
+    if (num_pairs == 0) return VMX_OK;
+    int64_t chunks = (bytes_per_block / 16 + 255) / 256;
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(num_pairs, (unsigned)(2 * chunks)), dim3(256), 0, vmx_stream(stream), (unsigned char *)k_cache,
+                       (unsigned char *)v_cache, block_mapping, bytes_per_block);
+    VMX_CHECK_LAUNCH("copy_blocks");
     return VMX_OK;
 }
 

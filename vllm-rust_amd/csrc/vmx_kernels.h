@@ -113,3 +113,6 @@ int vmx_iq_dequantize_split_bf16(int ggml_type, const void *blocks, uint16_t *hi
 int vmx_iq_dequant_split(int ggml_type, const void *blocks, void *workspace, int N, int K, hipStream_t st);
 int vmx_split_gemm_f32(const uint16_t *A, const void *workspace, float *C, int M, int N, int K, int ldc, hipStream_t st);
 int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st);
+// bf16 matrix-core GEMM y = bf16(bf16(x @ W^T) + bias), W [N, K] bf16 (fp8_kernels.hip)
+int vmx_bf16_gemm_nt(uint16_t *y, const uint16_t *x, const uint16_t *w, const uint16_t *bias, int M, int N, int K, hipStream_t st);
+

@@ -13,7 +13,7 @@ from ._lib import check, lib
 __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_mmvq_packed_geglu", "iq_subdots_packed",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
-    "rms_norm", "rope_neox", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
+    "rms_norm", "rope_neox", "rope_gptj", "reshape_and_cache_hnd", "copy_blocks", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
     "topk_softmax", "moe_align_block_size", "moe_int4_forward",
 ]
@@ -173,6 +173,12 @@ def rope_neox(positions: torch.Tensor, q: torch.Tensor, k, cos_sin: torch.Tensor
                                  num_heads, num_kv_heads, _stream()))
 
 
+def rope_gptj(positions: torch.Tensor, q: torch.Tensor, k, cos_sin: torch.Tensor, rot_dim: int, head_size: int,
+              num_heads: int, num_kv_heads: int) -> None:
+    check(lib.vmx_rope_gptj_bf16(_ptr(positions), _ptr(q), _ptr(k), _ptr(cos_sin), positions.numel(), rot_dim, head_size,
+                                 num_heads, num_kv_heads, _stream()))
+
+
 def silu_and_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(gate)
     check(lib.vmx_silu_and_mul_bf16(_ptr(out), _ptr(gate), _ptr(up), gate.numel(), _stream()))
@@ -224,6 +230,17 @@ def reshape_and_cache(key, value, k_cache, v_cache, slots, kv_heads: int, head_d
                       kv_dtype: int = 0, k_scale=None, v_scale=None) -> None:
     check(lib.vmx_reshape_and_cache(_ptr(key), _ptr(value), _ptr(k_cache), _ptr(v_cache), _ptr(slots), slots.numel(),
                                     kv_heads, head_dim, block_size, kv_dtype, _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
+def reshape_and_cache_hnd(key, value, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int) -> None:
+    """Scatter into caches laid out [blocks, kv_heads, block_size, head_dim] (16-bit elements)."""
+    check(lib.vmx_reshape_and_cache_hnd(_ptr(key), _ptr(value), _ptr(k_cache), _ptr(v_cache), _ptr(slots), slots.numel(), kv_heads,
+                                        head_dim, block_size, _stream()))
+
+
+def copy_blocks(k_cache, v_cache, block_mapping: torch.Tensor, bytes_per_block: int) -> None:
+    """block_mapping int32 [pairs, 2] = (src, dst) block indices; copies whole blocks inside both caches."""
+    check(lib.vmx_copy_blocks(_ptr(k_cache), _ptr(v_cache), _ptr(block_mapping), block_mapping.numel() // 2, int(bytes_per_block), _stream()))
 
 
 def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, scale: float, num_heads: int, num_kv_heads: int,
