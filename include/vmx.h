@@ -493,6 +493,12 @@ int vmx_qwen3_load_tensor(vmx_qwen3 *m, int which, int layer, const void *src, s
  * merged into one linear each once all their parts have arrived. */
 int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
                               const uint16_t *scales_f16, void *stream);
+/* One projection of a 4-bit GPTQ checkpoint (GptqLinear / MarlinLinear::load_weights, quantization/gptq.rs:430-460,
+ * marlin.rs:473-560): qweight u32 [in/8, out] (eight k per word), scales f16 [in/group, out], qzeros u32 [in/group, out/8] or NULL.
+ * With qzeros: w = (nib - z) * s, z as stored (gptq_dequant.cu:48-87); NULL: w = (nib - 8) * s (marlin_gemm.cu:43-48).
+ * g_idx is not an argument: as in the reference's kernels the group of row k is k / group_size. */
+int vmx_qwen3_load_gptq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
+                               const uint16_t *scales_f16, void *stream);
 
 /* Load one expert of a mixture-of-experts layer in GPTQ form (QuantizedMoELayer / MarlinLinear, models/mixtral_quantized.rs:92-130;
  * w = (nib - 8) * scale as marlin_gemm.cu:43-48): w1 = gate, w3 = up (qweight u32 [hidden/8, inter], scales f16 [hidden/g, inter]),

@@ -116,6 +116,7 @@ _SIGS = {
     "vmx_qwen3_destroy": (None, [_p]),
     "vmx_qwen3_load_tensor": (_i, [_p, _i, _i, _p, _sz, _p]),
     "vmx_qwen3_load_awq_linear": (_i, [_p, _i, _i, _p, _p, _p, _p]),
+    "vmx_qwen3_load_gptq_linear": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "vmx_qwen3_load_iq_linear": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "vmx_qwen3_load_dense_linear": (_i, [_p, _i, _i, _p, _sz, _p]),
     "vmx_qwen3_set_rows_share_cache": (_i, [_p, _i]),

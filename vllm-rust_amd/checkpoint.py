@@ -173,3 +173,110 @@ def load_qwen3_awq_checkpoint(model, model_dir):
     finally:
         ck.close()
     return det
+
+
+def _backbone_bf16(ck, name):
+    """A norm / embedding / lm_head tensor as torch bf16: bf16 checkpoints as stored, fp16 ones (EXL3 backbones) converted."""
+    import torch
+    a = ck.get(name)
+    f = ck._file(ck.where[name])
+    dtype = f.info(lib.vmx_safetensors_find(f._h, name.encode()))[1]
+    if dtype == "BF16":
+        return torch.from_numpy(a.view(np.int16)).view(torch.bfloat16)
+    if dtype == "F16":
+        return torch.from_numpy(a.view(np.int16)).view(torch.float16).to(torch.bfloat16)
+    if dtype == "F32":
+        return torch.from_numpy(a).to(torch.bfloat16)
+    raise ValueError(f"{name}: backbone tensor of dtype {dtype}")
+
+
+def _load_backbone(model, ck):
+    from .qwen3 import T_EMBED, T_FINAL_NORM, T_INPUT_LN, T_K_NORM, T_LM_HEAD, T_POST_LN, T_Q_NORM
+    s = model.spec
+    model.load_tensor(T_EMBED, 0, _backbone_bf16(ck, "model.embed_tokens.weight").cuda())
+    if not s.tie_word_embeddings:
+        model.load_tensor(T_LM_HEAD, 0, _backbone_bf16(ck, "lm_head.weight").cuda())
+    model.load_tensor(T_FINAL_NORM, 0, _backbone_bf16(ck, "model.norm.weight").cuda())
+    for li in range(s.num_layers):
+        pre = f"model.layers.{li}."
+        model.load_tensor(T_INPUT_LN, li, _backbone_bf16(ck, pre + "input_layernorm.weight").cuda())
+        model.load_tensor(T_POST_LN, li, _backbone_bf16(ck, pre + "post_attention_layernorm.weight").cuda())
+        if s.qk_norm:
+            model.load_tensor(T_Q_NORM, li, _backbone_bf16(ck, pre + "self_attn.q_norm.weight").cuda())
+            model.load_tensor(T_K_NORM, li, _backbone_bf16(ck, pre + "self_attn.k_norm.weight").cuda())
+
+
+def load_qwen3_gptq_checkpoint(model, model_dir, use_zeros=None):
+    """Fill a QuantizedQwen3ForCausalLM from an AutoGPTQ-format directory (GptqWeightLoader, quantization/weight_loader.rs:
+    tensors "model.layers.N.<proj>.{qweight,qzeros,scales,g_idx}": qweight i32 [in/8, out], qzeros i32 [in/group, out/8],
+    scales f16 [in/group, out]).  Detection must say gptq / gptq_marlin at 4 bits with the model's group size; desc_act
+    checkpoints (activation-ordered groups) are refused: like the reference's kernels this path takes group = k / group_size.
+    use_zeros None: symmetric checkpoints ("sym": true, the Marlin form (nib - 8) * s) ignore qzeros, others use them as stored."""
+    import torch
+    det = detect_from_directory(model_dir)
+    if det.method not in ("gptq", "gptq_marlin") or det.bits not in (None, 4):
+        raise ValueError(f"{model_dir}: detected {det.method} ({det.bits} bits); this loader takes 4-bit GPTQ checkpoints")
+    if det.desc_act:
+        raise ValueError(f"{model_dir}: desc_act (activation-ordered) GPTQ checkpoints are not supported")
+    s = model.spec
+    if det.group_size is not None and det.group_size != s.group_size:
+        raise ValueError(f"{model_dir}: group size {det.group_size}, model built for {s.group_size}")
+    if use_zeros is None:
+        sym = True
+        for fn in ("quantize_config.json", "config.json"):
+            p = Path(model_dir) / fn
+            if p.exists():
+                j = json.loads(p.read_text())
+                j = j.get("quantization_config", j)
+                if "sym" in j:
+                    sym = bool(j["sym"])
+                    break
+        use_zeros = not sym
+    ck = CheckpointDir(model_dir)
+    try:
+        _load_backbone(model, ck)
+        for li in range(s.num_layers):
+            pre = f"model.layers.{li}."
+            for slot, proj in enumerate(_PROJ):
+                qw, sc = ck.get(f"{pre}{proj}.qweight"), ck.get(f"{pre}{proj}.scales")
+                qz = torch.from_numpy(ck.get(f"{pre}{proj}.qzeros")).cuda() if use_zeros else None
+                model.load_gptq_linear(li, slot, torch.from_numpy(qw).cuda(), qz, torch.from_numpy(sc.view(np.int16)).view(torch.float16).cuda())
+    finally:
+        ck.close()
+    return det
+
+
+def load_qwen3_exl3_checkpoint(model, model_dir):
+    """Fill a QuantizedQwen3ForCausalLM from an ExLlamaV3 directory (Exl3WeightLoader::load_linear, quantization/
+    weight_loader.rs:470-559): per projection "<prefix>.trellis" i16 [in/16, out/16, 16 * bpw] (bits per weight from the last
+    dimension, 2..8, may differ between tensors), ".suh" f16 [in], ".svh" f16 [out], and the codebook from the presence of the
+    flag tensors ".mcg" / ".mul1" (exl3.rs:90-152).  Backbone tensors of such checkpoints are fp16; this executor keeps its
+    residual stream in bf16, so they are converted on the way in."""
+    import torch
+    det = detect_from_directory(model_dir)
+    if det.method != "exl3":
+        raise ValueError(f"{model_dir}: detected {det.method}; this loader takes EXL3 checkpoints")
+    s = model.spec
+    shapes = model.linear_shapes()
+    ck = CheckpointDir(model_dir)
+    try:
+        _load_backbone(model, ck)
+        for li in range(s.num_layers):
+            pre = f"model.layers.{li}."
+            for slot, proj in enumerate(_PROJ):
+                K, N = shapes[slot]
+                tr = ck.get(f"{pre}{proj}.trellis")
+                if tr.ndim != 3:
+                    raise ValueError(f"exl3 loader: `{pre}{proj}.trellis` rank must be 3, got dims {tr.shape}")
+                if tr.shape[0] != K // 16 or tr.shape[1] != N // 16:
+                    raise ValueError(f"exl3 loader: `{pre}{proj}.trellis` shape {tr.shape} doesn't match (in_features/16, out_features/16, *) "
+                                     f"= ({K // 16}, {N // 16}, *)")
+                if tr.shape[2] == 0 or tr.shape[2] % 16 or not 2 <= tr.shape[2] // 16 <= 8:
+                    raise ValueError(f"exl3 loader: `{pre}{proj}.trellis` last dim {tr.shape[2]} is not 16 * bpw with bpw in 2..8")
+                codebook = 1 if f"{pre}{proj}.mcg" in ck else (2 if f"{pre}{proj}.mul1" in ck else 0)
+                suh, svh = ck.get(f"{pre}{proj}.suh"), ck.get(f"{pre}{proj}.svh")
+                model.load_exl3_linear(li, slot, torch.from_numpy(tr).cuda(), torch.from_numpy(suh.view(np.int16)).view(torch.float16).cuda(),
+                                       torch.from_numpy(svh.view(np.int16)).view(torch.float16).cuda(), codebook)
+    finally:
+        ck.close()
+    return det

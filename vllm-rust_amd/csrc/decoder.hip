@@ -518,6 +518,7 @@ int stage_alloc(MergeStage &s, int K, int Ntot, int group) {
 }
 
 void stage_free(MergeStage &s) {
+    s.filled = 0;   // a later reload of the group starts from an empty stage
     s.qweight.release();
     s.qzeros.release();
     s.scales.release();
@@ -533,6 +534,34 @@ int stage_put(MergeStage &s, const uint32_t *qweight, const uint32_t *qzeros, co
     hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scales_f16,
                        (uint16_t *)s.scales.p + col0, n, N, Ntot);
     VMX_CHECK_LAUNCH("scales f16->bf16");
+    return VMX_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_u32_cols_kernel(uint32_t *__restrict__ dst, uint32_t value, int64_t n, int cols, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[(i / cols) * ld + (i % cols)] = value;
+}
+
+// GPTQ checkpoint tensors of one projection (qweight u32 [K/8, N] with eight k per word, qzeros u32 [K/group, N/8] with eight n
+// per word or NULL for the symmetric zero point 8, scales f16 [K/group, N]) -> columns [col0, col0+N) of the staging tensors, whose
+// layout is that same GPTQ-sequential form (what awq_to_gptq_qweight / repack_awq_nibbles produce for AWQ input).
+int stage_put_gptq(MergeStage &s, const uint32_t *qweight, const uint32_t *qzeros, const uint16_t *scales_f16, int K, int N, int group,
+                   int Ntot, int col0, hipStream_t st) {
+    VMX_REQUIRE(N % 8 == 0 && col0 % 8 == 0, "load_gptq_linear: column range [%d, %d) not aligned to the 8-wide zero words", col0, col0 + N);
+    VMX_CHECK_HIP(hipMemcpy2DAsync((uint32_t *)s.qweight.p + col0, (size_t)Ntot * 4, qweight, (size_t)N * 4, (size_t)N * 4, K / 8,
+                                   hipMemcpyDefault, st));
+    if (qzeros) {
+        VMX_CHECK_HIP(hipMemcpy2DAsync((uint32_t *)s.qzeros.p + col0 / 8, (size_t)(Ntot / 8) * 4, qzeros, (size_t)(N / 8) * 4,
+                                       (size_t)(N / 8) * 4, K / group, hipMemcpyDefault, st));
+    } else {
+        const int64_t n = (int64_t)(K / group) * (N / 8);
+        hipLaunchKernelGGL(fill_u32_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint32_t *)s.qzeros.p + col0 / 8,
+                           0x88888888u, n, N / 8, Ntot / 8);
+    }
+    const int64_t n = (int64_t)(K / group) * N;
+    hipLaunchKernelGGL(f16_to_bf16_into_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scales_f16,
+                       (uint16_t *)s.scales.p + col0, n, N, Ntot);
+    VMX_CHECK_LAUNCH("gptq staging");
     return VMX_OK;
 }
 
@@ -726,15 +755,19 @@ extern "C" int vmx_qwen3_load_tensor(vmx_qwen3 *m, int which, int layer, const v
     return VMX_OK;
 }
 
-extern "C" int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
-                                         const uint16_t *scales_f16, void *stream) {
-    VMX_REQUIRE(m && qweight && qzeros && scales_f16, "qwen3_load_awq_linear: null pointer");
-    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "qwen3_load_awq_linear: layer %d out of range", layer);
+namespace {
+// format 0: AWQ tensors (stage_put), 1: GPTQ tensors (stage_put_gptq; qzeros may be NULL)
+int load_int4_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros, const uint16_t *scales_f16, int format,
+                     void *stream) {
     const vmx_qwen3_config &c = m->cfg;
     Layer &L = m->layers[layer];
     hipStream_t st = vmx_stream(stream);
     const int H = c.hidden_size, I = c.intermediate_size, hd = c.head_dim, g = c.group_size;
     const int NQ = c.num_heads * hd, NKV = c.num_kv_heads * hd;
+    auto put = [&](MergeStage &stg, int K, int N, int Ntot, int col0) {
+        return format == 0 ? stage_put(stg, qweight, qzeros, scales_f16, K, N, g, Ntot, col0, st)
+                           : stage_put_gptq(stg, qweight, qzeros, scales_f16, K, N, g, Ntot, col0, st);
+    };
     MergeStage single;
     switch (slot) {
         case VMX_L_Q: case VMX_L_K: case VMX_L_V: {
@@ -742,36 +775,55 @@ extern "C" int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, cons
             if (int rc = stage_alloc(L.qkv_stage, H, Ntot, g)) return rc;
             const int N = slot == VMX_L_Q ? NQ : NKV;
             const int col0 = slot == VMX_L_Q ? 0 : (slot == VMX_L_K ? NQ : NQ + NKV);
-            if (int rc = stage_put(L.qkv_stage, qweight, qzeros, scales_f16, H, N, g, Ntot, col0, st)) return rc;
+            if (int rc = put(L.qkv_stage, H, N, Ntot, col0)) return rc;
             L.qkv_stage.filled |= 1 << (slot - VMX_L_Q);
             if (L.qkv_stage.filled == 7) return stage_pack(L.qkv_stage, L.qkv, st);
             return VMX_OK;
         }
         case VMX_L_GATE: case VMX_L_UP: {
             if (int rc = stage_alloc(L.gu_stage, H, 2 * I, g)) return rc;
-            if (int rc = stage_put(L.gu_stage, qweight, qzeros, scales_f16, H, I, g, 2 * I, slot == VMX_L_GATE ? 0 : I, st)) return rc;
+            if (int rc = put(L.gu_stage, H, I, 2 * I, slot == VMX_L_GATE ? 0 : I)) return rc;
             L.gu_stage.filled |= slot == VMX_L_GATE ? 1 : 2;
             if (L.gu_stage.filled == 3) return stage_pack(L.gu_stage, L.gate_up, st, true);
             return VMX_OK;
         }
         case VMX_L_O: {
             if (int rc = stage_alloc(single, NQ, H, g)) return rc;
-            int rc = stage_put(single, qweight, qzeros, scales_f16, NQ, H, g, H, 0, st);
+            int rc = put(single, NQ, H, H, 0);
             if (!rc) rc = stage_pack(single, L.o, st);
             stage_free(single);
             return rc;
         }
         case VMX_L_DOWN: {
             if (int rc = stage_alloc(single, I, H, g)) return rc;
-            int rc = stage_put(single, qweight, qzeros, scales_f16, I, H, g, H, 0, st);
+            int rc = put(single, I, H, H, 0);
             if (!rc) rc = stage_pack(single, L.down, st);
             stage_free(single);
             return rc;
         }
         default:
-            vmx_set_error("qwen3_load_awq_linear: unknown slot %d", slot);
+            vmx_set_error("qwen3_load_int4_linear: unknown slot %d", slot);
             return VMX_EINVAL;
     }
+}
+}  // namespace
+
+extern "C" int vmx_qwen3_load_awq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
+                                         const uint16_t *scales_f16, void *stream) {
+    VMX_REQUIRE(m && qweight && qzeros && scales_f16, "qwen3_load_awq_linear: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "qwen3_load_awq_linear: layer %d out of range", layer);
+    return load_int4_linear(m, layer, slot, qweight, qzeros, scales_f16, 0, stream);
+}
+
+// GptqLinear / MarlinLinear::load_weights (crates/core/src/quantization/gptq.rs:430-460, marlin.rs:473-560) for one projection of a
+// 4-bit GPTQ checkpoint: qweight u32 [in/8, out], scales f16 [in/group, out], qzeros u32 [in/group, out/8] or NULL.
+// With qzeros the weight is (nib - z) * s with z as stored (gptq_dequant.cu:48-87); without, (nib - 8) * s, the Marlin form that
+// ignores the zero tensor (marlin_gemm.cu:43-48).  g_idx is not taken: like the reference's kernels, groups follow k / group_size.
+extern "C" int vmx_qwen3_load_gptq_linear(vmx_qwen3 *m, int layer, int slot, const uint32_t *qweight, const uint32_t *qzeros,
+                                          const uint16_t *scales_f16, void *stream) {
+    VMX_REQUIRE(m && qweight && scales_f16, "qwen3_load_gptq_linear: null pointer");
+    VMX_REQUIRE(layer >= 0 && layer < (int)m->layers.size(), "qwen3_load_gptq_linear: layer %d out of range", layer);
+    return load_int4_linear(m, layer, slot, qweight, qzeros, scales_f16, 1, stream);
 }
 
 // One GPTQ expert of a mixture-of-experts layer (MarlinLinear semantics, w = (nib - 8) * scale, qzeros / g_idx ignored:

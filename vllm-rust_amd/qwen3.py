@@ -123,6 +123,15 @@ class QuantizedQwen3ForCausalLM:
                                             self._stream()))
         torch.cuda.current_stream().synchronize()
 
+    def load_gptq_linear(self, layer: int, slot: int, qweight: torch.Tensor, qzeros, scales_f16: torch.Tensor):
+        """qweight int32 [in/8, out], qzeros int32 [in/group, out/8] or None (symmetric zero point 8), scales f16 [in/group, out]."""
+        assert qweight.dtype == torch.int32 and scales_f16.dtype == torch.float16 and (qzeros is None or qzeros.dtype == torch.int32)
+        qweight, scales_f16 = qweight.contiguous(), scales_f16.contiguous()
+        qzeros = qzeros.contiguous() if qzeros is not None else None
+        check(lib.vmx_qwen3_load_gptq_linear(self._h, layer, slot, qweight.data_ptr(), qzeros.data_ptr() if qzeros is not None else None,
+                                             scales_f16.data_ptr(), self._stream()))
+        torch.cuda.current_stream().synchronize()
+
     def load_iq_linear(self, layer: int, slot: int, ggml_type: int, blocks: torch.Tensor) -> None:
         """blocks: uint8 tensor (device or host) with the raw GGUF bytes of the [out, in] weight."""
         blocks = blocks.contiguous()
