@@ -251,7 +251,7 @@ def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
         model.mmvq_select(15)
     dom = max(("qkv", "o_proj", "gate_up", "down_proj"), key=lambda k: kinds[k]["us_per_step"])
     mmvq_kernel = {"qkv": "iq_mmvq_multi_kernel (q|k|v, three I-quant types in one launch)", "o_proj": "iq_mmvq_kernel (o_proj)",
-                   "gate_up": "iq_pk_mmvq_kernel (gate|up, packed 8-row units, codebook + sign tables in LDS)",
+                   "gate_up": "iq_pk_mmvq_kernel<GLU> (gate|up, packed 8-row units, codebook + sign tables in LDS, GeGLU + q8_1 epilogue)",
                    "down_proj": "iq_mmvq_pipe_kernel (down_proj, rows split over 4 waves)"}
     traffic = None
     try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_mmvq.py), when one exists for it

@@ -1087,8 +1087,17 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
             if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
         const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
         const int goffs[2] = {0, I};
-        if (mask & 4)
-            if (int rc = mmvq_group(m, gu, goffs, 2, proj, 2 * I, batch, st)) return rc;
+        if (mask & 4) {   // what the step launches: the fused gate|up + GeGLU form where it applies
+            const VmxMmvqSeg gate_pk = {L.lin[VMX_L_GATE].packed.p, L.lin[VMX_L_GATE].ggml_type, L.lin[VMX_L_GATE].out_features, 0};
+            const VmxMmvqSeg up_pk = {L.lin[VMX_L_UP].packed.p, L.lin[VMX_L_UP].ggml_type, L.lin[VMX_L_UP].out_features, 0};
+            if (batch == 1 && vmx_iq_packed_geglu_ok(&gate_pk, &up_pk, H, batch)) {
+                if (int rc = vmx_iq_mmvq_packed_geglu(&gate_pk, &up_pk, (const int8_t *)m->q8.p,
+                                                      (const float *)((const char *)m->q8.p + (((size_t)H + 255) & ~(size_t)255)),
+                                                      (uint16_t *)m->act.p, (int8_t *)m->q8b.p,
+                                                      (float *)((char *)m->q8b.p + (((size_t)I + 255) & ~(size_t)255)), H, st))
+                    return rc;
+            } else if (int rc = mmvq_group(m, gu, goffs, 2, proj, 2 * I, batch, st)) return rc;
+        }
         if (mask & 8)
             if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
     }
