@@ -128,11 +128,14 @@ def test_qwen3_8b_awq_three_launch_attention_forced(gpu):
 
 
 def test_qwen3_8b_awq_five_launch_layers(gpu):
-    """One and two decode rows take the five-launch layer (RMSNorm in the prologue of q|k|v and gate|up, residual add in the
+    """One to four decode rows take the five-launch layer (RMSNorm in the prologue of q|k|v and gate|up, residual add in the
     epilogue of o_proj and down_proj); three layers, so that the first (norm kernel after the embedding), a middle and the
     last layer (final norm kernel) are all covered; B = 2 with one row in each attention regime."""
     _qwen3_case(gpu, _spec_8b(max_batch=1, num_layers=3), "load_synthetic", start_lens=[41], steps=3, first_ids=[5])
     _qwen3_case(gpu, _spec_8b(max_batch=2, num_layers=3), "load_synthetic", start_lens=[7, 1023], steps=3, first_ids=[11, 4242])
+    # three and four rows: the same layer with wider row staging (rows 2 and 3 of the matrix tile, four-row residual epilogue)
+    _qwen3_case(gpu, _spec_8b(max_batch=3, num_layers=3), "load_synthetic", start_lens=[0, 300, 1020], steps=3, first_ids=[9, 8, 7])
+    _qwen3_case(gpu, _spec_8b(max_batch=4, num_layers=3), "load_synthetic", start_lens=[15, 16, 511, 700], steps=3, first_ids=[1, 22, 333, 4444])
 
 
 def test_qwen3_8b_awq_fp8_kv_batch16(gpu):

@@ -674,7 +674,7 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     TRY(m->act.alloc((size_t)B * I * 2));
     TRY(m->logits.alloc((size_t)c.max_batch * VL * 2));
     TRY(m->positions.alloc((size_t)B * 4));
-    TRY(m->ssq.alloc((size_t)2 * (H / 16 + 4) * 4));   // two decode rows' per-tile sums of squares
+    TRY(m->ssq.alloc((size_t)4 * (H / 16 + 4) * 4));   // per-tile sums of squares of up to four decode rows
     TRY(m->red_bf16.alloc((size_t)B * H * 2));
     {   // q8_1 staging for I-quant linears: int8 [B][Kmax] + f32 [B][Kmax/32]
         const size_t kmax = (size_t)(H > I ? (H > NO ? H : NO) : (I > NO ? I : NO));

@@ -530,11 +530,11 @@ __device__ unsigned long long vmx_wide_stamp_buf[8192 * 8];
 #endif
 
 template <int NWV, int UPW, int NTW, bool GLU, int MR, bool DOT2 = false>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 1 ? WIDE_WAVES_PER_EU : 4))) void int4_gemm_wide_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 1 ? WIDE_WAVES_PER_EU : (MR == 2 ? 4 : 3)))) void int4_gemm_wide_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                                    const uint16_t *__restrict__ hres, const uint16_t *__restrict__ norm_w,
                                                                    float eps, const float *__restrict__ ssq, float *__restrict__ partial,
                                                                    uint16_t *__restrict__ act, int N, int K, int group) {
-    // MR = rows (1 or 2), compiled in: every load instruction a wave issues costs the CU's memory pipeline time, used or not
+    // MR = rows (1..4), compiled in: every load instruction a wave issues costs the CU's memory pipeline time, used or not
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = MR;
     constexpr int TH = 64 * NWV, KBS = NWV * UPW, KS = KBS * KB, XROW = KS + 8, CPR = KS / 8;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
     float *sumx = reinterpret_cast<float *>(smem + (((size_t)MR * XROW * 2 + 15) & ~(size_t)15));  // [KBS][4 rows]
     float *red = sumx + KBS * 4;                                                                 // [NTW][NWV][16 columns][4 rows]
     uint32_t *szs = reinterpret_cast<uint32_t *>(red + NTW * NWV * 64);                          // [NTW][KBS][16]
-    float *invs = reinterpret_cast<float *>(szs + NTW * KBS * 16);                               // [2]
+    float *invs = reinterpret_cast<float *>(szs + NTW * KBS * 16);                               // [4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 15, hh = lane >> 4;
     const int groups = (N / NT) / NTW, kblocks = K / KB, G = K / group;
     const int nt0 = ((int)blockIdx.x % groups) * NTW, ks = (int)blockIdx.x / groups;
@@ -596,9 +596,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
         }
     }
     __syncthreads();
-    float inv[2];
-    inv[0] = invs[0];
-    inv[1] = MR > 1 ? invs[1] : 0.f;
+    float inv[MR];
+#pragma unroll
+    for (int m = 0; m < MR; m++) inv[m] = invs[m];
 #pragma unroll
     for (int j = 0; j < XCF; j++) {
         const int c = tid + TH * j;
@@ -607,7 +607,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
         float hv[8], wv[8];
         bf16x8_to_f32(xv[j], hv);
         bf16x8_to_f32(nwv[j], wv);
-        const float iv = m == 1 ? inv[1] : inv[0];
+        float iv = inv[0];
+#pragma unroll
+        for (int r = 1; r < MR; r++) iv = m == r ? inv[r] : iv;
         uint32_t pk[4];
 #pragma unroll
         for (int e = 0; e < 4; e++)
@@ -716,8 +718,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
     WIDE_STAMP(4);
     __syncthreads();
     // thread = (tile t, row m, column c): sum over the waves in wave order
-    for (int i = tid; i < NTW * 32; i += TH) {
-        const int t = i >> 5, m = (i >> 4) & 1, c = i & 15;
+    constexpr int RSH = MR > 2 ? 6 : 5;   // 32 (two rows) or 64 (four rows) threads per tile
+    for (int i = tid; i < (NTW << RSH); i += TH) {
+        const int t = i >> RSH, m = (i >> 4) & (MR > 2 ? 3 : 1), c = i & 15;
         if (m >= M) continue;
         if (GLU) {
             if (c >= 8) continue;
@@ -754,7 +757,7 @@ struct AttnMergeArgs {
     int P, HD;
 };
 
-template <int UPW, int PM>
+template <int UPW, int PM, int MRR = 2>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void int4_gemm_resid_kernel(
     const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ, const uint16_t *__restrict__ x, uint16_t *__restrict__ h,
     float *__restrict__ ssq, int M, int N, int K, int group, AttnMergeArgs am) {
@@ -762,9 +765,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     // issued back to back (surplus threads re-read a valid address and drop the value)
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NWV = 16, KBLK = NWV * UPW, KK = KBLK * KB, XROW = KK + 8, CPR = KK / 8;
-    constexpr int XCF = (2 * CPR + 1023) / 1024;   // chunks per thread for two rows
-    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                                   // [2][XROW]
-    float *sumx = reinterpret_cast<float *>(smem + (((size_t)2 * XROW * 2 + 15) & ~(size_t)15));   // [KBLK][16]
+    constexpr int XCF = (MRR * CPR + 1023) / 1024;   // chunks per thread for MRR (2 or 4) rows
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                                   // [MRR][XROW]
+    float *sumx = reinterpret_cast<float *>(smem + (((size_t)MRR * XROW * 2 + 15) & ~(size_t)15));   // [KBLK][16]
     float *red = sumx + KBLK * 16;                                                        // [16 waves][16 columns][4 rows]
     uint32_t *szs = reinterpret_cast<uint32_t *>(red + NWV * 16 * 4);                     // [KBLK][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -874,13 +877,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
         fin[2] += s * (acc[2] - zo * sx.z);
         fin[3] += s * (acc[3] - zo * sx.w);
     }
-    if (hh == 0) {   // rows 0 and 1 of the MFMA tile (M <= 2), laid out [row][column][wave] so that the sum below reads 4 x 16 bytes
-        red[(nl) * 16 + wave] = fin[0];
-        red[(16 + nl) * 16 + wave] = fin[1];
+    if (hh == 0) {   // rows 0 .. MRR - 1 of the MFMA tile, laid out [row][column][wave] so that the sum below reads 4 x 16 bytes
+#pragma unroll
+        for (int r = 0; r < MRR; r++) red[(r * 16 + nl) * 16 + wave] = fin[r];
     }
     __syncthreads();
     if (tid < 64) {   // wave 0; thread = (row m, column c): sum of the 16 waves in wave order
-        const int m = (tid >> 4) & 1, c = tid & 15;
+        const int m = (tid >> 4) & (MRR - 1), c = tid & 15;
         float v = 0.f;
         const float4 *rp = reinterpret_cast<const float4 *>(red + (m * 16 + c) * 16);
 #pragma unroll
@@ -1257,7 +1260,7 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
 
 // ---- the norm-in-prologue / residual-in-epilogue forms (M <= 2): see int4_gemm_body<NORM> and int4_gemm_resid_kernel
 bool vmx_int4_resid_fusable(int M, int N, int K) {
-    return M >= 1 && M <= 2 && K % (16 * KB) == 0 && K / (16 * KB) <= 8 && N % NT == 0;   // whole k-blocks for each of the 16 waves
+    return M >= 1 && M <= 4 && K % (16 * KB) == 0 && K / (16 * KB) <= 8 && N % NT == 0;   // whole k-blocks for each of the 16 waves
 }
 
 namespace {
@@ -1318,6 +1321,14 @@ int launch_wide_t(const WidePlan &p, const uint4 *W, const uint32_t *SZ, const u
         return VMX_EINVAL;
     } else {
         if (M == 1) return launch_wide_m<NWV, UPW, NTW, GLU, 1>(p, W, SZ, h, norm_w, eps, ssq, partial, act, N, K, group, st);
+        if constexpr (NTW == 1) {   // three and four rows: the planner's own shapes only (one tile per workgroup)
+            if (M == 3) return launch_wide_m<NWV, UPW, NTW, GLU, 3>(p, W, SZ, h, norm_w, eps, ssq, partial, act, N, K, group, st);
+            if (M == 4) return launch_wide_m<NWV, UPW, NTW, GLU, 4>(p, W, SZ, h, norm_w, eps, ssq, partial, act, N, K, group, st);
+        }
+        if (M != 2) {
+            vmx_set_error("int4_gemm(wide): %d rows with %d tiles per workgroup", M, NTW);
+            return VMX_EUNSUPPORTED;
+        }
         return launch_wide_m<NWV, UPW, NTW, GLU, 2>(p, W, SZ, h, norm_w, eps, ssq, partial, act, N, K, group, st);
     }
 }
@@ -1356,8 +1367,11 @@ extern "C" int vmx_debug_wide_stamps_read(void *dst, size_t bytes) {
 // split-K slices the norm-in-prologue form leaves in `partial` (0: shape not supported)
 int vmx_int4_norm_splits(int M, int N, int K, int glu) {
     WidePlan p;
-    if (M < 1 || M > 2 || K > 8192 || K % KB || N % NT || (glu && N % 32)) return 0;
-    return plan_wide(N, K, glu != 0, &p) ? p.splits : 0;
+    static const int max_rows = tune("VMX_INT4_FOLD_ROWS", 4);   // measurement: 2 restores the two-row limit
+    if (M < 1 || M > 4 || M > max_rows || K > 8192 || K % KB || N % NT || (glu && N % 32)) return 0;
+    if (!plan_wide(N, K, glu != 0, &p)) return 0;
+    if (M > 2 && p.ntw != 1) return 0;
+    return p.splits;
 }
 
 int vmx_int4_gemm_partial_norm(const void *packed, const uint16_t *h, const uint16_t *norm_w, float eps, const float *ssq, float *partial,
@@ -1392,14 +1406,20 @@ static int resid_launch(const void *packed, const uint16_t *x, const VmxAttnPart
     }
     // VMX_INT4_RESID_LDS: pad the workgroup's LDS request (bytes) to steer how many workgroups share a CU (measurement aid)
     static const int lds_pad = tune("VMX_INT4_RESID_LDS", 0);
-    size_t lds = (((size_t)2 * (K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(K / KB) * 16 * 4 * 2 + 16 * 16 * 4 * 4;
+    const int mrr = M <= 2 ? 2 : 4;   // rows the workgroup stages
+    size_t lds = (((size_t)mrr * (K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(K / KB) * 16 * 4 * 2 + 16 * 16 * 4 * 4;
     if ((size_t)lds_pad > lds) lds = lds_pad;
     const dim3 grid((unsigned)(N / NT)), block(1024);
-#define RSD_P(U, PMV)                                                                                                                  \
+#define RSD_M(U, PMV, R)                                                                                                               \
     do {                                                                                                                               \
         if (lds > 64 * 1024)                                                                                                           \
-            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_resid_kernel<U, PMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((int4_gemm_resid_kernel<U, PMV>), grid, block, lds, st, W, SZ, x, h, ssq, M, N, K, group, am);              \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_resid_kernel<U, PMV, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((int4_gemm_resid_kernel<U, PMV, R>), grid, block, lds, st, W, SZ, x, h, ssq, M, N, K, group, am);           \
+    } while (0)
+#define RSD_P(U, PMV)                           \
+    do {                                        \
+        if (mrr == 2) RSD_M(U, PMV, 2);         \
+        else RSD_M(U, PMV, 4);                  \
     } while (0)
 #define RSD(U)                                  \
     do {                                        \
@@ -1419,6 +1439,7 @@ static int resid_launch(const void *packed, const uint16_t *x, const VmxAttnPart
     }
 #undef RSD
 #undef RSD_P
+#undef RSD_M
     VMX_CHECK_LAUNCH("int4_gemm(resid)");
     return VMX_OK;
 }
