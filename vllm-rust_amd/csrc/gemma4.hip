@@ -53,12 +53,12 @@ __global__ __launch_bounds__(256) void g4_embed_kernel(uint16_t *__restrict__ ou
 }
 
 // One workgroup per token; thread t owns the 8-element chunks t, t+256, ... (CH of them) in registers.
-//   o given:  o_r = bf16(o);  n = bf16(o_r * rsqrt(mean(o_r^2) + eps) * w_post);  h = bf16(n + h);
+//   o given:  o_r = bf16(o);  n = bf16(o_r * rsqrt(mean(o_r^2) + eps) * w_post);  h = bf16(n + h_in);
 //             scalar given: h = bf16(h * scalar)                       (post-norm, residual add, layer_scalar)
 //   always:   x = bf16(h * rsqrt(mean(h^2) + eps) * w_next)  (+ its q8_1 form)   (the next sub-block's pre-norm);
 //             w_next == nullptr: x = h (the per-layer-input gate projects the residual stream itself)
 template <int CH>
-__global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x, const float *__restrict__ o,
+__global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, const uint16_t *__restrict__ h_in, uint16_t *__restrict__ x, const float *__restrict__ o,
                                                        const uint16_t *__restrict__ w_post, const uint16_t *__restrict__ scalar,
                                                        const uint16_t *__restrict__ w_next, float eps, int hidden,
                                                        int8_t *__restrict__ aq, float *__restrict__ ad) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void g4_norm_kernel(uint16_t *__restrict__ h, 
             ob[c] = *reinterpret_cast<const float4 *>(o + row + 8 * ci + 4);
             wp[c] = *reinterpret_cast<const uint4 *>(w_post + 8 * ci);
         }
-        hraw[c] = *reinterpret_cast<const uint4 *>(h + row + 8 * ci);
+        hraw[c] = *reinterpret_cast<const uint4 *>(h_in + row + 8 * ci);   // h_in == h, or the buffer the fused gate|up launch left the stream in
         wn[c] = w_next ? *reinterpret_cast<const uint4 *>(w_next + 8 * ci) : make_uint4(0, 0, 0, 0);
     }
     const float sc = scalar ? vmx_bf16_to_f32(scalar[0]) : 1.0f;
@@ -362,7 +362,7 @@ struct vmx_gemma4 {
     vmx_gemma4_config cfg;
     std::vector<G4Layer> layers;
     Buf embed, final_norm, cos_sin_s, cos_sin_f;
-    Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8, q8b, positions;
+    Buf h, x, q, attn, act, proj, out, logits, logits_f32, x_f32, attn_ws, argmax_ws, q8, q8b, h2, positions;
     void *q8_alt = nullptr;   // non-null while a linear reads its q8_1 activations from q8b (written by the fused gate|up + GeGLU launch)
     float embed_scale = 1.f;
     // per-layer inputs (hidden_size_per_layer_input > 0): embed_tokens_per_layer, per_layer_model_projection and its norm, and the
@@ -438,11 +438,12 @@ int g4_tp_reduce(vmx_gemma4 *m, float *out, int tokens, int hidden, hipStream_t 
 }
 
 void launch_norm(hipStream_t st, int tokens, uint16_t *h, uint16_t *x, const float *o, const uint16_t *w_post, const uint16_t *scalar,
-                 const uint16_t *w_next, float eps, int hidden, int8_t *aq, float *ad) {
-    if (hidden <= 2048) hipLaunchKernelGGL(g4_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
-    else if (hidden <= 4096) hipLaunchKernelGGL(g4_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
-    else if (hidden <= 8192) hipLaunchKernelGGL(g4_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
-    else hipLaunchKernelGGL(g4_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+                 const uint16_t *w_next, float eps, int hidden, int8_t *aq, float *ad, const uint16_t *h_in = nullptr) {
+    if (!h_in) h_in = h;
+    if (hidden <= 2048) hipLaunchKernelGGL(g4_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, h_in, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+    else if (hidden <= 4096) hipLaunchKernelGGL(g4_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, h_in, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+    else if (hidden <= 8192) hipLaunchKernelGGL(g4_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, h_in, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
+    else hipLaunchKernelGGL(g4_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, h_in, x, o, w_post, scalar, w_next, eps, hidden, aq, ad);
 }
 }  // namespace
 
@@ -636,6 +637,7 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         kmax = (size_t)P > kmax ? (size_t)P : kmax;
         TRY(m->q8.alloc(R * kmax + 256 + R * (kmax / 32) * 4));
         TRY(m->q8b.alloc(kmax + 256 + (kmax / 32) * 4));   // one row: the fused gate|up launch reads q8 and writes this
+        TRY(m->h2.alloc((size_t)H * 2));                   // one row of the residual stream, written by the norm-fused gate|up launch
     }
     {
         const size_t a = vmx_paged_attention_workspace_bytes(B, c.num_heads, max_hd, c.max_seq_len);
@@ -664,7 +666,7 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     m->ple_model_proj.packed.release();
     for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage, &m->red_bf16, &m->keys, &m->gemm_ws}) b->release();
     for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
-                   &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8, &m->q8b})
+                   &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8, &m->q8b, &m->h2})
         b->release();
     delete m;
 }
@@ -783,6 +785,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
     // pending: the previous layer's last linear output still to be post-normed, added, scaled
     const float *pending = nullptr;
     const uint16_t *pending_w = nullptr, *pending_scalar = nullptr;
+    const uint16_t *h_src = nullptr;   // non-null: the stream was left in m->h2 by a norm-fused gate|up launch; the next norm moves it back to h
     int li = -1;
     for (const G4Layer &L : m->layers) {
         li++;
@@ -792,7 +795,8 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         const int ntot = NQ + (nseg - 1) * NKV;
         // (previous layer's tail) + input_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H, aq_of(m),
-                    ad_of(m, B, H));
+                    ad_of(m, B, H), h_src);
+        h_src = nullptr;
         {
             const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
             const int offs[3] = {0, NQ, NQ + NKV};
@@ -855,12 +859,27 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         if (int rc = g4_linear(m, L.lin[VMX_L_O], attn, out, H, B, st)) return rc;
         if (tp)
             if (int rc = g4_tp_reduce(m, out, B, H, st)) return rc;
+        const VmxMmvqSeg gate_pk = {L.lin[VMX_L_GATE].packed.p, L.lin[VMX_L_GATE].ggml_type, L.lin[VMX_L_GATE].out_features, 0};
+        const VmxMmvqSeg up_pk = {L.lin[VMX_L_UP].packed.p, L.lin[VMX_L_UP].ggml_type, L.lin[VMX_L_UP].out_features, 0};
+        // one row, no per-layer-input block behind the MLP (it reads x and h of this norm): post_attention_layernorm + residual +
+        // pre_feedforward_layernorm + q8_1 happen in the prologue of the gate|up launch, every workgroup for itself
+        const bool norm_in_mlp = B == 1 && !L.ple && vmx_iq_packed_norm_geglu_ok(&gate_pk, &up_pk, H, B);
+        if (norm_in_mlp) {
+            m->q8_alt = m->q8b.p;
+            const int rc_glu = vmx_iq_mmvq_packed_norm_geglu(&gate_pk, &up_pk, out, h, (uint16_t *)m->h2.p, (const uint16_t *)L.post_attn_ln.p,
+                                                             (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, act, aq_of(m), ad_of(m, B, I), H, st);
+            if (rc_glu) {
+                m->q8_alt = nullptr;
+                return rc_glu;
+            }
+            h_src = (const uint16_t *)m->h2.p;
+        } else {
         // post_attention_layernorm + residual, pre_feedforward_layernorm -> x, q8_1(x)
         launch_norm(st, B, h, x, out, (const uint16_t *)L.post_attn_ln.p, nullptr, (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, H,
                     aq_of(m), ad_of(m, B, H));
-        const VmxMmvqSeg gate_pk = {L.lin[VMX_L_GATE].packed.p, L.lin[VMX_L_GATE].ggml_type, L.lin[VMX_L_GATE].out_features, 0};
-        const VmxMmvqSeg up_pk = {L.lin[VMX_L_UP].packed.p, L.lin[VMX_L_UP].ggml_type, L.lin[VMX_L_UP].out_features, 0};
-        if (B == 1 && vmx_iq_packed_geglu_ok(&gate_pk, &up_pk, H, B)) {
+        }
+        if (norm_in_mlp) {
+        } else if (B == 1 && vmx_iq_packed_geglu_ok(&gate_pk, &up_pk, H, B)) {
             // one launch: both projections, the GeGLU and q8_1 of the result.  It reads q8_1(x) from q8 while other workgroups
             // already write q8_1(act), so the result goes to q8b and the down projection reads it from there.
             m->q8_alt = m->q8b.p;
@@ -888,7 +907,8 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         pending_w = (const uint16_t *)L.post_ffn_ln.p;
         pending_scalar = (const uint16_t *)L.scalar.p;
         if (L.ple) {   // apply_ple (:1663-1683): h += norm(per_layer_projection(gelu_tanh(gate(h)) * pli[layer])), before the scalar
-            launch_norm(st, B, h, x, pending, pending_w, nullptr, nullptr, c.rms_norm_eps, H, aq_of(m), ad_of(m, B, H));
+            launch_norm(st, B, h, x, pending, pending_w, nullptr, nullptr, c.rms_norm_eps, H, aq_of(m), ad_of(m, B, H), h_src);
+            h_src = nullptr;
             if (int rc = g4_linear(m, L.lin[VMX_L_PLE_GATE], x, proj, P, B, st)) return rc;
             hipLaunchKernelGGL(g4_ple_gate_kernel, dim3((unsigned)(((int64_t)B * P / 8 + 255) / 256)), dim3(256), 0, st, proj,
                                (const uint16_t *)m->pli.p + (size_t)li * P, (int64_t)LP, B, P, act, aq_of(m), ad_of(m, B, P));
@@ -896,7 +916,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
             pending_w = (const uint16_t *)L.post_ple_norm.p;
         }
     }
-    launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr);
+    launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr, h_src);
     VMX_CHECK_LAUNCH("gemma4 layers");
     for (G4Layer &L : m->layers) L.kv_calibrated = true;   // every cache has had its first write
     return VMX_OK;

@@ -329,16 +329,97 @@ struct PkArgs {
     uint16_t *glu_act;   // bf16 [inter]
     int8_t *glu_aq;      // its q8_1 form for the down projection
     float *glu_ad;
+    // sandwich-norm prologue (NORM = true): the activation row is computed by every workgroup from the previous linear's f32 output
+    // o and the residual stream h instead of being read as q8_1 (see pk_norm_prologue)
+    const float *n_o;
+    const uint16_t *n_h_in, *n_wpost, *n_wnext;
+    uint16_t *n_h_out;
+    float n_eps;
 };
+
+__device__ __forceinline__ float pk_rbf(float x) { return vmx_bf16_to_f32(vmx_f32_to_bf16(x)); }
+__device__ __forceinline__ void pk_unpack8(const uint4 &v, float f[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+}
+__device__ __forceinline__ uint4 pk_pack8(const float f[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = (uint32_t)vmx_f32_to_bf16(f[2 * j]) | ((uint32_t)vmx_f32_to_bf16(f[2 * j + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Registers of the norm prologue: thread t < hidden / 8 owns the 8-element chunk t of the row
+struct PkNormIn {
+    float4 oa, ob;
+    uint4 h, wp, wn;
+};
+
+__device__ __forceinline__ void pk_norm_request(PkNormIn &r, const PkArgs &a, int n_in, int tid) {
+    const int ci = min(tid, (n_in >> 3) - 1);
+    r.oa = *reinterpret_cast<const float4 *>(a.n_o + 8 * ci);
+    r.ob = *reinterpret_cast<const float4 *>(a.n_o + 8 * ci + 4);
+    r.h = *reinterpret_cast<const uint4 *>(a.n_h_in + 8 * ci);
+    r.wp = *reinterpret_cast<const uint4 *>(a.n_wpost + 8 * ci);
+    r.wn = *reinterpret_cast<const uint4 *>(a.n_wnext + 8 * ci);
+}
+
+// Gemma's sandwich norms between o_proj and the MLP (gemma4_quantized.rs:1372-1392), with the bf16 rounding points of the
+// separate norm kernel:  o_r = bf16(o);  n = bf16(o_r * rsqrt(mean(o_r^2) + eps) * w_post);  h' = bf16(n + h);
+// x = bf16(h' * rsqrt(mean(h'^2) + eps) * w_next);  q8_1(x) -> LDS (aq_s int8 [hidden], ad_s f32 [hidden / 32]).
+// Every workgroup computes the whole row (hidden <= 4096: one chunk per thread at most); workgroup 0 also stores h' to
+// n_h_out, a buffer other than n_h_in (the other workgroups may still be reading that one).  Ends with the LDS stores
+// issued, not yet waited for: the caller's barrier does that.
+__device__ __forceinline__ void pk_norm_prologue(const PkNormIn &r, const PkArgs &a, int n_in, int tid, int8_t *aq_s, float *ad_s, float *red) {
+    const int nchunk = n_in >> 3, wave = tid >> 6, nw = blockDim.x >> 6;
+    const bool live = tid < nchunk;
+    float ov[8] = {r.oa.x, r.oa.y, r.oa.z, r.oa.w, r.ob.x, r.ob.y, r.ob.z, r.ob.w};
+    float v1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ov[j] = pk_rbf(ov[j]); v1 += live ? ov[j] * ov[j] : 0.f; }
+    v1 = vmx_wave_sum(v1);
+    if ((tid & 63) == 0) red[wave] = v1;
+    __syncthreads();
+    float t1 = 0.f;
+    for (int w = 0; w < nw; w++) t1 += red[w];
+    const float inv1 = rsqrtf(t1 / (float)n_in + a.n_eps);
+    float wv[8], hr[8], hv[8];
+    pk_unpack8(r.wp, wv);
+    pk_unpack8(r.h, hr);
+    float v2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { hv[j] = pk_rbf(pk_rbf(ov[j] * inv1 * wv[j]) + hr[j]); v2 += live ? hv[j] * hv[j] : 0.f; }
+    if (blockIdx.x == 0 && live) *reinterpret_cast<uint4 *>(a.n_h_out + 8 * tid) = pk_pack8(hv);
+    v2 = vmx_wave_sum(v2);
+    if ((tid & 63) == 0) red[16 + wave] = v2;
+    __syncthreads();
+    float t2 = 0.f;
+    for (int w = 0; w < nw; w++) t2 += red[16 + w];
+    const float inv2 = rsqrtf(t2 / (float)n_in + a.n_eps);
+    pk_unpack8(r.wn, wv);
+    float xr[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) xr[j] = pk_rbf(hv[j] * inv2 * wv[j]);
+    // four consecutive threads hold one 32-value block (nchunk % 4 == 0: a group is all live or all not)
+    const int ci = live ? tid : nchunk - 1;
+    float scratch_d;
+    vmx_q8_1_emit8(xr, live ? aq_s + 8 * ci : aq_s + n_in, live ? ad_s + (ci >> 2) : &scratch_d, (ci & 3) == 0);
+}
 
 // One wave = one work item = PPW row pairs of one unit (rows 2 PPW c .. 2 PPW (c + 1) - 1 of row group g, K-slice s; item
 // index ((g * (4 / PPW) + c) * S + s).  Workgroup = W waves on consecutive items of one segment (W % S == 0, so the S slices
 // of a row set sit in one workgroup and are combined through LDS in slice order).
-template <int T, int PPW, bool DBG, int ABL = 0, bool GLU = false>
+template <int T, int PPW, bool DBG, int ABL = 0, bool GLU = false, bool NORM = false>
 __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const PkSeg &sg, int wg, const int8_t *__restrict__ aq,
-                                        const float *__restrict__ ad, int n_in, int S, int32_t *__restrict__ dbg, int issue_barrier) {
+                                        const float *__restrict__ ad, int n_in, int S, int32_t *__restrict__ dbg, int issue_barrier,
+                                        const PkArgs &na) {
     constexpr int TS = Pk<T>::TS, CPU_ = 4 / PPW, NR = 2 * PPW;   // chunks per unit, rows per item
-    constexpr int AHEAD = VMX_IQ_AHEAD;                           // rows requested ahead of the one being decoded
+#ifndef VMX_IQ_AHEAD_NORM
+#define VMX_IQ_AHEAD_NORM VMX_IQ_AHEAD
+#endif
+    // rows requested ahead of the one being decoded (NORM: the requests made before the prologue are all that is in flight during it)
+    constexpr int AHEAD = NORM ? VMX_IQ_AHEAD_NORM : VMX_IQ_AHEAD;
     const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = nthreads >> 6;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ABL == 3: shader-clock stamps of this wave
@@ -348,6 +429,12 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
     stamp(0, 0.f);
     unsigned long long rt0 = 0;
     if constexpr (ABL == 3) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+    // NORM: the activation row is computed here; its inputs are requested first (loads retire in issue order)
+    PkNormIn nin;
+    int8_t *aq_s = reinterpret_cast<int8_t *>(part) + 512;                 // [n_in] + 8 spare bytes
+    float *ad_s = reinterpret_cast<float *>(aq_s + 4096 + 16);             // [n_in / 32]
+    float *nred = ad_s + 128;                                              // [32]
+    if constexpr (NORM) pk_norm_request(nin, na, n_in, tid);
 #ifndef VMX_IQ_NOTAB
     pk_tables_request<T>(smem, wave, W, lane);
 #endif
@@ -369,8 +456,12 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
 #else
     const int4 *up = reinterpret_cast<const int4 *>(aq + (int64_t)g0 * 32);
 #endif
-    const int4 u0 = up[0], u1 = up[1], u2 = up[2], u3 = up[3];
-    const float2 dav = *reinterpret_cast<const float2 *>(ad + g0);
+    int4 u0, u1, u2, u3;
+    float2 dav;
+    if constexpr (!NORM) {
+        u0 = up[0]; u1 = up[1]; u2 = up[2]; u3 = up[3];
+        dav = *reinterpret_cast<const float2 *>(ad + g0);
+    }
     // weights: every load of the item, in the order the decode wants them back
     const uint8_t *U = sg.w + (int64_t)group * PK_ROWS * nsb * TS + (int64_t)PK_ROWS * TS * sb0;
     PkPart<T> raw[PPW];
@@ -391,8 +482,15 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
         for (int r = 0; r < (NR < AHEAD ? NR : AHEAD); r++) pk_load_row<T>(raw, U, L, lc, chunk * PPW, r);
     }
     stamp(1, 0.f);
-    // tables of every wave of the workgroup (and this wave's first row pair) have landed
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (NORM) pk_norm_prologue(nin, na, n_in, tid, aq_s, ad_s, nred);
+    // tables of every wave of the workgroup (and this wave's first row pair) have landed (NORM: and the q8_1 row is in LDS)
+    if constexpr (NORM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (NORM) {
+        const int4 *us = reinterpret_cast<const int4 *>(aq_s + g0 * 32);
+        u0 = us[0]; u1 = us[1]; u2 = us[2]; u3 = us[3];
+        dav = *reinterpret_cast<const float2 *>(ad_s + g0);
+    }
     stamp(5, 0.f);
     float da[2] = {live ? dav.x : 0.f, live ? dav.y : 0.f};
     if constexpr (ABL == 1) {   // measurement: the weight stream alone
@@ -485,7 +583,7 @@ __device__ __forceinline__ void pk_body(unsigned char *smem, float *part, const 
     }
 }
 
-template <int PPW, bool DBG, int ABL = 0, bool GLU = false>
+template <int PPW, bool DBG, int ABL = 0, bool GLU = false, bool NORM = false>
 __global__ __launch_bounds__(1024) void iq_pk_mmvq_kernel(PkArgs a, const int8_t *__restrict__ aq, const float *__restrict__ ad, int n_in,
                                                            int S, int32_t *__restrict__ dbg, int lds_tables, int issue_barrier) {
     // the only LDS object of the kernel, so the tables start at LDS address 0 and a gather needs no base add
@@ -502,9 +600,9 @@ __global__ __launch_bounds__(1024) void iq_pk_mmvq_kernel(PkArgs a, const int8_t
     const PkSeg &sg = a.seg[si];
     float *part = reinterpret_cast<float *>(pk_smem + lds_tables);   // [waves][8] slice sums (512 B) behind the tables, then the compact table copy
     switch (GLU ? a.seg[0].type : sg.type) {   // workgroup-uniform (GLU: gate and up share a type)
-        case 18: pk_body<18, PPW, DBG, ABL, GLU>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
-        case 21: pk_body<21, PPW, DBG, ABL, GLU>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
-        default: pk_body<22, PPW, DBG, ABL, GLU>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier); break;
+        case 18: pk_body<18, PPW, DBG, ABL, GLU, NORM>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier, a); break;
+        case 21: pk_body<21, PPW, DBG, ABL, GLU, NORM>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier, a); break;
+        default: pk_body<22, PPW, DBG, ABL, GLU, NORM>(pk_smem, part, sg, wg, aq, ad, n_in, S, dbg, issue_barrier, a); break;
     }
     if constexpr (GLU) {
         // act = bf16(bf16(gelu_erf(bf16(gate))) * bf16(up)) and its q8_1 form (two 32-wide blocks), as g4_geglu_kernel computes them
@@ -530,11 +628,11 @@ __global__ __launch_bounds__(1024) void iq_pk_mmvq_kernel(PkArgs a, const int8_t
     }
 }
 
-template <int PPW, bool DBG, int ABL = 0, bool GLU = false> int pk_launch_ppw(const PkArgs &a, int wgs, int W, int lds, const int8_t *aq, const float *ad, int n_in, int S,
+template <int PPW, bool DBG, int ABL = 0, bool GLU = false, bool NORM = false> int pk_launch_ppw(const PkArgs &a, int wgs, int W, int lds, const int8_t *aq, const float *ad, int n_in, int S,
                                                int32_t *dbg, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)iq_pk_mmvq_kernel<PPW, DBG, ABL, GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512 + 8192);
+        hipError_t e = hipFuncSetAttribute((const void *)iq_pk_mmvq_kernel<PPW, DBG, ABL, GLU, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 512 + 8192);
         if (e != hipSuccess) {
             vmx_set_error("iq_mmvq(packed): hipFuncSetAttribute: %s", hipGetErrorString(e));
             return VMX_ELAUNCH;
@@ -542,7 +640,7 @@ template <int PPW, bool DBG, int ABL = 0, bool GLU = false> int pk_launch_ppw(co
         attr_set = true;
     }
     static const int issue_barrier = getenv("VMX_IQ_ISSUE_BARRIER") ? atoi(getenv("VMX_IQ_ISSUE_BARRIER")) : 1;
-    hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL, GLU>), dim3(wgs), dim3(64 * W), lds + 512 + 8192, st, a, aq, ad, n_in, S, dbg, lds, issue_barrier);
+    hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL, GLU, NORM>), dim3(wgs), dim3(64 * W), lds + 512 + 8192, st, a, aq, ad, n_in, S, dbg, lds, issue_barrier);
     VMX_CHECK_LAUNCH("iq_mmvq(packed)");
     return VMX_OK;
 }
@@ -707,6 +805,42 @@ int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const
     a.glu_aq = aq_out;
     a.glu_ad = ad_out;
     return pk_launch_ppw<4, false, 0, true>(a, gate->n_out / 64, 16, pk_lds_bytes(gate->ggml_type), aq, ad, n_in, 1, nullptr, st);
+}
+
+// The same launch with Gemma's sandwich norms in its prologue: the activation row is bf16(norm(h + bf16(norm(o)))) computed by
+// every workgroup from the o_proj output `o` (f32 [n_in]) and the residual stream; h_out (!= h_in) receives the updated stream.
+int vmx_iq_mmvq_packed_norm_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const float *o, const uint16_t *h_in, uint16_t *h_out,
+                                  const uint16_t *w_post, const uint16_t *w_next, float eps, uint16_t *act, int8_t *aq_out, float *ad_out,
+                                  int n_in, hipStream_t st) {
+    static const int off = getenv("VMX_IQ_NO_NORM_FUSION") ? atoi(getenv("VMX_IQ_NO_NORM_FUSION")) : 0;
+    if (off || !vmx_iq_packed_geglu_ok(gate, up, n_in, 1) || n_in % 32 || n_in > 4096 || h_in == h_out) {
+        vmx_set_error("iq_mmvq(packed, norm + GeGLU): not eligible (n_in %d)", n_in);
+        return VMX_EUNSUPPORTED;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_pk_tables_ready[dev]) {
+        vmx_set_error("iq_mmvq(packed): vmx_init(%d) has not run on this device (it builds the decode tables)", dev);
+        return VMX_EINVAL;
+    }
+    PkArgs a = {};
+    a.nseg = 2;
+    a.seg[0] = PkSeg{(const uint8_t *)gate->w, nullptr, gate->ggml_type, gate->n_out, 0};
+    a.seg[1] = PkSeg{(const uint8_t *)up->w, nullptr, up->ggml_type, up->n_out, 0};
+    a.glu_act = act;
+    a.glu_aq = aq_out;
+    a.glu_ad = ad_out;
+    a.n_o = o;
+    a.n_h_in = h_in;
+    a.n_h_out = h_out;
+    a.n_wpost = w_post;
+    a.n_wnext = w_next;
+    a.n_eps = eps;
+    return pk_launch_ppw<4, false, 0, true, true>(a, gate->n_out / 64, 16, pk_lds_bytes(gate->ggml_type), nullptr, nullptr, n_in, 1, nullptr, st);
+}
+
+bool vmx_iq_packed_norm_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, int n_in, int m) {
+    static const int off = getenv("VMX_IQ_NO_NORM_FUSION") ? atoi(getenv("VMX_IQ_NO_NORM_FUSION")) : 0;
+    return !off && n_in % 32 == 0 && n_in <= 4096 && vmx_iq_packed_geglu_ok(gate, up, n_in, m);
 }
 
 extern "C" int vmx_iq_mmvq_packed_geglu_bf16(int ggml_type, const void *gate_packed, const void *up_packed, const int8_t *aq, const float *ad,

@@ -99,6 +99,11 @@ bool vmx_iq_packed_preferred(const VmxMmvqSeg *segs_packed, int nseg, int n_in, 
 int vmx_iq_mmvq_packed_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, hipStream_t st);
 // gate|up MMVQ + GeGLU + q8_1 of the result in one launch (packed tensors of one type, one activation row)
 bool vmx_iq_packed_geglu_ok(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, int n_in, int m);
+// ... and with Gemma's post-attention / pre-feedforward norms and the residual add in the prologue (o: f32 output of o_proj)
+bool vmx_iq_packed_norm_geglu_ok(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, int n_in, int m);
+int vmx_iq_mmvq_packed_norm_geglu(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, const float *o, const uint16_t *h_in,
+                                  uint16_t *h_out, const uint16_t *w_post, const uint16_t *w_next, float eps, uint16_t *act, int8_t *aq_out,
+                                  float *ad_out, int n_in, hipStream_t st);
 int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, const int8_t *aq, const float *ad, uint16_t *act,
                              int8_t *aq_out, float *ad_out, int n_in, hipStream_t st);
 
