@@ -148,6 +148,26 @@ def cpu_baseline_exl3(budget_s=8.0):
             "sample": f"oracle EXL3 linear [4096 -> 512] at 4.0 bpw x{reps} ({t * 1e3:.1f} ms), scaled by weight count to 36 layers x 7 projections"}
 
 
+def prefill_block(tokens, seconds, spec):
+    """The prompt pass of the primary: tok/s, the arithmetic rate of its linears (2 flop per weight per token, lm_head on the last
+    row only) against the dense bf16 MFMA peak, and the MFMA-busy share measured by the committed counter passes of the same
+    kernels (rocprofv3 cannot run inside this process)."""
+    H, I = spec.hidden_size, spec.intermediate_size
+    nq, nkv = spec.num_heads * spec.head_dim, spec.num_kv_heads * spec.head_dim
+    flop = 2.0 * tokens * spec.num_layers * (H * (nq + 2 * nkv) + nq * H + 3 * H * I) + 2.0 * spec.vocab_size * H
+    blk = {"tokens": tokens, "ms": round(seconds * 1e3, 3), "tok_s": round(tokens / seconds, 1),
+           "linear_TFLOP_s": round(flop / seconds / 1e12, 1), "mfma_peak_TFLOP_s": 2500.0,
+           "frac_of_mfma_peak": round(flop / seconds / 1e12 / 2500.0, 4),
+           "note": "one vmx_qwen3_prefill call (64x128-tile MFMA int4 GEMM, MFMA prefill attention); untimed part of the job"}
+    try:
+        k = json.loads((ROOT / "profiles" / "r02_pmc_prefill_mfma.json").read_text())["kernels"]
+        blk["mfma_busy_frac"] = {name.split(" (")[0]: v["mfma_busy_frac"] for name, v in k.items()}
+        blk["mfma_busy_source"] = "profiles/r02_pmc_prefill_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES over the same kernels and shapes)"
+    except Exception:
+        pass
+    return blk
+
+
 def time_linear_kinds(model, side, B, reps):
     """Each kind of linear launch of a decode step alone (and all four), captured into a graph on the model's own buffers and
     replayed back to back between two HIP events on the stream the kernels run on: duration per launch = elapsed / launches."""
@@ -744,8 +764,7 @@ def main():
                        "parallelism": "tp1" if world == 1 else (f"tp{world} ({allreduce_path})" if use_tp else f"dp{world} replicas (tp1 each)"),
                        "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
                        "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
-            "prefill": {"tokens": args.prompt, "ms": round(prefill_s * 1e3, 3), "tok_s": round(args.prompt / prefill_s, 1),
-                        "note": "one vmx_qwen3_prefill call (64x128-tile MFMA int4 GEMM, MFMA prefill attention); untimed part of the job"},
+            "prefill": prefill_block(args.prompt, prefill_s, spec),
             "roofline": roofline,
             "cpu_baseline": None if (args.no_cpu_baseline or exl3) else cpu_baseline(spec),
             "secondary": secondary,
