@@ -173,6 +173,12 @@ def test_mixtral_8x7b_moe_layers(gpu):
     spec = Qwen3Spec(4096, 2, 32, 8, 128, 14336, VOCAB, rms_norm_eps=1e-5, rope_theta=1e6, qk_norm=False, num_experts=8, experts_per_tok=2,
                      max_position=2048, num_blocks=160, max_batch=2, max_seq_len=2048)
     _qwen3_case(gpu, spec, "load_synthetic_moe", start_lens=[15, 1024], steps=2, first_ids=[11, 12], bar=3e-2)
+    # contexts of at most 1024 tokens on one to four rows: norm in the q|k|v prologue, attention partitions merged by o_proj, the
+    # layer's residual add inside the expert combine; three layers so that a middle layer starts from the combine's tile sums
+    spec3 = Qwen3Spec(4096, 3, 32, 8, 128, 14336, VOCAB, rms_norm_eps=1e-5, rope_theta=1e6, qk_norm=False, num_experts=8, experts_per_tok=2,
+                      max_position=2048, num_blocks=200, max_batch=4, max_seq_len=1024)
+    _qwen3_case(gpu, spec3, "load_synthetic_moe", start_lens=[300], steps=3, first_ids=[5], bar=3e-2)
+    _qwen3_case(gpu, spec3, "load_synthetic_moe", start_lens=[0, 15, 16, 700], steps=2, first_ids=[1, 2, 3, 4], bar=3e-2)
 
 
 def test_qwen3_0_6b_tied(gpu):

@@ -1064,7 +1064,13 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         const bool fold = folded_layers_enabled() && !tp && !moe && !one && L.int4_ready() && L.gate_up.glu && !pending &&
                           vmx_int4_norm_splits(B, NQKV_, H, 0) > 0 && vmx_int4_norm_splits(B, 2 * I, H, 1) == 1 &&
                           vmx_int4_resid_fusable(B, H, NQ) && vmx_int4_resid_fusable(B, H, I);
-        const bool fold_in = fold && have_ssq;   // the first layer's h comes from the embedding: no tile sums yet
+        // Mixture-of-experts layer on one to four decode rows: the attention half takes the same forms (norm in the q|k|v prologue,
+        // attention partitions merged by o_proj, residual add in o_proj's epilogue) and the expert combine adds the layer's
+        // output to the residual stream itself, leaving the tile sums for the next layer's q|k|v.
+        const bool mfold = moe && folded_layers_enabled() && !tp && !pending && prefill_offset < 0 && !m->rows_share_cache &&
+                           L.int4_attn_ready() && H % 256 == 0 && NQ <= 4 * 16 * 128 && vmx_int4_norm_splits(B, NQKV_, H, 0) > 0 &&
+                           vmx_int4_resid_fusable(B, H, NQ) && vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0) > 0;
+        const bool fold_in = (fold || mfold) && have_ssq;   // the first layer's h comes from the embedding: no tile sums yet
         if (!fold_in)
             launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
                               iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh);
@@ -1090,7 +1096,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         } else if (int rc = run_linear(m, L.qkv, x, PA, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
         // five-launch layers: attention spread over several workgroups per KV head, merged by o_proj while it stages its activations
-        const bool split_attn = fold && prefill_offset < 0 && !m->rows_share_cache && NQ <= 4 * 16 * 128 &&
+        const bool split_attn = (fold || mfold) && prefill_offset < 0 && !m->rows_share_cache && NQ <= 4 * 16 * 128 &&
                                 vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0) > 0;
         VmxAttnParts sparts{};
         const bool fused_attn = !split_attn && prefill_offset < 0 && !m->rows_share_cache &&
@@ -1140,6 +1146,24 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                                                 L.gate_up.group, st))
                 return rc;
             if (int rc = vmx_int4_gemm_resid(L.down.packed.p, act, h, ssq, B, H, I, L.down.group, st)) return rc;
+            pending = nullptr;
+            have_ssq = true;
+            continue;
+        }
+        if (mfold) {   // h += o_proj(attn);  x = rms_norm(h);  h += experts(x)
+            if (split_attn) {
+                if (int rc = vmx_int4_gemm_resid_attn(L.o.packed.p, &sparts, hd, h, ssq, B, H, NQ, L.o.group, st)) return rc;
+            } else if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, B, H, NQ, L.o.group, st)) return rc;
+            launch_resid_norm(st, h, x, nullptr, 0, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, nullptr, nullptr, nullptr);
+            uint16_t *rl = (uint16_t *)m->router_logits.p;
+            if (int rc = vmx_dense_gemv_launch(rl, x, (const uint16_t *)L.router.p, nullptr, B, c.num_experts, H, st)) return rc;
+            if (int rc = vmx_topk_softmax(rl, VMX_BF16, (float *)m->topk_w.p, (int32_t *)m->topk_ids.p, B, c.num_experts, c.experts_per_tok, 1, 1, st))
+                return rc;
+            if (int rc = vmx_moe_int4_forward_glu((uint16_t *)m->moe_out.p, x, (const float *)m->topk_w.p, (const int32_t *)m->topk_ids.p,
+                                                  (const void *const *)L.w13_table.p, (const void *const *)L.w2_table.p, B, c.experts_per_tok,
+                                                  c.num_experts, H, I, c.group_size, m->moe_ws.p, m->moe_ws.bytes,
+                                                  vmx_int4_glu_fusable(2 * I, H) ? 1 : 0, st, h, ssq))
+                return rc;
             pending = nullptr;
             have_ssq = true;
             continue;

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void moe_align_kernel(const int32_t *__restric
 __global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t *__restrict__ out, const float *__restrict__ partial, int splits,
                                                            int pairs, const float *__restrict__ w, int k, int hidden,
                                                            const void *const *__restrict__ w2_table, const int32_t *__restrict__ ids,
-                                                           int num_experts) {
+                                                           int num_experts, uint16_t *__restrict__ h_resid, float *__restrict__ ssq) {
+    // h_resid != NULL: the layer's residual add happens here as well, h = bf16(h + out), and ssq[t][hidden / 16] receives the
+    // sums of squares of the 16-column tiles of the new h (what the norm prologue of the next layer's q|k|v GEMM reads);
+    // the launch then has one thread per column (hidden % 256 == 0), so a tile is 16 consecutive lanes.
     const int t = blockIdx.y;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hidden; i += gridDim.x * 256) {
         float acc = 0.f;
@@ -132,6 +135,17 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t *__restrict__
             acc = rb(acc + rb(rb(o) * rb(w[p])));
         }
         out[(int64_t)t * hidden + i] = vmx_f32_to_bf16(acc);
+        if (h_resid) {
+            const uint16_t hn = vmx_f32_to_bf16(vmx_bf16_to_f32(h_resid[(int64_t)t * hidden + i]) + acc);
+            h_resid[(int64_t)t * hidden + i] = hn;
+            float sq = vmx_bf16_to_f32(hn);
+            sq *= sq;
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            sq += __shfl_xor(sq, 4, 64);
+            sq += __shfl_xor(sq, 8, 64);
+            if ((i & 15) == 0) ssq[(int64_t)t * (hidden >> 4) + (i >> 4)] = sq;
+        }
     }
 }
 
@@ -198,12 +212,14 @@ extern "C" int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const floa
                                     const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
                                     int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream) {
     return vmx_moe_int4_forward_glu(out, x, topk_weights, topk_ids, w13_packed, w2_packed, tokens, k, num_experts, hidden, inter, group,
-                                    workspace, workspace_bytes, 0, vmx_stream(stream));
+                                    workspace, workspace_bytes, 0, vmx_stream(stream), nullptr, nullptr);
 }
 
 int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
                              const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts, int hidden,
-                             int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st) {
+                             int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st, uint16_t *h_resid,
+                             float *ssq) {
+    VMX_REQUIRE(!h_resid || (ssq && hidden % 256 == 0), "moe_int4_forward: the residual epilogue needs ssq and hidden %% 256 == 0");
     VMX_REQUIRE(out && x && topk_weights && topk_ids && w13_packed && w2_packed && workspace, "moe_int4_forward: null pointer");
     VMX_REQUIRE(tokens >= 1 && k >= 1 && num_experts >= 1, "moe_int4_forward: bad counts");
     VMX_REQUIRE(hidden % 128 == 0 && inter % 128 == 0 && group > 0 && group % 128 == 0 && hidden % group == 0 && inter % group == 0,
@@ -229,7 +245,7 @@ int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk
     // down projection; x row = pair
     if (int rc = vmx_int4_gemm_grouped(w2_packed, topk_ids, num_experts, act, 1, p2, pairs, hidden, inter, group, st)) return rc;
     hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden + 255) / 256, tokens), dim3(256), 0, st, out, p2, s2, pairs, topk_weights, k, hidden, w2_packed, topk_ids,
-                       num_experts);
+                       num_experts, h_resid, ssq);
     VMX_CHECK_LAUNCH("moe_combine");
     return VMX_OK;
 }

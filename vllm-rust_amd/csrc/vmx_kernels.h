@@ -16,7 +16,8 @@ int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *ex
 // moe_kernels.hip: vmx_moe_int4_forward with the experts' gate|up tensors packed for the fused activation (w13_glu != 0)
 int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
                              const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts, int hidden,
-                             int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st);
+                             int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st,
+                             uint16_t *h_resid = nullptr, float *ssq = nullptr);   // h_resid: also h = bf16(h + out) and its tile sums of squares
 int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int M, int N, int K, int group, hipStream_t st);
 // decode rows (M <= 2): RMSNorm of the residual stream in the prologue (q|k|v, gate|up) and the residual add in the epilogue
 // (o_proj, down_proj), so that a dense int4 layer is five launches
