@@ -12,6 +12,7 @@
 // whole step is a fixed launch sequence without allocation or host reads (hipGraph-capturable).
 #include "vmx_kernels.h"
 
+#include <float.h>
 #include <stdlib.h>
 #include <new>
 #include <vector>
@@ -183,6 +184,99 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
             }
         }
     }
+}
+
+// The three launches in front of a mixture-of-experts MLP as one (MoE layers with at most EMAX experts): one workgroup per token,
+//   x = bf16(h * rsqrt(mean(h^2) + eps) * w)                                        (post_attention_layernorm, x also stored)
+//   logit_e = bf16(sum_i x_i * router[e][i])                                        (the dense `gate`, mixtral_quantized.rs:118-119)
+//   softmax over the experts rounded to bf16, top-k (ties: lower index), renormalised  (topk_softmax_kernel, renorm = 1)
+// The router rows are requested together with h, ahead of the norm's reduction.
+template <int CH, int EMAX>
+__global__ __launch_bounds__(256) void norm_router_topk_kernel(const uint16_t *__restrict__ h, uint16_t *__restrict__ x,
+                                                                const uint16_t *__restrict__ w, float eps, int hidden,
+                                                                const uint16_t *__restrict__ router, int E, int k,
+                                                                float *__restrict__ topk_w, int32_t *__restrict__ topk_ids) {
+    __shared__ float red[4];
+    __shared__ float pds[4][EMAX];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = (int64_t)t * hidden;
+    const int nchunk = hidden >> 3;
+    uint4 hraw[CH], wraw[CH], rraw[EMAX][CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int ci = min(tid + 256 * c, nchunk - 1);
+        hraw[c] = *reinterpret_cast<const uint4 *>(h + row + 8 * ci);
+        wraw[c] = *reinterpret_cast<const uint4 *>(w + 8 * ci);
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; e++)
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+            rraw[e][c] = *reinterpret_cast<const uint4 *>(router + (int64_t)min(e, E - 1) * hidden + 8 * min(tid + 256 * c, nchunk - 1));
+    float hv[CH][8], var = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        unpack_bf16x8(hraw[c], hv[c]);
+        if (tid + 256 * c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) var += hv[c][j] * hv[c][j];
+        }
+    }
+    var = vmx_block_sum_256(var, red);
+    const float inv = rsqrtf(var / (float)hidden + eps);
+    float pd[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; e++) pd[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int ci = tid + 256 * c;
+        if (ci < nchunk) {
+            float wv[8], o[8], xr[8];
+            unpack_bf16x8(wraw[c], wv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = hv[c][j] * inv * wv[j];
+            const uint4 packed = pack_bf16x8(o);
+            *reinterpret_cast<uint4 *>(x + row + 8 * ci) = packed;
+            unpack_bf16x8(packed, xr);
+#pragma unroll
+            for (int e = 0; e < EMAX; e++) {
+                float rv[8];
+                unpack_bf16x8(rraw[e][c], rv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) pd[e] += xr[j] * rv[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; e++) {
+        const float s = vmx_wave_sum(pd[e]);
+        if (lane == 0) pds[wave][e] = s;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // wave 0: lane e < E holds expert e
+    float v = -FLT_MAX;
+    if (lane < E) v = round_bf16((pds[0][lane] + pds[1][lane]) + (pds[2][lane] + pds[3][lane]));
+    const float mx = vmx_wave_max(v);
+    float p = lane < E ? expf(v - mx) : 0.f;
+    const float sum = vmx_wave_sum(p);
+    p = lane < E ? round_bf16(p / sum) : -FLT_MAX;
+    float selected = 0.f, mine = 0.f;
+    for (int ki = 0; ki < k; ki++) {
+        float bv = p;
+        int bi = lane < E ? lane : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == ki) { mine = bv; topk_ids[(int64_t)t * k + ki] = bi; }
+        selected += bv;
+        if (lane == bi) p = -FLT_MAX;
+    }
+    const float f = selected > 0.f ? 1.0f / selected : 1.0f;
+    if (lane < k) topk_w[(int64_t)t * k + lane] = mine * f;
 }
 
 // grid (heads_q + 2*heads_kv, tokens), block 64.  Takes the merged qkv linear output as f32
@@ -1154,11 +1248,24 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             if (split_attn) {
                 if (int rc = vmx_int4_gemm_resid_attn(L.o.packed.p, &sparts, hd, h, ssq, B, H, NQ, L.o.group, st)) return rc;
             } else if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, B, H, NQ, L.o.group, st)) return rc;
-            launch_resid_norm(st, h, x, nullptr, 0, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, nullptr, nullptr, nullptr);
-            uint16_t *rl = (uint16_t *)m->router_logits.p;
-            if (int rc = vmx_dense_gemv_launch(rl, x, (const uint16_t *)L.router.p, nullptr, B, c.num_experts, H, st)) return rc;
-            if (int rc = vmx_topk_softmax(rl, VMX_BF16, (float *)m->topk_w.p, (int32_t *)m->topk_ids.p, B, c.num_experts, c.experts_per_tok, 1, 1, st))
-                return rc;
+            static const bool router_fused = !(getenv("VMX_NO_ROUTER_FUSION") && atoi(getenv("VMX_NO_ROUTER_FUSION")));
+            if (router_fused && c.num_experts <= 8 && c.experts_per_tok <= c.num_experts && H <= 4096) {
+                // post_attention_layernorm, the dense router and the top-k softmax in one launch
+                if (H <= 2048)
+                    hipLaunchKernelGGL((norm_router_topk_kernel<1, 8>), dim3(B), dim3(256), 0, st, h, x, (const uint16_t *)L.post_ln.p, c.rms_norm_eps,
+                                       H, (const uint16_t *)L.router.p, c.num_experts, c.experts_per_tok, (float *)m->topk_w.p, (int32_t *)m->topk_ids.p);
+                else
+                    hipLaunchKernelGGL((norm_router_topk_kernel<2, 8>), dim3(B), dim3(256), 0, st, h, x, (const uint16_t *)L.post_ln.p, c.rms_norm_eps,
+                                       H, (const uint16_t *)L.router.p, c.num_experts, c.experts_per_tok, (float *)m->topk_w.p, (int32_t *)m->topk_ids.p);
+                VMX_CHECK_LAUNCH("norm + router + top-k");
+            } else {
+                launch_resid_norm(st, h, x, nullptr, 0, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, nullptr, nullptr, nullptr);
+                uint16_t *rl = (uint16_t *)m->router_logits.p;
+                if (int rc = vmx_dense_gemv_launch(rl, x, (const uint16_t *)L.router.p, nullptr, B, c.num_experts, H, st)) return rc;
+                if (int rc = vmx_topk_softmax(rl, VMX_BF16, (float *)m->topk_w.p, (int32_t *)m->topk_ids.p, B, c.num_experts, c.experts_per_tok, 1, 1,
+                                              st))
+                    return rc;
+            }
             if (int rc = vmx_moe_int4_forward_glu((uint16_t *)m->moe_out.p, x, (const float *)m->topk_w.p, (const int32_t *)m->topk_ids.p,
                                                   (const void *const *)L.w13_table.p, (const void *const *)L.w2_table.p, B, c.experts_per_tok,
                                                   c.num_experts, H, I, c.group_size, m->moe_ws.p, m->moe_ws.bytes,
