@@ -4,7 +4,8 @@ process, and every decode step's greedy ids and logits are compared.  Dense Qwen
 argmax.  Mixtral: tensor-parallel attention + expert-parallel MLP (each rank holds half of the experts; one all-reduce combines
 them, which for two experts per token is the same single bf16 addition as on one GPU).  Gemma 4: I-quant projections split by
 output rows / 256-element input blocks, the one full-attention KV head replicated, a KV-shared last layer, vocabulary-parallel tied
-Q3_K lm_head."""
+Q3_K lm_head.  EXL3 (BASELINE's TP configuration of Qwen3-8B EXL3): trellis tensors split by whole 128-column / 128-row Hadamard
+blocks (parallel.py: shard_exl3_column / shard_exl3_row), row-parallel fp16 outputs summed through the same all-reduce."""
 import multiprocessing as mp
 
 import numpy as np
@@ -17,9 +18,30 @@ def _spec(moe):
     from vllm_rust_amd.qwen3 import Qwen3Spec
     kw = dict(hidden_size=256, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64, intermediate_size=512, vocab_size=1024,
               group_size=128, max_position=64, num_blocks=8, block_size=16, max_batch=2, max_seq_len=64)
-    if moe:
+    if moe == "exl3":   # every shard must hold whole 128-wide Hadamard blocks: 128-wide heads, two KV heads, 512-wide MLP
+        kw.update(head_dim=128, intermediate_size=512)
+    elif moe:
         kw.update(num_experts=4, experts_per_tok=2, qk_norm=False)
     return Qwen3Spec(**kw)
+
+
+def _load_exl3_shard(model, ck, full, rank, world):
+    """This rank's slice of the EXL3 checkpoint `ck` (host copy of load_synthetic_exl3): q/k/v/gate/up by output columns, o/down by
+    input rows; norms and the embedding whole, lm_head by vocabulary rows."""
+    from vllm_rust_amd.parallel import shard_exl3_column, shard_exl3_row
+    from vllm_rust_amd.qwen3 import T_EMBED, T_FINAL_NORM, T_INPUT_LN, T_K_NORM, T_LM_HEAD, T_POST_LN, T_Q_NORM
+    VL = full.vocab_size // world
+    model.load_tensor(T_EMBED, 0, ck["embed"].cuda())
+    model.load_tensor(T_LM_HEAD, 0, ck["lm_head"][rank * VL:(rank + 1) * VL].contiguous().cuda())
+    model.load_tensor(T_FINAL_NORM, 0, ck["final_norm"].cuda())
+    for li in range(full.num_layers):
+        for tid, key in ((T_INPUT_LN, "input_ln"), (T_POST_LN, "post_ln"), (T_Q_NORM, "q_norm"), (T_K_NORM, "k_norm")):
+            model.load_tensor(tid, li, ck[f"{li}.{key}"].cuda())
+        for slot in range(7):
+            bits, cb, tr, suh, svh = ck[f"{li}.{slot}.exl3"]
+            row_parallel = slot in (3, 6)   # o_proj, down_proj
+            tr, suh, svh = (shard_exl3_row if row_parallel else shard_exl3_column)(tr, suh, svh, rank, world)
+            model.load_exl3_linear(li, slot, tr.cuda(), suh.cuda(), svh.cuda(), cb)
 
 
 def _gemma_spec():
@@ -70,6 +92,16 @@ def _worker(rank, world, moe, conns, result_q):
                     for mdl in (shard, ref):
                         if mdl is not None:
                             mdl.load_tensor(which, li, w)
+        elif moe == "exl3":
+            full = _spec(moe)
+            whole = QuantizedQwen3ForCausalLM(full)   # every rank draws the one seeded checkpoint; rank 0 keeps it as the reference
+            ck = whole.load_synthetic_exl3(bits=4, codebook=0, seed=7, keep_host_copy=True)
+            shard = QuantizedQwen3ForCausalLM(shard_spec(full, rank, world))
+            _load_exl3_shard(shard, ck, full, rank, world)
+            if rank == 0:
+                ref = whole
+            else:
+                whole.close()
         else:
             full = _spec(moe)
             shard = QuantizedQwen3ForCausalLM(shard_spec(full, rank, world))
@@ -113,7 +145,7 @@ def _worker(rank, world, moe, conns, result_q):
         result_q.put((rank, [("exception", repr(e), traceback.format_exc())], None, -1))
 
 
-@pytest.mark.parametrize("moe", [False, True, "gemma"])
+@pytest.mark.parametrize("moe", [False, True, "gemma", "exl3"])
 def test_two_rank_executor_matches_single_gpu(moe):
     world = 2
     ctx = mp.get_context("spawn")
