@@ -156,11 +156,22 @@ template <int CB> __device__ __forceinline__ uint32_t exl3_hash(uint32_t w) {  /
 
 // decoded weights of the windows w0, w1 as a packed fp16 pair (w0 low)
 template <int CB> __device__ __forceinline__ uint32_t exl3_decode_pair(uint32_t w0, uint32_t w1) {
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
     if constexpr (CB == 0 || CB == 1) {
+#ifdef VMX_EXL3_PERM_ADD
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+#endif
         const uint32_t x0 = (exl3_hash<CB>(w0) & 0x8fff8fffu) ^ 0x3b603b60u, x1 = (exl3_hash<CB>(w1) & 0x8fff8fffu) ^ 0x3b603b60u;
+#ifdef VMX_EXL3_PERM_ADD
         const uint32_t lo = __builtin_amdgcn_perm(x1, x0, 0x05040100u), hi = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
         return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, lo) + __builtin_bit_cast(h2, hi));
+#else
+        // half(lo16) + half(hi16) of each word with the operand halves picked by sub-dword addressing (SDWA): two instructions for the pair instead of
+        // two byte permutes and a packed add.  The second add writes the high half of d and keeps the low one.
+        uint32_t d;
+        asm("v_add_f16_sdwa %0, %1, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(d) : "v"(x0));
+        asm("v_add_f16_sdwa %0, %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(d) : "v"(x1));
+        return d;
+#endif
     } else {
         return (uint32_t)half_to_bits(exl3_decode<2>(w0)) | ((uint32_t)half_to_bits(exl3_decode<2>(w1)) << 16);
     }
