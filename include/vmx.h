@@ -43,6 +43,8 @@ extern "C" {
 /* KV-cache dtypes (crates/core/src/kv_cache/quantization.rs:16). */
 #define VMX_KV_AUTO 0     /* same 16-bit type as the activations */
 #define VMX_KV_FP8_E4M3 1
+#define VMX_KV_INT8 2     /* symmetric int8 stored as value + 128 (quantize_int8, kv_cache/quantization.rs:330-345): the standalone cache
+                           * write and decode attention take it; the whole-token executors keep bf16 / FP8 e4m3 caches */
 
 /* ------------------------------------------------------------------ runtime */
 
@@ -309,8 +311,9 @@ int vmx_kv_scales_calibrate_if_needed(void *state, const uint16_t *k, int64_t nk
 
 /* Replaces reshape_and_cache_bf16 and the FP8 quantise branch of CacheEngine::write_batch
  * (crates/core/kernels/cache_ops.cu:28-62; kv_cache/cache_engine.rs:196-247):
- * caches [blocks, block_size, kv_heads, head_dim]; kv_dtype VMX_KV_AUTO (bf16 copy) or
- * VMX_KV_FP8_E4M3 (k_scale/v_scale: device f32[1]). */
+ * caches [blocks, block_size, kv_heads, head_dim]; kv_dtype VMX_KV_AUTO (bf16 copy),
+ * VMX_KV_FP8_E4M3 or VMX_KV_INT8 (k_scale/v_scale: device f32[1]; INT8: byte = round(clamp(x / scale, +-127)) + 128,
+ * kv_cache/quantization.rs:330-345). */
 int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
                           const int32_t *slot_mapping, int tokens, int kv_heads, int head_dim, int block_size,
                           int kv_dtype, const float *k_scale, const float *v_scale, void *stream);

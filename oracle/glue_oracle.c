@@ -220,6 +220,12 @@ void orc_copy_blocks(uint8_t *k_cache, uint8_t *v_cache, const int32_t *mapping,
     }
 }
 
+static inline uint8_t orc_kv_int8_quant(uint16_t x_bf16, float scale) {
+    float a = orc_bf16_to_f32(x_bf16) / scale;
+    a = a < -127.0f ? -127.0f : (a > 127.0f ? 127.0f : a);
+    return (uint8_t)((int)roundf(a) + 128); /* Tensor::round = round half away from zero */
+}
+
 /* Scatter K/V rows [tokens, kv_heads*head_dim] into the paged cache
  * [blocks, block_size, kv_heads, head_dim]; slot < 0 skips.  kv_dtype 0 = bf16
  * copy, 1 = FP8 e4m3 with per-tensor scales. */
@@ -236,6 +242,9 @@ void orc_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_c
             if (kv_dtype == 0) {
                 ((uint16_t *)k_cache)[dst + i] = key[t * row + i];
                 ((uint16_t *)v_cache)[dst + i] = value[t * row + i];
+            } else if (kv_dtype == 2) { /* quantize_int8 (kv_cache/quantization.rs:330-345): clamp(x / scale, +-127), round, + 128 */
+                ((uint8_t *)k_cache)[dst + i] = orc_kv_int8_quant(key[t * row + i], k_scale);
+                ((uint8_t *)v_cache)[dst + i] = orc_kv_int8_quant(value[t * row + i], v_scale);
             } else {
                 ((uint8_t *)k_cache)[dst + i] = orc_kv_fp8_quant(key[t * row + i], k_scale);
                 ((uint8_t *)v_cache)[dst + i] = orc_kv_fp8_quant(value[t * row + i], v_scale);
@@ -246,6 +255,7 @@ void orc_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_c
 
 static inline float kv_load(const void *cache, int64_t idx, int kv_dtype, float scale) {
     if (kv_dtype == 0) return orc_bf16_to_f32(((const uint16_t *)cache)[idx]);
+    if (kv_dtype == 2) return ((float)((const uint8_t *)cache)[idx] - 128.0f) * scale; /* paged_attention.cu:83-95 */
     return orc_fp8_e4m3_decode(((const uint8_t *)cache)[idx]) * scale;
 }
 

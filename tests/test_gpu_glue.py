@@ -92,7 +92,7 @@ def test_argmax(gpu):
     assert vmx.argmax(_bf(torch, neg)).item() == 63
 
 
-@pytest.mark.parametrize("kv_dtype", [0, 1])
+@pytest.mark.parametrize("kv_dtype", [0, 1, 2])
 def test_reshape_and_cache(gpu, kv_dtype):
     from oracle import oracle as orc
     vmx, torch = gpu
@@ -109,7 +109,7 @@ def test_reshape_and_cache(gpu, kv_dtype):
     kc = torch.zeros((NB, BS, KVH, D), dtype=tdt, device="cuda"); vc = torch.zeros_like(kc)
     sk = torch.tensor([ks], dtype=torch.float32, device="cuda"); sv = torch.tensor([vs], dtype=torch.float32, device="cuda")
     vmx.reshape_and_cache(_bf(torch, k), _bf(torch, v), kc, vc, torch.from_numpy(slots).cuda(), KVH, D, BS, kv_dtype, sk, sv)
-    assert np.array_equal(kc.cpu().numpy().view(dt), kc_ref)       # byte-exact, FP8 included
+    assert np.array_equal(kc.cpu().numpy().view(dt), kc_ref)       # byte-exact, FP8 and INT8 (value + 128) included
     assert np.array_equal(vc.cpu().numpy().view(dt), vc_ref)
 
 
@@ -286,3 +286,39 @@ def test_reshape_and_cache_hnd_and_copy_blocks(gpu):
     vmx.copy_blocks(kc, vc, torch.from_numpy(mapping).cuda(), bpb)
     assert np.array_equal(kc.cpu().numpy().view(np.uint16), kc_ref) and np.array_equal(vc.cpu().numpy().view(np.uint16), vc_ref)
     vmx.copy_blocks(kc, vc, torch.zeros((0, 2), dtype=torch.int32).cuda(), bpb)     # no pairs: nothing to do
+
+
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (16, 1, 512), (4, 4, 64)])
+def test_paged_attention_int8_kv(gpu, H, KVH, D):
+    """INT8 KV cache (KVCacheDtype::Int8: bytes = round(clamp(x / scale, +-127)) + 128, read back as (byte - 128) * scale,
+    kv_cache/quantization.rs:330-345, paged_attention.cu:83-95): the cache written by vmx_reshape_and_cache is byte for byte the
+    oracle's, and decode attention over it matches the oracle within the floating-point bar."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(H + D)
+    BS, NB, MB = 16, 48, 24
+    seq_lens = np.array([1, 37, 300], np.int32)
+    S = len(seq_lens)
+    T = NB * BS
+    k = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    v = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    ks = float(np.abs(orc.bf16_to_f32(k)).max() / 127.0)
+    vs = float(np.abs(orc.bf16_to_f32(v)).max() * 0.5 / 127.0)      # half the range: exercises the clamp
+    slots = rng.permutation(T).astype(np.int32)
+    kc = np.zeros((NB, BS, KVH, D), np.uint8); vc = np.zeros_like(kc)
+    orc.reshape_and_cache(k, v, kc, vc, slots, KVH, D, BS, 2, ks, vs)
+    assert vc.min() == 1 and vc.max() == 255 and kc.min() >= 1
+    kcd = torch.zeros((NB, BS, KVH, D), dtype=torch.uint8, device="cuda"); vcd = torch.zeros_like(kcd)
+    sk = torch.tensor([ks], dtype=torch.float32, device="cuda"); sv = torch.tensor([vs], dtype=torch.float32, device="cuda")
+    vmx.reshape_and_cache(_bf(torch, k), _bf(torch, v), kcd, vcd, torch.from_numpy(slots).cuda(), KVH, D, BS, 2, sk, sv)
+    assert np.array_equal(kcd.cpu().numpy(), kc) and np.array_equal(vcd.cpu().numpy(), vc)
+    bt = np.stack([rng.permutation(NB)[:MB] for _ in range(S)]).astype(np.int32)
+    q = orc.f32_to_bf16(rng.standard_normal((S, H * D)).astype(np.float32))
+    scale = float(1.0 / np.sqrt(D))
+    for window in (0, 100):
+        got = _u16(torch, vmx.paged_attention(_bf(torch, q), kcd, vcd, torch.from_numpy(bt).cuda(), torch.from_numpy(seq_lens).cuda(),
+                                              scale, H, KVH, D, BS, int(seq_lens.max()), window, 2, sk, sv))
+        ref = orc.paged_attention_v2(q, kc, vc, bt, seq_lens, scale, H, KVH, D, BS, 256, window, 2, ks, vs)
+        g, r = orc.bf16_to_f32(got), orc.bf16_to_f32(ref)
+        assert np.abs(g - r).max() <= (1e-3 + 2 ** -7) * np.abs(r).max(), window
+        assert np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum()) <= 1e-3 + 2 ** -8

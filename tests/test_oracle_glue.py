@@ -207,3 +207,13 @@ def test_reshape_and_cache_hnd_and_copy_blocks():
     orc.copy_blocks(kc.view(np.uint8), vc.view(np.uint8), mapping, KVH * BS * D * 2)
     assert np.array_equal(kc[0], k_before[1]) and np.array_equal(kc[3], k_before[4]) and np.array_equal(kc[1], k_before[1])
     assert np.array_equal(vc[3], vc[4])
+
+
+def test_int8_kv_quantiser_known_values():
+    """quantize_int8 (kv_cache/quantization.rs:330-345): clamp(x / scale, +-127), round half away from zero, + 128."""
+    vals = np.array([[0.0, 1.0, -1.0, 0.5, -0.5, 1.5, 200.0, -200.0]], np.float32)
+    k = orc.f32_to_bf16(vals)
+    kc = np.zeros((1, 1, 1, 8), np.uint8); vc = np.zeros_like(kc)
+    orc.reshape_and_cache(k, k, kc, vc, np.array([0], np.int32), 1, 8, 1, 2, 1.0, 0.5)
+    assert kc.reshape(-1).tolist() == [128, 129, 127, 129, 127, 130, 255, 1]
+    assert vc.reshape(-1).tolist() == [128, 130, 126, 129, 127, 131, 255, 1]

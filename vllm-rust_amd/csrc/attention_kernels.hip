@@ -42,15 +42,17 @@ namespace {
 
 
 // Raw (unconverted) cache accesses, so that many rows can wait in registers cheaply.
-template <bool FP8> struct Raw8 { using T = uint4; };
-template <> struct Raw8<true> { using T = uint2; };
+// FP8: the cache's element type as a template value -- 0 bf16, 1 FP8 e4m3 bytes, 2 INT8 bytes stored as value + 128
+// (load_kv_to_f32<int8_t>, crates/core/kernels/paged_attention.cu:83-95); callers that know only bf16 / e4m3 pass false / true.
+template <int FP8> struct Raw8 { using T = uint2; };
+template <> struct Raw8<0> { using T = uint4; };
 
-template <bool FP8> __device__ __forceinline__ typename Raw8<FP8>::T load8_raw(const void *base, int64_t idx) {
+template <int FP8> __device__ __forceinline__ typename Raw8<FP8>::T load8_raw(const void *base, int64_t idx) {
     if constexpr (!FP8) return *reinterpret_cast<const uint4 *>((const uint16_t *)base + idx);
     else return *reinterpret_cast<const uint2 *>((const uint8_t *)base + idx);
 }
 
-template <bool FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8>::T v, float scale, float f[8]) {
+template <int FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8>::T v, float scale, float f[8]) {
     if constexpr (!FP8) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -58,6 +60,10 @@ template <bool FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8
             f[2 * j] = __uint_as_float(w[j] << 16);
             f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
         }
+    } else if constexpr (FP8 == 2) {
+        const uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+        for (int j = 0; j < 8; j++) f[j] = ((float)((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) - 128.0f) * scale;
     } else {
         f[0] = __builtin_amdgcn_cvt_f32_fp8(v.x, 0) * scale;
         f[1] = __builtin_amdgcn_cvt_f32_fp8(v.x, 1) * scale;
@@ -70,15 +76,18 @@ template <bool FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8
     }
 }
 
-template <bool FP8> __device__ __forceinline__ uint32_t load2_raw(const void *base, int64_t idx) {
+template <int FP8> __device__ __forceinline__ uint32_t load2_raw(const void *base, int64_t idx) {
     if constexpr (!FP8) return *reinterpret_cast<const uint32_t *>((const uint16_t *)base + idx);
     else return *reinterpret_cast<const uint16_t *>((const uint8_t *)base + idx);
 }
 
-template <bool FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale, float &a, float &b) {
+template <int FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale, float &a, float &b) {
     if constexpr (!FP8) {
         a = __uint_as_float(w << 16);
         b = __uint_as_float(w & 0xFFFF0000u);
+    } else if constexpr (FP8 == 2) {
+        a = ((float)(w & 0xFFu) - 128.0f) * scale;
+        b = ((float)((w >> 8) & 0xFFu) - 128.0f) * scale;
     } else {
         a = __builtin_amdgcn_cvt_f32_fp8(w, 0) * scale;
         b = __builtin_amdgcn_cvt_f32_fp8(w, 1) * scale;
@@ -86,7 +95,7 @@ template <bool FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale
 }
 
 // One 16-token tile of K and V as fetched from the cache (unconverted), waiting in registers.
-template <int HD, bool FP8> struct AttnTile {
+template <int HD, int FP8> struct AttnTile {
     typename Raw8<FP8>::T kraw[HD / 32];
     uint32_t vraw[16][HD >= 128 ? HD / 128 : 1];
 };
@@ -96,7 +105,7 @@ template <int HD, bool FP8> struct AttnTile {
 // end re-read the last valid row; their logits are masked later.
 // BTREG: lane l of bt_reg holds the sequence's block-table entry l (read once at kernel start) and the lookup is a lane
 // exchange instead of a dependent global load.
-template <int HD, bool FP8, bool BTREG = false>
+template <int HD, int FP8, bool BTREG = false>
 __device__ __forceinline__ void attn_tile_load(AttnTile<HD, FP8> &t, const void *__restrict__ k_cache, const void *__restrict__ v_cache,
                                                const int32_t *__restrict__ bt_row, int t0, int p1, int block_size, int64_t tok_stride,
                                                int kvh, int lane, int bt_reg = 0) {
@@ -125,7 +134,7 @@ __device__ __forceinline__ void attn_tile_load(AttnTile<HD, FP8> &t, const void 
 // Fold one tile into the running softmax state.  QK^T: one v_mfma_f32_16x16x32_bf16 per 32 head dims (A = q rows, row =
 // head; B = K^T, column = token); softmax over the tile's tokens with 4 butterfly steps inside each 16-lane row group;
 // PV on the vector ALU, p[head][token] broadcast with v_readlane.
-template <int HD, int QPK, bool FP8>
+template <int HD, int QPK, int FP8>
 __device__ __forceinline__ void attn_tile_fold(const AttnTile<HD, FP8> &t, int ntok, const uint4 (&qa)[HD / 32], float lscale, float vsc,
                                                int lane, float (&m_run)[4], float (&s_run)[4],
                                                float (&o)[QPK][HD >= 128 ? HD / 128 : 1][2]) {
@@ -194,7 +203,7 @@ __device__ __forceinline__ void attn_tile_fold(const AttnTile<HD, FP8> &t, int n
 // qa: the q rows as MFMA A fragments (lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)); bt_row: the
 // sequence's block-table row.  `first` holds tile p0 when first_loaded (requested by the caller ahead of other work).
 // Returns running max / sum per head row 4*dg + r and the un-normalised output accumulator.
-template <int HD, int QPK, bool FP8, bool BTREG = false>
+template <int HD, int QPK, int FP8, bool BTREG = false>
 __device__ __forceinline__ void attn_walk(const uint4 (&qa)[HD / 32], const void *__restrict__ k_cache, const void *__restrict__ v_cache,
                                           const int32_t *__restrict__ bt_row, int p0, int p1, int block_size, int64_t tok_stride,
                                           int kvh, float lscale, float vsc, int lane, float (&m_run)[4], float (&s_run)[4],
@@ -229,7 +238,7 @@ __device__ __forceinline__ void attn_walk(const uint4 (&qa)[HD / 32], const void
 //         lane that holds it with v_readlane (wave-uniform, no LDS).
 // Everything a tile needs from HBM (K pieces, V rows, q) is requested before its arithmetic starts;
 // with several tiles per partition the next tile's block-table entry is fetched one tile ahead.
-template <int HD, int QPK, bool FP8>
+template <int HD, int QPK, int FP8>
 __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
     const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_small_kernel(uint16_t *
 //   B  after a workgroup barrier (stores of a workgroup are visible to its own waves: one CU, one vector L1) every wave
 //      walks its share of [start, seq_len) exactly like a partition of the split kernel;
 //   C  the partitions are merged through LDS with the same log-sum-exp rule (paged_attention.cu:840-953).
-template <int HD, int QPK, bool FP8, int NW>
+template <int HD, int QPK, int FP8, int NW>
 __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     uint16_t *__restrict__ out, const float *__restrict__ partial, int splits, int tokens, void *__restrict__ k_cache,
     void *__restrict__ v_cache, const uint16_t *__restrict__ q_norm_w, const uint16_t *__restrict__ k_norm_w, float eps,
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
 //      workgroup to its waves in contiguous sub-ranges, each walked with the online softmax of attn_walk;
 //   C  the waves' states are merged through LDS and the partition's normalised output, max logit and sum go to
 //      tmp_out / max_logits / exp_sums [seq][head][P] (a partition without tokens writes sum 0 and a zero row).
-template <int HD, int QPK, bool FP8, int NW>
+template <int HD, int QPK, int FP8, int NW>
 __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
     float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const float *__restrict__ partial, int splits,
     int tokens, void *__restrict__ k_cache, void *__restrict__ v_cache, const uint16_t *__restrict__ q_norm_w,
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
 constexpr int fused_nw(int hd) { return hd <= 128 ? 16 : 8; }
 constexpr int fused_max_ctx(int hd) { return fused_nw(hd) * 64; }
 
-template <int HD, int QPK, bool FP8>
+template <int HD, int QPK, int FP8>
 int launch_fused(dim3 grid, hipStream_t st, uint16_t *out, const float *partial, int splits, int tokens, void *kc, void *vc,
                  const uint16_t *qn, const uint16_t *kn, float eps, const float *cos_sin, const int32_t *positions, const int32_t *slots,
                  const int32_t *bt, const int32_t *sl, float scale, int Hq, int Hkv, int rot_dim, int mbps, int bs, int window,
@@ -809,7 +818,7 @@ int launch_fused(dim3 grid, hipStream_t st, uint16_t *out, const float *partial,
     return VMX_OK;
 }
 
-template <int HD, int QPK, bool FP8, int NW>
+template <int HD, int QPK, int FP8, int NW>
 int launch_split(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const float *partial, int splits, int tokens,
                  void *kc, void *vc, const uint16_t *qn, const uint16_t *kn, float eps, const float *cos_sin, const int32_t *positions,
                  const int32_t *slots, const int32_t *bt, const int32_t *sl, float scale, int Hq, int Hkv, int rot_dim, int mbps, int bs,
@@ -825,7 +834,7 @@ int launch_split(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, flo
     return VMX_OK;
 }
 
-template <int HD, int QPK, bool FP8>
+template <int HD, int QPK, int FP8>
 int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const uint16_t *q, const void *kc,
                 const void *vc, const int32_t *bt, const int32_t *sl, float scale, int H, int KVH, int mbps, int bs, int max_parts,
                 int window, const float *ks, const float *vs, int tiles_per_part) {
@@ -861,7 +870,7 @@ static int parts_for_impl(int max_seq_len) {
 // O^T keeps a query row in one accumulator column, so the online-softmax rescale is a per-lane multiply.
 typedef short vmx_s16x4 __attribute__((ext_vector_type(4)));
 
-template <int HD, int QPK, bool FP8>
+template <int HD, int QPK, int FP8>
 __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ q,
                                                             const void *__restrict__ k_cache, const void *__restrict__ v_cache,
                                                             const int32_t *__restrict__ block_table, int q_len, int offset, float scale,
@@ -980,7 +989,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
     }
 }
 
-template <int HD, int QPK, bool FP8>
+template <int HD, int QPK, int FP8>
 int launch_prefill(hipStream_t st, uint16_t *out, const uint16_t *q, const void *kc, const void *vc, const int32_t *bt, int q_len, int offset,
                    float scale, int H, int KVH, int bs, int window, const float *ks, const float *vs) {
     constexpr int HPW = QPK < 4 ? QPK : 4, TT = 4 / HPW;
@@ -1060,17 +1069,18 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
     const int tpp = tiles_per_part_for(max_seq_len);
     out->part_tokens = tpp * 16;
     const dim3 grid(num_kv_heads, num_seqs, P);
-    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
+    const int kvt = kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0);
     int rc = VMX_EUNSUPPORTED;
 #define ARGS grid, st, tmp_out, exp_sums, max_logits, q, k_cache, v_cache, block_tables, seq_lens, scale, num_heads, num_kv_heads, \
              max_blocks_per_seq, block_size, P, window, k_scale, v_scale, tpp
+#define BY_KV(HD, Q) rc = kvt == 2 ? launch_part<HD, Q, 2>(ARGS) : (kvt == 1 ? launch_part<HD, Q, 1>(ARGS) : launch_part<HD, Q, 0>(ARGS))
 #define BY_QPK(HD)                                                                                                         \
     switch (qpk) {                                                                                                         \
-        case 1: rc = fp8 ? launch_part<HD, 1, true>(ARGS) : launch_part<HD, 1, false>(ARGS); break;                        \
-        case 2: rc = fp8 ? launch_part<HD, 2, true>(ARGS) : launch_part<HD, 2, false>(ARGS); break;                        \
-        case 4: rc = fp8 ? launch_part<HD, 4, true>(ARGS) : launch_part<HD, 4, false>(ARGS); break;                        \
-        case 8: rc = fp8 ? launch_part<HD, 8, true>(ARGS) : launch_part<HD, 8, false>(ARGS); break;                        \
-        case 16: rc = fp8 ? launch_part<HD, 16, true>(ARGS) : launch_part<HD, 16, false>(ARGS); break;                     \
+        case 1: BY_KV(HD, 1); break;                                                                                       \
+        case 2: BY_KV(HD, 2); break;                                                                                       \
+        case 4: BY_KV(HD, 4); break;                                                                                       \
+        case 8: BY_KV(HD, 8); break;                                                                                       \
+        case 16: BY_KV(HD, 16); break;                                                                                     \
         default: vmx_set_error("paged_attention: %d query heads per KV head unsupported (1..16)", num_heads / num_kv_heads); return VMX_EUNSUPPORTED; \
     }
     switch (head_dim) {
@@ -1083,6 +1093,7 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
             return VMX_EUNSUPPORTED;
     }
 #undef BY_QPK
+#undef BY_KV
 #undef ARGS
     return rc;
 }
@@ -1244,7 +1255,8 @@ extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const 
     VMX_REQUIRE(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
                 "paged_attention: num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
     VMX_REQUIRE(block_size > 0 && max_blocks_per_seq > 0 && window >= 0, "paged_attention: bad cache geometry");
-    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3, "paged_attention: unsupported kv dtype %d", kv_dtype);
+    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3 || kv_dtype == VMX_KV_INT8, "paged_attention: unsupported kv dtype %d",
+                kv_dtype);
     VMX_REQUIRE(workspace_bytes >= vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len),
                 "paged_attention: workspace too small");
     if (num_seqs == 0) return VMX_OK;
