@@ -337,6 +337,12 @@ int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cac
                              int num_heads, int num_kv_heads, int max_blocks_per_seq, int max_seq_len,
                              int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
                              const float *v_scale, void *workspace, size_t workspace_bytes, void *stream);
+/* The fp16 variants of the same kernels (paged_attention_v2_f16 / _reduce_f16, crates/core/kernels/paged_attention.cu;
+ * load_kv_to_f32<__half> :59-61): q, both caches and out are fp16; no quantised cache in this form. */
+int vmx_paged_attention_f16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                            const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
+                            int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* No counterpart in the reference: vmx_paged_attention_bf16 for callers that cannot allocate or size a workspace (code
  * under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  The split-KV partials live in a static

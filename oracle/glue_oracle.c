@@ -256,6 +256,7 @@ void orc_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_c
 static inline float kv_load(const void *cache, int64_t idx, int kv_dtype, float scale) {
     if (kv_dtype == 0) return orc_bf16_to_f32(((const uint16_t *)cache)[idx]);
     if (kv_dtype == 2) return ((float)((const uint8_t *)cache)[idx] - 128.0f) * scale; /* paged_attention.cu:83-95 */
+    if (kv_dtype == 3) return orc_f16_to_f32(((const uint16_t *)cache)[idx]);               /* the _f16 kernel variants, :59-61 */
     return orc_fp8_e4m3_decode(((const uint8_t *)cache)[idx]) * scale;
 }
 
@@ -294,7 +295,7 @@ void orc_paged_attention_v2(const uint16_t *q, const void *k_cache, const void *
                     int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * head_dim;
                     float qk = 0.0f;
                     for (int d = 0; d < head_dim; d++)
-                        qk += orc_bf16_to_f32(qv[d]) * kv_load(k_cache, base + d, kv_dtype, k_scale);
+                        qk += (kv_dtype == 3 ? orc_f16_to_f32(qv[d]) : orc_bf16_to_f32(qv[d])) * kv_load(k_cache, base + d, kv_dtype, k_scale);
                     float l = qk * scale;
                     logits[t - t0] = l;
                     if (l > m) m = l;
@@ -321,7 +322,7 @@ void orc_paged_attention_v2(const uint16_t *q, const void *k_cache, const void *
             }
             uint16_t *o = out + (s * num_heads + h) * head_dim;
             if (nparts == 1) {
-                for (int d = 0; d < head_dim; d++) o[d] = orc_f32_to_bf16(all_tmp[d]);
+                for (int d = 0; d < head_dim; d++) o[d] = kv_dtype == 3 ? orc_f32_to_f16(all_tmp[d]) : orc_f32_to_bf16(all_tmp[d]);
             } else {
                 float gsum = 0.0f;
                 for (int p = 0; p < nparts; p++) {
@@ -332,7 +333,7 @@ void orc_paged_attention_v2(const uint16_t *q, const void *k_cache, const void *
                 for (int d = 0; d < head_dim; d++) {
                     float a = 0.0f;
                     for (int p = 0; p < nparts; p++) a += all_tmp[(int64_t)p * head_dim + d] * all_sum[p];
-                    o[d] = orc_f32_to_bf16(a * inv);
+                    o[d] = kv_dtype == 3 ? orc_f32_to_f16(a * inv) : orc_f32_to_bf16(a * inv);
                 }
             }
             free(all_tmp); free(all_sum); free(all_max); free(logits);

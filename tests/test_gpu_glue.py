@@ -322,3 +322,29 @@ def test_paged_attention_int8_kv(gpu, H, KVH, D):
         g, r = orc.bf16_to_f32(got), orc.bf16_to_f32(ref)
         assert np.abs(g - r).max() <= (1e-3 + 2 ** -7) * np.abs(r).max(), window
         assert np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum()) <= 1e-3 + 2 ** -8
+
+
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (4, 4, 64), (16, 1, 512)])
+def test_paged_attention_f16(gpu, H, KVH, D):
+    """The fp16 kernel variants (paged_attention_v2_f16 / _reduce_f16): fp16 q, cache and output against the oracle's fp16 form."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(H + D + 3)
+    BS, NB, MB = 16, 48, 24
+    seq_lens = np.array([1, 37, 256, 300], np.int32)
+    S = len(seq_lens)
+    kc = rng.standard_normal((NB, BS, KVH, D)).astype(np.float16)
+    vc = rng.standard_normal((NB, BS, KVH, D)).astype(np.float16)
+    q = rng.standard_normal((S, H * D)).astype(np.float16)
+    bt = np.stack([rng.permutation(NB)[:MB] for _ in range(S)]).astype(np.int32)
+    scale = float(1.0 / np.sqrt(D))
+    for window in (0, 100):
+        got = vmx.paged_attention_f16(torch.from_numpy(q).cuda(), torch.from_numpy(kc).cuda(), torch.from_numpy(vc).cuda(),
+                                      torch.from_numpy(bt).cuda(), torch.from_numpy(seq_lens).cuda(), scale, H, KVH, D, BS,
+                                      int(seq_lens.max()), window).cpu().numpy().astype(np.float32)
+        ref = orc.paged_attention_v2(q.view(np.uint16), kc.view(np.uint16), vc.view(np.uint16), bt, seq_lens, scale, H, KVH, D, BS, 256,
+                                     window, 3, 1.0, 1.0).view(np.float16).astype(np.float32)
+        assert np.abs(got - ref).max() <= (1e-3 + 2 ** -10) * np.abs(ref).max(), window
+        assert np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()) <= 1e-3 + 2 ** -11
+    from vllm_rust_amd._lib import lib
+    assert lib.vmx_paged_attention_f16(None, None, None, None, None, None, 1.0, 1, 4, 4, 1, 16, 64, 16, 0, None, 0, None) != 0

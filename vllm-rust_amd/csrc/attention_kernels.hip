@@ -43,17 +43,28 @@ namespace {
 
 // Raw (unconverted) cache accesses, so that many rows can wait in registers cheaply.
 // FP8: the cache's element type as a template value -- 0 bf16, 1 FP8 e4m3 bytes, 2 INT8 bytes stored as value + 128
-// (load_kv_to_f32<int8_t>, crates/core/kernels/paged_attention.cu:83-95); callers that know only bf16 / e4m3 pass false / true.
+// (load_kv_to_f32<int8_t>, crates/core/kernels/paged_attention.cu:83-95), 3 fp16 with fp16 queries (the paged_attention_*_f16
+// variants: load_kv_to_f32<__half>, :59-61); callers that know only bf16 / e4m3 pass false / true.
 template <int FP8> struct Raw8 { using T = uint2; };
 template <> struct Raw8<0> { using T = uint4; };
+template <> struct Raw8<3> { using T = uint4; };
+template <int FP8> constexpr bool kv16() { return FP8 == 0 || FP8 == 3; }
+__device__ __forceinline__ float attn_h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16); }
 
 template <int FP8> __device__ __forceinline__ typename Raw8<FP8>::T load8_raw(const void *base, int64_t idx) {
-    if constexpr (!FP8) return *reinterpret_cast<const uint4 *>((const uint16_t *)base + idx);
+    if constexpr (kv16<FP8>()) return *reinterpret_cast<const uint4 *>((const uint16_t *)base + idx);
     else return *reinterpret_cast<const uint2 *>((const uint8_t *)base + idx);
 }
 
 template <int FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8>::T v, float scale, float f[8]) {
-    if constexpr (!FP8) {
+    if constexpr (FP8 == 3) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f[2 * j] = attn_h2f(w[j] & 0xFFFFu);
+            f[2 * j + 1] = attn_h2f(w[j] >> 16);
+        }
+    } else if constexpr (!FP8) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -77,12 +88,15 @@ template <int FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8>
 }
 
 template <int FP8> __device__ __forceinline__ uint32_t load2_raw(const void *base, int64_t idx) {
-    if constexpr (!FP8) return *reinterpret_cast<const uint32_t *>((const uint16_t *)base + idx);
+    if constexpr (kv16<FP8>()) return *reinterpret_cast<const uint32_t *>((const uint16_t *)base + idx);
     else return *reinterpret_cast<const uint16_t *>((const uint8_t *)base + idx);
 }
 
 template <int FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale, float &a, float &b) {
-    if constexpr (!FP8) {
+    if constexpr (FP8 == 3) {
+        a = attn_h2f(w & 0xFFFFu);
+        b = attn_h2f(w >> 16);
+    } else if constexpr (!FP8) {
         a = __uint_as_float(w << 16);
         b = __uint_as_float(w & 0xFFFF0000u);
     } else if constexpr (FP8 == 2) {
@@ -144,7 +158,11 @@ __device__ __forceinline__ void attn_tile_fold(const AttnTile<HD, FP8> &t, int n
 #pragma unroll
     for (int i = 0; i < KSTEPS; i++) {
         uint4 kb;
-        if constexpr (!FP8) {
+        if constexpr (FP8 == 3) {   // fp16 queries and keys: the fp16 form of the same matrix instruction
+            typedef _Float16 attn_f16x8 __attribute__((ext_vector_type(8)));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(attn_f16x8, qa[i]), __builtin_bit_cast(attn_f16x8, t.kraw[i]), acc, 0, 0, 0);
+            continue;
+        } else if constexpr (!FP8) {
             kb = t.kraw[i];
         } else {  // e4m3 -> bf16 is exact
             float f[8];
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
                                                                  const float *__restrict__ max_logits,
                                                                  const int32_t *__restrict__ seq_lens, int num_heads, int head_dim,
                                                                  int max_parts, int window, int part_tokens, int8_t *__restrict__ aq,
-                                                                 float *__restrict__ ad) {
+                                                                 float *__restrict__ ad, int out_f16) {
     __shared__ float w_s[64];
     __shared__ float inv_s;
     const int head = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
             for (int p = 0; p < np; p++) acc += tp[(int64_t)p * head_dim + d] * w_s[p];
             val = acc * inv;
         }
-        const uint16_t vb = vmx_f32_to_bf16(val);
+        const uint16_t vb = out_f16 ? __builtin_bit_cast(uint16_t, (_Float16)val) : vmx_f32_to_bf16(val);
         o[d] = vb;
         if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block (iq_dequant.cu:253-267)
             const float v = vmx_bf16_to_f32(vb);
@@ -1069,11 +1087,13 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
     const int tpp = tiles_per_part_for(max_seq_len);
     out->part_tokens = tpp * 16;
     const dim3 grid(num_kv_heads, num_seqs, P);
-    const int kvt = kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0);
+    const int kvt = kv_dtype == VMX_KV_F16_INTERNAL ? 3 : (kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0));
     int rc = VMX_EUNSUPPORTED;
 #define ARGS grid, st, tmp_out, exp_sums, max_logits, q, k_cache, v_cache, block_tables, seq_lens, scale, num_heads, num_kv_heads, \
              max_blocks_per_seq, block_size, P, window, k_scale, v_scale, tpp
-#define BY_KV(HD, Q) rc = kvt == 2 ? launch_part<HD, Q, 2>(ARGS) : (kvt == 1 ? launch_part<HD, Q, 1>(ARGS) : launch_part<HD, Q, 0>(ARGS))
+#define BY_KV(HD, Q)                                                                                                       \
+    rc = kvt == 3 ? launch_part<HD, Q, 3>(ARGS)                                                                            \
+                  : (kvt == 2 ? launch_part<HD, Q, 2>(ARGS) : (kvt == 1 ? launch_part<HD, Q, 1>(ARGS) : launch_part<HD, Q, 0>(ARGS)))
 #define BY_QPK(HD)                                                                                                         \
     switch (qpk) {                                                                                                         \
         case 1: BY_KV(HD, 1); break;                                                                                       \
@@ -1099,18 +1119,21 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
 }
 
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
-                              int head_dim, int window, hipStream_t st, int8_t *aq, float *ad) {
+                              int head_dim, int window, hipStream_t st, int8_t *aq, float *ad, int out_f16) {
     const dim3 grid(num_heads, num_seqs);
 #define SMALL(NP, EPT)                                                                                                                  \
     hipLaunchKernelGGL((paged_attn_reduce_small_kernel<NP, EPT>), grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,          \
                        parts->max_logits, seq_lens, num_heads, aq, ad)
-    if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 256) SMALL(4, 2);
+    if (out_f16)
+        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
+                           seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad, 1);
+    else if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 256) SMALL(4, 2);
     else if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 128) SMALL(4, 1);
     else if (parts->part_tokens == 0 && parts->max_parts == 2 && head_dim == 256) SMALL(2, 2);
     else if (parts->part_tokens == 0 && parts->max_parts == 8 && head_dim == 256) SMALL(8, 2);
     else
         hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
-                           seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad);
+                           seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad, 0);
 #undef SMALL
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
@@ -1246,31 +1269,49 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
     return rc;
 }
 
-extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
-                                        const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
-                                        int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size,
-                                        int window, int kv_dtype, const float *k_scale, const float *v_scale, void *workspace,
-                                        size_t workspace_bytes, void *stream) {
+static int paged_attention_impl(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
+                                int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size,
+                                int window, int kv_dtype, const float *k_scale, const float *v_scale, void *workspace,
+                                size_t workspace_bytes, void *stream, int f16) {
     VMX_REQUIRE(out && q && k_cache && v_cache && block_tables && seq_lens && workspace, "paged_attention: null pointer");
     VMX_REQUIRE(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
                 "paged_attention: num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
     VMX_REQUIRE(block_size > 0 && max_blocks_per_seq > 0 && window >= 0, "paged_attention: bad cache geometry");
-    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3 || kv_dtype == VMX_KV_INT8, "paged_attention: unsupported kv dtype %d",
-                kv_dtype);
+    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || (!f16 && (kv_dtype == VMX_KV_FP8_E4M3 || kv_dtype == VMX_KV_INT8)),
+                "paged_attention: unsupported kv dtype %d%s", kv_dtype, f16 ? " (the fp16 form takes an fp16 cache only)" : "");
     VMX_REQUIRE(workspace_bytes >= vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len),
                 "paged_attention: workspace too small");
     if (num_seqs == 0) return VMX_OK;
     hipStream_t st = vmx_stream(stream);
     VmxAttnParts parts;
     if (int rc = vmx_paged_attention_parts(q, k_cache, v_cache, block_tables, seq_lens, scale, num_seqs, num_heads, num_kv_heads,
-                                           max_blocks_per_seq, max_seq_len, head_dim, block_size, window, kv_dtype, k_scale, v_scale,
-                                           workspace, &parts, st))
+                                           max_blocks_per_seq, max_seq_len, head_dim, block_size, window,
+                                           f16 ? VMX_KV_F16_INTERNAL : kv_dtype, k_scale, v_scale, workspace, &parts, st))
         return rc;
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts.tmp_out, parts.exp_sums,
                        parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window, parts.part_tokens, (int8_t *)nullptr,
-                       (float *)nullptr);
+                       (float *)nullptr, f16);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
+}
+
+extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                        const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
+                                        int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size,
+                                        int window, int kv_dtype, const float *k_scale, const float *v_scale, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    return paged_attention_impl(out, q, k_cache, v_cache, block_tables, seq_lens, scale, num_seqs, num_heads, num_kv_heads, max_blocks_per_seq,
+                                max_seq_len, head_dim, block_size, window, kv_dtype, k_scale, v_scale, workspace, workspace_bytes, stream, 0);
+}
+
+// paged_attention_v2_f16 + paged_attention_v2_reduce_f16 (crates/core/kernels/paged_attention.cu): fp16 queries, fp16 cache, fp16 output
+extern "C" int vmx_paged_attention_f16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                       const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
+                                       int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
+    return paged_attention_impl(out, q, k_cache, v_cache, block_tables, seq_lens, scale, num_seqs, num_heads, num_kv_heads, max_blocks_per_seq,
+                                max_seq_len, head_dim, block_size, window, VMX_KV_AUTO, nullptr, nullptr, workspace, workspace_bytes, stream, 1);
 }
 
 extern "C" size_t vmx_paged_attention_static_max_bytes(void) { return VMX_ATTN_SCRATCH_BYTES; }

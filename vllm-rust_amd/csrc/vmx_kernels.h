@@ -60,8 +60,9 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
                               int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window, int kv_dtype,
                               const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st);
 // aq/ad (optional): also emit the q8_1 form of the output rows [seqs][heads * head_dim] for an I-quant consumer
+#define VMX_KV_F16_INTERNAL 3   // vmx_paged_attention_parts only: fp16 queries over an fp16 cache
 int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const int32_t *seq_lens, int num_seqs, int num_heads,
-                              int head_dim, int window, hipStream_t st, int8_t *aq = nullptr, float *ad = nullptr);
+                              int head_dim, int window, hipStream_t st, int8_t *aq = nullptr, float *ad = nullptr, int out_f16 = 0);
 
 // attention_kernels.hip: the same work as vmx_fused_decode_attention spread over P workgroups per KV head; the P partition
 // results stay in `workspace` (described by *out) for a consumer that merges them (vmx_int4_gemm_resid_attn)

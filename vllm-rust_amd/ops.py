@@ -13,7 +13,7 @@ from ._lib import check, lib
 __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_mmvq_packed_geglu", "iq_subdots_packed",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
-    "rms_norm", "rope_neox", "rope_gptj", "reshape_and_cache_hnd", "copy_blocks", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_static", "dense_gemv",
+    "rms_norm", "rope_neox", "rope_gptj", "reshape_and_cache_hnd", "copy_blocks", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_f16", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
     "topk_softmax", "moe_align_block_size", "moe_int4_forward",
 ]
@@ -230,6 +230,20 @@ def reshape_and_cache(key, value, k_cache, v_cache, slots, kv_heads: int, head_d
                       kv_dtype: int = 0, k_scale=None, v_scale=None) -> None:
     check(lib.vmx_reshape_and_cache(_ptr(key), _ptr(value), _ptr(k_cache), _ptr(v_cache), _ptr(slots), slots.numel(),
                                     kv_heads, head_dim, block_size, kv_dtype, _ptr(k_scale), _ptr(v_scale), _stream()))
+
+
+def paged_attention_f16(q, k_cache, v_cache, block_tables, seq_lens, scale: float, num_heads: int, num_kv_heads: int, head_dim: int,
+                        block_size: int, max_seq_len: int, window: int = 0, workspace=None) -> torch.Tensor:
+    """fp16 queries over an fp16 paged cache -> fp16 [seqs, heads * head_dim]."""
+    num_seqs = seq_lens.numel()
+    need = lib.vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len)
+    if workspace is None:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    out = torch.empty((num_seqs, num_heads * head_dim), dtype=torch.float16, device=q.device)
+    check(lib.vmx_paged_attention_f16(_ptr(out), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(block_tables), _ptr(seq_lens), scale, num_seqs,
+                                      num_heads, num_kv_heads, block_tables.shape[1], max_seq_len, head_dim, block_size, window,
+                                      _ptr(workspace), workspace.numel(), _stream()))
+    return out
 
 
 def reshape_and_cache_hnd(key, value, k_cache, v_cache, slots, kv_heads: int, head_dim: int, block_size: int) -> None:
