@@ -19,7 +19,7 @@ int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk
                              int inter, int group, void *workspace, size_t workspace_bytes, int w13_glu, hipStream_t st,
                              uint16_t *h_resid = nullptr, float *ssq = nullptr);   // h_resid: also h = bf16(h + out) and its tile sums of squares
 int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int M, int N, int K, int group, hipStream_t st);
-// decode rows (M <= 2): RMSNorm of the residual stream in the prologue (q|k|v, gate|up) and the residual add in the epilogue
+// decode rows (M <= 4): RMSNorm of the residual stream in the prologue (q|k|v, gate|up) and the residual add in the epilogue
 // (o_proj, down_proj), so that a dense int4 layer is five launches
 int vmx_int4_norm_splits(int M, int N, int K, int glu);   // split-K slices of the _norm forms; 0 = shape not supported
 bool vmx_int4_resid_fusable(int M, int N, int K);
