@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
     const float *__restrict__ cos_sin, const int32_t *__restrict__ positions, const int32_t *__restrict__ slots,
     const int32_t *__restrict__ block_tables, const int32_t *__restrict__ seq_lens, float scale, int Hq, int Hkv, int rot_dim,
     int max_blocks_per_seq, int block_size, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr,
-    int8_t *__restrict__ aq, float *__restrict__ ad, int v_norm) {
+    int8_t *__restrict__ aq, float *__restrict__ ad, int v_norm, const uint16_t *__restrict__ had_svh) {
     constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1, EPL = HD / 64;   // EPL: elements per lane in phase A
     const int nq = Hq / Hkv;   // query heads per KV head (<= QPK, the compiled capacity)
     extern __shared__ __align__(16) unsigned char smem_attn[];
@@ -485,7 +485,30 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
         for (int j = 0; j < EPL; j++) {
             float a = 0.f;
             for (int sp = 0; sp < splits; sp++) a += partial[sp * slice + base + lane + 64 * j];
-            v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(a));
+            v[j] = a;
+        }
+        if constexpr (HD == 128) {
+            // EXL3 linear (exl3.rs:256-286): `partial` is the trellis GEMM before its output transform, and a 128-wide head is
+            // exactly one Hadamard block: H_128 in f32 (element bits 0..5 = lane bits, bit 6 = the in-lane pair, in the stage
+            // order of the separate transform kernel), * 1/sqrt(128), round to fp16, * svh in fp16
+            if (had_svh) {
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    const float p0 = __shfl_xor(v[0], m, 64), p1 = __shfl_xor(v[1], m, 64);
+                    const bool neg = (lane & m) != 0;
+                    v[0] = (neg ? -v[0] : v[0]) + p0;
+                    v[1] = (neg ? -v[1] : v[1]) + p1;
+                }
+                const float s0 = v[0] + v[1], d0 = v[0] - v[1];
+                const _Float16 sv0 = __builtin_bit_cast(_Float16, had_svh[(int64_t)head * HD + lane]);
+                const _Float16 sv1 = __builtin_bit_cast(_Float16, had_svh[(int64_t)head * HD + lane + 64]);
+                v[0] = (float)((_Float16)(s0 * 0.088388347648f) * sv0);
+                v[1] = (float)((_Float16)(d0 * 0.088388347648f) * sv1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j]));
             ss += v[j] * v[j];
         }
         const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
@@ -824,14 +847,15 @@ template <int HD, int QPK, int FP8>
 int launch_fused(dim3 grid, hipStream_t st, uint16_t *out, const float *partial, int splits, int tokens, void *kc, void *vc,
                  const uint16_t *qn, const uint16_t *kn, float eps, const float *cos_sin, const int32_t *positions, const int32_t *slots,
                  const int32_t *bt, const int32_t *sl, float scale, int Hq, int Hkv, int rot_dim, int mbps, int bs, int window,
-                 const float *ks, const float *vs, int8_t *aq, float *ad, int v_norm) {
+                 const float *ks, const float *vs, int8_t *aq, float *ad, int v_norm, const uint16_t *had_svh) {
     constexpr int FUSED_NW = fused_nw(HD);
     const size_t lds = (size_t)QPK * HD * 2 + (size_t)FUSED_NW * QPK * HD * 4 + (size_t)2 * FUSED_NW * QPK * 4;
     if (lds > 64 * 1024)
         VMX_CHECK_HIP(hipFuncSetAttribute((const void *)fused_decode_attn_kernel<HD, QPK, FP8, FUSED_NW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((fused_decode_attn_kernel<HD, QPK, FP8, FUSED_NW>), grid, dim3(64 * FUSED_NW), lds, st, out, partial, splits, tokens,
-                       kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks, vs, aq, ad, v_norm);
+                       kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks, vs, aq, ad, v_norm,
+                       had_svh);
     VMX_CHECK_LAUNCH("fused_decode_attention");
     return VMX_OK;
 }
@@ -1166,13 +1190,14 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
                                const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
                                float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
                                int max_blocks_per_seq, int block_size, int window, int kv_dtype, const float *k_scale,
-                               const float *v_scale, int8_t *aq, float *ad, int v_norm, hipStream_t st) {
+                               const float *v_scale, int8_t *aq, float *ad, int v_norm, hipStream_t st, const uint16_t *had_svh) {
     const int qpk = qpk_capacity(num_heads / num_kv_heads);
     const dim3 grid(num_kv_heads, num_seqs);
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
+    VMX_REQUIRE(!had_svh || head_dim == 128, "fused_decode_attention: the output Hadamard form needs 128-wide heads");
     int rc = VMX_EUNSUPPORTED;
 #define FARGS grid, st, out, qkv_partial, splits, num_seqs, k_cache, v_cache, q_norm_w, k_norm_w, eps, cos_sin, positions, slots, block_tables, \
-              seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size, window, k_scale, v_scale, aq, ad, v_norm
+              seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size, window, k_scale, v_scale, aq, ad, v_norm, had_svh
 #define F_QPK(HD)                                                                                         \
     switch (qpk) {                                                                                        \
         case 1: rc = fp8 ? launch_fused<HD, 1, true>(FARGS) : launch_fused<HD, 1, false>(FARGS); break;   \

@@ -1171,12 +1171,21 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         pending_svh = nullptr;
         have_ssq = false;
         if (fold_in) s_qkv = vmx_int4_norm_splits(B, NQKV_, H, 0);   // the wide kernel has its own k slicing
+        const float *qkv_src = PA;
+        const uint16_t *qkv_svh = nullptr;
         if (fold_in) {
             if (int rc = vmx_int4_gemm_partial_norm(L.qkv.packed.p, h, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, ssq, PA, B, NQKV_, H,
                                                     L.qkv.group, st))
                 return rc;
         } else if (ex && B <= 4 && L.ex_svh_qkv.p) {
-            if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, PA, NQKV_, B, st)) return rc;
+            // a 128-wide head is one Hadamard block: the fused attention kernel applies the output transform of q|k|v itself
+            static const bool no_had_fusion = getenv("VMX_EXL3_NO_HAD_FUSION") && atoi(getenv("VMX_EXL3_NO_HAD_FUSION"));
+            const bool in_attn = !no_had_fusion && hd == 128 && prefill_offset < 0 && !m->rows_share_cache &&
+                                 vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
+            if (in_attn) {
+                if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, nullptr, NQKV_, B, st, &qkv_src, &s_qkv)) return rc;
+                qkv_svh = (const uint16_t *)L.ex_svh_qkv.p;
+            } else if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, PA, NQKV_, B, st)) return rc;
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_Q], x, PA, NQKV_, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_K], x, PA + NQ, NQKV_, B, st)) return rc;
@@ -1204,11 +1213,11 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                                                     st))
                 return rc;
         } else if (fused_attn) {
-            if (int rc = vmx_fused_decode_attention(attn, PA, s_qkv, L.k_cache.p, L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
+            if (int rc = vmx_fused_decode_attention(attn, qkv_src, s_qkv, L.k_cache.p, L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
                                                     Hkv, hd, hd, max_blocks_per_seq, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
-                                                    iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr, 0, st))
+                                                    iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr, 0, st, qkv_svh))
                 return rc;
         } else
         hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, s_qkv, B, q, L.k_cache.p,

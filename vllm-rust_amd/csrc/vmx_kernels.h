@@ -44,7 +44,8 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
                                const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
                                float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
                                int max_blocks_per_seq, int block_size, int window, int kv_dtype, const float *k_scale,
-                               const float *v_scale, int8_t *aq, float *ad, int v_norm, hipStream_t st);   // v_norm: weightless RMSNorm on v
+                               const float *v_scale, int8_t *aq, float *ad, int v_norm, hipStream_t st,   // v_norm: weightless RMSNorm on v
+                               const uint16_t *had_svh = nullptr);   // EXL3: qkv_partial is the trellis GEMM before its output transform
 
 // exl3_kernels.hip: Exl3Linear::forward for the whole-token executor; workspace = vmx_exl3_gemm_workspace_bytes(M, K, N)
 int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, const uint16_t *suh, const uint16_t *svh, float *y32,
