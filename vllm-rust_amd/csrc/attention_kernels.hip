@@ -430,6 +430,26 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_small_kernel(uint16_t *
     }
 }
 
+// Sum of the split-K slices of this lane's EPL elements (element j at p[sp * slice + 64 * j]), slices added in index order.
+// Eight (four) slices are requested before the first add: a plain loop over a run-time count waits for every load in turn.
+template <int EPL>
+__device__ __forceinline__ void attn_sum_splits(const float *__restrict__ p, int splits, int64_t slice, float v[EPL]) {
+#pragma unroll
+    for (int j = 0; j < EPL; j++) v[j] = 0.f;
+    constexpr int UB = EPL > 2 ? 4 : 8;   // 256-wide heads: four at a time (registers)
+    for (int s0 = 0; s0 < splits; s0 += UB) {
+        float t[UB][EPL];
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+#pragma unroll
+            for (int j = 0; j < EPL; j++) t[u][j] = p[min(s0 + u, splits - 1) * slice + 64 * j];
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+#pragma unroll
+            for (int j = 0; j < EPL; j++) v[j] += s0 + u < splits ? t[u][j] : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Short-context decode in ONE launch: grid (kv_heads, seqs), block = NW waves.  A decode step is a chain of dependent
 // launches and each link costs ~4-5 us whatever it computes, so for contexts of up to NW*64 tokens the three links
@@ -481,12 +501,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
         const int64_t slice = (int64_t)tokens * ntot, base = (int64_t)seq * ntot + (int64_t)head * HD;
         float v[EPL];
         float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < EPL; j++) {
-            float a = 0.f;
-            for (int sp = 0; sp < splits; sp++) a += partial[sp * slice + base + lane + 64 * j];
-            v[j] = a;
-        }
+        attn_sum_splits<EPL>(partial + base + lane, splits, slice, v);
         if constexpr (HD == 128) {
             // EXL3 linear (exl3.rs:256-286): `partial` is the trellis GEMM before its output transform, and a 128-wide head is
             // exactly one Hadamard block: H_128 in f32 (element bits 0..5 = lane bits, bit 6 = the in-lane pair, in the stage
@@ -683,12 +698,8 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
         const int64_t slice = (int64_t)tokens * ntot, base = (int64_t)seq * ntot + (int64_t)(has_head ? head : 0) * HD;
         const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
 #pragma unroll
-        for (int j = 0; j < EPL; j++) {
-            float a = 0.f;
-            for (int sp = 0; sp < splits; sp++) a += partial[sp * slice + base + lane + 64 * j];
-            v[j] = a;
-            nwf[j] = nw ? vmx_bf16_to_f32(nw[lane + 64 * j]) : 1.0f;
-        }
+        for (int j = 0; j < EPL; j++) nwf[j] = nw ? vmx_bf16_to_f32(nw[lane + 64 * j]) : 1.0f;
+        attn_sum_splits<EPL>(partial + base + lane, splits, slice, v);
     }
     // rotation factors of this lane's pairs (position known after the first round trip)
     const int half = rot_dim >> 1;

@@ -186,6 +186,47 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
     }
 }
 
+// The residual half of resid_norm_kernel for an EXL3 producer at decode sizes, spread over hidden/512 workgroups per token
+// (one workgroup there walks splits x hidden f32 -- 24 x 16 KB behind down_proj of Qwen3-8B -- on one CU).  A wave owns one
+// 128-column Hadamard block: all its split-K loads are requested at once (two columns per lane), then the transform (same
+// stage order and arithmetic as exl3_out_transform8), h = bf16(h + bf16(o)) and the block's sum of squares of the new h
+// into blk_ssq [tokens][hidden / 128].  The consuming linear normalises its rows itself from those sums.
+__global__ __launch_bounds__(256) void exl3_resid_stats_kernel(uint16_t *__restrict__ h, const float *__restrict__ partial, int splits,
+                                                                int tokens, int hidden, const uint16_t *__restrict__ had_svh,
+                                                                float *__restrict__ blk_ssq) {
+    const int t = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblk = hidden >> 7, blk = blockIdx.x * 4 + wave;
+    const int64_t row = (int64_t)t * hidden, slice = (int64_t)tokens * hidden;
+    if (blk >= nblk) return;
+    const int col = blk * 128 + 2 * lane;
+    const uint32_t hraw = *reinterpret_cast<const uint32_t *>(h + row + col);
+    const uint32_t sv = *reinterpret_cast<const uint32_t *>(had_svh + col);
+    float e0 = 0.f, e1 = 0.f;
+#pragma unroll 8
+    for (int sp = 0; sp < splits; sp++) {
+        const float2 v = *reinterpret_cast<const float2 *>(partial + sp * slice + row + col);
+        e0 += v.x;
+        e1 += v.y;
+    }
+    const float s = e0 + e1, d = e0 - e1;
+    e0 = s;
+    e1 = d;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float p0 = __shfl_xor(e0, m, 64), p1 = __shfl_xor(e1, m, 64);
+        const bool neg = (lane & m) != 0;
+        e0 = (neg ? -e0 : e0) + p0;
+        e1 = (neg ? -e1 : e1) + p1;
+    }
+    const float o0 = (float)((_Float16)(e0 * 0.088388347648f) * __builtin_bit_cast(_Float16, (uint16_t)(sv & 0xffffu)));
+    const float o1 = (float)((_Float16)(e1 * 0.088388347648f) * __builtin_bit_cast(_Float16, (uint16_t)(sv >> 16)));
+    const float h0 = round_bf16(__uint_as_float(hraw << 16) + round_bf16(o0));
+    const float h1 = round_bf16(__uint_as_float(hraw & 0xffff0000u) + round_bf16(o1));
+    *reinterpret_cast<uint32_t *>(h + row + col) = (__float_as_uint(h0) >> 16) | (__float_as_uint(h1) & 0xffff0000u);
+    const float var = vmx_wave_sum(h0 * h0 + h1 * h1);
+    if (lane == 0) blk_ssq[t * nblk + blk] = var;
+}
+
 // The three launches in front of a mixture-of-experts MLP as one (MoE layers with at most EMAX experts): one workgroup per token,
 //   x = bf16(h * rsqrt(mean(h^2) + eps) * w)                                        (post_attention_layernorm, x also stored)
 //   logit_e = bf16(sum_i x_i * router[e][i])                                        (the dense `gate`, mixtral_quantized.rs:118-119)
@@ -403,6 +444,17 @@ __global__ __launch_bounds__(256) void embed_kernel(uint16_t *__restrict__ out, 
     for (int i = threadIdx.x; i < (hidden >> 3); i += 256) dst[i] = ok ? src[i] : make_uint4(0, 0, 0, 0);
 }
 
+// EXL3 decode rows: h += transform(partial) and the block sums the next linear's prologue normalises with (no x row)
+bool exl3_resid_stats_ok(int tokens, int splits, int hidden) {
+    static const bool off = getenv("VMX_EXL3_NO_NORM_FUSION") && atoi(getenv("VMX_EXL3_NO_NORM_FUSION"));
+    return !off && tokens <= 4 && splits > 0 && hidden % 128 == 0 && hidden <= 8192;
+}
+void launch_exl3_resid_stats(hipStream_t st, uint16_t *h, const float *partial, int splits, int tokens, int hidden, const uint16_t *had_svh,
+                             float *blk_ssq) {
+    hipLaunchKernelGGL(exl3_resid_stats_kernel, dim3((hidden / 128 + 3) / 4, tokens), dim3(256), 0, st, h, partial, splits, tokens, hidden,
+                       had_svh, blk_ssq);
+}
+
 void launch_resid_norm(hipStream_t st, uint16_t *h, uint16_t *x, const float *partial, int splits, int tokens, const uint16_t *w,
                        float eps, int hidden, int8_t *aq = nullptr, float *ad = nullptr, const uint16_t *had_svh = nullptr) {
     if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
@@ -553,7 +605,8 @@ int exl3_forward(vmx_qwen3 *m, const Exl3Lin &l, const uint16_t *x, float *y, in
 
 // Several EXL3 projections of one layer that share x, as one launch pair (M <= 4)
 int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> slots, const DevBuf &svh, const uint16_t *x, float *y, int ldy,
-                       int tokens, hipStream_t st, const float **partial_out = nullptr, int *splits_out = nullptr) {
+                       int tokens, hipStream_t st, const float **partial_out = nullptr, int *splits_out = nullptr,
+                       const uint16_t *norm_w = nullptr, const float *blk_ssq = nullptr, float eps = 0.f) {
     const void *tr[3];
     const uint16_t *suh[3];
     int n_out[3], n = 0;
@@ -564,7 +617,7 @@ int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> 
     }
     const Exl3Lin &f = L.ex[*slots.begin()];
     return vmx_exl3_forward_multi_f32(x, 1, n, tr, suh, n_out, (const uint16_t *)svh.p, y, ldy, tokens, f.in_features, f.bits, f.codebook,
-                                      m->exl3_ws.p, m->exl3_ws.bytes, st, partial_out, splits_out);
+                                      m->exl3_ws.p, m->exl3_ws.bytes, st, partial_out, splits_out, norm_w, blk_ssq, eps);
 }
 
 __global__ __launch_bounds__(256) void bf16_rows_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int rows, int cols,
@@ -1165,7 +1218,11 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                            L.int4_attn_ready() && H % 256 == 0 && NQ <= 4 * 16 * 128 && vmx_int4_norm_splits(B, NQKV_, H, 0) > 0 &&
                            vmx_int4_resid_fusable(B, H, NQ) && vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0) > 0;
         const bool fold_in = (fold || mfold) && have_ssq;   // the first layer's h comes from the embedding: no tile sums yet
-        if (!fold_in)
+        // EXL3 decode rows: the residual kernel leaves block sums of squares and q|k|v normalises its rows itself
+        const bool ex_norm_in = ex && B <= 4 && L.ex_svh_qkv.p && pending_svh && exl3_resid_stats_ok(B, pending_splits, H);
+        const uint16_t *ex_in = ex_norm_in ? h : x, *ex_in_w = ex_norm_in ? (const uint16_t *)L.input_ln.p : nullptr;
+        if (ex_norm_in) launch_exl3_resid_stats(st, h, pending, pending_splits, B, H, pending_svh, ssq);
+        else if (!fold_in)
             launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
                               iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh);
         pending_svh = nullptr;
@@ -1183,9 +1240,13 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             const bool in_attn = !no_had_fusion && hd == 128 && prefill_offset < 0 && !m->rows_share_cache &&
                                  vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
             if (in_attn) {
-                if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, nullptr, NQKV_, B, st, &qkv_src, &s_qkv)) return rc;
+                if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, ex_in, nullptr, NQKV_, B, st, &qkv_src, &s_qkv,
+                                                ex_in_w, ssq, c.rms_norm_eps))
+                    return rc;
                 qkv_svh = (const uint16_t *)L.ex_svh_qkv.p;
-            } else if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, x, PA, NQKV_, B, st)) return rc;
+            } else if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, ex_in, PA, NQKV_, B, st, nullptr, nullptr,
+                                                   ex_in_w, ssq, c.rms_norm_eps))
+                return rc;
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_Q], x, PA, NQKV_, B, st)) return rc;
             if (int rc = exl3_forward(m, L.ex[VMX_L_K], x, PA + NQ, NQKV_, B, st)) return rc;
@@ -1303,6 +1364,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             o_src = (const float *)m->red_bf16.p;
             o_splits = -1;
         }
+        const bool ex_norm_gu = ex_fold && o_svh && exl3_resid_stats_ok(B, o_splits, H);
+        if (ex_norm_gu) launch_exl3_resid_stats(st, h, o_src, o_splits, B, H, o_svh, ssq);
+        else
         launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, iq ? q8_aq(m) : nullptr,
                           iq ? q8_ad(m, B, H) : nullptr, o_svh);
         if (moe) {
@@ -1332,7 +1396,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         int gu_splits = s_gu;
         const uint16_t *gu_svh = nullptr;
         if (ex_fold) {
-            if (int rc = exl3_forward_group(m, L, {VMX_L_GATE, VMX_L_UP}, L.ex_svh_gu, x, nullptr, 2 * I, B, st, &gu_src, &gu_splits)) return rc;
+            if (int rc = exl3_forward_group(m, L, {VMX_L_GATE, VMX_L_UP}, L.ex_svh_gu, ex_norm_gu ? h : x, nullptr, 2 * I, B, st, &gu_src, &gu_splits,
+                                            ex_norm_gu ? (const uint16_t *)L.post_ln.p : nullptr, ssq, c.rms_norm_eps))
+                return rc;
             gu_svh = (const uint16_t *)L.ex_svh_gu.p;
         } else if (ex && B <= 4 && L.ex_svh_gu.p) {
             if (int rc = exl3_forward_group(m, L, {VMX_L_GATE, VMX_L_UP}, L.ex_svh_gu, x, PA, 2 * I, B, st)) return rc;

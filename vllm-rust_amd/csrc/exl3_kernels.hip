@@ -183,10 +183,16 @@ template <int CB> __device__ __forceinline__ uint32_t exl3_decode_pair(uint32_t 
 // transform is repeated by every column group.
 // Up to three tensors that share the activation rows (q|k|v, gate|up) go out as ONE launch: the column groups (64 columns)
 // [cg_end[s-1], cg_end[s]) of the merged output belong to tensor s, which has its own trellis and input sign vector.
+// norm_w != NULL (HAD form, bf16 rows): the rows are a residual stream h and the activation is its RMSNorm,
+// x = bf16(h * rsqrt(sum(blk_ssq[row][0..K/128)) / K + eps) * norm_w), with the per-128-column sums of squares of h left by
+// the kernel that wrote h; the normed row is never stored.
 struct Exl3Segs {
     const uint16_t *tr[3];
     const uint16_t *suh[3];
     int cg_end[3];
+    const uint16_t *norm_w = nullptr;
+    const float *blk_ssq = nullptr;
+    float eps = 0.f;
 };
 
 template <int BITS, int CB, int KT, bool HAD>
@@ -232,12 +238,20 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(Exl3Segs segs, const uin
     // fused input transform: this wave's (row, 128-block) items, requested ahead of the weights (loads retire in issue order)
     constexpr int NB = KT / 8;   // 128-blocks of the slice
     uint32_t hin[NB], hsc[NB];   // M <= 4: at most NB items per wave
+    uint32_t hnw[NB];
+    float hss[NB];
     if constexpr (HAD) {
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int it = min(wave + 4 * i, M * NB - 1), m = it / NB, kb = min(k0 + (it % NB) * 128, K - 128);
             hin[i] = *reinterpret_cast<const uint32_t *>(a_had + (int64_t)m * K + kb + 2 * lane);
             hsc[i] = suh ? *reinterpret_cast<const uint32_t *>(suh + kb + 2 * lane) : 0x3c003c00u;
+            hnw[i] = 0;
+            hss[i] = 0.f;
+            if (segs.norm_w) {   // uniform; K <= 64 * 128 (checked on the host): one block sum per lane
+                hnw[i] = *reinterpret_cast<const uint32_t *>(segs.norm_w + kb + 2 * lane);
+                hss[i] = segs.blk_ssq[m * (K >> 7) + min(lane, (K >> 7) - 1)];
+            }
         }
     }
     uint4 wr[NCH][LPT];
@@ -256,7 +270,14 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(Exl3Segs segs, const uin
             const int it = wave + 4 * i;
             if (it < M * NB) {   // wave-uniform
                 const int m = it / NB, kb = k0 + (it % NB) * 128;
-                const uint32_t in = hin[i], sc = hsc[i];
+                uint32_t in = hin[i];
+                const uint32_t sc = hsc[i];
+                if (segs.norm_w) {
+                    const float inv = rsqrtf(vmx_wave_sum(lane < (K >> 7) ? hss[i] : 0.f) / (float)K + segs.eps);
+                    const float x0 = __uint_as_float(in << 16) * inv * __uint_as_float(hnw[i] << 16);
+                    const float x1 = __uint_as_float(in & 0xffff0000u) * inv * __uint_as_float(hnw[i] & 0xffff0000u);
+                    in = (uint32_t)vmx_f32_to_bf16(x0) | ((uint32_t)vmx_f32_to_bf16(x1) << 16);
+                }
                 half_t a, b;
                 if (x_bf16) { a = (half_t)__uint_as_float(in << 16); b = (half_t)__uint_as_float(in & 0xffff0000u); }
                 else { a = bits_to_half(in & 0xffffu); b = bits_to_half(in >> 16); }
@@ -496,8 +517,10 @@ int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, con
 // consumer that applies the output transform itself.
 int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const void *const *trellis, const uint16_t *const *suh,
                                const int *n_out, const uint16_t *svh_merged, float *y32, int ld, int M, int K, int bits, int codebook,
-                               void *workspace, size_t workspace_bytes, hipStream_t st, const float **partial_out, int *splits_out) {
+                               void *workspace, size_t workspace_bytes, hipStream_t st, const float **partial_out, int *splits_out,
+                               const uint16_t *norm_w, const float *blk_ssq, float eps) {
     VMX_REQUIRE(nseg >= 1 && nseg <= 3 && M >= 1 && M <= 4, "exl3_forward_multi: %d tensors / %d rows unsupported", nseg, M);
+    VMX_REQUIRE(!norm_w || (x_bf16 && blk_ssq && K <= 8192), "exl3_forward_multi: the norm form takes bf16 rows of at most 8192 columns");
     int N = 0;
     Exl3Segs sg;
     for (int i = 0; i < 3; i++) {
@@ -510,6 +533,9 @@ int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const vo
         sg.suh[i] = suh[j];
         sg.cg_end[i] = N / 64;
     }
+    sg.norm_w = norm_w;
+    sg.blk_ssq = blk_ssq;
+    sg.eps = eps;
     VMX_REQUIRE(workspace_bytes >= vmx_exl3_gemm_workspace_bytes(M, K, N), "exl3_forward_multi: workspace too small");
     float *partial = (float *)((char *)workspace + (((size_t)M * K * 2 + 255) & ~(size_t)255));
     const int splits = exl3_plan(N, K, bits).splits;

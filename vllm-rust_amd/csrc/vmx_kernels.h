@@ -35,7 +35,9 @@ int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros
 int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const void *const *trellis, const uint16_t *const *suh,
                                const int *n_out, const uint16_t *svh_merged, float *y32, int ld, int M, int K, int bits, int codebook,
                                void *workspace, size_t workspace_bytes, hipStream_t st, const float **partial_out = nullptr,
-                               int *splits_out = nullptr);   // y32 == NULL: GEMM only, the consumer transforms *partial_out
+                               int *splits_out = nullptr,   // y32 == NULL: GEMM only, the consumer transforms *partial_out
+                               const uint16_t *norm_w = nullptr, const float *blk_ssq = nullptr, float eps = 0.f);
+// norm_w: x is the residual stream and the linear's input is its RMSNorm; blk_ssq [M][K / 128] = sums of squares of x's 128-column blocks
 
 // attention_kernels.hip: q/k/v post-processing + short-context decode attention + merge in one launch
 bool vmx_fused_decode_attention_ok(int head_dim, int qpk, int rot_dim, int max_seq_len, int window);
