@@ -63,12 +63,20 @@ __device__ __forceinline__ void exl3_out_transform8(const float *__restrict__ pa
                                                     const uint16_t *__restrict__ svh, int col, float o[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] = 0.f;
-#pragma unroll 4
-    for (int sp = 0; sp < splits; sp++) {
-        const float4 a = *reinterpret_cast<const float4 *>(partial + sp * slice_stride + idx);
-        const float4 b = *reinterpret_cast<const float4 *>(partial + sp * slice_stride + idx + 4);
-        o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
-        o[4] += b.x; o[5] += b.y; o[6] += b.z; o[7] += b.w;
+    for (int s0 = 0; s0 < splits; s0 += 8) {   // eight slices requested before the first add (branch-free: a slice past the end re-reads the last one)
+        float4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float *src = partial + min(s0 + u, splits - 1) * slice_stride + idx;
+            a[u] = *reinterpret_cast<const float4 *>(src);
+            b[u] = *reinterpret_cast<const float4 *>(src + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool in = s0 + u < splits;
+            o[0] += in ? a[u].x : 0.f; o[1] += in ? a[u].y : 0.f; o[2] += in ? a[u].z : 0.f; o[3] += in ? a[u].w : 0.f;
+            o[4] += in ? b[u].x : 0.f; o[5] += in ? b[u].y : 0.f; o[6] += in ? b[u].z : 0.f; o[7] += in ? b[u].w : 0.f;
+        }
     }
 #pragma unroll
     for (int st = 1; st < 8; st <<= 1) {
