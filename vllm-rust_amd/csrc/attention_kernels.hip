@@ -430,6 +430,22 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_small_kernel(uint16_t *
     }
 }
 
+// Output transform of an EXL3 linear (exl3.rs:256-286) on one 128-wide head held as elements lane, lane + 64: H_128 in f32
+// (element bits 0..5 = lane bits, bit 6 = the in-lane pair, in the stage order of the separate transform kernel),
+// * 1/sqrt(128), round to fp16, * svh in fp16.
+__device__ __forceinline__ void attn_exl3_out_transform(float v[2], int lane, uint16_t sv0, uint16_t sv1) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float p0 = __shfl_xor(v[0], m, 64), p1 = __shfl_xor(v[1], m, 64);
+        const bool neg = (lane & m) != 0;
+        v[0] = (neg ? -v[0] : v[0]) + p0;
+        v[1] = (neg ? -v[1] : v[1]) + p1;
+    }
+    const float s0 = v[0] + v[1], d0 = v[0] - v[1];
+    v[0] = (float)((_Float16)(s0 * 0.088388347648f) * __builtin_bit_cast(_Float16, sv0));
+    v[1] = (float)((_Float16)(d0 * 0.088388347648f) * __builtin_bit_cast(_Float16, sv1));
+}
+
 // Sum of the split-K slices of this lane's EPL elements (element j at p[sp * slice + 64 * j]), slices added in index order.
 // Eight (four) slices are requested before the first add: a plain loop over a run-time count waits for every load in turn.
 template <int EPL>
@@ -502,24 +518,8 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
         float v[EPL];
         float ss = 0.f;
         attn_sum_splits<EPL>(partial + base + lane, splits, slice, v);
-        if constexpr (HD == 128) {
-            // EXL3 linear (exl3.rs:256-286): `partial` is the trellis GEMM before its output transform, and a 128-wide head is
-            // exactly one Hadamard block: H_128 in f32 (element bits 0..5 = lane bits, bit 6 = the in-lane pair, in the stage
-            // order of the separate transform kernel), * 1/sqrt(128), round to fp16, * svh in fp16
-            if (had_svh) {
-#pragma unroll
-                for (int m = 1; m < 64; m <<= 1) {
-                    const float p0 = __shfl_xor(v[0], m, 64), p1 = __shfl_xor(v[1], m, 64);
-                    const bool neg = (lane & m) != 0;
-                    v[0] = (neg ? -v[0] : v[0]) + p0;
-                    v[1] = (neg ? -v[1] : v[1]) + p1;
-                }
-                const float s0 = v[0] + v[1], d0 = v[0] - v[1];
-                const _Float16 sv0 = __builtin_bit_cast(_Float16, had_svh[(int64_t)head * HD + lane]);
-                const _Float16 sv1 = __builtin_bit_cast(_Float16, had_svh[(int64_t)head * HD + lane + 64]);
-                v[0] = (float)((_Float16)(s0 * 0.088388347648f) * sv0);
-                v[1] = (float)((_Float16)(d0 * 0.088388347648f) * sv1);
-            }
+        if constexpr (HD == 128) {   // EXL3: `partial` is the trellis GEMM before its output transform; a head is one Hadamard block
+            if (had_svh) attn_exl3_out_transform(v, lane, had_svh[(int64_t)head * HD + lane], had_svh[(int64_t)head * HD + lane + 64]);
         }
 #pragma unroll
         for (int j = 0; j < EPL; j++) {
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
     const uint16_t *__restrict__ k_norm_w, float eps, const float *__restrict__ cos_sin, const int32_t *__restrict__ positions,
     const int32_t *__restrict__ slots, const int32_t *__restrict__ block_tables, const int32_t *__restrict__ seq_lens, float scale, int Hq,
     int Hkv, int rot_dim, int max_blocks_per_seq, int block_size, int window, const float *__restrict__ k_scale_ptr,
-    const float *__restrict__ v_scale_ptr, int v_norm) {
+    const float *__restrict__ v_scale_ptr, int v_norm, const uint16_t *__restrict__ had_svh) {
     constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1, EPL = HD / 64;
     const int nq = Hq / Hkv, P = gridDim.z;
     extern __shared__ __align__(16) unsigned char smem_attn[];
@@ -692,8 +692,12 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
     const bool has_head = wave < nq + 2;
     const bool is_q = wave < nq, is_k = wave == nq;
     float v[EPL], nwf[EPL];
+    uint16_t sv0 = 0x3c00, sv1 = 0x3c00;   // EXL3 output scales of this lane's two elements (HD == 128)
     {
         const int head = is_q ? kvh * nq + wave : (is_k ? Hq + kvh : Hq + Hkv + kvh);
+        if constexpr (HD == 128) {
+            if (had_svh) { sv0 = had_svh[(int64_t)(has_head ? head : 0) * HD + lane]; sv1 = had_svh[(int64_t)(has_head ? head : 0) * HD + lane + 64]; }
+        }
         const int ntot = (Hq + 2 * Hkv) * HD;
         const int64_t slice = (int64_t)tokens * ntot, base = (int64_t)seq * ntot + (int64_t)(has_head ? head : 0) * HD;
         const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
@@ -737,6 +741,9 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
 
     // ---- A (arithmetic): bf16 round, optional per-head RMSNorm, NeoX RoPE; q -> LDS, k and v -> cache (owner only)
     if (has_head && g0 < T && (is_q || owner)) {
+        if constexpr (HD == 128) {   // EXL3: the sums are the trellis GEMM before its output transform; a head is one Hadamard block
+            if (had_svh) attn_exl3_out_transform(v, lane, sv0, sv1);
+        }
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < EPL; j++) {
@@ -875,14 +882,14 @@ template <int HD, int QPK, int FP8, int NW>
 int launch_split(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const float *partial, int splits, int tokens,
                  void *kc, void *vc, const uint16_t *qn, const uint16_t *kn, float eps, const float *cos_sin, const int32_t *positions,
                  const int32_t *slots, const int32_t *bt, const int32_t *sl, float scale, int Hq, int Hkv, int rot_dim, int mbps, int bs,
-                 int window, const float *ks, const float *vs, int v_norm) {
+                 int window, const float *ks, const float *vs, int v_norm, const uint16_t *had_svh) {
     const size_t lds = (size_t)QPK * HD * 2 + (size_t)NW * QPK * HD * 4 + (size_t)2 * NW * QPK * 4;
     if (lds > 64 * 1024)
         VMX_CHECK_HIP(hipFuncSetAttribute((const void *)split_decode_attn_kernel<HD, QPK, FP8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
     hipLaunchKernelGGL((split_decode_attn_kernel<HD, QPK, FP8, NW>), grid, dim3(64 * NW), lds, st, tmp_out, exp_sums, max_logits, partial,
                        splits, tokens, kc, vc, qn, kn, eps, cos_sin, positions, slots, bt, sl, scale, Hq, Hkv, rot_dim, mbps, bs, window, ks,
-                       vs, v_norm);
+                       vs, v_norm, had_svh);
     VMX_CHECK_LAUNCH("split_decode_attention");
     return VMX_OK;
 }
@@ -1263,7 +1270,8 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
                                const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
                                float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
                                int max_blocks_per_seq, int max_seq_len, int block_size, int window, int kv_dtype, const float *k_scale,
-                               const float *v_scale, int v_norm, hipStream_t st) {
+                               const float *v_scale, int v_norm, hipStream_t st, const uint16_t *had_svh) {
+    VMX_REQUIRE(!had_svh || head_dim == 128, "split_decode_attention: the output Hadamard form needs 128-wide heads");
     const int qpk = qpk_capacity(num_heads / num_kv_heads);
     const int P = split_parts_impl(head_dim, num_heads / num_kv_heads, rot_dim, max_seq_len, window, true);
     VMX_REQUIRE(P > 0 && workspace && out, "split_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head, context %d)",
@@ -1281,7 +1289,7 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
     int rc = VMX_EUNSUPPORTED;
 #define SARGS grid, st, out->tmp_out, out->exp_sums, out->max_logits, qkv_partial, splits, num_seqs, k_cache, v_cache, q_norm_w, k_norm_w, eps, \
               cos_sin, positions, slots, block_tables, seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size,     \
-              window, k_scale, v_scale, v_norm
+              window, k_scale, v_scale, v_norm, had_svh
 #define S_ONE(HD, Q)                                                                                                          \
     rc = wide ? (fp8 ? launch_split<HD, Q, true, 16>(SARGS) : launch_split<HD, Q, false, 16>(SARGS))                           \
               : (fp8 ? launch_split<HD, Q, true, (Q + 2 > 8 ? 16 : 8)>(SARGS) : launch_split<HD, Q, false, (Q + 2 > 8 ? 16 : 8)>(SARGS))

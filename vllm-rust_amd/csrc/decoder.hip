@@ -614,7 +614,7 @@ int exl3_forward(vmx_qwen3 *m, const Exl3Lin &l, const uint16_t *x, float *y, in
 // Several EXL3 projections of one layer that share x, as one launch pair (M <= 4)
 int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> slots, const DevBuf &svh, const uint16_t *x, float *y, int ldy,
                        int tokens, hipStream_t st, const float **partial_out = nullptr, int *splits_out = nullptr,
-                       const uint16_t *norm_w = nullptr, const float *blk_ssq = nullptr, float eps = 0.f) {
+                       const uint16_t *norm_w = nullptr, const float *blk_ssq = nullptr, float eps = 0.f, const VmxAttnParts *attn_parts = nullptr) {
     const void *tr[3];
     const uint16_t *suh[3];
     int n_out[3], n = 0;
@@ -625,7 +625,7 @@ int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> 
     }
     const Exl3Lin &f = L.ex[*slots.begin()];
     return vmx_exl3_forward_multi_f32(x, 1, n, tr, suh, n_out, (const uint16_t *)svh.p, y, ldy, tokens, f.in_features, f.bits, f.codebook,
-                                      m->exl3_ws.p, m->exl3_ws.bytes, st, partial_out, splits_out, norm_w, blk_ssq, eps);
+                                      m->exl3_ws.p, m->exl3_ws.bytes, st, partial_out, splits_out, norm_w, blk_ssq, eps, attn_parts);
 }
 
 __global__ __launch_bounds__(256) void bf16_rows_to_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int rows, int cols,
@@ -1238,6 +1238,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         if (fold_in) s_qkv = vmx_int4_norm_splits(B, NQKV_, H, 0);   // the wide kernel has its own k slicing
         const float *qkv_src = PA;
         const uint16_t *qkv_svh = nullptr;
+        bool ex_split = false;
         if (fold_in) {
             if (int rc = vmx_int4_gemm_partial_norm(L.qkv.packed.p, h, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, ssq, PA, B, NQKV_, H,
                                                     L.qkv.group, st))
@@ -1247,6 +1248,10 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             static const bool no_had_fusion = getenv("VMX_EXL3_NO_HAD_FUSION") && atoi(getenv("VMX_EXL3_NO_HAD_FUSION"));
             const bool in_attn = !no_had_fusion && hd == 128 && prefill_offset < 0 && !m->rows_share_cache &&
                                  vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
+            // ... and so does the attention spread over several workgroups per KV head, whose partitions o_proj merges in its prologue
+            static const bool no_ex_split = getenv("VMX_EXL3_NO_SPLIT_ATTN") && atoi(getenv("VMX_EXL3_NO_SPLIT_ATTN"));
+            const int ex_p = vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0);
+            ex_split = in_attn && !no_ex_split && !tp && H % 128 == 0 && I % 128 == 0 && L.ex_svh_gu.p && ex_p >= 1 && ex_p <= 4;
             if (in_attn) {
                 if (int rc = exl3_forward_group(m, L, {VMX_L_Q, VMX_L_K, VMX_L_V}, L.ex_svh_qkv, ex_in, nullptr, NQKV_, B, st, &qkv_src, &s_qkv,
                                                 ex_in_w, ssq, c.rms_norm_eps))
@@ -1268,18 +1273,18 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         } else if (int rc = run_linear(m, L.qkv, x, PA, B, st)) return rc;
         const float *ks = (const float *)L.kv_scales.p;
         // five-launch layers: attention spread over several workgroups per KV head, merged by o_proj while it stages its activations
-        const bool split_attn = (fold || mfold) && prefill_offset < 0 && !m->rows_share_cache && NQ <= 4 * 16 * 128 &&
-                                vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0) > 0;
+        const bool split_attn = ex_split || ((fold || mfold) && prefill_offset < 0 && !m->rows_share_cache && NQ <= 4 * 16 * 128 &&
+                                             vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0) > 0);
         VmxAttnParts sparts{};
         const bool fused_attn = !split_attn && prefill_offset < 0 && !m->rows_share_cache &&
                                 vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
         if (split_attn) {
-            if (int rc = vmx_split_decode_attention(&sparts, m->attn_ws.p, PA, s_qkv, L.k_cache.p, L.v_cache.p,
+            if (int rc = vmx_split_decode_attention(&sparts, m->attn_ws.p, qkv_src, s_qkv, L.k_cache.p, L.v_cache.p,
                                                     c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
                                                     Hkv, hd, hd, max_blocks_per_seq, max_seq_len, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, 0,
-                                                    st))
+                                                    st, qkv_svh))
                 return rc;
         } else if (fused_attn) {
             if (int rc = vmx_fused_decode_attention(attn, qkv_src, s_qkv, L.k_cache.p, L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
@@ -1357,7 +1362,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         int o_splits = s_o;
         const uint16_t *o_svh = nullptr;
         if (ex_fold) {
-            if (int rc = exl3_forward_group(m, L, {VMX_L_O}, L.ex[VMX_L_O].svh, attn, nullptr, H, B, st, &o_src, &o_splits)) return rc;
+            if (int rc = exl3_forward_group(m, L, {VMX_L_O}, L.ex[VMX_L_O].svh, attn, nullptr, H, B, st, &o_src, &o_splits, nullptr, nullptr, 0.f,
+                                            ex_split ? &sparts : nullptr))
+                return rc;
             o_svh = (const uint16_t *)L.ex[VMX_L_O].svh.p;
         } else if (ex) {
             if (int rc = exl3_forward(m, L.ex[VMX_L_O], attn, PB, H, B, st)) return rc;

@@ -193,9 +193,15 @@ struct Exl3Segs {
     const uint16_t *norm_w = nullptr;
     const float *blk_ssq = nullptr;
     float eps = 0.f;
+    // attn_tmp != NULL (HAD form, K = heads * 128): the rows are the decode-attention output still split into attn_p <= 4
+    // partitions per (row, head) (split_decode_attn_kernel): tmp [M][K/128][P][128] f32, max logit / sum [M][K/128][P]; the
+    // prologue merges them, x = bf16(sum_p tmp_p w_p / (sum_p w_p + 1e-6)), w_p = sum_p * exp(max_p - max over p)
+    // (paged_attention.cu:840-953) -- what the separate merge kernel would have written.
+    const float *attn_tmp = nullptr, *attn_mx = nullptr, *attn_sm = nullptr;
+    int attn_p = 0;
 };
 
-template <int BITS, int CB, int KT, bool HAD>
+template <int BITS, int CB, int KT, bool HAD, bool ATTN = false>
 __global__ __launch_bounds__(256) void exl3_gemm_kernel(Exl3Segs segs, const uint16_t *__restrict__ a_had, int x_bf16,
                                                          float *__restrict__ partial, int M, int N, int K) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -240,10 +246,24 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(Exl3Segs segs, const uin
     uint32_t hin[NB], hsc[NB];   // M <= 4: at most NB items per wave
     uint32_t hnw[NB];
     float hss[NB];
+    constexpr int PMX = 4, NBA = ATTN ? NB : 1;
+    float2 pt[NBA][PMX];
+    float pmx[NBA][PMX], psm[NBA][PMX];
     if constexpr (HAD) {
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int it = min(wave + 4 * i, M * NB - 1), m = it / NB, kb = min(k0 + (it % NB) * 128, K - 128);
+            if constexpr (ATTN) {
+                const int64_t rh = ((int64_t)m * (K >> 7) + (kb >> 7)) * segs.attn_p;
+#pragma unroll
+                for (int p = 0; p < PMX; p++) {   // partitions past attn_p re-read the last one; their weight is zeroed below
+                    const int64_t rp = rh + min(p, segs.attn_p - 1);
+                    pt[i][p] = *reinterpret_cast<const float2 *>(segs.attn_tmp + rp * 128 + 2 * lane);
+                    pmx[i][p] = segs.attn_mx[rp];
+                    psm[i][p] = segs.attn_sm[rp];
+                }
+                hin[i] = 0;
+            } else
             hin[i] = *reinterpret_cast<const uint32_t *>(a_had + (int64_t)m * K + kb + 2 * lane);
             hsc[i] = suh ? *reinterpret_cast<const uint32_t *>(suh + kb + 2 * lane) : 0x3c003c00u;
             hnw[i] = 0;
@@ -272,6 +292,21 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(Exl3Segs segs, const uin
                 const int m = it / NB, kb = k0 + (it % NB) * 128;
                 uint32_t in = hin[i];
                 const uint32_t sc = hsc[i];
+                if constexpr (ATTN) {
+                    float gmax = -3.402823466e+38f;
+#pragma unroll
+                    for (int p = 0; p < PMX; p++) gmax = fmaxf(gmax, p < segs.attn_p ? pmx[i][p] : -3.402823466e+38f);
+                    float a0 = 0.f, a1 = 0.f, gsum = 0.f;
+#pragma unroll
+                    for (int p = 0; p < PMX; p++) {
+                        const float wt = p < segs.attn_p ? psm[i][p] * __expf(pmx[i][p] - gmax) : 0.f;
+                        gsum += wt;
+                        a0 += pt[i][p].x * wt;
+                        a1 += pt[i][p].y * wt;
+                    }
+                    const float ginv = 1.0f / (gsum + 1e-6f);
+                    in = (uint32_t)vmx_f32_to_bf16(a0 * ginv) | ((uint32_t)vmx_f32_to_bf16(a1 * ginv) << 16);
+                }
                 if (segs.norm_w) {
                     const float inv = rsqrtf(vmx_wave_sum(lane < (K >> 7) ? hss[i] : 0.f) / (float)K + segs.eps);
                     const float x0 = __uint_as_float(in << 16) * inv * __uint_as_float(hnw[i] << 16);
@@ -378,7 +413,9 @@ int launch_exl3_gemm_kt(const Exl3Segs &segs, const uint16_t *a, int fuse_had, i
                                               (int)lds));                                                                                \
         hipLaunchKernelGGL((exl3_gemm_kernel<BITS, CB, KT, H>), grid, dim3(256), lds, st, segs, a, x_bf16, partial, M, N, K);             \
     } while (0)
-    if (fuse_had) EXL3_GO(true);
+    if (fuse_had && segs.attn_tmp) {
+        hipLaunchKernelGGL((exl3_gemm_kernel<BITS, CB, KT, true, true>), grid, dim3(256), lds, st, segs, a, x_bf16, partial, M, N, K);
+    } else if (fuse_had) EXL3_GO(true);
     else EXL3_GO(false);
 #undef EXL3_GO
     VMX_CHECK_LAUNCH("exl3_gemm");
@@ -518,7 +555,7 @@ int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, con
 int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const void *const *trellis, const uint16_t *const *suh,
                                const int *n_out, const uint16_t *svh_merged, float *y32, int ld, int M, int K, int bits, int codebook,
                                void *workspace, size_t workspace_bytes, hipStream_t st, const float **partial_out, int *splits_out,
-                               const uint16_t *norm_w, const float *blk_ssq, float eps) {
+                               const uint16_t *norm_w, const float *blk_ssq, float eps, const VmxAttnParts *attn_parts) {
     VMX_REQUIRE(nseg >= 1 && nseg <= 3 && M >= 1 && M <= 4, "exl3_forward_multi: %d tensors / %d rows unsupported", nseg, M);
     VMX_REQUIRE(!norm_w || (x_bf16 && blk_ssq && K <= 8192), "exl3_forward_multi: the norm form takes bf16 rows of at most 8192 columns");
     int N = 0;
@@ -536,6 +573,14 @@ int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const vo
     sg.norm_w = norm_w;
     sg.blk_ssq = blk_ssq;
     sg.eps = eps;
+    if (attn_parts) {
+        VMX_REQUIRE(x_bf16 && !norm_w && K % 128 == 0 && attn_parts->max_parts >= 1 && attn_parts->max_parts <= 4 && attn_parts->part_tokens == 0,
+                    "exl3_forward_multi: attention partitions (%d) not mergeable here", attn_parts->max_parts);
+        sg.attn_tmp = attn_parts->tmp_out;
+        sg.attn_mx = attn_parts->max_logits;
+        sg.attn_sm = attn_parts->exp_sums;
+        sg.attn_p = attn_parts->max_parts;
+    }
     VMX_REQUIRE(workspace_bytes >= vmx_exl3_gemm_workspace_bytes(M, K, N), "exl3_forward_multi: workspace too small");
     float *partial = (float *)((char *)workspace + (((size_t)M * K * 2 + 255) & ~(size_t)255));
     const int splits = exl3_plan(N, K, bits).splits;

@@ -32,11 +32,14 @@ int vmx_int4_gemm_resid(const void *packed, const uint16_t *x, uint16_t *h, floa
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out, int K,
                          int N, int group, int Ntot, int col0, hipStream_t st);
 
+struct VmxAttnParts;
 int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const void *const *trellis, const uint16_t *const *suh,
                                const int *n_out, const uint16_t *svh_merged, float *y32, int ld, int M, int K, int bits, int codebook,
                                void *workspace, size_t workspace_bytes, hipStream_t st, const float **partial_out = nullptr,
                                int *splits_out = nullptr,   // y32 == NULL: GEMM only, the consumer transforms *partial_out
-                               const uint16_t *norm_w = nullptr, const float *blk_ssq = nullptr, float eps = 0.f);
+                               const uint16_t *norm_w = nullptr, const float *blk_ssq = nullptr, float eps = 0.f,
+                               const struct VmxAttnParts *attn_parts = nullptr);
+// attn_parts: the input rows are the merge of these decode-attention partitions (128-wide heads, at most 4 partitions), x unused
 // norm_w: x is the residual stream and the linear's input is its RMSNorm; blk_ssq [M][K / 128] = sums of squares of x's 128-column blocks
 
 // attention_kernels.hip: q/k/v post-processing + short-context decode attention + merge in one launch
@@ -77,7 +80,7 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
                                const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
                                float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
                                int max_blocks_per_seq, int max_seq_len, int block_size, int window, int kv_dtype, const float *k_scale,
-                               const float *v_scale, int v_norm, hipStream_t st);
+                               const float *v_scale, int v_norm, hipStream_t st, const uint16_t *had_svh = nullptr);   // as above
 // int4_kernels.hip: vmx_int4_gemm_resid whose activations are the merge of those partitions (K = heads * head_dim)
 int vmx_int4_gemm_resid_attn(const void *packed, const VmxAttnParts *parts, int head_dim, uint16_t *h, float *ssq, int M, int N, int K,
                              int group, hipStream_t st);
