@@ -124,19 +124,40 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t *__restrict__
     // the launch then has one thread per column (hidden % 256 == 0), so a tile is 16 consecutive lanes.
     const int t = blockIdx.y;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hidden; i += gridDim.x * 256) {
+        // The launch is a chain of memory round trips, so the loads of two experts and eight split-K slices go out together
+        // (branch-free: a slot past the end re-reads the last valid one and is not added); sums in slice order, experts in j order.
+        const uint16_t hold = h_resid ? h_resid[(int64_t)t * hidden + i] : (uint16_t)0;
         float acc = 0.f;
-        for (int j = 0; j < k; j++) {
-            const int p = t * k + j;
-            int e = ids[p];
-            e = e < 0 ? 0 : (e >= num_experts ? num_experts - 1 : e);
-            if (!w2_table[e]) continue;
-            float o = 0.f;
-            for (int s = 0; s < splits; s++) o += partial[((int64_t)s * pairs + p) * hidden + i];
-            acc = rb(acc + rb(rb(o) * rb(w[p])));
+        for (int j0 = 0; j0 < k; j0 += 2) {
+            int p[2];
+            bool live[2];
+            float wv[2], o[2] = {0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                p[u] = t * k + min(j0 + u, k - 1);
+                int e = ids[p[u]];
+                e = e < 0 ? 0 : (e >= num_experts ? num_experts - 1 : e);
+                live[u] = j0 + u < k && w2_table[e] != nullptr;
+                wv[u] = w[p[u]];
+            }
+            for (int s0 = 0; s0 < splits; s0 += 8) {
+                float v[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[u][q] = partial[((int64_t)min(s0 + q, splits - 1) * pairs + p[u]) * hidden + i];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int q = 0; q < 8; q++) o[u] += s0 + q < splits ? v[u][q] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (live[u]) acc = rb(acc + rb(rb(o[u]) * rb(wv[u])));
         }
         out[(int64_t)t * hidden + i] = vmx_f32_to_bf16(acc);
         if (h_resid) {
-            const uint16_t hn = vmx_f32_to_bf16(vmx_bf16_to_f32(h_resid[(int64_t)t * hidden + i]) + acc);
+            const uint16_t hn = vmx_f32_to_bf16(vmx_bf16_to_f32(hold) + acc);
             h_resid[(int64_t)t * hidden + i] = hn;
             float sq = vmx_bf16_to_f32(hn);
             sq *= sq;
