@@ -167,6 +167,16 @@ def test_qwen3_8b_exl3_4bpw(gpu):
     _qwen3_case(gpu, _spec_8b(max_batch=2), "load_synthetic_exl3", start_lens=[15, 1023], steps=2, first_ids=[5, 6], bar=3e-2, bits=4)
 
 
+def test_qwen3_8b_exl3_decode_rows(gpu):
+    """One and four decode rows of the EXL3 layer at short contexts: residual kernel with block sums + RMSNorm in the
+    prologue of q|k|v and gate|up, output transform of q|k|v inside the spread attention, partitions merged in the prologue of
+    o_proj (several (row, head) items per wave from two rows on); three layers at one row, so that the first (norm kernel
+    after the embedding), a middle and the last layer (final norm kernel) are covered."""
+    _qwen3_case(gpu, _spec_8b(max_batch=1, num_layers=3), "load_synthetic_exl3", start_lens=[41], steps=2, first_ids=[5], bar=3e-2, bits=4)
+    _qwen3_case(gpu, _spec_8b(max_batch=4), "load_synthetic_exl3", start_lens=[0, 16, 511, 1020], steps=1, first_ids=[1, 22, 333, 4444],
+                bar=3e-2, bits=4)
+
+
 def test_mixtral_8x7b_moe_layers(gpu):
     """Mixtral-8x7B layers (no q/k norms, 8 GPTQ experts top-2 at 4096 -> 14336 with the grouped gated epilogue)."""
     from vllm_rust_amd.qwen3 import Qwen3Spec
