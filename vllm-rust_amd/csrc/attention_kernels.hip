@@ -1265,19 +1265,38 @@ size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, i
     return (size_t)num_seqs * num_heads * 8 * ((size_t)head_dim + 2) * 4;
 }
 
+// Contexts beyond the reach of the few-partition form: the same kernel with up to 64 workgroups of 8 waves per KV head (one
+// 16-token tile per wave up to 8192 tokens) and the separate merge (vmx_paged_attention_merge) behind it, in place of
+// "q/k/v post-processing + one wave per partition + merge": at 8192 tokens the one-wave partitions put 464 waves on the
+// chip for 24 us per layer (Qwen3-8B, one row).  Returns the partition count, 0 = not covered.  VMX_NO_SPLIT_ATTN_LONG=1
+// switches the form off.
+int vmx_split_decode_attention_long_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
+    static const bool off = getenv("VMX_NO_SPLIT_ATTN_LONG") && atoi(getenv("VMX_NO_SPLIT_ATTN_LONG"));
+    if (off || !(head_dim == 64 || head_dim == 128) || qpk < 1 || qpk > 8) return 0;
+    const int half = rot_dim / 2;
+    if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return 0;
+    const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
+    if (ctx <= 1024) return 0;
+    const int tiles = (ctx + 15) / 16, p = (tiles + 7) / 8;
+    return p < 8 ? 8 : (p > 64 ? 64 : p);
+}
+size_t vmx_split_decode_attention_long_workspace_bytes(int num_seqs, int num_heads, int head_dim, int parts) {
+    return (size_t)num_seqs * num_heads * parts * ((size_t)head_dim + 2) * 4;
+}
+
 int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *qkv_partial, int splits, void *k_cache, void *v_cache,
                                const uint16_t *q_norm_w, const uint16_t *k_norm_w, float eps, const float *cos_sin,
                                const int32_t *positions, const int32_t *slots, const int32_t *block_tables, const int32_t *seq_lens,
                                float scale, int num_seqs, int num_heads, int num_kv_heads, int head_dim, int rot_dim,
                                int max_blocks_per_seq, int max_seq_len, int block_size, int window, int kv_dtype, const float *k_scale,
-                               const float *v_scale, int v_norm, hipStream_t st, const uint16_t *had_svh) {
+                               const float *v_scale, int v_norm, hipStream_t st, const uint16_t *had_svh, int long_parts) {
     VMX_REQUIRE(!had_svh || head_dim == 128, "split_decode_attention: the output Hadamard form needs 128-wide heads");
     const int qpk = qpk_capacity(num_heads / num_kv_heads);
-    const int P = split_parts_impl(head_dim, num_heads / num_kv_heads, rot_dim, max_seq_len, window, true);
+    const int P = long_parts > 0 ? long_parts : split_parts_impl(head_dim, num_heads / num_kv_heads, rot_dim, max_seq_len, window, true);
     VMX_REQUIRE(P > 0 && workspace && out, "split_decode_attention: geometry not covered (head_dim %d, %d query heads per KV head, context %d)",
                 head_dim, num_heads / num_kv_heads, max_seq_len);
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
-    const bool wide = ctx > 1024;   // 16 waves per workgroup for the long contexts, else 8 (one per head of phase A)
+    const bool wide = ctx > 1024 && long_parts <= 0;   // 16 waves per workgroup for the long contexts, else 8 (one per head of phase A)
     const size_t rows = (size_t)num_seqs * num_heads * P;
     out->tmp_out = (float *)workspace;
     out->exp_sums = out->tmp_out + rows * head_dim;
