@@ -202,6 +202,41 @@ def test_paged_attention(gpu, H, KVH, D, kv_dtype):
             assert rel <= 1e-3 + 2 ** -8
 
 
+@pytest.mark.parametrize("H,KVH,D,kv_dtype", [(32, 8, 128, 0), (8, 2, 128, 1), (4, 4, 64, 0), (40, 8, 128, 0)])
+def test_paged_attention_long_context(gpu, H, KVH, D, kv_dtype):
+    """Contexts of several thousand tokens: partitions of four and more tiles are walked by four waves each (a partition that
+    ends inside its first quarter, a sequence far shorter than the bound and a window in the same batch)."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(H * D + kv_dtype)
+    BS, NB, MB = 16, 560, 520
+    seq_lens = np.array([8192, 4097, 5000, 130, 1], np.int32)
+    S = len(seq_lens)
+    kf = rng.standard_normal((NB, BS, KVH, D)).astype(np.float32)
+    vf = rng.standard_normal((NB, BS, KVH, D)).astype(np.float32)
+    ks = vs = 1.0
+    if kv_dtype == 0:
+        kc, vc = orc.f32_to_bf16(kf), orc.f32_to_bf16(vf)
+        kcd = torch.from_numpy(kc.view(np.int16)).cuda(); vcd = torch.from_numpy(vc.view(np.int16)).cuda()
+    else:
+        ks = float(np.abs(kf).max() * 1.5 / 448.0); vs = float(np.abs(vf).max() * 1.5 / 448.0)
+        enc = np.vectorize(orc.fp8_e4m3_encode_rne, otypes=[np.uint8])
+        kc, vc = enc(kf / ks), enc(vf / vs)
+        kcd = torch.from_numpy(kc).cuda(); vcd = torch.from_numpy(vc).cuda()
+    bt = np.stack([rng.permutation(NB)[:MB] for _ in range(S)]).astype(np.int32)
+    q = orc.f32_to_bf16(rng.standard_normal((S, H * D)).astype(np.float32))
+    scale = float(1.0 / np.sqrt(D))
+    sk = torch.tensor([ks], dtype=torch.float32, device="cuda"); sv = torch.tensor([vs], dtype=torch.float32, device="cuda")
+    for window in (0, 4500):
+        got = _u16(torch, vmx.paged_attention(_bf(torch, q), kcd, vcd, torch.from_numpy(bt).cuda(), torch.from_numpy(seq_lens).cuda(),
+                                              scale, H, KVH, D, BS, int(seq_lens.max()), window, kv_dtype, sk, sv))
+        ref = orc.paged_attention_v2(q, kc, vc, bt, seq_lens, scale, H, KVH, D, BS, 512, window, kv_dtype, ks, vs)
+        g, r = orc.bf16_to_f32(got), orc.bf16_to_f32(ref)
+        assert np.abs(g - r).max() <= (1e-3 + 2 ** -7) * np.abs(r).max(), window
+        rel = np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum())
+        assert rel <= 1e-3 + 2 ** -8
+
+
 def test_fused_qknorm_rope_add_gelu(gpu):
     from oracle import oracle as orc
     from vllm_rust_amd._lib import lib, check

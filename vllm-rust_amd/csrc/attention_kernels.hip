@@ -315,6 +315,88 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     (void)HG;
 }
 
+// The same partition walked by four waves (long contexts: with at most 64 partitions per sequence a partition of a
+// 8192-token context is 8 tiles, and one wave per partition leaves the chip with a few hundred waves).  Wave w takes the
+// w-th quarter of the partition's tiles; the four states are merged through LDS with the log-sum-exp rule of the reduce
+// kernel and the workgroup writes one partition result, so tmp_out / exp_sums / max_logits keep their meaning.
+template <int HD, int QPK, int FP8>
+__global__ __launch_bounds__(256) void paged_attn_partition4_kernel(
+    float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
+    const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
+    const int32_t *__restrict__ seq_lens, float scale, int num_heads, int num_kv_heads, int max_blocks_per_seq, int block_size,
+    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part, int nq) {
+    constexpr int KSTEPS = HD / 32, NP = HD >= 128 ? HD / 128 : 1, NW = 4;
+    __shared__ float mo[NW * QPK * HD];
+    __shared__ float mm[NW * QPK], ms[NW * QPK];
+    const int kvh = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, dg = lane >> 4;
+    const int seq_len = seq_lens[seq];
+    if (seq_len == 0) return;
+    const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
+    const int part_tokens = tiles_per_part * 16;
+    const int q0 = start + part * part_tokens;
+    if (q0 >= seq_len) return;                      // workgroup-uniform
+    const int q1 = min(q0 + part_tokens, seq_len);
+    const int nt = (q1 - q0 + 15) >> 4, tpw = (nt + NW - 1) / NW;   // tiles of this partition / per wave
+    const int p0 = q0 + 16 * wave * tpw, p1 = min(p0 + 16 * tpw, q1);
+    const bool active = p0 < q1;
+    const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
+    const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
+    const int head0 = kvh * nq;
+    const bool lane_live = (HD >= 128) || (lane < 32);
+    float m_run[4], s_run[4];
+    float o[QPK][NP][2];
+    if (active) {
+        uint4 qa[KSTEPS];
+#pragma unroll
+        for (int i = 0; i < KSTEPS; i++) {
+            qa[i] = make_uint4(0, 0, 0, 0);
+            if (tl < nq) qa[i] = *reinterpret_cast<const uint4 *>(q + ((int64_t)seq * num_heads + head0 + tl) * HD + 32 * i + 8 * dg);
+        }
+        AttnTile<HD, FP8> tile;
+        attn_walk<HD, QPK, FP8>(qa, k_cache, v_cache, block_tables + (int64_t)seq * max_blocks_per_seq, p0, p1, block_size,
+                                (int64_t)num_kv_heads * HD, kvh, scale * ksc, vsc, lane, m_run, s_run, o, tile, false);
+    }
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        float sh = 0.f, mh = -FLT_MAX;
+        if (active) {
+            sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s_run[h & 3]), 16 * (h >> 2)));
+            mh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m_run[h & 3]), 16 * (h >> 2)));
+        }
+        if (lane == 0) { mm[wave * QPK + h] = mh; ms[wave * QPK + h] = sh; }
+        if (active && lane_live) {
+            const float inv = 1.0f / (sh + 1e-6f);
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+                *reinterpret_cast<float2 *>(mo + (wave * QPK + h) * HD + 2 * lane + 128 * p) = make_float2(o[h][p][0] * inv, o[h][p][1] * inv);
+        }
+    }
+    __syncthreads();
+    const int nwv = min(NW, (nt + tpw - 1) / tpw);   // waves that saw tokens
+    for (int idx = tid; idx < nq * HD; idx += 64 * NW) {
+        const int h = idx / HD, d = idx % HD;
+        float val, gmax = -FLT_MAX, gsum = 0.f;
+        if (nwv == 1) {
+            val = mo[h * HD + d];
+            gmax = mm[h];
+            gsum = ms[h];
+        } else {
+            for (int w = 0; w < nwv; w++) gmax = fmaxf(gmax, mm[w * QPK + h]);
+            float acc = 0.f;
+            for (int w = 0; w < nwv; w++) {
+                const float wt = ms[w * QPK + h] * __expf(mm[w * QPK + h] - gmax);
+                gsum += wt;
+                acc += mo[(w * QPK + h) * HD + d] * wt;
+            }
+            val = acc * (1.0f / (gsum + 1e-6f));
+        }
+        const int64_t po = ((int64_t)seq * num_heads + head0 + h) * max_parts + part;
+        tmp_out[po * HD + d] = val;
+        if (d == 0) { max_logits[po] = gmax; exp_sums[po] = gsum; }
+    }
+}
+
 // grid (heads, seqs); block 128.  Merge as paged_attention.cu:840-953 (single partition = copy):
 // out = sum_p tmp_p * w_p / (sum_p w_p + 1e-6), w_p = exp_sum_p * exp(max_p - gmax).  np <= 64, so the
 // weights are computed by one lane each and shared through LDS; the partition rows are then read
@@ -898,6 +980,17 @@ template <int HD, int QPK, int FP8>
 int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const uint16_t *q, const void *kc,
                 const void *vc, const int32_t *bt, const int32_t *sl, float scale, int H, int KVH, int mbps, int bs, int max_parts,
                 int window, const float *ks, const float *vs, int tiles_per_part) {
+    // four waves per partition from four tiles per partition on (contexts of 4096 tokens and more); 64- and 128-wide heads,
+    // bf16 / FP8 cache, up to 8 query heads per KV head
+    if constexpr ((HD == 64 || HD == 128) && (FP8 == 0 || FP8 == 1) && QPK <= 8) {
+        static const bool off = getenv("VMX_NO_PARTITION4") && atoi(getenv("VMX_NO_PARTITION4"));
+        if (tiles_per_part >= 4 && !off) {
+            hipLaunchKernelGGL((paged_attn_partition4_kernel<HD, QPK, FP8>), grid, dim3(256), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
+                               bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part, H / KVH);
+            VMX_CHECK_LAUNCH("paged_attention(partition, four waves)");
+            return VMX_OK;
+        }
+    }
     hipLaunchKernelGGL((paged_attn_partition_kernel<HD, QPK, FP8>), grid, dim3(64), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
                        bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part, H / KVH);
     VMX_CHECK_LAUNCH("paged_attention(partition)");
