@@ -794,10 +794,27 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
         const int nseg = L.kv_shared ? 1 : (L.k_eq_v ? 2 : 3);
         const int ntot = NQ + (nseg - 1) * NKV;
         // (previous layer's tail) + input_layernorm -> x, q8_1(x)
-        launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H, aq_of(m),
-                    ad_of(m, B, H), h_src);
-        h_src = nullptr;
-        {
+        // One row whose stream the previous layer's norm-fused gate|up launch left in h2: post_feedforward_layernorm + residual +
+        // layer scalar + input_layernorm + q8_1 happen in the prologue of the q|k|v launch (every workgroup for itself; the
+        // stream goes back to h), so the layer boundary costs no launch of its own.
+        bool norm_in_qkv = false;
+        if (B == 1 && pending && h_src && h_src != h) {
+            const int offs[3] = {0, NQ, NQ + NKV};
+            VmxMmvqSeg pk[3];
+            for (int i = 0; i < nseg; i++)
+                pk[i] = VmxMmvqSeg{L.lin[VMX_L_Q + i].packed.p, L.lin[VMX_L_Q + i].ggml_type, L.lin[VMX_L_Q + i].out_features, offs[i]};
+            if (vmx_iq_packed_norm_multi_ok(pk, nseg, H, B)) {
+                if (int rc = vmx_iq_mmvq_packed_norm_multi(pk, nseg, pending, h_src, h, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p,
+                                                           c.rms_norm_eps, proj, H, st))
+                    return rc;
+                norm_in_qkv = true;
+                h_src = nullptr;
+            }
+        }
+        if (!norm_in_qkv) {
+            launch_norm(st, B, h, x, pending, pending_w, pending_scalar, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H, aq_of(m),
+                        ad_of(m, B, H), h_src);
+            h_src = nullptr;
             const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
             const int offs[3] = {0, NQ, NQ + NKV};
             if (int rc = g4_linears(m, qkv, offs, nseg, x, proj, ntot, B, st)) return rc;

@@ -335,6 +335,7 @@ struct PkArgs {
     const uint16_t *n_h_in, *n_wpost, *n_wnext;
     uint16_t *n_h_out;
     float n_eps;
+    const uint16_t *n_scalar;   // optional layer scalar: h' = bf16(h' * scalar) before the second norm
 };
 
 __device__ __forceinline__ float pk_rbf(float x) { return vmx_bf16_to_f32(vmx_f32_to_bf16(x)); }
@@ -354,6 +355,7 @@ __device__ __forceinline__ uint4 pk_pack8(const float f[8]) {
 struct PkNormIn {
     float4 oa, ob;
     uint4 h, wp, wn;
+    uint16_t sc;
 };
 
 __device__ __forceinline__ void pk_norm_request(PkNormIn &r, const PkArgs &a, int n_in, int tid) {
@@ -363,6 +365,7 @@ __device__ __forceinline__ void pk_norm_request(PkNormIn &r, const PkArgs &a, in
     r.h = *reinterpret_cast<const uint4 *>(a.n_h_in + 8 * ci);
     r.wp = *reinterpret_cast<const uint4 *>(a.n_wpost + 8 * ci);
     r.wn = *reinterpret_cast<const uint4 *>(a.n_wnext + 8 * ci);
+    r.sc = a.n_scalar ? a.n_scalar[0] : (uint16_t)0x3f80;
 }
 
 // Gemma's sandwich norms between o_proj and the MLP (gemma4_quantized.rs:1372-1392), with the bf16 rounding points of the
@@ -389,7 +392,11 @@ __device__ __forceinline__ void pk_norm_prologue(const PkNormIn &r, const PkArgs
     pk_unpack8(r.h, hr);
     float v2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { hv[j] = pk_rbf(pk_rbf(ov[j] * inv1 * wv[j]) + hr[j]); v2 += live ? hv[j] * hv[j] : 0.f; }
+    for (int j = 0; j < 8; j++) {
+        hv[j] = pk_rbf(pk_rbf(ov[j] * inv1 * wv[j]) + hr[j]);
+        if (a.n_scalar) hv[j] = pk_rbf(hv[j] * vmx_bf16_to_f32(r.sc));   // layer_scalar of the layer whose tail this is
+        v2 += live ? hv[j] * hv[j] : 0.f;
+    }
     if (blockIdx.x == 0 && live) *reinterpret_cast<uint4 *>(a.n_h_out + 8 * tid) = pk_pack8(hv);
     v2 = vmx_wave_sum(v2);
     if ((tid & 63) == 0) red[16 + wave] = v2;
@@ -648,7 +655,8 @@ template <int PPW, bool DBG, int ABL = 0, bool GLU = false, bool NORM = false> i
 bool g_pk_tables_ready[64] = {};   // per device: the table images exist (vmx_init)
 void *g_pk_stamps = nullptr;   // measurement: per-wave clock stamps of the next launches (vmx_debug_iq_packed_stamps)
 
-int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int32_t *dbg, hipStream_t st) {
+int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int32_t *dbg, hipStream_t st,
+              const PkArgs *norm = nullptr) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_pk_tables_ready[dev]) {
         vmx_set_error("iq_mmvq(packed): vmx_init(%d) has not run on this device (it builds the decode tables)", dev);
@@ -686,6 +694,17 @@ int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
         const int items = (segs[i].n_out + PK_ROWS - 1) / PK_ROWS * cpu_ * S;
         a.seg[i] = PkSeg{(const uint8_t *)segs[i].w, y + segs[i].y_off, segs[i].ggml_type, segs[i].n_out, wg};
         wg += (items + W - 1) / W;
+    }
+    if (norm) {   // sandwich-norm prologue: every workgroup computes the row, one 8-element chunk per thread
+        if (S != 1 || 64 * W * 8 < n_in) {
+            vmx_set_error("iq_mmvq(packed, norm): %d-wave workgroups / %d K-slices cannot hold a row of %d", W, S, n_in);
+            return VMX_EUNSUPPORTED;
+        }
+        a.n_o = norm->n_o; a.n_h_in = norm->n_h_in; a.n_h_out = norm->n_h_out; a.n_wpost = norm->n_wpost; a.n_wnext = norm->n_wnext;
+        a.n_eps = norm->n_eps; a.n_scalar = norm->n_scalar;
+        if (ppw == 4) return pk_launch_ppw<4, false, 0, false, true>(a, wg, W, lds, nullptr, nullptr, n_in, S, nullptr, st);
+        if (ppw == 2) return pk_launch_ppw<2, false, 0, false, true>(a, wg, W, lds, nullptr, nullptr, n_in, S, nullptr, st);
+        return pk_launch_ppw<1, false, 0, false, true>(a, wg, W, lds, nullptr, nullptr, n_in, S, nullptr, st);
     }
     if (dbg) return pk_launch_ppw<4, true>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
     static const int abl = getenv("VMX_IQ_ABL") ? atoi(getenv("VMX_IQ_ABL")) : 0;   // measurement only: 1 = stream alone, 2 = decode alone
@@ -841,6 +860,37 @@ int vmx_iq_mmvq_packed_norm_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, 
 bool vmx_iq_packed_norm_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, int n_in, int m) {
     static const int off = getenv("VMX_IQ_NO_NORM_FUSION") ? atoi(getenv("VMX_IQ_NO_NORM_FUSION")) : 0;
     return !off && n_in % 32 == 0 && n_in <= 4096 && vmx_iq_packed_geglu_ok(gate, up, n_in, m);
+}
+
+// Up to three packed tensors behind Gemma's layer-boundary norms (gemma4_quantized.rs:1400-1424 then :1311-1320): the row is
+//   h' = bf16(bf16(norm(bf16(o)) * w_post) + h) [* scalar];  x = bf16(norm(h') * w_next);  q8_1(x)
+// computed by every workgroup from the previous layer's down-projection output o and the residual stream; h_out (!= h_in)
+// receives h'.  One activation row, whole rows in one K-slice, n_in <= 4096, workgroups of at least n_in / 8 threads.
+bool vmx_iq_packed_norm_multi_ok(const VmxMmvqSeg *segs, int nseg, int n_in, int m) {
+    static const int off = getenv("VMX_IQ_NO_QKV_NORM_FUSION") ? atoi(getenv("VMX_IQ_NO_QKV_NORM_FUSION")) : 0;
+    if (off || m != 1 || nseg < 1 || nseg > 3 || n_in % 256 || n_in > 4096) return false;
+    if (pk_num_slices(n_in / 256) != 1) return false;
+    int units = 0;
+    for (int i = 0; i < nseg; i++) {
+        if (!pk_supported(segs[i].ggml_type) || !segs[i].w) return false;
+        units += (segs[i].n_out + PK_ROWS - 1) / PK_ROWS;
+    }
+    // the launch plan of pk_launch: waves per workgroup from the item count
+    const int ppw = units >= 2048 ? 4 : (units >= 1024 ? 2 : 1);
+    int W = (units * (4 / ppw) + vmx_num_cus() - 1) / vmx_num_cus();
+    W = W < 1 ? 1 : (W > 16 ? 16 : W);
+    return 64 * W * 8 >= n_in;
+}
+int vmx_iq_mmvq_packed_norm_multi(const VmxMmvqSeg *segs, int nseg, const float *o, const uint16_t *h_in, uint16_t *h_out,
+                                  const uint16_t *w_post, const uint16_t *scalar, const uint16_t *w_next, float eps, float *y, int n_in,
+                                  hipStream_t st) {
+    if (!vmx_iq_packed_norm_multi_ok(segs, nseg, n_in, 1) || h_in == h_out) {
+        vmx_set_error("iq_mmvq(packed, norm): not eligible (n_in %d, %d tensors)", n_in, nseg);
+        return VMX_EUNSUPPORTED;
+    }
+    PkArgs na = {};
+    na.n_o = o; na.n_h_in = h_in; na.n_h_out = h_out; na.n_wpost = w_post; na.n_wnext = w_next; na.n_eps = eps; na.n_scalar = scalar;
+    return pk_launch(segs, nseg, nullptr, nullptr, y, n_in, nullptr, st, &na);
 }
 
 extern "C" int vmx_iq_mmvq_packed_geglu_bf16(int ggml_type, const void *gate_packed, const void *up_packed, const int8_t *aq, const float *ad,

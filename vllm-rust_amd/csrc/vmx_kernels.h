@@ -115,6 +115,12 @@ bool vmx_iq_packed_norm_geglu_ok(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg
 int vmx_iq_mmvq_packed_norm_geglu(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, const float *o, const uint16_t *h_in,
                                   uint16_t *h_out, const uint16_t *w_post, const uint16_t *w_next, float eps, uint16_t *act, int8_t *aq_out,
                                   float *ad_out, int n_in, hipStream_t st);
+// up to three packed tensors behind the norms of a layer boundary (post-feedforward norm of `o` + residual [* scalar] + the next
+// input norm), computed in the prologue like the form above; y + segs[i].y_off receive the f32 outputs
+bool vmx_iq_packed_norm_multi_ok(const VmxMmvqSeg *segs_packed, int nseg, int n_in, int m);
+int vmx_iq_mmvq_packed_norm_multi(const VmxMmvqSeg *segs_packed, int nseg, const float *o, const uint16_t *h_in, uint16_t *h_out,
+                                  const uint16_t *w_post, const uint16_t *scalar, const uint16_t *w_next, float eps, float *y, int n_in,
+                                  hipStream_t st);
 int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, const int8_t *aq, const float *ad, uint16_t *act,
                              int8_t *aq_out, float *ad_out, int n_in, hipStream_t st);
 
