@@ -161,24 +161,50 @@ __global__ __launch_bounds__(64) void g4_qkv_post_kernel(const float *__restrict
     int src_head = head;
     if (!is_q && !is_k && v_from_k) src_head = head - Hkv;
     const int64_t base = (int64_t)t * ntot + (int64_t)src_head * hd;
+    // The kernel is a chain of memory round trips, so everything with a known address is requested at once (hd <= 512: at
+    // most 8 elements per lane); only the cos / sin row waits for the position.
+    const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
+    const int pos = positions[t];
+    const int slot = (is_q || stage) ? 0 : slots[t];
+    const float kv_sc = (!is_q && !stage && fp8) ? (is_k ? *k_scale : *v_scale) : 1.0f;
+    float pv[8], nwv[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = min(lane + 64 * j, hd - 1);
+        pv[j] = proj[base + i];
+        nwv[j] = nw ? vmx_bf16_to_f32(nw[i]) : 1.0f;
+    }
+    const int half = rot_dim >> 1;
+    const bool rot = (is_q || is_k) && half > 0;
+    const float *cs = cos_sin + (int64_t)pos * rot_dim;
+    float cv[4], sv[4];   // pair i = lane + 64 j < half (half <= 256)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = max(min(lane + 64 * j, half - 1), 0);
+        cv[j] = rot ? cs[i] : 1.0f;
+        sv[j] = rot ? cs[half + i] : 0.0f;
+    }
     float ss = 0.f;
-    for (int i = lane; i < hd; i += 64) {
-        const float v = rbf(proj[base + i]);
-        vals[i] = v;
-        ss += v * v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        pv[j] = rbf(pv[j]);
+        if (lane + 64 * j < hd) ss += pv[j] * pv[j];
     }
     ss = vmx_wave_sum(ss);
     const float inv = rsqrtf(ss / (float)hd + eps);
-    const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
-    for (int i = lane; i < hd; i += 64) vals[i] = rbf(vals[i] * inv * (nw ? vmx_bf16_to_f32(nw[i]) : 1.0f));
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (lane + 64 * j < hd) vals[lane + 64 * j] = rbf(pv[j] * inv * nwv[j]);
     __syncthreads();
-    if (is_q || is_k) {
-        const int half = rot_dim >> 1;
-        const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
-        for (int i = lane; i < half; i += 64) {
-            const float xv = vals[i], yv = vals[half + i], c = cs[i], s = cs[half + i];
-            vals[i] = rbf(xv * c - yv * s);
-            vals[half + i] = rbf(yv * c + xv * s);
+    if (rot) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = lane + 64 * j;
+            if (i < half) {
+                const float xv = vals[i], yv = vals[half + i], c = cv[j], sn = sv[j];
+                vals[i] = rbf(xv * c - yv * sn);
+                vals[half + i] = rbf(yv * c + xv * sn);
+            }
         }
         __syncthreads();
     }
@@ -192,14 +218,13 @@ __global__ __launch_bounds__(64) void g4_qkv_post_kernel(const float *__restrict
         for (int i = lane; i < hd; i += 64) dst_row[i] = vmx_f32_to_bf16(vals[i]);
         return;
     }
-    const int slot = slots[t];
     if (slot < 0) return;
     const int64_t dst = ((int64_t)slot * Hkv + kvh) * hd;
     void *cache = is_k ? k_cache : v_cache;
     if (!fp8) {
         for (int i = lane; i < hd; i += 64) ((uint16_t *)cache)[dst + i] = vmx_f32_to_bf16(vals[i]);
     } else {   // clamp(x / scale, +-448) -> bf16 -> e4m3 (kv_cache/cache_engine.rs:202-223)
-        const float sc = is_k ? *k_scale : *v_scale;
+        const float sc = kv_sc;
         for (int i = lane; i < hd; i += 64) {
             float a = vals[i] / sc;
             a = rbf(fminf(fmaxf(a, -448.0f), 448.0f));
