@@ -261,12 +261,17 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const uint16_t *__restrict__ q,
     const void *__restrict__ k_cache, const void *__restrict__ v_cache, const int32_t *__restrict__ block_tables,
     const int32_t *__restrict__ seq_lens, float scale, int num_heads, int num_kv_heads, int max_blocks_per_seq, int block_size,
-    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part, int nq) {
-    // nq = query heads per KV head (<= QPK, the compiled capacity: rows nq..QPK-1 of the A fragment stay zero)
+    int max_parts, int window, const float *__restrict__ k_scale_ptr, const float *__restrict__ v_scale_ptr, int tiles_per_part, int nq_all,
+    int hsplit) {
+    // nq = query heads of this wave (<= QPK, the compiled capacity: rows nq..QPK-1 of the A fragment stay zero).  hsplit > 1:
+    // the nq_all query heads of a KV head are dealt to hsplit waves (blockIdx.x = kv head * hsplit + group), each re-reading
+    // the K/V tiles -- for wide heads with many query heads per KV head and few partitions (Gemma 4 full-attention layers: one
+    // 512-wide KV head, 16 query heads, 25 tiles at 400 tokens = 25 waves on the whole chip otherwise)
     constexpr int KSTEPS = HD / 32;                 // MFMA k-steps per tile
     constexpr int NP = HD >= 128 ? HD / 128 : 1;    // V: pairs of dims per lane
     constexpr int HG = (QPK + 3) / 4;               // 16-lane row groups that hold live heads
-    const int kvh = blockIdx.x, seq = blockIdx.y, part = blockIdx.z;
+    const int kvh = blockIdx.x / hsplit, hgrp = blockIdx.x % hsplit, seq = blockIdx.y, part = blockIdx.z;
+    const int nq = nq_all / hsplit;
     const int lane = threadIdx.x, tl = lane & 15, dg = lane >> 4;
     const int seq_len = seq_lens[seq];
     if (seq_len == 0) return;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64) void paged_attn_partition_kernel(
     const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
     const float lscale = scale * ksc;
     const int64_t tok_stride = (int64_t)num_kv_heads * HD;
-    const int head0 = kvh * nq;
+    const int head0 = kvh * nq_all + hgrp * nq;
     const bool lane_live = (HD >= 128) || (lane < 32);
 
     // q rows as MFMA A fragments: lane (row = head tl, dim group dg) holds dims [32*i + 8*dg, +8)
@@ -979,12 +984,12 @@ int launch_split(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, flo
 template <int HD, int QPK, int FP8>
 int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, float *max_logits, const uint16_t *q, const void *kc,
                 const void *vc, const int32_t *bt, const int32_t *sl, float scale, int H, int KVH, int mbps, int bs, int max_parts,
-                int window, const float *ks, const float *vs, int tiles_per_part) {
+                int window, const float *ks, const float *vs, int tiles_per_part, int hsplit = 1) {
     // four waves per partition from four tiles per partition on (contexts of 4096 tokens and more); 64- and 128-wide heads,
     // bf16 / FP8 cache, up to 8 query heads per KV head
     if constexpr ((HD == 64 || HD == 128) && (FP8 == 0 || FP8 == 1) && QPK <= 8) {
         static const bool off = getenv("VMX_NO_PARTITION4") && atoi(getenv("VMX_NO_PARTITION4"));
-        if (tiles_per_part >= 4 && !off) {
+        if (tiles_per_part >= 4 && !off && hsplit == 1) {
             hipLaunchKernelGGL((paged_attn_partition4_kernel<HD, QPK, FP8>), grid, dim3(256), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
                                bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part, H / KVH);
             VMX_CHECK_LAUNCH("paged_attention(partition, four waves)");
@@ -992,7 +997,7 @@ int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, floa
         }
     }
     hipLaunchKernelGGL((paged_attn_partition_kernel<HD, QPK, FP8>), grid, dim3(64), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
-                       bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part, H / KVH);
+                       bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part, H / KVH, hsplit);
     VMX_CHECK_LAUNCH("paged_attention(partition)");
     return VMX_OK;
 }
@@ -1211,7 +1216,11 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
                               int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size, int window, int kv_dtype,
                               const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st) {
     const int P = parts_for_impl(max_seq_len);
-    const int qpk = qpk_capacity(num_heads / num_kv_heads);
+    // wide heads, many query heads per KV head, few waves: the query heads of a KV head are dealt to four waves
+    static const bool no_hsplit = getenv("VMX_NO_ATTN_HEAD_SPLIT") && atoi(getenv("VMX_NO_ATTN_HEAD_SPLIT"));
+    const int ratio = num_heads / num_kv_heads;
+    const int hsplit = (!no_hsplit && head_dim >= 256 && ratio >= 8 && ratio % 4 == 0 && (int64_t)num_kv_heads * num_seqs * P < 1024) ? 4 : 1;
+    const int qpk = qpk_capacity(ratio / hsplit);
     float *tmp_out = (float *)workspace;
     float *exp_sums = tmp_out + (size_t)num_seqs * num_heads * P * head_dim;
     float *max_logits = exp_sums + (size_t)num_seqs * num_heads * P;
@@ -1221,11 +1230,11 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
     out->max_parts = P;
     const int tpp = tiles_per_part_for(max_seq_len);
     out->part_tokens = tpp * 16;
-    const dim3 grid(num_kv_heads, num_seqs, P);
+    const dim3 grid(num_kv_heads * hsplit, num_seqs, P);
     const int kvt = kv_dtype == VMX_KV_F16_INTERNAL ? 3 : (kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0));
     int rc = VMX_EUNSUPPORTED;
 #define ARGS grid, st, tmp_out, exp_sums, max_logits, q, k_cache, v_cache, block_tables, seq_lens, scale, num_heads, num_kv_heads, \
-             max_blocks_per_seq, block_size, P, window, k_scale, v_scale, tpp
+             max_blocks_per_seq, block_size, P, window, k_scale, v_scale, tpp, hsplit
 #define BY_KV(HD, Q)                                                                                                       \
     rc = kvt == 3 ? launch_part<HD, Q, 3>(ARGS)                                                                            \
                   : (kvt == 2 ? launch_part<HD, Q, 2>(ARGS) : (kvt == 1 ? launch_part<HD, Q, 1>(ARGS) : launch_part<HD, Q, 0>(ARGS)))
