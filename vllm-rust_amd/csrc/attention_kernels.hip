@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void paged_attn_partition4_kernel(
 // out = sum_p tmp_p * w_p / (sum_p w_p + 1e-6), w_p = exp_sum_p * exp(max_p - gmax).  np <= 64, so the
 // weights are computed by one lane each and shared through LDS; the partition rows are then read
 // with independent loads.
-__global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__restrict__ out, const float *__restrict__ tmp_out,
+__global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__restrict__ out, const float *__restrict__ tmp_out,
                                                                  const float *__restrict__ exp_sums,
                                                                  const float *__restrict__ max_logits,
                                                                  const int32_t *__restrict__ seq_lens, int num_heads, int head_dim,
@@ -439,14 +439,20 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(uint16_t *__rest
         __syncthreads();
         inv = inv_s;
     }
-    for (int d = tid; d < head_dim; d += 128) {   // head_dim % 64 == 0: a wave is all in or all out
+    // block = min(head_dim, 512) threads (a 512-wide head is one round of loads per thread, not four in a row)
+    for (int d = tid; d < head_dim; d += blockDim.x) {   // head_dim % 64 == 0: a wave is all in or all out
         float val;
         if (np == 1) {
             val = tp[d];
         } else {
             float acc = 0.f;
-#pragma unroll 8
-            for (int p = 0; p < np; p++) acc += tp[(int64_t)p * head_dim + d] * w_s[p];
+            for (int p0 = 0; p0 < np; p0 += 8) {   // eight partition rows per round trip; rows past np re-read the last one with weight 0 (w_s is zero there)
+                float r[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) r[u] = tp[(int64_t)min(p0 + u, np - 1) * head_dim + d];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += r[u] * w_s[p0 + u];
+            }
             val = acc * inv;
         }
         const uint16_t vb = out_f16 ? __builtin_bit_cast(uint16_t, (_Float16)val) : vmx_f32_to_bf16(val);
@@ -1269,14 +1275,14 @@ int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const in
     hipLaunchKernelGGL((paged_attn_reduce_small_kernel<NP, EPT>), grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,          \
                        parts->max_logits, seq_lens, num_heads, aq, ad)
     if (out_f16)
-        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
+        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(head_dim >= 512 ? 512 : (head_dim >= 256 ? 256 : 128)), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
                            seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad, 1);
     else if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 256) SMALL(4, 2);
     else if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 128) SMALL(4, 1);
     else if (parts->part_tokens == 0 && parts->max_parts == 2 && head_dim == 256) SMALL(2, 2);
     else if (parts->part_tokens == 0 && parts->max_parts == 8 && head_dim == 256) SMALL(8, 2);
     else
-        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
+        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(head_dim >= 512 ? 512 : (head_dim >= 256 ? 256 : 128)), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
                            seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad, 0);
 #undef SMALL
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
@@ -1454,7 +1460,7 @@ static int paged_attention_impl(uint16_t *out, const uint16_t *q, const void *k_
                                            max_blocks_per_seq, max_seq_len, head_dim, block_size, window,
                                            f16 ? VMX_KV_F16_INTERNAL : kv_dtype, k_scale, v_scale, workspace, &parts, st))
         return rc;
-    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(128), 0, st, out, parts.tmp_out, parts.exp_sums,
+    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(head_dim >= 512 ? 512 : (head_dim >= 256 ? 256 : 128)), 0, st, out, parts.tmp_out, parts.exp_sums,
                        parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window, parts.part_tokens, (int8_t *)nullptr,
                        (float *)nullptr, f16);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
