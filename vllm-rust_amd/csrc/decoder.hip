@@ -456,6 +456,51 @@ __global__ __launch_bounds__(256) void embed_kernel(uint16_t *__restrict__ out, 
     for (int i = threadIdx.x; i < (hidden >> 3); i += 256) dst[i] = ok ? src[i] : make_uint4(0, 0, 0, 0);
 }
 
+// gateup_act_kernel for an EXL3 gate|up launch at decode sizes: a wave owns one 128-column block of the intermediate row and
+// requests the split-K slices of its gate and up columns in one go (two columns per lane), applies both output transforms
+// (stage order and arithmetic of exl3_out_transform8) and writes act = bf16(silu(bf16 gate) * bf16 up).
+// partial: [splits][tokens][2 * inter], gate columns first; svh: the merged gate|up scale vector.  grid (inter / 512, tokens).
+__global__ __launch_bounds__(256) void exl3_gateup_act_kernel(const float *__restrict__ partial, int splits, int tokens,
+                                                               uint16_t *__restrict__ act, int inter, const uint16_t *__restrict__ svh) {
+    const int t = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = blockIdx.x * 4 + wave;
+    if (blk >= (inter >> 7)) return;
+    const int col = blk * 128 + 2 * lane;
+    const int64_t slice = (int64_t)tokens * 2 * inter, row = (int64_t)t * 2 * inter;
+    const uint32_t svg = *reinterpret_cast<const uint32_t *>(svh + col), svu = *reinterpret_cast<const uint32_t *>(svh + inter + col);
+    float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
+    for (int s0 = 0; s0 < splits; s0 += 8) {
+        float2 gv[8], uv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float *src = partial + min(s0 + q, splits - 1) * slice + row + col;
+            gv[q] = *reinterpret_cast<const float2 *>(src);
+            uv[q] = *reinterpret_cast<const float2 *>(src + inter);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool in = s0 + q < splits;
+            g0 += in ? gv[q].x : 0.f; g1 += in ? gv[q].y : 0.f;
+            u0 += in ? uv[q].x : 0.f; u1 += in ? uv[q].y : 0.f;
+        }
+    }
+    float e[4] = {g0 + g1, g0 - g1, u0 + u1, u0 - u1};
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const bool neg = (lane & m) != 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float p = __shfl_xor(e[j], m, 64);
+            e[j] = (neg ? -e[j] : e[j]) + p;
+        }
+    }
+    const uint32_t sc[4] = {svg & 0xffffu, svg >> 16, svu & 0xffffu, svu >> 16};
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = round_bf16((float)((_Float16)(e[j] * 0.088388347648f) * __builtin_bit_cast(_Float16, (uint16_t)sc[j])));
+    const float a0 = (e[0] / (1.0f + expf(-e[0]))) * e[2], a1 = (e[1] / (1.0f + expf(-e[1]))) * e[3];
+    *reinterpret_cast<uint32_t *>(act + (int64_t)t * inter + col) = (uint32_t)vmx_f32_to_bf16(a0) | ((uint32_t)vmx_f32_to_bf16(a1) << 16);
+}
+
 // EXL3 decode rows: h += transform(partial) and the block sums the next linear's prologue normalises with (no x row)
 bool exl3_resid_stats_ok(int tokens, int splits, int hidden) {
     static const bool off = getenv("VMX_EXL3_NO_NORM_FUSION") && atoi(getenv("VMX_EXL3_NO_NORM_FUSION"));
@@ -1450,7 +1495,10 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         } else if (L.gate_up.glu) {  // act comes out of the GEMM epilogue
             if (int rc = L.gate_up.forward_glu(x, act, B, st)) return rc;
         } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
-        if (one || !L.gate_up.glu) {
+        static const bool no_ex_act = getenv("VMX_EXL3_NO_WAVE_ACT") && atoi(getenv("VMX_EXL3_NO_WAVE_ACT"));
+        if (ex_fold && gu_svh && !no_ex_act) {
+            hipLaunchKernelGGL(exl3_gateup_act_kernel, dim3((I / 128 + 3) / 4, B), dim3(256), 0, st, gu_src, gu_splits, B, act, I, gu_svh);
+        } else if (one || !L.gate_up.glu) {
             int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
             hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, gu_src, gu_splits, B, act, I,
                                iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr, gu_svh);
