@@ -134,10 +134,17 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
                                                           const float *__restrict__ partial, int splits, int tokens,
                                                           const uint16_t *__restrict__ w, float eps, int hidden,
                                                           int8_t *__restrict__ aq, float *__restrict__ ad,
-                                                          const uint16_t *__restrict__ had_svh) {
+                                                          const uint16_t *__restrict__ had_svh,
+                                                          const uint16_t *__restrict__ emb_table, const int32_t *__restrict__ emb_ids,
+                                                          int vocab) {
     __shared__ float red[4];
     const int t = blockIdx.x;
     const int64_t row = (int64_t)t * hidden;
+    // emb_table != NULL (no partial): the row is the token's embedding (an id outside the table reads as zeros), stored to h as
+    // the embedding kernel would have -- the first norm of a step without a launch for the lookup
+    const int emb_id = emb_table ? emb_ids[t] : 0;
+    const bool emb_ok = emb_id >= 0 && emb_id < vocab;
+    const uint16_t *hsrc = emb_table ? emb_table + (int64_t)(emb_ok ? emb_id : 0) * hidden : h + row;
     const int64_t slice = (int64_t)tokens * hidden;
     const int nchunk = hidden >> 3;
     float hv[CH][8];
@@ -160,7 +167,8 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
                 for (int j = 0; j < 8; j++) var += hv[c][j] * hv[c][j];
             }
         } else if (ci < nchunk) {
-            unpack_bf16x8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
+            unpack_bf16x8(emb_table && !emb_ok ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(hsrc + 8 * ci), hv[c]);
+            if (emb_table) *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack_bf16x8(hv[c]);
             if (partial) {
                 float o[8];
                 if (splits < 0) unpack_bf16x8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(partial) + row + 8 * ci), o);
@@ -513,11 +521,12 @@ void launch_exl3_resid_stats(hipStream_t st, uint16_t *h, const float *partial, 
 }
 
 void launch_resid_norm(hipStream_t st, uint16_t *h, uint16_t *x, const float *partial, int splits, int tokens, const uint16_t *w,
-                       float eps, int hidden, int8_t *aq = nullptr, float *ad = nullptr, const uint16_t *had_svh = nullptr) {
-    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
-    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
-    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
-    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh);
+                       float eps, int hidden, int8_t *aq = nullptr, float *ad = nullptr, const uint16_t *had_svh = nullptr,
+                       const uint16_t *emb_table = nullptr, const int32_t *emb_ids = nullptr, int vocab = 0) {
+    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
 }
 
 struct DevBuf {
@@ -1246,7 +1255,10 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
     VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
 
-    hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
+    // the lookup is folded into the first layer's norm kernel (VMX_NO_EMBED_FUSION=1: its own launch)
+    static const bool no_embed_fusion = getenv("VMX_NO_EMBED_FUSION") && atoi(getenv("VMX_NO_EMBED_FUSION"));
+    bool embed_pending = !no_embed_fusion;
+    if (!embed_pending) hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
     const float *pending = nullptr;  // down-projection output (f32 slices in PB) not yet folded into the residual stream
     int pending_splits = 0;
     const uint16_t *pending_svh = nullptr;  // EXL3: `pending` holds raw split-K sums whose output transform the norm kernel applies
@@ -1281,10 +1293,16 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         // EXL3 decode rows: the residual kernel leaves block sums of squares and q|k|v normalises its rows itself
         const bool ex_norm_in = ex && B <= 4 && L.ex_svh_qkv.p && pending_svh && exl3_resid_stats_ok(B, pending_splits, H);
         const uint16_t *ex_in = ex_norm_in ? h : x, *ex_in_w = ex_norm_in ? (const uint16_t *)L.input_ln.p : nullptr;
+        if (embed_pending && (ex_norm_in || fold_in || pending)) {   // not reached: the first layer has neither pending output nor tile sums
+            hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
+            embed_pending = false;
+        }
         if (ex_norm_in) launch_exl3_resid_stats(st, h, pending, pending_splits, B, H, pending_svh, ssq);
         else if (!fold_in)
             launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
-                              iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh);
+                              iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh,
+                              embed_pending ? (const uint16_t *)m->embed.p : nullptr, input_ids, c.vocab_size);
+        embed_pending = false;
         pending_svh = nullptr;
         have_ssq = false;
         if (fold_in) s_qkv = vmx_int4_norm_splits(B, NQKV_, H, 0);   // the wide kernel has its own k slicing
