@@ -414,6 +414,7 @@ __global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__rest
                                                                  float *__restrict__ ad, int out_f16) {
     __shared__ float w_s[64];
     __shared__ float inv_s;
+    __shared__ float acc_s[512];
     const int head = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
     const int seq_len = seq_lens[seq];
     if (seq_len == 0) return;
@@ -425,6 +426,15 @@ __global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__rest
     const float *tp = tmp_out + mo * head_dim;
     const int64_t obase = ((int64_t)seq * num_heads + head) * head_dim;
     uint16_t *o = out + obase;
+    // 512 threads = G groups of head_dim threads; group g takes the batches g, g + G, ... of eight partition rows, the first
+    // of them requested before the weights are known (the launch is a chain of memory round trips); the groups' sums are
+    // added in group order through LDS.
+    const int G = blockDim.x / head_dim > 0 ? blockDim.x / head_dim : 1;
+    const int g = tid / head_dim, d = tid - g * head_dim;
+    const bool in_grid = g < G;                 // blockDim.x not a multiple of head_dim: surplus threads only take the barriers
+    float r[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) r[u] = (in_grid && np > 1 && 8 * g < np) ? tp[(int64_t)min(8 * g + u, np - 1) * head_dim + d] : 0.f;
     float inv = 1.0f;
     if (np > 1) {
         if (tid < 64) {
@@ -438,21 +448,27 @@ __global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__rest
         }
         __syncthreads();
         inv = inv_s;
+        float acc = 0.f;
+        if (in_grid) {
+            for (int p0 = 8 * g; p0 < np; p0 += 8 * G) {   // rows past np were read as the last one and weigh 0 (w_s is zero there)
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += r[u] * w_s[p0 + u];
+                if (p0 + 8 * G < np) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r[u] = tp[(int64_t)min(p0 + 8 * G + u, np - 1) * head_dim + d];
+                }
+            }
+            acc_s[tid] = acc;
+        }
+        __syncthreads();
     }
-    // block = min(head_dim, 512) threads (a 512-wide head is one round of loads per thread, not four in a row)
-    for (int d = tid; d < head_dim; d += blockDim.x) {   // head_dim % 64 == 0: a wave is all in or all out
+    if (g == 0) {
         float val;
         if (np == 1) {
             val = tp[d];
         } else {
             float acc = 0.f;
-            for (int p0 = 0; p0 < np; p0 += 8) {   // eight partition rows per round trip; rows past np re-read the last one with weight 0 (w_s is zero there)
-                float r[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) r[u] = tp[(int64_t)min(p0 + u, np - 1) * head_dim + d];
-#pragma unroll
-                for (int u = 0; u < 8; u++) acc += r[u] * w_s[p0 + u];
-            }
+            for (int k = 0; k < G; k++) acc += acc_s[k * head_dim + d];
             val = acc * inv;
         }
         const uint16_t vb = out_f16 ? __builtin_bit_cast(uint16_t, (_Float16)val) : vmx_f32_to_bf16(val);
@@ -1275,14 +1291,14 @@ int vmx_paged_attention_merge(uint16_t *out, const VmxAttnParts *parts, const in
     hipLaunchKernelGGL((paged_attn_reduce_small_kernel<NP, EPT>), grid, dim3(128), 0, st, out, parts->tmp_out, parts->exp_sums,          \
                        parts->max_logits, seq_lens, num_heads, aq, ad)
     if (out_f16)
-        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(head_dim >= 512 ? 512 : (head_dim >= 256 ? 256 : 128)), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
+        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(512), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
                            seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad, 1);
     else if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 256) SMALL(4, 2);
     else if (parts->part_tokens == 0 && parts->max_parts == 4 && head_dim == 128) SMALL(4, 1);
     else if (parts->part_tokens == 0 && parts->max_parts == 2 && head_dim == 256) SMALL(2, 2);
     else if (parts->part_tokens == 0 && parts->max_parts == 8 && head_dim == 256) SMALL(8, 2);
     else
-        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(head_dim >= 512 ? 512 : (head_dim >= 256 ? 256 : 128)), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
+        hipLaunchKernelGGL(paged_attn_reduce_kernel, grid, dim3(512), 0, st, out, parts->tmp_out, parts->exp_sums, parts->max_logits,
                            seq_lens, num_heads, head_dim, parts->max_parts, window, parts->part_tokens, aq, ad, 0);
 #undef SMALL
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
@@ -1460,7 +1476,7 @@ static int paged_attention_impl(uint16_t *out, const uint16_t *q, const void *k_
                                            max_blocks_per_seq, max_seq_len, head_dim, block_size, window,
                                            f16 ? VMX_KV_F16_INTERNAL : kv_dtype, k_scale, v_scale, workspace, &parts, st))
         return rc;
-    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(head_dim >= 512 ? 512 : (head_dim >= 256 ? 256 : 128)), 0, st, out, parts.tmp_out, parts.exp_sums,
+    hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(512), 0, st, out, parts.tmp_out, parts.exp_sums,
                        parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window, parts.part_tokens, (int8_t *)nullptr,
                        (float *)nullptr, f16);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
