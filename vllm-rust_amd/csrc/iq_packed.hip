@@ -879,7 +879,12 @@ bool vmx_iq_packed_norm_multi_ok(const VmxMmvqSeg *segs, int nseg, int n_in, int
     const int ppw = units >= 2048 ? 4 : (units >= 1024 ? 2 : 1);
     int W = (units * (4 / ppw) + vmx_num_cus() - 1) / vmx_num_cus();
     W = W < 1 ? 1 : (W > 16 ? 16 : W);
-    return 64 * W * 8 >= n_in;
+    // measured on the Gemma-4-12B shapes: with 8-wave workgroups (sliding layers, 1 024 units) the fused launch takes 9.9 us against
+    // 6.9 + 5.5 us for the raw-layout launch behind a norm kernel; the 9-wave plan of the full-attention layers (1 152 units, one
+    // workgroup per compute unit) takes 18.1 us against 8.1 + 5.5 us in the kernel trace, so those keep the two launches (on the
+    // whole step the two choices measured within noise of each other: 327-330 vs 328 tok/s)
+    static const int max_w = getenv("VMX_IQ_QKV_NORM_MAX_W") ? atoi(getenv("VMX_IQ_QKV_NORM_MAX_W")) : 8;
+    return 64 * W * 8 >= n_in && W <= max_w;
 }
 int vmx_iq_mmvq_packed_norm_multi(const VmxMmvqSeg *segs, int nseg, const float *o, const uint16_t *h_in, uint16_t *h_out,
                                   const uint16_t *w_post, const uint16_t *scalar, const uint16_t *w_next, float eps, float *y, int n_in,
