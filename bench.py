@@ -463,8 +463,8 @@ def batch_sweep_secondary(prompt, steps, warmup, batches=(1, 4, 8, 16)):
 
 def context_sweep_secondary(steps, warmup, contexts=(1024, 8192)):
     """Decode tok/s of the headline model (Qwen3-8B AWQ, batch 1) at longer contexts: the prompt goes through the native
-    prompt pass in chunks of 2048 tokens, then `steps` timed tokens from one hipGraph.  Beyond 1024 tokens the attention of a
-    layer is the split kernel with up to 64 workgroups of 8 waves per KV head and the separate merge launch."""
+    prompt pass in chunks of 2048 tokens, then `steps` timed tokens from one hipGraph.  Beyond 512 tokens the attention of a
+    layer is the split kernel with one workgroup of 8 waves per compute unit and the separate merge launch."""
     from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
     chunk = 2048
     top = max(contexts) + warmup + steps + 8

@@ -1358,6 +1358,13 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
 
 // ---- decode attention spread over P workgroups per KV head, merged by the consumer (split_decode_attn_kernel)
 // Partition count for a context bound, 0 = not covered.  VMX_SPLIT_ATTN_P overrides the count (measurement), VMX_NO_SPLIT_ATTN=1 switches the path off.
+// Context length from which the many-partition form with its own merge launch takes over from the few-partition form whose
+// partitions the consuming linear merges (VMX_SPLIT_LONG_MIN_CTX overrides, for measurement)
+static int split_long_min_ctx() {
+    // Qwen3-8B AWQ, one row, same box: 300 tokens 563 (few partitions) vs 554 tok/s (many), 600 tokens 540 vs 551, 900 tokens 531 vs 550
+    static const int v = getenv("VMX_SPLIT_LONG_MIN_CTX") ? atoi(getenv("VMX_SPLIT_LONG_MIN_CTX")) : 512;
+    return v;
+}
 static int split_parts_impl(int head_dim, int qpk, int rot_dim, int max_seq_len, int window, bool wide_heads) {
     static const bool off = getenv("VMX_NO_SPLIT_ATTN") && atoi(getenv("VMX_NO_SPLIT_ATTN"));
     static const int p_env = getenv("VMX_SPLIT_ATTN_P") ? atoi(getenv("VMX_SPLIT_ATTN_P")) : 0;
@@ -1369,7 +1376,8 @@ static int split_parts_impl(int head_dim, int qpk, int rot_dim, int max_seq_len,
     // Measured on MI355X (Qwen3-8B, batch 1): up to 1024 tokens 4 workgroups per KV head beat both the one-workgroup kernel
     // and the three-launch path (560 vs 530 tok/s at 300 tokens); beyond that the three-launch path with its 64 partitions
     // per sequence wins (2048 tokens: 478 vs 460 tok/s with 8 workgroups here), because the consumer's merge grows with P.
-    if (ctx <= 0 || ctx > 1024) return 0;
+    // beyond that the many-partition form takes over where it exists (64- / 128-wide heads); 256-wide heads keep this one up to 1024
+    if (ctx <= 0 || ctx > 1024 || (ctx > split_long_min_ctx() && (head_dim == 64 || head_dim == 128))) return 0;
     // 256-wide heads (Gemma 4 sliding layers, merged by paged_attn_reduce_small_kernel): 8 workgroups per KV head measured best
     // (Gemma-4-12B shape, 300-400 tokens: 2 / 4 / 8 workgroups = 297 / 305 / 310 tok/s, three-launch path 295)
     return p_env >= 1 && p_env <= 8 ? p_env : (head_dim == 256 ? 8 : 4);
@@ -1389,20 +1397,25 @@ size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, i
     return (size_t)num_seqs * num_heads * 8 * ((size_t)head_dim + 2) * 4;
 }
 
-// Contexts beyond the reach of the few-partition form: the same kernel with up to 64 workgroups of 8 waves per KV head (one
-// 16-token tile per wave up to 8192 tokens) and the separate merge (vmx_paged_attention_merge) behind it, in place of
+// Contexts beyond the reach of the few-partition form (from 512 tokens on): the same kernel with 8 ... 64 workgroups of 8 waves per KV head (as many
+// as give every compute unit one workgroup) and the separate merge (vmx_paged_attention_merge) behind it, in place of
 // "q/k/v post-processing + one wave per partition + merge": at 8192 tokens the one-wave partitions put 464 waves on the
 // chip for 24 us per layer (Qwen3-8B, one row).  Returns the partition count, 0 = not covered.  VMX_NO_SPLIT_ATTN_LONG=1
 // switches the form off.
-int vmx_split_decode_attention_long_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
+int vmx_split_decode_attention_long_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window, int num_kv_heads, int num_seqs) {
     static const bool off = getenv("VMX_NO_SPLIT_ATTN_LONG") && atoi(getenv("VMX_NO_SPLIT_ATTN_LONG"));
     if (off || !(head_dim == 64 || head_dim == 128) || qpk < 1 || qpk > 8) return 0;
     const int half = rot_dim / 2;
     if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return 0;
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
-    if (ctx <= 1024) return 0;
-    const int tiles = (ctx + 15) / 16, p = (tiles + 7) / 8;
-    return p < 8 ? 8 : (p > 64 ? 64 : p);
+    if (ctx <= split_long_min_ctx()) return 0;
+    static const int p_env = getenv("VMX_SPLIT_LONG_P") ? atoi(getenv("VMX_SPLIT_LONG_P")) : 0;   // measurement: force the count
+    if (p_env >= 8 && p_env <= 64) return p_env;
+    // one workgroup per compute unit: measured on Qwen3-8B (8 KV heads, one row) at 1024 ... 32768 tokens, 32 partitions beat
+    // 12 / 16 / 24 / 64 at every length (8192 tokens: 420 / 440 / 475 / 441 against 478 tok/s; 33 partitions = 264 workgroups
+    // on 256 compute units cost 6 %)
+    const int per = vmx_num_cus() / (num_kv_heads * num_seqs > 0 ? num_kv_heads * num_seqs : 1);
+    return per < 8 ? 8 : (per > 64 ? 64 : per);
 }
 size_t vmx_split_decode_attention_long_workspace_bytes(int num_seqs, int num_heads, int head_dim, int parts) {
     return (size_t)num_seqs * num_heads * parts * ((size_t)head_dim + 2) * 4;

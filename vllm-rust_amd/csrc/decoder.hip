@@ -904,8 +904,8 @@ extern "C" int vmx_qwen3_create(const vmx_qwen3_config *cfg, vmx_qwen3 **out) {
     {
         const size_t a = vmx_paged_attention_workspace_bytes(c.max_batch, c.num_heads, hd, c.max_seq_len);
         size_t b = vmx_split_decode_attention_workspace_bytes(c.max_batch, c.num_heads, hd);
-        const int lp = vmx_split_decode_attention_long_parts(hd, c.num_heads / c.num_kv_heads, hd, c.max_seq_len, 0);
-        const size_t l = lp > 0 ? vmx_split_decode_attention_long_workspace_bytes(c.max_batch, c.num_heads, hd, lp) : 0;
+        const int lp = vmx_split_decode_attention_long_parts(hd, c.num_heads / c.num_kv_heads, hd, c.max_seq_len, 0, c.num_kv_heads, 1);
+        const size_t l = lp > 0 ? vmx_split_decode_attention_long_workspace_bytes(c.max_batch, c.num_heads, hd, 64) : 0;   // any count
         if (l > b) b = l;
         TRY(m->attn_ws.alloc(a > b ? a : b));
     }
@@ -1346,19 +1346,19 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         const bool split_attn = ex_split || ((fold || mfold) && prefill_offset < 0 && !m->rows_share_cache && NQ <= 4 * 16 * 128 &&
                                              vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0) > 0);
         VmxAttnParts sparts{};
-        const bool fused_attn = !split_attn && prefill_offset < 0 && !m->rows_share_cache &&
-                                vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
         // long contexts: the same kernel with many partitions and the separate merge instead of the three-launch path
-        int long_p = !split_attn && !fused_attn && prefill_offset < 0 && !m->rows_share_cache && qkv_src == PA
-                         ? vmx_split_decode_attention_long_parts(hd, Hq / Hkv, hd, max_seq_len, 0) : 0;
+        int long_p = !split_attn && prefill_offset < 0 && !m->rows_share_cache
+                         ? vmx_split_decode_attention_long_parts(hd, Hq / Hkv, hd, max_seq_len, 0, Hkv, B) : 0;
         if (long_p > 0 && vmx_split_decode_attention_long_workspace_bytes(B, Hq, hd, long_p) > m->attn_ws.bytes) long_p = 0;
+        const bool fused_attn = !split_attn && long_p == 0 && prefill_offset < 0 && !m->rows_share_cache &&
+                                vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
         if (long_p > 0) {
-            if (int rc = vmx_split_decode_attention(&sparts, m->attn_ws.p, PA, s_qkv, L.k_cache.p, L.v_cache.p,
+            if (int rc = vmx_split_decode_attention(&sparts, m->attn_ws.p, qkv_src, s_qkv, L.k_cache.p, L.v_cache.p,
                                                     c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
                                                     Hkv, hd, hd, max_blocks_per_seq, max_seq_len, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, 0,
-                                                    st, nullptr, long_p))
+                                                    st, qkv_svh, long_p))
                 return rc;
             if (int rc = vmx_paged_attention_merge(attn, &sparts, seq_lens, B, Hq, hd, 0, st, iq ? q8_aq(m) : nullptr,
                                                    iq ? q8_ad(m, B, NQ) : nullptr))

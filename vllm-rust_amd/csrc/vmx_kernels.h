@@ -82,7 +82,8 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
                                int max_blocks_per_seq, int max_seq_len, int block_size, int window, int kv_dtype, const float *k_scale,
                                const float *v_scale, int v_norm, hipStream_t st, const uint16_t *had_svh = nullptr,   // as above
                                int long_parts = 0);   // > 0: that many partitions (vmx_split_decode_attention_long_parts), merged by vmx_paged_attention_merge
-int vmx_split_decode_attention_long_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window);   // 0 = not covered
+int vmx_split_decode_attention_long_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window, int num_kv_heads,
+                                          int num_seqs);   // 0 = not covered; at most 64
 size_t vmx_split_decode_attention_long_workspace_bytes(int num_seqs, int num_heads, int head_dim, int parts);
 // int4_kernels.hip: vmx_int4_gemm_resid whose activations are the merge of those partitions (K = heads * head_dim)
 int vmx_int4_gemm_resid_attn(const void *packed, const VmxAttnParts *parts, int head_dim, uint16_t *h, float *ssq, int M, int N, int K,
