@@ -423,7 +423,7 @@ int vmx_comm_world(const vmx_comm *c);
 int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t count, void *stream);
 int vmx_comm_all_reduce_max_u64(vmx_comm *c, unsigned long long *buf, size_t count, void *stream);
 /* One-shot all-reduce over peer-mapped memory for the decode-sized messages (design reference: the one-shot kernel of
- * crates/core/kernels/custom_allreduce.cu:264-484; SURVEY's target for the 8 KiB x 72 per token row-parallel sums).  Set-up,
+ * crates/core/kernels/custom_allreduce.cu:264-484; meant for the 8 KiB x 72 per token row-parallel sums of a decode step).  Set-up,
  * once per communicator and on every rank: vmx_comm_p2p_export allocates this rank's staging slots (2 x max_bytes, max_bytes
  * <= 256 KiB) and flag words and returns two hipIpc handles (128 bytes); the caller all-gathers them in rank order;
  * vmx_comm_p2p_import maps the peers.  From then on vmx_comm_all_reduce_sum_bf16 takes this path for messages of at most
