@@ -25,8 +25,16 @@ namespace {
 __device__ __forceinline__ float round_bf16(float v) { return vmx_bf16_to_f32(vmx_f32_to_bf16(v)); }
 
 __device__ __forceinline__ float sum_partials(const float *__restrict__ partial, int splits, int64_t slice_stride, int64_t idx) {
+    // four slices requested before the first add (branch-free: a slice past the end re-reads the last one and is not added);
+    // a plain loop over the run-time count waits for every load in turn
     float v = 0.f;
-    for (int s = 0; s < splits; s++) v += partial[s * slice_stride + idx];
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) t[u] = partial[min(s0 + u, splits - 1) * slice_stride + idx];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v += s0 + u < splits ? t[u] : 0.f;
+    }
     return v;
 }
 
@@ -37,20 +45,18 @@ __device__ __forceinline__ void sum_partials8(const float *__restrict__ partial,
                                               float out[8]) {
     float4 a[SMAX], b[SMAX];
 #pragma unroll
-    for (int s = 0; s < SMAX; s++) {
-        if (s < splits) {
-            a[s] = *reinterpret_cast<const float4 *>(partial + s * slice_stride + idx);
-            b[s] = *reinterpret_cast<const float4 *>(partial + s * slice_stride + idx + 4);
-        }
+    for (int s = 0; s < SMAX; s++) {   // branch-free: a slice past the end re-reads the last one and is not added
+        const float *src = partial + min(s, splits - 1) * slice_stride + idx;
+        a[s] = *reinterpret_cast<const float4 *>(src);
+        b[s] = *reinterpret_cast<const float4 *>(src + 4);
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) out[j] = 0.f;
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
-        if (s < splits) {
-            out[0] += a[s].x; out[1] += a[s].y; out[2] += a[s].z; out[3] += a[s].w;
-            out[4] += b[s].x; out[5] += b[s].y; out[6] += b[s].z; out[7] += b[s].w;
-        }
+        const bool in = s < splits;
+        out[0] += in ? a[s].x : 0.f; out[1] += in ? a[s].y : 0.f; out[2] += in ? a[s].z : 0.f; out[3] += in ? a[s].w : 0.f;
+        out[4] += in ? b[s].x : 0.f; out[5] += in ? b[s].y : 0.f; out[6] += in ? b[s].z : 0.f; out[7] += in ? b[s].w : 0.f;
     }
 }
 
