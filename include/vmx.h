@@ -407,33 +407,84 @@ int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_wei
                          const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
                          int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream);
 
-/* ------------------------------------------------- tensor-parallel communicator */
+/* ------------------------------------------------- device communicator (tensor / expert parallel group) */
 
-/* RCCL over xGMI, resolved with dlopen like the reference's NCCL binding (crates/core/src/distributed/nccl.rs:479-560;
- * DeviceCommunicator, distributed/communicator.rs:29-98).  One process per GPU: rank 0 calls vmx_comm_unique_id, the
- * 128 bytes travel to the other ranks out of band (the launcher's TCP exchange in the reference,
- * torch.distributed in bench.py), then every rank calls vmx_comm_create.  Collectives run on the caller's stream. */
+/* RCCL over xGMI, resolved with dlopen like the reference's NCCL binding (crates/core/src/distributed/nccl.rs:479-560), behind
+ * the operations of DeviceCommunicator (distributed/communicator.rs:29-94).  One process per GPU: rank 0 calls
+ * vmx_comm_unique_id, the 128 bytes travel to the other ranks out of band (the launcher's TCP exchange in the reference,
+ * torch.distributed in bench.py), then every rank calls vmx_comm_create.  Collectives run on the caller's stream and can be
+ * captured into a hipGraph.  Element types and reductions use RCCL's numbering. */
 typedef struct vmx_comm vmx_comm;
+#define VMX_COMM_I8 0
+#define VMX_COMM_U8 1
+#define VMX_COMM_I32 2
+#define VMX_COMM_U32 3
+#define VMX_COMM_I64 4
+#define VMX_COMM_U64 5
+#define VMX_COMM_F16 6
+#define VMX_COMM_F32 7
+#define VMX_COMM_F64 8
+#define VMX_COMM_BF16 9
+#define VMX_COMM_SUM 0   /* ReduceOp::Sum, Product, Max, Min, Average (communicator.rs:12-24) */
+#define VMX_COMM_PROD 1
+#define VMX_COMM_MAX 2
+#define VMX_COMM_MIN 3
+#define VMX_COMM_AVG 4
 int vmx_comm_unique_id(void *out128);
 int vmx_comm_create(const void *id128, int rank, int world, vmx_comm **out);
 void vmx_comm_destroy(vmx_comm *c);
 int vmx_comm_rank(const vmx_comm *c);
 int vmx_comm_world(const vmx_comm *c);
-/* all_reduce(Sum) of row-parallel linear outputs (parallel_layers.rs:296) and all_reduce(Max) of argmax keys. */
+/* all_reduce (communicator.rs:36), in place.  The two typed forms are the ones a decode step makes: Sum of the row-parallel
+ * linear outputs (parallel_layers.rs:296) and Max of the 64-bit argmax keys of the vocabulary-parallel head. */
+int vmx_comm_all_reduce(vmx_comm *c, void *buf, size_t count, int dtype, int op, void *stream);
 int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t count, void *stream);
 int vmx_comm_all_reduce_max_u64(vmx_comm *c, unsigned long long *buf, size_t count, void *stream);
-/* One-shot all-reduce over peer-mapped memory for the decode-sized messages (design reference: the one-shot kernel of
- * crates/core/kernels/custom_allreduce.cu:264-484; meant for the 8 KiB x 72 per token row-parallel sums of a decode step).  Set-up,
- * once per communicator and on every rank: vmx_comm_p2p_export allocates this rank's staging slots (2 x max_bytes, max_bytes
- * <= 256 KiB) and flag words and returns two hipIpc handles (128 bytes); the caller all-gathers them in rank order;
- * vmx_comm_p2p_import maps the peers.  From then on vmx_comm_all_reduce_sum_bf16 takes this path for messages of at most
- * max_bytes (count % 8 == 0, 16-byte aligned): one kernel, ranks added in rank order (identical bits everywhere), hipGraph-
- * replayable (call counters live in device memory).  Larger messages keep using RCCL.  A flag wait gives up after ~2 s and is
- * counted (vmx_comm_p2p_timeouts) instead of hanging.  vmx_comm_create_local makes a communicator without RCCL (at most 8 ranks). */
+/* all_gather along dimension 0 (communicator.rs:44; ColumnParallelLinear's gather_output, parallel_layers.rs:152):
+ * out [world][bytes_per_rank]. */
+int vmx_comm_all_gather(vmx_comm *c, const void *in, void *out, size_t bytes_per_rank, void *stream);
+/* reduce_scatter(Sum) along dimension 0 (communicator.rs:51): in [world][count_per_rank], out [count_per_rank] = this rank's
+ * chunk of the sum; dtype VMX_COMM_BF16 or VMX_COMM_F32. */
+int vmx_comm_reduce_scatter_sum(vmx_comm *c, const void *in, void *out, size_t count_per_rank, int dtype, void *stream);
+/* broadcast from `root`, in place (communicator.rs:56; the step header of tensor_parallel.rs:91-165). */
+int vmx_comm_broadcast(vmx_comm *c, void *buf, size_t bytes, int root, void *stream);
+/* point-to-point (communicator.rs:59-62; RCCL side only). */
+int vmx_comm_send(vmx_comm *c, const void *buf, size_t bytes, int dst, void *stream);
+int vmx_comm_recv(vmx_comm *c, void *buf, size_t bytes, int src, void *stream);
+/* barrier (communicator.rs:65): the stream continues once every rank's stream has arrived. */
+int vmx_comm_barrier(vmx_comm *c, void *stream);
+/* all_to_all / all_to_all_v (communicator.rs:67-93; grouped send/recv of nccl.rs:876-1007): segment r of `in` goes to rank r,
+ * segment r of `out` comes from rank r; counts in elements of elem_bytes, host arrays of `world` entries. */
+int vmx_comm_all_to_all(vmx_comm *c, const void *in, void *out, size_t bytes_per_rank, void *stream);
+int vmx_comm_all_to_all_v(vmx_comm *c, const void *in, const size_t *send_counts, void *out, const size_t *recv_counts,
+                          size_t elem_bytes, void *stream);
+/* all_to_all_v with the counts in device memory: send_rows[world] (int32) is read by the kernel, recv_rows[world] is written,
+ * received rows are packed in rank order (at most out_capacity_rows).  It folds the count exchange of the expert dispatch
+ * (moe/token_dispatch.rs:306-327) into the transfer, so routing never visits the host.  Peer-mapped transport only. */
+int vmx_comm_all_to_all_v_dev(vmx_comm *c, const void *in, const int32_t *send_rows, void *out, int32_t *recv_rows,
+                              size_t row_bytes, size_t out_capacity_rows, void *stream);
+/* Collectives over peer-mapped memory for the latency-bound messages of a decode step (design reference: the one-shot kernel of
+ * crates/core/kernels/custom_allreduce.cu:264-484; meant for the 8 KiB x 72 per token row-parallel sums).  Set-up, once per
+ * communicator and on every rank: vmx_comm_p2p_export allocates this rank's staging (two all-reduce slots of max_bytes <= 256
+ * KiB, two exchange slots of exchange_bytes, fine-grained device memory -- VMX_EUNSUPPORTED when the device refuses it) and
+ * flag words and returns two hipIpc handles (128 bytes); the caller all-gathers them in rank order; vmx_comm_p2p_import maps
+ * the peers.  All ranks must agree that the set-up succeeded (else every rank calls vmx_comm_p2p_disable) because the
+ * transport of a call is chosen from that state and the message size alone: all-reduce messages of at most max_bytes
+ * (count % 8 == 0; the buffer must be 16-byte aligned), all-gather / reduce-scatter / broadcast payloads of at most
+ * exchange_bytes (and at most 256 KiB when RCCL is available), barriers, and all_to_all(_v) of a communicator without RCCL go
+ * over it: one kernel, ranks added in rank order (identical bits everywhere), hipGraph-replayable (call counters live in
+ * device memory).  A flag wait gives up after the time-out (2 s; vmx_comm_p2p_set_timeout_ms): the rank's results become NaN,
+ * its peers are told, and every later call on the communicator -- and on an executor it is attached to -- returns VMX_ELAUNCH
+ * (vmx_comm_error reads the code without synchronising; vmx_comm_p2p_timeouts counts the waits that gave up).
+ * vmx_comm_create_local makes a communicator without RCCL (at most 8 ranks). */
 int vmx_comm_create_local(int rank, int world, vmx_comm **out);
-int vmx_comm_p2p_export(vmx_comm *c, size_t max_bytes, void *handles_out128);
+int vmx_comm_p2p_export(vmx_comm *c, size_t max_bytes, size_t exchange_bytes, void *handles_out128);
 int vmx_comm_p2p_import(vmx_comm *c, const void *all_handles);
+int vmx_comm_p2p_disable(vmx_comm *c);
+int vmx_comm_p2p_ready(const vmx_comm *c);
+int vmx_comm_p2p_set_timeout_ms(vmx_comm *c, int ms);
 int vmx_comm_p2p_timeouts(vmx_comm *c, int *out);
+int vmx_comm_error(const vmx_comm *c, int *code_out);
 
 /* ------------------------------------------------------- whole-token decoder */
 

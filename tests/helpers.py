@@ -69,3 +69,46 @@ def awq_lcg_case(m, k, n, group, seed=0x9E3779B9):
     scales = np.array([(np.float32(r.next(2000)) - np.float32(1000.0)) * np.float32(1e-4) for _ in range(g * n)], np.float32)
     inputs = np.array([(np.float32(r.next(2000)) - np.float32(1000.0)) * np.float32(1e-3) for _ in range(m * k)], np.float32)
     return qw.reshape(pk, n), qz.reshape(g, pn), scales.reshape(g, n), inputs.reshape(m, k)
+
+
+# ---------------------------------------------------------------- several ranks as processes on one GPU
+def make_exchange(rank, world, conns):
+    """exchange(mine) -> [every rank's object in rank order] over the pipes spawn_ranks made (conns[rank] = ends to the others)."""
+    def exchange(mine):
+        for c in conns[rank]:
+            c.send((rank, mine))
+        got = {rank: mine}
+        for c in conns[rank]:
+            r, b = c.recv()
+            got[r] = b
+        return [got[r] for r in range(world)]
+    return exchange
+
+
+def spawn_ranks(world, target, extra_args=(), timeout=240):
+    """Run target(rank, world, conns, result_queue, *extra_args) in `world` spawned processes (they share the box's one GPU and
+    join through peer-mapped memory); every process must put (rank, payload) on the queue.  Returns {rank: payload}."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    conns = {r: [] for r in range(world)}
+    for i in range(world):
+        for j in range(i + 1, world):
+            a, b = ctx.Pipe()
+            conns[i].append(a)
+            conns[j].append(b)
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, conns, q) + tuple(extra_args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            r, payload = q.get(timeout=timeout)
+            results[r] = payload
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert set(results) == set(range(world)), f"ranks that reported: {sorted(results)}"
+    return results

@@ -108,10 +108,24 @@ _SIGS = {
     "vmx_comm_world": (_i, [_p]),
     "vmx_comm_all_reduce_sum_bf16": (_i, [_p, _p, _sz, _p]),
     "vmx_comm_all_reduce_max_u64": (_i, [_p, _p, _sz, _p]),
+    "vmx_comm_all_reduce": (_i, [_p, _p, _sz, _i, _i, _p]),
+    "vmx_comm_all_gather": (_i, [_p, _p, _p, _sz, _p]),
+    "vmx_comm_reduce_scatter_sum": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "vmx_comm_broadcast": (_i, [_p, _p, _sz, _i, _p]),
+    "vmx_comm_send": (_i, [_p, _p, _sz, _i, _p]),
+    "vmx_comm_recv": (_i, [_p, _p, _sz, _i, _p]),
+    "vmx_comm_barrier": (_i, [_p, _p]),
+    "vmx_comm_all_to_all": (_i, [_p, _p, _p, _sz, _p]),
+    "vmx_comm_all_to_all_v": (_i, [_p, _p, _p, _p, _p, _sz, _p]),
+    "vmx_comm_all_to_all_v_dev": (_i, [_p, _p, _p, _p, _p, _sz, _sz, _p]),
     "vmx_comm_create_local": (_i, [_i, _i, _p]),
-    "vmx_comm_p2p_export": (_i, [_p, _sz, _p]),
+    "vmx_comm_p2p_export": (_i, [_p, _sz, _sz, _p]),
     "vmx_comm_p2p_import": (_i, [_p, _p]),
+    "vmx_comm_p2p_disable": (_i, [_p]),
+    "vmx_comm_p2p_ready": (_i, [_p]),
+    "vmx_comm_p2p_set_timeout_ms": (_i, [_p, _i]),
     "vmx_comm_p2p_timeouts": (_i, [_p, _p]),
+    "vmx_comm_error": (_i, [_p, _p]),
     "vmx_qwen3_set_comm": (_i, [_p, _p]),
     "vmx_qwen3_create": (_i, [_p, _p]),
     "vmx_qwen3_destroy": (None, [_p]),

@@ -1260,6 +1260,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
     const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
     VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
+    if (int rc = vmx_comm_check_health(m->comm, "qwen3 forward")) return rc;   // an earlier collective of this group failed
 
     // the lookup is folded into the first layer's norm kernel (VMX_NO_EMBED_FUSION=1: its own launch)
     static const bool no_embed_fusion = getenv("VMX_NO_EMBED_FUSION") && atoi(getenv("VMX_NO_EMBED_FUSION"));

@@ -784,6 +784,7 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
     const int fp8 = c.kv_cache_dtype == VMX_KV_FP8_E4M3;
     const bool tp = c.tp_size > 1 || m->comm != nullptr;   // a 1-rank communicator still exercises the collective path
     VMX_REQUIRE(!tp || m->comm, "gemma4: tp_size %d but no communicator attached (vmx_gemma4_set_comm)", c.tp_size);
+    if (int rc = vmx_comm_check_health(m->comm, "gemma4 forward")) return rc;   // an earlier collective of this group failed
 
     if (c.embed_ggml_type == 0) {
         hipLaunchKernelGGL(g4_embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size,

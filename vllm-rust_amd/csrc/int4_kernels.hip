@@ -913,19 +913,53 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
 // per tile) act [M][N/2] bf16.
 constexpr int PF_BM = 64, PF_XROW = KB + 8;
 
-template <bool GLU>
+// GROUPED (token-grouped mixture-of-experts GEMM; the grouped GEMM over sorted_token_ids / expert_ids of
+// crates/core/kernels/fused_moe_gemm.cu:72-545 with int4 experts): row block blockIdx.y belongs to expert
+// block_expert[blockIdx.y] and holds the (token, slot) pairs sorted[64 * blockIdx.y ...] (an entry >= numel is padding), as
+// moe_align_block_size with block_size 64 leaves them.  Pair p reads activation row p / x_row_div and writes output row p, so an
+// expert's tile stream is read once per 64 of its rows instead of once per pair.
+struct Int4GroupedArgs {
+    const void *const *table;        // [num_experts] tile streams; a null entry = expert held by another rank
+    const int32_t *sorted;           // [blocks * 64] pair indices
+    const int32_t *block_expert;     // [blocks]
+    const int32_t *total_post_pad;   // [1] padded length: blocks beyond it have nothing to do
+    int numel, x_row_div, num_experts;
+};
+
+template <bool GLU, bool GROUPED = false>
 __global__ __launch_bounds__(256) void int4_gemm_tiled_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                                const uint16_t *__restrict__ x, float *__restrict__ partial,
                                                                uint16_t *__restrict__ act, int M, int N, int K, int group,
-                                                               int kb_per_split, int slice_rows) {
+                                                               int kb_per_split, int slice_rows, Int4GroupedArgs ga) {
     __shared__ __align__(16) uint16_t xs[2][PF_BM * PF_XROW];
     __shared__ float sumx[2][PF_BM];
+    __shared__ int32_t prow_s[PF_BM];   // GROUPED: pair index of each row of the block (-1: padding)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, h = lane >> 4;
     const int kblocks = K / KB, G = K / group;
     const int row0 = blockIdx.y * PF_BM, ks = blockIdx.z;
     const int nt0 = blockIdx.x * 8 + wave * 2;   // this wave's two column tiles
     const int kb_begin = ks * kb_per_split, kb_end = min(kblocks, kb_begin + kb_per_split);
+    int xrow[4] = {-1, -1, -1, -1};   // GROUPED: activation row of this thread's four staging chunks
+    if constexpr (GROUPED) {
+        if (row0 >= ga.total_post_pad[0]) return;
+        int e = ga.block_expert[blockIdx.y];
+        e = e < 0 ? 0 : (e >= ga.num_experts ? ga.num_experts - 1 : e);
+        const char *packed = static_cast<const char *>(ga.table[e]);
+        if (!packed) return;
+        W = reinterpret_cast<const uint4 *>(packed);
+        SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
+        if (tid < PF_BM) {
+            const int p = ga.sorted[row0 + tid];
+            prow_s[tid] = p >= 0 && p < ga.numel ? p : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p = ga.sorted[row0 + ((tid + 256 * j) >> 4)];
+            xrow[j] = p >= 0 && p < ga.numel ? p / ga.x_row_div : -1;
+        }
+        __syncthreads();
+    }
 
     vmx_f32x4 fin[4][2];
 #pragma unroll
@@ -940,9 +974,9 @@ __global__ __launch_bounds__(256) void int4_gemm_tiled_kernel(const uint4 *__res
     auto fetch = [&](int kb) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int c = tid + 256 * j, row = row0 + (c >> 4);
+            const int c = tid + 256 * j, row = GROUPED ? xrow[j] : row0 + (c >> 4);
             xr[j] = make_uint4(0, 0, 0, 0);
-            if (row < M) xr[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)row * K + kb * KB + (c & 15) * 8);
+            if (GROUPED ? row >= 0 : row < M) xr[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)row * K + kb * KB + (c & 15) * 8);
         }
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -1011,7 +1045,11 @@ __global__ __launch_bounds__(256) void int4_gemm_tiled_kernel(const uint4 *__res
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = row0 + mt * 16 + 4 * h + r;
+                int row = row0 + mt * 16 + 4 * h + r;
+                if constexpr (GROUPED) {
+                    const int p = prow_s[mt * 16 + 4 * h + r];
+                    row = p < 0 ? M : p;   // padding rows fail the bound check below (M = numel)
+                }
                 if constexpr (GLU) {
                     const float up = __shfl_xor(fin[mt][c][r], 8, 64);
                     if (row < M && nl < 8) {
@@ -1247,7 +1285,7 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
     if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, the same split-K slices as the small-M plan
         const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
         hipLaunchKernelGGL(int4_gemm_tiled_kernel<false>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, p.splits), dim3(256), 0, st, W, SZ, x, partial,
-                           (uint16_t *)nullptr, M, N, K, group, kbs, M);
+                           (uint16_t *)nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{});
         VMX_CHECK_LAUNCH("int4_gemm(tiled)");
         return VMX_OK;
     }
@@ -1464,7 +1502,7 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
     if (tiled_ok(M, N)) {
         hipLaunchKernelGGL(int4_gemm_tiled_kernel<true>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, 1), dim3(256), 0, st, W, SZ, x, (float *)nullptr,
-                           act, M, N, K, group, K / KB, M);
+                           act, M, N, K, group, K / KB, M, Int4GroupedArgs{});
         VMX_CHECK_LAUNCH("int4_gemm(tiled glu)");
         return VMX_OK;
     }
@@ -1550,6 +1588,28 @@ int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *ex
     return VMX_OK;
 }
 
+// Token-grouped form: `sorted` / `block_expert` / `total_post_pad` as vmx_moe_align_block_size(block_size = 64) leaves them;
+// max_blocks = the host-side bound on the block count (blocks past total_post_pad exit at once).  act != NULL: experts packed
+// with glu = 1, act [pairs][N/2]; else partial [splits][pairs][N].
+int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *sorted, const int32_t *block_expert,
+                                const int32_t *total_post_pad, int max_blocks, int num_experts, const uint16_t *x, int x_row_div,
+                                float *partial, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st) {
+    VMX_REQUIRE(N % 128 == 0, "int4_gemm_token_grouped: N (%d) must be a multiple of 128", N);
+    const GemmPlan p = plan_gemm(N, K);
+    VMX_REQUIRE(!act || p.splits == 1, "int4_gemm_token_grouped: gated linear [%d -> %d] is split over k", K, N);
+    const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
+    Int4GroupedArgs ga{packed_table, sorted, block_expert, total_post_pad, pairs, x_row_div, num_experts};
+    const dim3 grid(N / 128, max_blocks, act ? 1 : p.splits);
+    if (act)
+        hipLaunchKernelGGL((int4_gemm_tiled_kernel<true, true>), grid, dim3(256), 0, st, (const uint4 *)nullptr, (const uint32_t *)nullptr, x,
+                           (float *)nullptr, act, pairs, N, K, group, kblocks, pairs, ga);
+    else
+        hipLaunchKernelGGL((int4_gemm_tiled_kernel<false, true>), grid, dim3(256), 0, st, (const uint4 *)nullptr, (const uint32_t *)nullptr, x,
+                           partial, (uint16_t *)nullptr, pairs, N, K, group, kbs, pairs, ga);
+    VMX_CHECK_LAUNCH("int4_gemm(token grouped)");
+    return VMX_OK;
+}
+
 // AWQ checkpoint tensors -> columns [col0, col0+N) of merged GPTQ-sequential tensors with Ntot columns.
 int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, uint32_t *qweight_out, uint32_t *qzeros_out,
                          int K, int N, int group, int Ntot, int col0, hipStream_t st) {
@@ -1589,7 +1649,7 @@ extern "C" int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *pa
     if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, then the slices are summed (+ bias) into bf16
         const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
         hipLaunchKernelGGL(int4_gemm_tiled_kernel<false>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, p.splits), dim3(256), 0, st, W, SZ, x, partial,
-                           (uint16_t *)nullptr, M, N, K, group, kbs, M);
+                           (uint16_t *)nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{});
         VMX_CHECK_LAUNCH("int4_gemm(tiled)");
         const int64_t total = (int64_t)M * N;
         hipLaunchKernelGGL(int4_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, bias, y, M, N, p.splits);

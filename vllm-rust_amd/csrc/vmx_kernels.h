@@ -13,6 +13,10 @@ int vmx_int4_pack_cols(const uint32_t *qweight, const uint16_t *scales_bf16, con
 bool vmx_int4_glu_fusable(int N, int K);
 int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *expert_ids, int num_experts, const uint16_t *x,
                               int x_row_div, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st);
+// token-grouped matrix-core form: pairs sorted by expert in blocks of 64 rows (vmx_moe_align_block_size); act != NULL = gated epilogue
+int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *sorted, const int32_t *block_expert,
+                                const int32_t *total_post_pad, int max_blocks, int num_experts, const uint16_t *x, int x_row_div,
+                                float *partial, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st);
 // moe_kernels.hip: vmx_moe_int4_forward with the experts' gate|up tensors packed for the fused activation (w13_glu != 0)
 int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
                              const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts, int hidden,
@@ -88,6 +92,9 @@ size_t vmx_split_decode_attention_long_workspace_bytes(int num_seqs, int num_hea
 // int4_kernels.hip: vmx_int4_gemm_resid whose activations are the merge of those partitions (K = heads * head_dim)
 int vmx_int4_gemm_resid_attn(const void *packed, const VmxAttnParts *parts, int head_dim, uint16_t *h, float *ssq, int M, int N, int K,
                              int group, hipStream_t st);
+
+// comm.hip: VMX_ELAUNCH (and the message) when the communicator's peer-mapped transport has failed; a host read, no device call
+int vmx_comm_check_health(const vmx_comm *c, const char *what);
 
 // glue_kernels.hip
 int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,

@@ -12,10 +12,14 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import math
 
 import torch
 
 from ._lib import check, lib
+
+
+VMX_COMM_BF16, VMX_COMM_F32 = 9, 7
 
 
 class Communicator:
@@ -40,28 +44,135 @@ class Communicator:
         check(lib.vmx_comm_create(raw, rank, world, C.byref(self.handle)))
         self.rank, self.world = rank, world
 
-    def enable_p2p(self, max_bytes: int = 64 * 1024, group=None) -> None:
-        """Set up the one-shot peer-mapped all-reduce for messages of at most max_bytes: every rank exports its staging buffer
-        and flag words as hipIpc handles, the handles are all-gathered through torch.distributed, every rank maps its peers."""
+    def enable_p2p(self, max_bytes: int = 64 * 1024, exchange_bytes: int = 0, group=None, self_test: bool = True) -> bool:
+        """Set up the peer-mapped transport for all-reduce messages of at most max_bytes (and exchange collectives of at most
+        exchange_bytes): every rank exports its staging buffer and flag words as hipIpc handles, the handles are all-gathered
+        through torch.distributed, every rank maps its peers and (self_test) all-reduces a known row over the new transport.
+        The outcome is agreed between the ranks after every stage: if any rank failed, ALL ranks drop the transport and stay on
+        RCCL, so the ranks of a group never take different transports.  Returns whether the transport is in use."""
         import torch.distributed as dist
+
+        def all_agree(ok: bool) -> bool:
+            if self.world == 1:
+                return ok
+            flags = [None] * self.world
+            dist.all_gather_object(flags, bool(ok), group=group)
+            return all(flags)
+
+        self.p2p_note = ""
         mine = (C.c_uint8 * 128)()
-        check(lib.vmx_comm_p2p_export(self.handle, int(max_bytes), mine))
+        rc = lib.vmx_comm_p2p_export(self.handle, int(max_bytes), int(exchange_bytes), mine)
+        if rc != 0:
+            self.p2p_note = lib.vmx_last_error().decode("utf-8", "replace")
+        if not all_agree(rc == 0):
+            check(lib.vmx_comm_p2p_disable(self.handle))
+            self.p2p_note = self.p2p_note or "a peer rank could not export its staging memory"
+            return False
         gathered = [None] * self.world
         if self.world > 1:
             dist.all_gather_object(gathered, bytes(mine), group=group)
         else:
             gathered = [bytes(mine)]
         allh = (C.c_uint8 * (128 * self.world))(*b"".join(gathered))
-        check(lib.vmx_comm_p2p_import(self.handle, allh))
+        rc = lib.vmx_comm_p2p_import(self.handle, allh)
+        if rc != 0:
+            self.p2p_note = lib.vmx_last_error().decode("utf-8", "replace")
+        if not all_agree(rc == 0):
+            check(lib.vmx_comm_p2p_disable(self.handle))
+            self.p2p_note = self.p2p_note or "a peer rank could not map the staging memory"
+            return False
+        if self_test:
+            ok = True
+            try:   # rank r contributes r + 1 in every element: the sum is world (world + 1) / 2 on every rank
+                t = torch.full((4096,), float(self.rank + 1), dtype=torch.bfloat16, device="cuda")
+                for _ in range(3):
+                    u = t.clone()
+                    self.all_reduce_sum_bf16(u)
+                    torch.cuda.synchronize()
+                    ok = ok and bool((u.float() == self.world * (self.world + 1) / 2).all().item())
+                ok = ok and self.error_code() == 0
+            except Exception as e:   # noqa: BLE001 - any failure means "do not use the transport"
+                self.p2p_note = repr(e)
+                ok = False
+            if not all_agree(ok):
+                check(lib.vmx_comm_p2p_disable(self.handle))
+                self.p2p_note = self.p2p_note or "the self-test all-reduce over peer-mapped memory gave a wrong sum on some rank"
+                return False
+        return True
+
+    def p2p_ready(self) -> bool:
+        return bool(lib.vmx_comm_p2p_ready(self.handle))
 
     def p2p_timeouts(self) -> int:
         n = C.c_int()
         check(lib.vmx_comm_p2p_timeouts(self.handle, C.byref(n)))
         return n.value
 
+    def error_code(self) -> int:
+        """Sticky error of the peer-mapped transport (0 = healthy); a host read, no synchronisation."""
+        n = C.c_int()
+        check(lib.vmx_comm_error(self.handle, C.byref(n)))
+        return n.value
+
+    def set_timeout_ms(self, ms: int) -> None:
+        check(lib.vmx_comm_p2p_set_timeout_ms(self.handle, int(ms)))
+
+    @staticmethod
+    def _st():
+        return torch.cuda.current_stream().cuda_stream
+
     def all_reduce_sum_bf16(self, t: torch.Tensor) -> None:
         assert t.dtype == torch.bfloat16 and t.is_contiguous()
-        check(lib.vmx_comm_all_reduce_sum_bf16(self.handle, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
+        check(lib.vmx_comm_all_reduce_sum_bf16(self.handle, t.data_ptr(), t.numel(), self._st()))
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """all_gather along dimension 0 (DeviceCommunicator::all_gather, communicator.rs:44)."""
+        assert t.is_contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        check(lib.vmx_comm_all_gather(self.handle, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(), self._st()))
+        return out
+
+    def reduce_scatter_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """reduce_scatter(Sum) along dimension 0 (communicator.rs:51); bf16 or f32."""
+        assert t.is_contiguous() and t.shape[0] % self.world == 0 and t.dtype in (torch.bfloat16, torch.float32)
+        out = torch.empty((t.shape[0] // self.world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        check(lib.vmx_comm_reduce_scatter_sum(self.handle, t.data_ptr(), out.data_ptr(), out.numel(),
+                                              VMX_COMM_BF16 if t.dtype == torch.bfloat16 else VMX_COMM_F32, self._st()))
+        return out
+
+    def broadcast(self, t: torch.Tensor, root: int) -> None:
+        assert t.is_contiguous()
+        check(lib.vmx_comm_broadcast(self.handle, t.data_ptr(), t.numel() * t.element_size(), int(root), self._st()))
+
+    def barrier(self) -> None:
+        check(lib.vmx_comm_barrier(self.handle, self._st()))
+
+    def all_to_all(self, t: torch.Tensor) -> torch.Tensor:
+        """Chunk r of dimension 0 goes to rank r (communicator.rs:67-76)."""
+        assert t.is_contiguous() and t.shape[0] % self.world == 0
+        out = torch.empty_like(t)
+        check(lib.vmx_comm_all_to_all(self.handle, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size() // self.world, self._st()))
+        return out
+
+    def all_to_all_v(self, t: torch.Tensor, send_splits, recv_splits) -> torch.Tensor:
+        """Rows of dimension 0 (communicator.rs:78-93): send_splits[r] rows to rank r, recv_splits[r] rows from rank r."""
+        assert t.is_contiguous() and len(send_splits) == len(recv_splits) == self.world and sum(send_splits) == t.shape[0]
+        row = math.prod(t.shape[1:])
+        out = torch.empty((sum(recv_splits),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        sc = (C.c_size_t * self.world)(*[int(v) for v in send_splits])
+        rc = (C.c_size_t * self.world)(*[int(v) for v in recv_splits])
+        check(lib.vmx_comm_all_to_all_v(self.handle, t.data_ptr(), sc, out.data_ptr(), rc, row * t.element_size(), self._st()))
+        return out
+
+    def all_to_all_v_dev(self, t: torch.Tensor, send_rows: torch.Tensor, capacity_rows: int):
+        """all_to_all_v of rows with the counts on the device: returns (rows [capacity_rows, ...], recv_rows int32 [world])."""
+        assert t.is_contiguous() and send_rows.dtype == torch.int32 and send_rows.numel() == self.world
+        out = torch.zeros((capacity_rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        recv = torch.zeros(self.world, dtype=torch.int32, device=t.device)
+        row = t.numel() // t.shape[0] * t.element_size()
+        check(lib.vmx_comm_all_to_all_v_dev(self.handle, t.data_ptr(), send_rows.data_ptr(), out.data_ptr(), recv.data_ptr(), row,
+                                            int(capacity_rows), self._st()))
+        return out, recv
 
     def close(self):
         if self.handle:
@@ -70,15 +181,15 @@ class Communicator:
 
 
 class LocalCommunicator(Communicator):
-    """A communicator without RCCL (vmx_comm_create_local): only the peer-mapped one-shot all-reduce, with the handle
-    exchange left to the caller (`exchange(my_128_bytes) -> list of every rank's bytes in rank order`)."""
+    """A communicator without RCCL (vmx_comm_create_local): only the peer-mapped transport, with the handle exchange left to
+    the caller (`exchange(my_128_bytes) -> list of every rank's bytes in rank order`)."""
 
-    def __init__(self, rank: int, world: int, exchange, max_bytes: int = 64 * 1024):
+    def __init__(self, rank: int, world: int, exchange, max_bytes: int = 64 * 1024, exchange_bytes: int = 0):
         self.handle = C.c_void_p()
         check(lib.vmx_comm_create_local(rank, world, C.byref(self.handle)))
         self.rank, self.world = rank, world
         mine = (C.c_uint8 * 128)()
-        check(lib.vmx_comm_p2p_export(self.handle, int(max_bytes), mine))
+        check(lib.vmx_comm_p2p_export(self.handle, int(max_bytes), int(exchange_bytes), mine))
         gathered = exchange(bytes(mine))
         allh = (C.c_uint8 * (128 * world))(*b"".join(gathered))
         check(lib.vmx_comm_p2p_import(self.handle, allh))
