@@ -400,12 +400,19 @@ int vmx_moe_align_block_size(const int32_t *topk_ids, int32_t *sorted_token_ids,
 
 /* Replaces QuantizedMoELayer::forward's expert loop (models/mixtral_quantized.rs:138-195) for int4 experts:
  * out[t] = sum_j bf16(w2_e(silu(w1_e x_t) * w3_e x_t) * weight[t,j]), e = ids[t,j], accumulated in bf16 in slot
- * order.  w13_packed / w2_packed: DEVICE arrays of num_experts pointers to tile streams (vmx_int4_pack) of the
+ * order.  From 12 (token, slot) pairs on the pairs are sorted by expert on the device (vmx_moe_align_block_size) and an
+ * expert's weights are streamed once per block of its rows (token-grouped GEMM on the matrix cores).  w13_packed / w2_packed: DEVICE arrays of num_experts pointers to tile streams (vmx_int4_pack) of the
  * merged gate|up [hidden -> 2*inter] and the down [inter -> hidden] projections.  No host read of the routing. */
 size_t vmx_moe_int4_workspace_bytes(int tokens, int k, int hidden, int inter);
 int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
                          const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
                          int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Measurement / parity aid: vmx_moe_int4_forward streams an expert once per (token, slot) pair for a few pairs, once per block
+ * of 16 sorted rows (small-M kernel) from 12 pairs and once per block of 64 rows (64 x 128-tile matrix-core kernel, the
+ * grouped GEMM of crates/core/kernels/fused_moe_gemm.cu:72-545) from 96 pairs; rows = 0 / 16 / 64 forces one form, -1 restores
+ * the choice by size. */
+int vmx_debug_moe_block_rows(int rows);
 
 /* ------------------------------------------------- device communicator (tensor / expert parallel group) */
 

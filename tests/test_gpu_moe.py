@@ -71,6 +71,100 @@ def test_moe_align_block_size(gpu):
         pos += padded
 
 
+@pytest.mark.parametrize("numel,E,bs", [(2, 8, 16), (1, 8, 64), (5000, 8, 64), (16384, 8, 64), (1500, 64, 16), (3001, 200, 16), (4096, 256, 64),
+                                         (700, 300, 16)])
+def test_moe_align_block_size_large_and_sparse(gpu, numel, E, bs):
+    """The O(numel) form (up to 256 experts) and the per-expert walk (more): long id lists, experts without rows, several
+    rounds of 1024 ids; an expert's indices ascend, padding is `numel`, every block names its expert."""
+    vmx, torch = gpu
+    rng = np.random.default_rng(numel + E)
+    live = rng.permutation(E)[:max(1, E * 2 // 3)]             # a third of the experts gets nothing
+    flat = live[rng.integers(0, len(live), size=numel)].astype(np.int32)
+    s, e, tot = vmx.moe_align_block_size(torch.from_numpy(flat.reshape(-1, 1)).cuda(), E, bs)
+    s, e, tot = s.cpu().numpy(), e.cpu().numpy(), int(tot.item())
+    counts = np.bincount(flat, minlength=E)
+    assert tot == int(((counts + bs - 1) // bs * bs).sum())
+    pos = 0
+    for ex in range(E):
+        n = counts[ex]; padded = (n + bs - 1) // bs * bs
+        assert np.array_equal(s[pos:pos + n], np.nonzero(flat == ex)[0])
+        assert (s[pos + n:pos + padded] == numel).all()
+        assert (e[pos // bs:(pos + padded) // bs] == ex).all()
+        pos += padded
+
+
+@pytest.fixture(scope="module")
+def mixtral_experts(gpu):
+    """Eight GPTQ-symmetric int4 experts at the Mixtral-8x7B shape (4096 -> 14336 -> 4096, g128), packed for the device and
+    kept on the host for the oracle."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(77)
+    E, H, I, g = 8, 4096, 14336, 128
+    packs13, packs2, experts = [], [], []
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if a.dtype == np.uint32 else np.int16)).cuda()
+    for ex in range(E):
+        def mk(K, N):
+            qw = rng.integers(0, 2 ** 32, size=(K // 8, N), dtype=np.uint32)
+            sc = orc.f32_to_bf16(((rng.random((K // g, N)) * 0.5 + 0.75) / (6.5 * np.sqrt(K))).astype(np.float32))
+            return qw, sc
+        w1, w3, w2 = mk(H, I), mk(H, I), mk(I, H)
+        experts.append((w1, w3, w2))
+        packs13.append(vmx.int4_pack(d(np.concatenate([w1[0], w3[0]], 1)), d(np.concatenate([w1[1], w3[1]], 1)), None, H, 2 * I, g))
+        packs2.append(vmx.int4_pack(d(w2[0]), d(w2[1]), None, I, H, g))
+    t13 = torch.tensor([p.data_ptr() for p in packs13], dtype=torch.int64, device="cuda")
+    t2 = torch.tensor([p.data_ptr() for p in packs2], dtype=torch.int64, device="cuda")
+    return dict(E=E, H=H, I=I, g=g, experts=experts, t13=t13, t2=t2, keep=(packs13, packs2))
+
+
+@pytest.mark.parametrize("T", [1, 7, 64, 256])
+def test_moe_token_grouped_true_shape_matches_expert_loop(gpu, mixtral_experts, T):
+    """The three forms of the expert layer -- one pass per (token, slot) pair, 16-row blocks, 64-row blocks on the matrix
+    cores -- at the true Mixtral-8x7B expert shape, E = 8 top-2, against the oracle's per-token expert loop
+    (mixtral_quantized.rs:138-195; rows of one expert go through the oracle together, each row's arithmetic is its own)."""
+    from oracle import oracle as orc
+    from vllm_rust_amd._lib import lib
+    vmx, torch = gpu
+    m = mixtral_experts
+    E, H, I, g, k = m["E"], m["H"], m["I"], m["g"], 2
+    rng = np.random.default_rng(1000 + T)
+    x = orc.f32_to_bf16(rng.standard_normal((T, H)).astype(np.float32))
+    logits = rng.standard_normal((T, E)).astype(np.float32)
+    if T >= 64:
+        logits[:, 5] -= 30.0          # an expert nobody picks: its blocks must not exist
+    xd = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16)
+    w, ids = vmx.topk_softmax(torch.from_numpy(logits).cuda(), k, True, True)
+    wn, idn = w.cpu().numpy(), ids.cpu().numpy()
+    eo = np.zeros((T, k, H), np.float32)
+    for ex in range(E):
+        tt, jj = np.nonzero(idn == ex)
+        if not len(tt):
+            continue
+        w1, w3, w2 = m["experts"][ex]
+        xe = np.ascontiguousarray(x[tt])
+        gate = orc.int4_gemv_bf16(xe, w1[0], w1[1], None, None, H, I, g)
+        up = orc.int4_gemv_bf16(xe, w3[0], w3[1], None, None, H, I, g)
+        hid = orc.silu_and_mul_bf16(gate, up)
+        eo[tt, jj] = orc.bf16_to_f32(orc.int4_gemv_bf16(hid, w2[0], w2[1], None, None, I, H, g))
+    ref = np.zeros((T, H), np.float32)
+    for j in range(k):
+        ws = orc.bf16_to_f32(orc.f32_to_bf16(wn[:, j].astype(np.float32)))[:, None]
+        ref = orc.bf16_to_f32(orc.f32_to_bf16(ref + orc.bf16_to_f32(orc.f32_to_bf16(eo[:, j] * ws))))
+    try:
+        for rows in (-1, 0, 16, 64):
+            if rows == 0 and T > 64:
+                continue                                  # 512 passes over the experts: covered at the smaller sizes
+            lib.vmx_debug_moe_block_rows(rows)
+            out = vmx.moe_int4_forward(xd, w, ids, m["t13"], m["t2"], E, H, I, g)
+            torch.cuda.synchronize()
+            got = orc.bf16_to_f32(out.cpu().view(torch.int16).numpy().view(np.uint16))
+            rel = np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum())
+            assert np.isfinite(got).all() and rel <= 1e-2, (rows, rel)
+            assert np.abs(got - ref).max() <= 2 ** -5 * np.abs(ref).max(), (rows, np.abs(got - ref).max(), np.abs(ref).max())
+    finally:
+        lib.vmx_debug_moe_block_rows(-1)
+
+
 @pytest.mark.parametrize("T", [1, 3])
 def test_moe_int4_forward_matches_reference_loop(gpu, T):
     from oracle import oracle as orc

@@ -181,10 +181,11 @@ __device__ __forceinline__ float chunk_sum16(const uint4 v) {
 }
 
 // Sum of the 4 waves' accumulators and the store.  Lane holds rows m = 4h + r, column n = nt*16 + nl.
+// omap (token-grouped experts): output row of block row m (LDS), instead of m itself.
 template <bool GLU>
 __device__ __forceinline__ void int4_gemm_epilogue(float *red, const vmx_f32x4 fin, const uint16_t *__restrict__ bias,
                                                    uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride, int M,
-                                                   int N, int nt, int ks) {
+                                                   int N, int nt, int ks, const int32_t *omap = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 15, h = lane >> 4;
     *reinterpret_cast<float4 *>(red + (wave * 64 + lane) * 4) = make_float4(fin[0], fin[1], fin[2], fin[3]);
     __syncthreads();
@@ -200,20 +201,21 @@ __device__ __forceinline__ void int4_gemm_epilogue(float *red, const vmx_f32x4 f
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int mrow = 4 * h + r;
+        const int orow = omap ? omap[mrow] : mrow;
         if (GLU) {
             const float up = __shfl_xor(out4[r], 8, 64);
             if (mrow < M && nl < 8) {
                 const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(out4[r]));
                 const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
-                y[(int64_t)mrow * (N >> 1) + nt * 8 + nl] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
+                y[(int64_t)orow * (N >> 1) + nt * 8 + nl] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
             }
         } else if (mrow < M) {
             if (y) {
                 float v = out4[r];
                 if (bias) v += vmx_bf16_to_f32(bias[n]);
-                y[(int64_t)mrow * N + n] = vmx_f32_to_bf16(v);
+                y[(int64_t)orow * N + n] = vmx_f32_to_bf16(v);
             } else {
-                partial[(int64_t)ks * slice_stride + (int64_t)mrow * N + n] = out4[r];
+                partial[(int64_t)ks * slice_stride + (int64_t)orow * N + n] = out4[r];
             }
         }
     }
@@ -391,7 +393,9 @@ template <int UPW, bool TAIL, bool GLU>
 __device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                       const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
                                                       uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride,
-                                                      int M, int N, int K, int group, int block) {
+                                                      int M, int N, int K, int group, int block,
+                                                      const int32_t *xmap = nullptr, const int32_t *omap = nullptr) {
+    // xmap / omap (token-grouped experts, LDS): activation row and output row of block row m
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int XS = 8;                  // k-blocks staged per pass
     static_assert((4 * UPW) % XS == 0 && XS % 4 == 0, "slice must be whole passes, a pass whole rounds of the 4 waves");
@@ -436,7 +440,7 @@ __device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ 
             const bool live = c < total;
             const int m = live ? c / CPR : 0, cc = live ? c % CPR : 0, k = kp0 + cc * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (live && (!TAIL || k < K)) v = *reinterpret_cast<const uint4 *>(x + (int64_t)m * K + k);
+            if (live && (!TAIL || k < K)) v = *reinterpret_cast<const uint4 *>(x + (int64_t)(xmap ? xmap[m] : m) * K + k);
             if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = v;
             const float sm = chunk_sum16(v);
             if (live && (tid & 15) == 0) sumx[(p * XS + (cc >> 4)) * 16 + m] = sm;
@@ -471,7 +475,7 @@ __device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ 
             }
         }
     }
-    int4_gemm_epilogue<GLU>(red, fin, bias, y, partial, slice_stride, M, N, nt, ks);
+    int4_gemm_epilogue<GLU>(red, fin, bias, y, partial, slice_stride, M, N, nt, ks, omap);
 }
 
 template <int UPW, bool TAIL>
@@ -1063,6 +1067,39 @@ __global__ __launch_bounds__(256) void int4_gemm_tiled_kernel(const uint4 *__res
             }
 }
 
+// Token-grouped form for a handful of rows per expert (decode batches): row block blockIdx.y = 16 sorted (token, slot) pairs
+// of one expert (moe_align_block_size with block_size 16); the expert's tile stream is read once for all of them, at the rate of
+// the small-M kernel.  GLU: act [pairs][N/2]; else partial [splits][pairs][N].
+template <int UPW, bool TAIL, bool GLU>
+__global__ __launch_bounds__(256) void int4_gemm_grouped16_kernel(Int4GroupedArgs ga, const uint16_t *__restrict__ x,
+                                                                   float *__restrict__ partial, uint16_t *__restrict__ act, int N,
+                                                                   int K, int group) {
+    __shared__ int32_t xmap[16], omap[16];
+    __shared__ int m_s;
+    const int row0 = blockIdx.y * 16, tid = threadIdx.x;
+    if (row0 >= ga.total_post_pad[0]) return;
+    int e = ga.block_expert[blockIdx.y];
+    e = e < 0 ? 0 : (e >= ga.num_experts ? ga.num_experts - 1 : e);
+    const char *packed = static_cast<const char *>(ga.table[e]);
+    if (!packed) return;   // expert held by another rank
+    if (tid < 64) {
+        const int p = tid < 16 ? ga.sorted[row0 + tid] : -1;
+        const bool valid = tid < 16 && p >= 0 && p < ga.numel;
+        if (tid < 16) {
+            xmap[tid] = valid ? p / ga.x_row_div : 0;
+            omap[tid] = valid ? p : 0;
+        }
+        const unsigned long long mask = __ballot(valid);   // the valid pairs of a block come first
+        if (tid == 0) m_s = __popcll(mask);
+    }
+    __syncthreads();
+    const int M = m_s;
+    if (M == 0) return;
+    const uint4 *W = reinterpret_cast<const uint4 *>(packed);
+    const uint32_t *SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
+    int4_gemm_body_looped<UPW, TAIL, GLU>(W, SZ, x, nullptr, act, partial, (int64_t)ga.numel * N, M, N, K, group, blockIdx.x, xmap, omap);
+}
+
 // Grouped form for mixture-of-experts decode: blockIdx.y = p selects one (token, expert slot) pair;
 // its weights are packed_table[expert_ids[p]], its activation row is x[p / x_row_div] and it writes
 // row p of partial[splits][pairs][N].  M = 1 per pair.
@@ -1591,14 +1628,36 @@ int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *ex
 // Token-grouped form: `sorted` / `block_expert` / `total_post_pad` as vmx_moe_align_block_size(block_size = 64) leaves them;
 // max_blocks = the host-side bound on the block count (blocks past total_post_pad exit at once).  act != NULL: experts packed
 // with glu = 1, act [pairs][N/2]; else partial [splits][pairs][N].
+bool vmx_int4_token_grouped16_ok(int N, int K) { return plan_gemm(N, K).upw >= 2; }
+
 int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *sorted, const int32_t *block_expert,
-                                const int32_t *total_post_pad, int max_blocks, int num_experts, const uint16_t *x, int x_row_div,
-                                float *partial, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st) {
-    VMX_REQUIRE(N % 128 == 0, "int4_gemm_token_grouped: N (%d) must be a multiple of 128", N);
+                                const int32_t *total_post_pad, int max_blocks, int block_rows, int num_experts, const uint16_t *x,
+                                int x_row_div, float *partial, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st) {
+    VMX_REQUIRE(block_rows == 16 || block_rows == 64, "int4_gemm_token_grouped: block_rows %d (16 or 64)", block_rows);
     const GemmPlan p = plan_gemm(N, K);
     VMX_REQUIRE(!act || p.splits == 1, "int4_gemm_token_grouped: gated linear [%d -> %d] is split over k", K, N);
     const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
     Int4GroupedArgs ga{packed_table, sorted, block_expert, total_post_pad, pairs, x_row_div, num_experts};
+    if (block_rows == 16) {
+        VMX_REQUIRE(p.upw >= 2, "int4_gemm_token_grouped: linear [%d -> %d] is too small for the 16-row form", K, N);
+        const size_t lds = gemm_lds_bytes_looped(16, p.upw);
+        const dim3 grid16((unsigned)((N / NT) * p.splits), (unsigned)max_blocks);
+        const bool tail = kblocks % (4 * p.upw) != 0;
+#define G16_T(U, T)                                                                                                              \
+        do {                                                                                                                     \
+            if (act) hipLaunchKernelGGL((int4_gemm_grouped16_kernel<U, T, true>), grid16, dim3(256), lds, st, ga, x, partial, act, N, K, group); \
+            else hipLaunchKernelGGL((int4_gemm_grouped16_kernel<U, T, false>), grid16, dim3(256), lds, st, ga, x, partial, act, N, K, group);    \
+        } while (0)
+#define G16(U) do { if (tail) G16_T(U, true); else G16_T(U, false); } while (0)
+        if (p.upw == 8) G16(8);
+        else if (p.upw == 4) G16(4);
+        else G16(2);
+#undef G16
+#undef G16_T
+        VMX_CHECK_LAUNCH("int4_gemm(token grouped, 16 rows)");
+        return VMX_OK;
+    }
+    VMX_REQUIRE(N % 128 == 0, "int4_gemm_token_grouped: N (%d) must be a multiple of 128", N);
     const dim3 grid(N / 128, max_blocks, act ? 1 : p.splits);
     if (act)
         hipLaunchKernelGGL((int4_gemm_tiled_kernel<true, true>), grid, dim3(256), 0, st, (const uint4 *)nullptr, (const uint32_t *)nullptr, x,

@@ -111,6 +111,81 @@ __global__ __launch_bounds__(256) void moe_align_kernel(const int32_t *__restric
     }
 }
 
+// The same result for up to 256 experts in O(numel / 1024) steps of one 1024-thread workgroup (the form above walks all ids once
+// per expert): histogram with LDS atomics, serial prefix over the experts, then the ids in rounds of 1024 -- inside a wave the
+// rank of an id among the earlier lanes with the same expert comes from ballots (one per distinct expert present in the wave),
+// across the 16 waves from per-(wave, expert) counts in LDS -- so that an expert's indices still ascend.  One workgroup on
+// purpose: the sort is a few microseconds in front of GEMMs that stream the experts, and a multi-workgroup form would cost
+// two more dependent launches.
+__global__ __launch_bounds__(1024) void moe_align_fast_kernel(const int32_t *__restrict__ topk_ids, int32_t *__restrict__ sorted,
+                                                               int32_t *__restrict__ expert_ids, int32_t *__restrict__ total_post_pad,
+                                                               int numel, int E, int block_size, int sorted_capacity) {
+    extern __shared__ int32_t sh[];   // counts[E] | offs[E + 1] | cursor[E] | wave_cnt[16][E]
+    int32_t *counts = sh, *offs = sh + E, *cursor = sh + 2 * E + 1, *wave_cnt = sh + 3 * E + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < E; e += 1024) counts[e] = 0;
+    for (int i = tid; i < 16 * E; i += 1024) wave_cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < numel; i += 1024) {
+        const int e = topk_ids[i];
+        if (e >= 0 && e < E) atomicAdd(&counts[e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int e = 0; e < E; e++) {
+            offs[e] = acc;
+            cursor[e] = acc;
+            acc += (counts[e] + block_size - 1) / block_size * block_size;
+        }
+        offs[E] = acc;
+        total_post_pad[0] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < sorted_capacity; i += 1024) sorted[i] = numel;
+    for (int b = tid; b < offs[E] / block_size; b += 1024) {
+        int lo = 0, hi = E - 1;   // the last expert whose run starts at or before this block (it is the one with rows there:
+        while (lo < hi) {         // an empty expert shares its start with its successor, which is then the later one)
+            const int mid = (lo + hi + 1) >> 1;
+            if (offs[mid] <= b * block_size) lo = mid;
+            else hi = mid - 1;
+        }
+        expert_ids[b] = lo;
+    }
+    __syncthreads();   // the padding fill is ordered before the placement below
+    for (int base = 0; base < numel; base += 1024) {
+        const int i = base + tid;
+        const int e = i < numel ? topk_ids[i] : -1;
+        const bool valid = e >= 0 && e < E;
+        int rank = 0;
+        unsigned long long remaining = __ballot(valid);
+        while (remaining) {   // wave-uniform: one pass per distinct expert among this wave's ids
+            const int leader = __ffsll((long long)remaining) - 1;
+            const int le = __shfl(e, leader, 64);
+            const unsigned long long mask = __ballot(valid && e == le);
+            if (valid && e == le) rank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == leader) wave_cnt[wave * E + le] = __popcll(mask);
+            remaining &= ~mask;
+        }
+        __syncthreads();
+        if (valid) {
+            int before = 0;
+            for (int w = 0; w < wave; w++) before += wave_cnt[w * E + e];
+            sorted[cursor[e] + before + rank] = i;
+        }
+        __syncthreads();
+        for (int ee = tid; ee < E; ee += 1024) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) {
+                tot += wave_cnt[w * E + ee];
+                wave_cnt[w * E + ee] = 0;
+            }
+            cursor[ee] += tot;
+        }
+        __syncthreads();
+    }
+}
+
 // out[t, :] = sum over slots j (in slot order) of bf16( bf16(expert_out[t*k+j, :]) * bf16(w[t,j]) ), each partial
 // sum rounded to bf16: the reference's `token_output + expert_out * weight` chain on bf16 tensors.
 // Pairs whose expert has a null table entry (held by another rank) contribute nothing: with expert parallelism every rank
@@ -213,8 +288,12 @@ extern "C" int vmx_moe_align_block_size(const int32_t *topk_ids, int32_t *sorted
     VMX_REQUIRE(numel >= 0 && num_experts >= 1 && num_experts <= 1024 && block_size >= 1, "moe_align_block_size: bad arguments");
     VMX_REQUIRE(sorted_capacity >= numel + num_experts * (block_size - 1), "moe_align_block_size: sorted_token_ids capacity %d too small",
                 sorted_capacity);
-    hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(256), (2 * num_experts + 1) * sizeof(int32_t), vmx_stream(stream), topk_ids,
-                       sorted_token_ids, expert_ids, total_tokens_post_pad, numel, num_experts, block_size, sorted_capacity);
+    if (num_experts <= 256)
+        hipLaunchKernelGGL(moe_align_fast_kernel, dim3(1), dim3(1024), (19 * num_experts + 1) * sizeof(int32_t), vmx_stream(stream), topk_ids,
+                           sorted_token_ids, expert_ids, total_tokens_post_pad, numel, num_experts, block_size, sorted_capacity);
+    else
+        hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(256), (2 * num_experts + 1) * sizeof(int32_t), vmx_stream(stream), topk_ids,
+                           sorted_token_ids, expert_ids, total_tokens_post_pad, numel, num_experts, block_size, sorted_capacity);
     VMX_CHECK_LAUNCH("moe_align_block_size");
     return VMX_OK;
 }
@@ -226,7 +305,30 @@ extern "C" size_t vmx_moe_int4_workspace_bytes(int tokens, int k, int hidden, in
     size_t a = s1 * pairs * 2 * inter * 4, b = s2 * pairs * hidden * 4;
     a = (a + 255) & ~(size_t)255;
     b = (b + 255) & ~(size_t)255;
-    return a + b + ((pairs * inter * 2 + 255) & ~(size_t)255);
+    // + the sorted (token, slot) indices and the blocks' experts of the token-grouped forms (up to 1024 experts)
+    const size_t sort_words = pairs + (size_t)1024 * 63 + pairs / 16 + 1024 + 64;
+    return a + b + ((pairs * inter * 2 + 255) & ~(size_t)255) + ((sort_words * 4 + 255) & ~(size_t)255);
+}
+
+namespace {
+// Pairs from which an expert's weights are streamed once per block of its rows instead of once per pair: 16-row blocks through
+// the small-M kernel for decode batches, 64-row blocks through the 64 x 128-tile kernel for prompts.  The thresholds are where
+// the sort launch and the slower per-byte rate of the block kernels are paid back (measured on Mixtral-8x7B shapes).
+int moe_block_rows(int pairs, int num_experts, int N1, int K1, int N2, int K2) {
+    if (pairs >= 96 && N1 % 128 == 0 && N2 % 128 == 0) return 64;
+    if (pairs >= 12 && vmx_int4_token_grouped16_ok(N1, K1) && vmx_int4_token_grouped16_ok(N2, K2)) return 16;
+    return 0;
+}
+}  // namespace
+
+namespace {
+int g_moe_force_rows = -1;   // tests: -1 = choose by size, 0 = one pass per pair, 16 / 64 = that block form
+}
+// Test hook: force the form vmx_moe_int4_forward takes (-1 restores the choice by size).
+extern "C" int vmx_debug_moe_block_rows(int rows) {
+    VMX_REQUIRE(rows == -1 || rows == 0 || rows == 16 || rows == 64, "debug_moe_block_rows: %d", rows);
+    g_moe_force_rows = rows;
+    return VMX_OK;
 }
 
 extern "C" int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
@@ -254,6 +356,35 @@ int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk
     float *p2 = (float *)ws;
     ws += ((size_t)s2 * pairs * hidden * 4 + 255) & ~(size_t)255;
     uint16_t *act = (uint16_t *)ws;
+    ws += ((size_t)pairs * inter * 2 + 255) & ~(size_t)255;
+    const int brows = g_moe_force_rows >= 0 ? g_moe_force_rows : moe_block_rows(pairs, num_experts, 2 * inter, hidden, hidden, inter);
+    if (brows) {
+        // token-grouped: sort the pairs by expert into blocks of `brows` rows, then one pass per block that streams the expert's
+        // tile stream once for all its rows (fused_moe_align.cu:34-278 + the grouped GEMM of fused_moe_gemm.cu:72-545)
+        VMX_REQUIRE(num_experts <= 1024, "moe_int4_forward: at most 1024 experts");
+        const int cap = pairs + num_experts * (brows - 1), max_blocks = (cap + brows - 1) / brows;
+        int32_t *sorted = (int32_t *)ws, *block_expert = sorted + ((cap + 63) & ~63), *total = block_expert + ((max_blocks + 63) & ~63);
+        if (int rc = vmx_moe_align_block_size(topk_ids, sorted, block_expert, total, pairs, num_experts, brows, cap, st)) return rc;
+        if (w13_glu) {
+            if (int rc = vmx_int4_gemm_token_grouped(w13_packed, sorted, block_expert, total, max_blocks, brows, num_experts, x, k, nullptr, act,
+                                                     pairs, 2 * inter, hidden, group, st))
+                return rc;
+        } else {
+            if (int rc = vmx_int4_gemm_token_grouped(w13_packed, sorted, block_expert, total, max_blocks, brows, num_experts, x, k, p1, nullptr,
+                                                     pairs, 2 * inter, hidden, group, st))
+                return rc;
+            int64_t blocks = ((int64_t)pairs * inter + 255) / 256;
+            hipLaunchKernelGGL(moe_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p1, s1, pairs, act, inter);
+            VMX_CHECK_LAUNCH("moe_act");
+        }
+        if (int rc = vmx_int4_gemm_token_grouped(w2_packed, sorted, block_expert, total, max_blocks, brows, num_experts, act, 1, p2, nullptr,
+                                                 pairs, hidden, inter, group, st))
+            return rc;
+        hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden + 255) / 256, tokens), dim3(256), 0, st, out, p2, s2, pairs, topk_weights, k, hidden,
+                           w2_packed, topk_ids, num_experts, h_resid, ssq);
+        VMX_CHECK_LAUNCH("moe_combine");
+        return VMX_OK;
+    }
     // gate|up of every (token, slot) pair with its expert's weights; x row = token
     if (w13_glu) {   // act straight from the GEMM epilogue
         if (int rc = vmx_int4_gemm_grouped_glu(w13_packed, topk_ids, num_experts, x, k, act, pairs, 2 * inter, hidden, group, st)) return rc;

@@ -14,9 +14,11 @@ bool vmx_int4_glu_fusable(int N, int K);
 int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *expert_ids, int num_experts, const uint16_t *x,
                               int x_row_div, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st);
 // token-grouped matrix-core form: pairs sorted by expert in blocks of 64 rows (vmx_moe_align_block_size); act != NULL = gated epilogue
+// block_rows 64: the 64 x 128-tile kernel (prompts); 16: the small-M kernel with gathered rows (decode batches)
 int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *sorted, const int32_t *block_expert,
-                                const int32_t *total_post_pad, int max_blocks, int num_experts, const uint16_t *x, int x_row_div,
-                                float *partial, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st);
+                                const int32_t *total_post_pad, int max_blocks, int block_rows, int num_experts, const uint16_t *x,
+                                int x_row_div, float *partial, uint16_t *act, int pairs, int N, int K, int group, hipStream_t st);
+bool vmx_int4_token_grouped16_ok(int N, int K);
 // moe_kernels.hip: vmx_moe_int4_forward with the experts' gate|up tensors packed for the fused activation (w13_glu != 0)
 int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
                              const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts, int hidden,
