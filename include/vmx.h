@@ -382,6 +382,8 @@ int vmx_embedding_lookup_bf16(uint16_t *out, const uint16_t *table, const int32_
 
 /* ---------------------------------------------------------- mixture of experts */
 
+typedef struct vmx_comm vmx_comm;   /* device communicator, declared below */
+
 /* Replaces topk_softmax_{f32,bf16}_warp / _generic (crates/core/kernels/topk_softmax.cu:63-311):
  * softmax over experts (expf, max-subtracted), k rounds of argmax (ties -> smaller index), optional
  * renormalisation by the selected sum.  round_probs_bf16 rounds the probabilities to bf16 before the
@@ -408,6 +410,21 @@ int vmx_moe_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_wei
                          const void *const *w13_packed, const void *const *w2_packed, int tokens, int k, int num_experts,
                          int hidden, int inter, int group, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Expert parallelism with token dispatch -- EPMoELayer::forward (crates/core/src/moe/ep_layer.rs:180-210) over
+ * TokenDispatcher::dispatch / combine (moe/token_dispatch.rs:113-231): every rank brings its OWN tokens (data-parallel
+ * attention) and holds num_experts / world whole experts (ExpertPlacement::Linear, or RoundRobin with round_robin = 1;
+ * moe/expert_map.rs:100-115,167-172); w13_local / w2_local: device arrays of the rank's num_experts / world tile streams in
+ * local order.  A (token, slot) pair's row goes to its expert's rank, the expert's bf16 output row comes back, the source
+ * sums the slots with the routing weights: out equals vmx_moe_int4_forward on the same tokens with every expert resident.
+ * Routing and counts stay on the device (vmx_comm_all_to_all_v_dev): no host read, hipGraph-capturable.  cap_rows: the most
+ * rows a rank can receive in one call (all ranks' tokens * k at worst); the communicator needs the peer-mapped transport with
+ * exchange_bytes >= tokens * k * hidden * 2 of the largest rank. */
+size_t vmx_moe_ep_workspace_bytes(int tokens, int k, int hidden, int inter, int cap_rows);
+int vmx_moe_ep_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
+                            const void *const *w13_local, const void *const *w2_local, int tokens, int k, int num_experts,
+                            int hidden, int inter, int group, int w13_glu, int round_robin, vmx_comm *comm, int cap_rows,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* Measurement / parity aid: vmx_moe_int4_forward streams an expert once per (token, slot) pair for a few pairs, once per block
  * of 16 sorted rows (small-M kernel) from 12 pairs and once per block of 64 rows (64 x 128-tile matrix-core kernel, the
  * grouped GEMM of crates/core/kernels/fused_moe_gemm.cu:72-545) from 96 pairs; rows = 0 / 16 / 64 forces one form, -1 restores
@@ -421,7 +438,6 @@ int vmx_debug_moe_block_rows(int rows);
  * vmx_comm_unique_id, the 128 bytes travel to the other ranks out of band (the launcher's TCP exchange in the reference,
  * torch.distributed in bench.py), then every rank calls vmx_comm_create.  Collectives run on the caller's stream and can be
  * captured into a hipGraph.  Element types and reductions use RCCL's numbering. */
-typedef struct vmx_comm vmx_comm;
 #define VMX_COMM_I8 0
 #define VMX_COMM_U8 1
 #define VMX_COMM_I32 2

@@ -75,6 +75,8 @@ _SIGS = {
     "vmx_moe_int4_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vmx_moe_int4_forward": (_i, [_p] * 6 + [_i] * 6 + [_p, _sz, _p]),
     "vmx_debug_moe_block_rows": (_i, [_i]),
+    "vmx_moe_ep_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "vmx_moe_ep_int4_forward": (_i, [_p] * 6 + [_i] * 8 + [_p, _i, _p, _sz, _p]),
     "vmx_fused_qknorm_rope_bf16": (_i, [_p] * 9 + [_i] * 5 + [_p]),
     "vmx_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "vmx_gelu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),

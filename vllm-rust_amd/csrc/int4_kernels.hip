@@ -397,7 +397,7 @@ __device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ 
                                                       const int32_t *xmap = nullptr, const int32_t *omap = nullptr) {
     // xmap / omap (token-grouped experts, LDS): activation row and output row of block row m
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int XS = 8;                  // k-blocks staged per pass
+    constexpr int XS = 4 * UPW < 8 ? 4 * UPW : 8;   // k-blocks staged per pass
     static_assert((4 * UPW) % XS == 0 && XS % 4 == 0, "slice must be whole passes, a pass whole rounds of the 4 waves");
     constexpr int PASSES = 4 * UPW / XS, UPP = XS / 4;   // units per wave per pass
     constexpr int XROW = XS * KB + 8, CPR = XS * KB / 8;
@@ -1177,7 +1177,7 @@ inline bool use_looped(int M, int upw) {
     return min_m > 0 && M >= min_m && upw >= 4;
 }
 inline size_t gemm_lds_bytes_looped(int M, int upw) {
-    return (size_t)M * (8 * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + 4 * 64 * 4 * 4 + (size_t)4 * upw * 16 * 4;
+    return (size_t)M * ((4 * upw < 8 ? 4 * upw : 8) * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + 4 * 64 * 4 * 4 + (size_t)4 * upw * 16 * 4;
 }
 
 inline size_t gemm_lds_bytes(int M, int upw) {
@@ -1628,7 +1628,7 @@ int vmx_int4_gemm_grouped_glu(const void *const *packed_table, const int32_t *ex
 // Token-grouped form: `sorted` / `block_expert` / `total_post_pad` as vmx_moe_align_block_size(block_size = 64) leaves them;
 // max_blocks = the host-side bound on the block count (blocks past total_post_pad exit at once).  act != NULL: experts packed
 // with glu = 1, act [pairs][N/2]; else partial [splits][pairs][N].
-bool vmx_int4_token_grouped16_ok(int N, int K) { return plan_gemm(N, K).upw >= 2; }
+bool vmx_int4_token_grouped16_ok(int N, int K) { return N % NT == 0 && K % KB == 0; }
 
 int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *sorted, const int32_t *block_expert,
                                 const int32_t *total_post_pad, int max_blocks, int block_rows, int num_experts, const uint16_t *x,
@@ -1639,7 +1639,6 @@ int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *
     const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
     Int4GroupedArgs ga{packed_table, sorted, block_expert, total_post_pad, pairs, x_row_div, num_experts};
     if (block_rows == 16) {
-        VMX_REQUIRE(p.upw >= 2, "int4_gemm_token_grouped: linear [%d -> %d] is too small for the 16-row form", K, N);
         const size_t lds = gemm_lds_bytes_looped(16, p.upw);
         const dim3 grid16((unsigned)((N / NT) * p.splits), (unsigned)max_blocks);
         const bool tail = kblocks % (4 * p.upw) != 0;
@@ -1651,7 +1650,8 @@ int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *
 #define G16(U) do { if (tail) G16_T(U, true); else G16_T(U, false); } while (0)
         if (p.upw == 8) G16(8);
         else if (p.upw == 4) G16(4);
-        else G16(2);
+        else if (p.upw == 2) G16(2);
+        else G16(1);
 #undef G16
 #undef G16_T
         VMX_CHECK_LAUNCH("int4_gemm(token grouped, 16 rows)");

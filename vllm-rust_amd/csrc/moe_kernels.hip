@@ -401,3 +401,203 @@ int vmx_moe_int4_forward_glu(uint16_t *out, const uint16_t *x, const float *topk
     VMX_CHECK_LAUNCH("moe_combine");
     return VMX_OK;
 }
+
+// ---------------------------------------------------------------- expert parallelism with token dispatch (data-parallel attention)
+// EPMoELayer::forward (crates/core/src/moe/ep_layer.rs:180-210) with TokenDispatcher::dispatch / combine
+// (moe/token_dispatch.rs:113-231): every rank holds its OWN tokens and E / world whole experts; a (token, slot) pair travels to
+// the rank that owns its expert, runs there, and its output row travels back, where the routing weights are applied.  The
+// reference reads the routing on the host, exchanges counts with all_to_all and rows with three all_to_all_v; here the routing
+// never leaves the device: the rows are grouped by destination rank by one workgroup, the counts ride in the header of the
+// exchange (vmx_comm_all_to_all_v_dev), and the receiver runs the token-grouped expert GEMMs over however many rows arrived.
+// The result equals vmx_moe_int4_forward on the rank's tokens with all experts resident, bit for bit: the value a row carries
+// back is the expert's bf16 output, the weighted sum over the slots is taken at the source in slot order.
+namespace {
+
+__device__ __forceinline__ int ep_owner(int e, int per, int world, int round_robin) { return round_robin ? e % world : e / per; }
+__device__ __forceinline__ int ep_local(int e, int per, int world, int round_robin) { return round_robin ? e / world : e % per; }
+
+// One workgroup of 1024 threads: send_pairs [pairs] = the (token, slot) pair indices grouped by destination rank (ascending
+// inside a group), pos_of_pair [pairs] = where each pair went, send_rows [world] = rows per destination.
+__global__ __launch_bounds__(1024) void ep_route_kernel(const int32_t *__restrict__ topk_ids, int pairs, int num_experts, int world,
+                                                         int round_robin, int32_t *__restrict__ send_pairs, int32_t *__restrict__ pos_of_pair,
+                                                         int32_t *__restrict__ send_rows) {
+    __shared__ int32_t counts[8], cursor[8], wave_cnt[16][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = num_experts / world;
+    if (tid < 8) counts[tid] = 0;
+    if (tid < 128) wave_cnt[tid >> 3][tid & 7] = 0;
+    __syncthreads();
+    for (int i = tid; i < pairs; i += 1024) {
+        const int e = topk_ids[i];
+        if (e >= 0 && e < num_experts) atomicAdd(&counts[ep_owner(e, per, world, round_robin)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int r = 0; r < world; r++) {
+            cursor[r] = acc;
+            send_rows[r] = counts[r];
+            acc += counts[r];
+        }
+    }
+    __syncthreads();
+    for (int base = 0; base < pairs; base += 1024) {
+        const int i = base + tid;
+        const int e = i < pairs ? topk_ids[i] : -1;
+        const bool valid = e >= 0 && e < num_experts;
+        const int dst = valid ? ep_owner(e, per, world, round_robin) : -1;
+        int rank = 0;
+        for (int r = 0; r < world; r++) {
+            const unsigned long long mask = __ballot(dst == r);
+            if (dst == r) rank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[wave][r] = __popcll(mask);
+        }
+        __syncthreads();
+        if (valid) {
+            int before = 0;
+            for (int w = 0; w < wave; w++) before += wave_cnt[w][dst];
+            const int pos = cursor[dst] + before + rank;
+            send_pairs[pos] = i;
+            pos_of_pair[i] = pos;
+        } else if (i < pairs) {
+            pos_of_pair[i] = -1;
+        }
+        __syncthreads();
+        if (tid < world) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += wave_cnt[w][tid];
+            cursor[tid] += tot;
+        }
+        __syncthreads();
+    }
+}
+
+// send_x [i] = x [token of send_pairs[i]], send_e [i] = the pair's expert as the destination rank numbers its experts
+__global__ __launch_bounds__(256) void ep_gather_kernel(const uint16_t *__restrict__ x, const int32_t *__restrict__ topk_ids,
+                                                         const int32_t *__restrict__ send_pairs, const int32_t *__restrict__ send_rows, int world,
+                                                         int k, int hidden, int num_experts, int round_robin, uint16_t *__restrict__ send_x,
+                                                         int32_t *__restrict__ send_e) {
+    int total = 0;
+    for (int r = 0; r < world; r++) total += send_rows[r];
+    const int i = blockIdx.x;
+    if (i >= total) return;
+    const int p = send_pairs[i];
+    const uint4 *src = reinterpret_cast<const uint4 *>(x + (int64_t)(p / k) * hidden);
+    uint4 *dst = reinterpret_cast<uint4 *>(send_x + (int64_t)i * hidden);
+    for (int c = threadIdx.x; c < hidden / 8; c += 256) dst[c] = src[c];
+    if (threadIdx.x == 0) send_e[i] = ep_local(topk_ids[p], num_experts / world, world, round_robin);
+}
+
+// y [i] = bf16(sum of the split-K slices of row i) for the rows that arrived; ids beyond them are -1
+__global__ __launch_bounds__(256) void ep_rows_finish_kernel(const float *__restrict__ partial, int splits, int cap_rows, int hidden,
+                                                              const int32_t *__restrict__ recv_e, uint16_t *__restrict__ y) {
+    const int i = blockIdx.y;
+    if (recv_e[i] < 0) return;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < hidden; c += gridDim.x * 256) {
+        float o = 0.f;
+        for (int sidx = 0; sidx < splits; sidx++) o += partial[((int64_t)sidx * cap_rows + i) * hidden + c];
+        y[(int64_t)i * hidden + c] = vmx_f32_to_bf16(o);
+    }
+}
+
+// out [t] = sum over the slots (in slot order) of bf16(bf16 expert output * bf16 weight), each partial sum rounded to bf16:
+// the arithmetic of moe_combine_kernel, with the expert outputs read from the rows that came back
+__global__ __launch_bounds__(256) void ep_combine_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ ret_y,
+                                                          const int32_t *__restrict__ pos_of_pair, const float *__restrict__ w, int k,
+                                                          int hidden) {
+    const int t = blockIdx.y;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < hidden; c += gridDim.x * 256) {
+        float acc = 0.f;
+        for (int j = 0; j < k; j++) {
+            const int pos = pos_of_pair[t * k + j];
+            if (pos < 0) continue;
+            const float o = vmx_bf16_to_f32(ret_y[(int64_t)pos * hidden + c]);
+            acc = rb(acc + rb(o * rb(w[t * k + j])));
+        }
+        out[(int64_t)t * hidden + c] = vmx_f32_to_bf16(acc);
+    }
+}
+
+size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+// cap_rows: the most rows this rank may receive in one call (at most world * tokens * k of the largest rank)
+extern "C" size_t vmx_moe_ep_workspace_bytes(int tokens, int k, int hidden, int inter, int cap_rows) {
+    if (tokens <= 0 || k <= 0 || hidden <= 0 || inter <= 0 || cap_rows <= 0) return 0;
+    const size_t pairs = (size_t)tokens * k;
+    return 3 * al256(pairs * 4) + 4 * 256 + al256((size_t)cap_rows * 4) + 2 * al256(pairs * hidden * 2) + 2 * al256((size_t)cap_rows * hidden * 2) +
+           vmx_moe_int4_workspace_bytes(cap_rows, 1, hidden, inter);
+}
+
+extern "C" int vmx_moe_ep_int4_forward(uint16_t *out, const uint16_t *x, const float *topk_weights, const int32_t *topk_ids,
+                                       const void *const *w13_local, const void *const *w2_local, int tokens, int k, int num_experts,
+                                       int hidden, int inter, int group, int w13_glu, int round_robin, vmx_comm *comm, int cap_rows,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(out && x && topk_weights && topk_ids && w13_local && w2_local && comm && workspace, "moe_ep_int4_forward: null pointer");
+    const int world = vmx_comm_world(comm);
+    VMX_REQUIRE(world >= 1 && world <= 8 && num_experts % world == 0, "moe_ep_int4_forward: %d experts over %d ranks (at most 8, whole experts per rank)",
+                num_experts, world);
+    VMX_REQUIRE(tokens >= 1 && k >= 1 && k <= num_experts && cap_rows >= tokens * k, "moe_ep_int4_forward: bad counts (cap_rows %d < %d)", cap_rows, tokens * k);
+    VMX_REQUIRE(hidden % 128 == 0 && inter % 128 == 0 && group > 0 && group % 128 == 0 && hidden % group == 0 && inter % group == 0,
+                "moe_ep_int4_forward: hidden (%d), inter (%d) and group (%d) must be multiples of 128", hidden, inter, group);
+    VMX_REQUIRE(!w13_glu || vmx_int4_glu_fusable(2 * inter, hidden), "moe_ep_int4_forward: gate|up [%d -> %d] cannot take the gated epilogue", hidden, 2 * inter);
+    VMX_REQUIRE(workspace_bytes >= vmx_moe_ep_workspace_bytes(tokens, k, hidden, inter, cap_rows), "moe_ep_int4_forward: workspace too small");
+    hipStream_t st = vmx_stream(stream);
+    const int pairs = tokens * k, per = num_experts / world;
+    char *ws = (char *)workspace;
+    auto take = [&](size_t bytes) { char *q = ws; ws += al256(bytes); return q; };
+    int32_t *send_pairs = (int32_t *)take((size_t)pairs * 4), *pos_of_pair = (int32_t *)take((size_t)pairs * 4), *send_e = (int32_t *)take((size_t)pairs * 4);
+    int32_t *send_rows = (int32_t *)take(64), *recv_rows = (int32_t *)take(64), *recv_rows2 = (int32_t *)take(64), *back_rows = (int32_t *)take(64);
+    int32_t *recv_e = (int32_t *)take((size_t)cap_rows * 4);
+    uint16_t *send_x = (uint16_t *)take((size_t)pairs * hidden * 2), *ret_y = (uint16_t *)take((size_t)pairs * hidden * 2);
+    uint16_t *recv_x = (uint16_t *)take((size_t)cap_rows * hidden * 2), *y = (uint16_t *)take((size_t)cap_rows * hidden * 2);
+    // 1. group the pairs by destination rank, gather their rows
+    hipLaunchKernelGGL(ep_route_kernel, dim3(1), dim3(1024), 0, st, topk_ids, pairs, num_experts, world, round_robin, send_pairs, pos_of_pair, send_rows);
+    VMX_CHECK_LAUNCH("ep_route");
+    hipLaunchKernelGGL(ep_gather_kernel, dim3(pairs), dim3(256), 0, st, x, topk_ids, send_pairs, send_rows, world, k, hidden, num_experts, round_robin,
+                       send_x, send_e);
+    VMX_CHECK_LAUNCH("ep_gather");
+    // 2. dispatch: expert ids and rows to the owners (counts travel with them)
+    VMX_CHECK_HIP(hipMemsetAsync(recv_e, 0xFF, (size_t)cap_rows * 4, st));
+    if (int rc = vmx_comm_all_to_all_v_dev(comm, send_e, send_rows, recv_e, recv_rows, 4, (size_t)cap_rows, st)) return rc;
+    if (int rc = vmx_comm_all_to_all_v_dev(comm, send_x, send_rows, recv_x, recv_rows2, (size_t)hidden * 2, (size_t)cap_rows, st)) return rc;
+    // 3. the local experts over the rows that arrived (one slot per row, ids < 0 = no row): token-grouped GEMMs
+    {
+        char *mws = ws;
+        const int s1 = vmx_int4_splits(2 * inter, hidden), s2 = vmx_int4_splits(hidden, inter);
+        float *p1 = (float *)mws;
+        mws += al256((size_t)s1 * cap_rows * 2 * inter * 4);
+        float *p2 = (float *)mws;
+        mws += al256((size_t)s2 * cap_rows * hidden * 4);
+        uint16_t *act = (uint16_t *)mws;
+        mws += al256((size_t)cap_rows * inter * 2);
+        const int brows = (cap_rows >= 96 && (2 * inter) % 128 == 0 && hidden % 128 == 0) ? 64
+                          : (vmx_int4_token_grouped16_ok(2 * inter, hidden) && vmx_int4_token_grouped16_ok(hidden, inter)) ? 16 : 64;
+        VMX_REQUIRE(brows == 16 || ((2 * inter) % 128 == 0 && hidden % 128 == 0), "moe_ep_int4_forward: shapes fit neither block form");
+        const int cap = cap_rows + per * (brows - 1), max_blocks = (cap + brows - 1) / brows;
+        int32_t *sorted = (int32_t *)mws, *block_expert = sorted + ((cap + 63) & ~63), *total = block_expert + ((max_blocks + 63) & ~63);
+        if (int rc = vmx_moe_align_block_size(recv_e, sorted, block_expert, total, cap_rows, per, brows, cap, st)) return rc;
+        if (w13_glu) {
+            if (int rc = vmx_int4_gemm_token_grouped(w13_local, sorted, block_expert, total, max_blocks, brows, per, recv_x, 1, nullptr, act, cap_rows,
+                                                     2 * inter, hidden, group, st))
+                return rc;
+        } else {
+            if (int rc = vmx_int4_gemm_token_grouped(w13_local, sorted, block_expert, total, max_blocks, brows, per, recv_x, 1, p1, nullptr, cap_rows,
+                                                     2 * inter, hidden, group, st))
+                return rc;
+            int64_t blocks = ((int64_t)cap_rows * inter + 255) / 256;
+            hipLaunchKernelGGL(moe_act_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p1, s1, cap_rows, act, inter);
+            VMX_CHECK_LAUNCH("moe_act");
+        }
+        if (int rc = vmx_int4_gemm_token_grouped(w2_local, sorted, block_expert, total, max_blocks, brows, per, act, 1, p2, nullptr, cap_rows, hidden,
+                                                 inter, group, st))
+            return rc;
+        hipLaunchKernelGGL(ep_rows_finish_kernel, dim3((hidden + 255) / 256, cap_rows), dim3(256), 0, st, p2, s2, cap_rows, hidden, recv_e, y);
+        VMX_CHECK_LAUNCH("ep_rows_finish");
+    }
+    // 4. combine: the rows go back the way they came, the source applies the routing weights in slot order
+    if (int rc = vmx_comm_all_to_all_v_dev(comm, y, recv_rows, ret_y, back_rows, (size_t)hidden * 2, (size_t)pairs, st)) return rc;
+    hipLaunchKernelGGL(ep_combine_kernel, dim3((hidden + 255) / 256, tokens), dim3(256), 0, st, out, ret_y, pos_of_pair, topk_weights, k, hidden);
+    VMX_CHECK_LAUNCH("ep_combine");
+    return VMX_OK;
+}

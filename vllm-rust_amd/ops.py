@@ -15,7 +15,7 @@ __all__ = [
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "rope_gptj", "reshape_and_cache_hnd", "copy_blocks", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_f16", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
-    "topk_softmax", "moe_align_block_size", "moe_int4_forward",
+    "topk_softmax", "moe_align_block_size", "moe_int4_forward", "moe_ep_int4_forward",
 ]
 
 
@@ -392,4 +392,17 @@ def moe_int4_forward(x, topk_weights, topk_ids, w13_table, w2_table, num_experts
     out = torch.empty((T, hidden), dtype=torch.bfloat16, device=x.device)
     check(lib.vmx_moe_int4_forward(_ptr(out), _ptr(x), _ptr(topk_weights), _ptr(topk_ids), _ptr(w13_table), _ptr(w2_table), T, k,
                                    num_experts, hidden, inter, group, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def moe_ep_int4_forward(x, topk_weights, topk_ids, w13_local, w2_local, num_experts: int, hidden: int, inter: int, group: int, comm,
+                        cap_rows: int, round_robin: bool = False, w13_glu: bool = False):
+    """Expert-parallel MoE layer with token dispatch: this rank's tokens x [T, hidden], the rank's experts in w13_local /
+    w2_local (int64 CUDA tensors of packed-buffer pointers, local order); comm: a Communicator with the exchange transport."""
+    T, k = topk_ids.shape
+    ws = torch.empty(lib.vmx_moe_ep_workspace_bytes(T, k, hidden, inter, cap_rows), dtype=torch.uint8, device=x.device)
+    out = torch.empty((T, hidden), dtype=torch.bfloat16, device=x.device)
+    check(lib.vmx_moe_ep_int4_forward(_ptr(out), _ptr(x), _ptr(topk_weights), _ptr(topk_ids), _ptr(w13_local), _ptr(w2_local), T, k,
+                                      num_experts, hidden, inter, group, int(w13_glu), int(round_robin), comm.handle, int(cap_rows),
+                                      _ptr(ws), ws.numel(), _stream()))
     return out
