@@ -271,14 +271,20 @@ def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
                            "GB_s": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_step": round(us, 1)}
         model.mmvq_select(15)
     dom = max(("qkv", "o_proj", "gate_up", "down_proj"), key=lambda k: kinds[k]["us_per_step"])
-    mmvq_kernel = {"qkv": "iq_mmvq_multi_kernel (q|k|v, three I-quant types in one launch)", "o_proj": "iq_mmvq_kernel (o_proj)",
-                   "gate_up": "iq_pk_mmvq_kernel<GLU> (gate|up, packed 8-row units, codebook + sign tables in LDS, GeGLU + q8_1 epilogue)",
+    # the launches are the variants the step makes (vmx_gemma4_mmvq_only mirrors run_layers): norms in the prologues included
+    mmvq_kernel = {"qkv": "iq_pk_mmvq_kernel<NORM> (q|k|v, three packed I-quant tensors in one launch, layer-boundary norms + q8_1 in the prologue; "
+                          "the first layer: iq_mmvq_multi_kernel)", "o_proj": "iq_mmvq_kernel (o_proj)",
+                   "gate_up": "iq_pk_mmvq_kernel<GLU, NORM> (gate|up, packed 8-row units, codebook + sign tables in LDS, post-attention / "
+                              "pre-feedforward norms + q8_1 in the prologue, GeGLU + q8_1 epilogue)",
                    "down_proj": "iq_mmvq_pipe_kernel (down_proj, rows split over 4 waves)"}
-    traffic = None
-    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_mmvq.py), when one exists for it
-        traffic = json.loads((ROOT / "profiles" / "r02_pmc_traffic_iq_mmvq.json").read_text())[dom]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    traffic, traffic_source = None, None
+    for name in ("r03_pmc_traffic_iq_mmvq.json", "r02_pmc_traffic_iq_mmvq.json"):
+        try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_mmvq.py), when one exists for it
+            traffic = json.loads((ROOT / "profiles" / name).read_text())[dom]["hbm_bytes_per_launch"]
+            traffic_source = f"profiles/{name} (committed rocprofv3 --pmc pass; not measured in this run)"
+            break
+        except Exception:
+            pass
     wbytes = model.iq_weight_bytes()
     embed_bytes = spec.vocab_size * (spec.hidden_size // 256) * 110
     model.close()
@@ -299,7 +305,7 @@ def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
                        "weights": "seeded random-init blocks of the architecture", "execution": "one hipGraph per step"},
             "weight_bytes_per_token": wbytes + embed_bytes,
             "roofline": {"bound": "hbm", "kernel": mmvq_kernel[dom], "achieved": kinds[dom]["GB_s"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kinds[dom]["frac"], "traffic": traffic,
+                         "unit": "GB/s", "frac": kinds[dom]["frac"], "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": kinds[dom]["launches_per_step"], "avg_launch_us": kinds[dom]["avg_launch_us"],
                          "alg_bytes_per_launch": kinds[dom]["alg_bytes_per_launch"], "mmvq": kinds}}
 
@@ -590,6 +596,150 @@ def mixtral_secondary(prompt, steps, warmup, batches=(1, 4, 16)):
             "batch_sweep": by_batch}
 
 
+def plan_job(gpus, world, replicas_flag, weights, local_ranks):
+    """What a launch of this script measures -- pure argument logic, no device.  N = 1: the single-GPU job.  N > 1 (one process
+    per GPU under torch.distributed.run): ONE model tensor-parallel over the N ranks (BASELINE.json's metric is the TP curve at
+    1/2/4/8 GPUs: strong scaling, all-reduce after every row-parallel linear), then N independent replicas as a secondary;
+    --replicas makes the replicas the primary (weak scaling, no data-path collective) and skips the TP job."""
+    from vllm_rust_amd.parallel import shard_spec
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    if world != max(gpus, 1):
+        raise ValueError(f"--gpus {gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {gpus}")
+    if world == 1:
+        return {"mode": "single", "scaling": "weak", "tp": 1, "secondary": None, "shards": None}
+    if replicas_flag:
+        return {"mode": "replicas", "scaling": "weak", "tp": 1, "secondary": None, "shards": None}
+    full = Qwen3Spec.qwen3_8b()
+    shards = [shard_spec(full, r, world) for r in range(world)]   # raises ValueError when the geometry does not divide
+    return {"mode": "tp", "scaling": "strong", "tp": world, "secondary": "replicas",
+            "shards": [(s.num_heads, s.num_kv_heads, s.intermediate_size, s.tp_rank) for s in shards],
+            "transport": "peer-mapped (one GPU, development)" if local_ranks else "rccl+peer-mapped", "weights": weights}
+
+
+class _Dist:
+    """torch.distributed plumbing of the benchmark: one process per GPU over RCCL; VMX_BENCH_LOCAL_RANKS=1 (development, one-GPU
+    boxes) puts every rank on GPU 0 and joins them over gloo + peer-mapped memory instead, to rehearse the multi-rank flow."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.on = self.world > 1
+        self.local = os.environ.get("VMX_BENCH_LOCAL_RANKS", "0") not in ("", "0")
+        self.device = 0 if self.local else self.local_rank
+        if self.on:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.local:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        torch.cuda.set_device(self.device)
+
+    def barrier(self):
+        if self.on:
+            self.dist.barrier()
+
+    def max_over_ranks(self, v):
+        if not self.on:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if self.local else torch.device("cuda", self.device))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_agree(self, ok):
+        if not self.on:
+            return bool(ok)
+        flags = [None] * self.world
+        self.dist.all_gather_object(flags, bool(ok))
+        return all(flags)
+
+    def make_comm(self):
+        """(communicator, description of the all-reduce path, note).  The transport is agreed between the ranks."""
+        from vllm_rust_amd.parallel import Communicator, LocalCommunicator
+        if self.local:
+            def exchange(mine):
+                got = [None] * self.world
+                self.dist.all_gather_object(got, mine)
+                return got
+            # no RCCL between processes that share a GPU: prompts of at most 32 rows so that every all-reduce fits the staging slot
+            return LocalCommunicator(self.rank, self.world, exchange, max_bytes=256 * 1024), "one-shot over peer-mapped memory (ranks share one GPU)", ""
+        comm = Communicator(self.rank, self.world)
+        if os.environ.get("VMX_NO_P2P_ALLREDUCE", "0") not in ("", "0"):
+            return comm, "RCCL", "peer-mapped path switched off (VMX_NO_P2P_ALLREDUCE)"
+        if comm.enable_p2p(64 * 1024):   # the 8 KiB row-parallel sums go over peer-mapped memory in one step; RCCL keeps the rest
+            return comm, "one-shot over peer-mapped memory (xGMI) for the row-parallel sums and argmax keys, RCCL for larger messages", ""
+        return comm, "RCCL", f"peer-mapped path unavailable on some rank: {comm.p2p_note}"
+
+    def finish(self):
+        if self.on:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def run_decode_job(d, args, spec, full_spec, comm, exl3, seed_per_rank):
+    """Load the model of this rank, run the prompt through the native prefill, capture one decode step (+ device-side
+    bookkeeping) into a hipGraph, replay `warmup` steps, then time exactly `steps` replays between barrier + synchronise on
+    both sides; the time is the maximum over the ranks.  Returns (seconds, prefill seconds, model, graph, side stream)."""
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM
+    model = QuantizedQwen3ForCausalLM(spec, device=d.device)
+    if exl3:
+        model.load_synthetic_exl3(bits=4, codebook=0, seed=1234 + (d.rank if seed_per_rank or comm is not None else 0))
+    elif comm is not None:   # every rank slices the SAME seeded checkpoint: the TP job computes the model of the single-GPU run
+        model.load_synthetic_tp(full_spec, seed=1234)
+    else:
+        model.load_synthetic(seed=1234 + (d.rank if seed_per_rank else 0))
+    if comm is not None:
+        model.set_comm(comm)
+    dev = model.device
+    B, block_size, P = 1, spec.block_size, args.prompt
+    n_blocks = spec.num_blocks
+    bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(B, n_blocks).contiguous()
+    prompt_ids = torch.randint(0, spec.vocab_size, (P,), dtype=torch.int32, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    ids = torch.empty(B, dtype=torch.int32, device=dev)
+    pos = torch.full((B,), P, dtype=torch.int32, device=dev)
+    slots = (bt[:, P // block_size] * block_size + P % block_size).to(torch.int32).contiguous()
+    seq_lens = torch.full((B,), P + 1, dtype=torch.int32, device=dev)
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+
+    def step():
+        model.forward_decode_batch(ids, pos, slots, bt, seq_lens, max_seq_len=spec.max_seq_len, out_ids=out)
+        model.advance(ids, out, pos, slots, seq_lens, bt)
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        # prompt: one native prefill pass (all rows through the linears, MFMA prefill attention); run twice, the second timed
+        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
+        torch.cuda.synchronize()
+        d.barrier()
+        tp0 = time.perf_counter()
+        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
+        torch.cuda.synchronize()
+        prefill_s = time.perf_counter() - tp0
+        step()  # first decode call outside capture (lazy module load); position P -> P + 1
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+        for _ in range(args.warmup):
+            graph.replay()
+    torch.cuda.synchronize()
+    d.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(side):
+        for _ in range(args.steps):
+            graph.replay()
+    torch.cuda.synchronize()
+    d.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pos_after = int(pos.item())
+    assert pos_after == P + 1 + args.warmup + args.steps, (pos_after, P, args.warmup, args.steps)
+    return d.max_over_ranks(elapsed), prefill_s, model, graph, side
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -598,31 +748,25 @@ def main():
     ap.add_argument("--prompt", type=int, default=256)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override the layer count (invalidates the number)")
     ap.add_argument("--weights", choices=["awq", "exl3"], default="awq",
-                    help="exl3: the same Qwen3-8B geometry with EXL3 4.0 bpw projections (BASELINE.json configs[3]; with --tp: its TP curve)")
+                    help="exl3: the same Qwen3-8B geometry with EXL3 4.0 bpw projections (BASELINE.json configs[3]: its TP curve for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the GGUF I-quant (Gemma-4-12B-shaped) secondary measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other models at N = 1, replicas at N > 1)")
     ap.add_argument("--no-moe", action="store_true", help="skip the Mixtral-8x7B-shaped fused-MoE secondary measurement")
     ap.add_argument("--workload", choices=["all", "qwen3", "gemma4", "mixtral", "exl3"], default="all",
                     help="profiling aid: run ONE workload alone (qwen3 = the primary without secondaries; the others print only "
                          "their own block), so that a kernel trace of the run holds that workload's launches only")
-    ap.add_argument("--tp", action="store_true",
-                    help="with --gpus N > 1: ONE model tensor-parallel over the N ranks (RCCL all-reduce after every row-parallel "
-                         "linear, strong scaling) instead of N independent replicas")
+    ap.add_argument("--tp", action="store_true", help="accepted for compatibility: with --gpus N > 1 the tensor-parallel job is the default")
+    ap.add_argument("--replicas", action="store_true",
+                    help="with --gpus N > 1: N independent replicas as the primary (weak scaling, no collective) instead of ONE model "
+                         "tensor-parallel over the N ranks")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist_on = world > 1
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-
+    d = _Dist()
+    rank, world = d.rank, d.world
     import vllm_rust_amd as vmx
-    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
-    vmx.init(local_rank)
+    from vllm_rust_amd.qwen3 import Qwen3Spec
+    vmx.init(d.device)
+    plan = plan_job(args.gpus, world, args.replicas, args.weights, d.local)
 
     K_steps, W_steps = args.steps, args.warmup
     if args.workload in ("gemma4", "mixtral", "exl3"):   # one secondary alone (single GPU)
@@ -640,87 +784,50 @@ def main():
     total_tokens = args.prompt + W_steps + 2 * K_steps + 8
     block_size = 16
     n_blocks = (total_tokens + block_size - 1) // block_size + 1
-    spec = Qwen3Spec.qwen3_8b(max_position=max(4096, total_tokens + 1), num_blocks=n_blocks, block_size=block_size, max_batch=1,
-                              max_seq_len=total_tokens + 1, max_prefill_tokens=args.prompt)
+    full_spec = Qwen3Spec.qwen3_8b(max_position=max(4096, total_tokens + 1), num_blocks=n_blocks, block_size=block_size, max_batch=1,
+                                   max_seq_len=total_tokens + 1, max_prefill_tokens=args.prompt)
     if args.layers:
-        spec.num_layers = args.layers
-    use_tp = args.tp and dist_on
-    comm = None
-    full_spec = spec
-    if use_tp:
-        from vllm_rust_amd.parallel import Communicator, shard_spec
-        spec = shard_spec(spec, rank, world)   # this rank's heads / MLP columns / lm_head rows
-        comm = Communicator(rank, world)
-        allreduce_path = "RCCL ring"
-        if os.environ.get("VMX_NO_P2P_ALLREDUCE", "0") in ("", "0"):
-            try:   # the 8 KiB row-parallel sums go over peer-mapped memory in one step; RCCL keeps the larger messages
-                comm.enable_p2p(64 * 1024)
-                allreduce_path = "one-shot over peer-mapped memory (xGMI) for the row-parallel sums, RCCL for the rest"
-            except Exception as e:
-                allreduce_path = f"RCCL ring (peer-mapped path unavailable: {e})"
-    model = QuantizedQwen3ForCausalLM(spec, device=local_rank)
+        full_spec.num_layers = args.layers
     exl3 = args.weights == "exl3"
-    if exl3:
-        model.load_synthetic_exl3(bits=4, codebook=0, seed=1234 + rank)
-    else:
-        if use_tp:   # every rank slices the SAME seeded checkpoint: the TP job computes the model of the single-GPU run
-            model.load_synthetic_tp(full_spec, seed=1234)
-        else:
-            model.load_synthetic(seed=1234 + rank)
-    if comm is not None:
-        model.set_comm(comm)
-
-    dev = model.device
     B = 1
-    bt = torch.arange(n_blocks, dtype=torch.int32, device=dev).flip(0).reshape(B, n_blocks).contiguous()
-    prompt_ids = torch.randint(0, spec.vocab_size, (args.prompt,), dtype=torch.int32, device=dev,
-                               generator=torch.Generator(device=dev).manual_seed(7))
-    ids = torch.empty(B, dtype=torch.int32, device=dev)
-    P = args.prompt
-    pos = torch.full((B,), P, dtype=torch.int32, device=dev)
-    slots = (bt[:, P // block_size] * block_size + P % block_size).to(torch.int32).contiguous()
-    seq_lens = torch.full((B,), P + 1, dtype=torch.int32, device=dev)
-    out = torch.empty(B, dtype=torch.int32, device=dev)
 
-    def step():
-        model.forward_decode_batch(ids, pos, slots, bt, seq_lens, max_seq_len=spec.max_seq_len, out_ids=out)
-        model.advance(ids, out, pos, slots, seq_lens, bt)
+    # ---- the primary job
+    comm, allreduce_path, comm_note = None, None, ""
+    spec = full_spec
+    mode = plan["mode"]
+    if mode == "tp":
+        from vllm_rust_amd.parallel import shard_spec
+        ok = True
+        try:
+            comm, allreduce_path, comm_note = d.make_comm()
+        except Exception as e:   # noqa: BLE001 - a rank that cannot join the group must take the others with it, not hang them
+            comm_note = f"communicator set-up failed on rank {rank}: {e!r}"
+            ok = False
+        if not d.all_agree(ok):   # no tensor-parallel group: every rank falls back to replicas and the line says so
+            if comm is not None:
+                comm.close()
+            comm, mode = None, "replicas"
+            plan = dict(plan, mode="replicas", scaling="weak", tp=1, secondary=None)
+            comm_note = comm_note or "communicator set-up failed on a peer rank"
+        else:
+            spec = shard_spec(full_spec, rank, world)   # this rank's heads / MLP columns / lm_head rows
+    elapsed, prefill_s, model, graph, side = run_decode_job(d, args, spec, full_spec, comm, exl3, seed_per_rank=mode == "replicas")
+    comm_state = None
+    if comm is not None:
+        comm_state = {"p2p_timeouts": comm.p2p_timeouts(), "error_code": comm.error_code()}
 
-    side = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(side):
-        # prompt: one native prefill pass (all rows through the linears, MFMA prefill attention); run twice, the second timed
-        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
-        torch.cuda.synchronize()
-        tp0 = time.perf_counter()
-        model.prefill(prompt_ids, 0, bt[0], out_id=ids)
-        torch.cuda.synchronize()
-        prefill_s = time.perf_counter() - tp0
-        step()  # first decode call outside capture (lazy module load); position P -> P + 1
-        graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(graph, stream=side):
-            step()
-        for _ in range(W_steps):
-            graph.replay()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(side):
-        for _ in range(K_steps):
-            graph.replay()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    pos_after = int(pos.item())
-    assert pos_after == args.prompt + 1 + W_steps + K_steps, (pos_after, args.prompt, W_steps, K_steps)
-    if dist_on:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # ---- N > 1, tensor-parallel primary: the N-replica job as a secondary (full model per rank, no collective)
+    replicas = None
+    if mode == "tp" and not args.no_secondary:
+        model.close()
+        del model, graph
+        torch.cuda.empty_cache()
+        r_elapsed, _, model, graph, side = run_decode_job(d, args, full_spec, full_spec, None, exl3, seed_per_rank=True)
+        replicas = {"metric": "aggregate decode tok/s of N independent replicas (batch=1 each, no data-path collective)",
+                    "value": round(world * B * K_steps / r_elapsed, 2), "unit": "tok/s", "scaling": "weak", "ms_per_step": round(r_elapsed / K_steps * 1e3, 4)}
+        roofline_model = model          # full-size kernels: the same launches as the N = 1 run
+    else:
+        roofline_model = model if mode != "tp" else None
 
     # ---- roofline of the dominant kernel: the step's int4 linear launches alone (same weights, same buffers), one kind at
     # a time, captured into a graph and replayed back to back between two HIP events recorded on the stream the kernels run
@@ -728,31 +835,34 @@ def main():
     # The four linears of a layer are four different kernels (norm prologue / residual epilogue variants); `roofline` is the
     # one the step spends most time in (gate|up), `linears` lists all four and their launch-weighted total.
     roofline = None
-    if rank == 0 and not exl3:
-        kinds = time_linear_kinds(model, side, B, max(8, K_steps // 4))
+    if rank == 0 and not exl3 and roofline_model is not None:
+        kinds = time_linear_kinds(roofline_model, side, B, max(8, K_steps // 4))
         dom = max(("qkv", "o_proj", "gate_up", "down_proj"), key=lambda k: kinds[k]["us_per_step"])
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 cannot run inside this process):
         # committed summary of `rocprofv3 --pmc ... -- python3 tools/pmc_linears.py`, same kernel, same shapes.
-        traffic = None
-        try:
-            traffic = json.loads((ROOT / "profiles" / "r02_pmc_traffic_int4_gemm.json").read_text())[dom]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        traffic, traffic_source = None, None
+        for name in ("r03_pmc_traffic_int4_gemm.json", "r02_pmc_traffic_int4_gemm.json"):
+            try:
+                traffic = json.loads((ROOT / "profiles" / name).read_text())[dom]["hbm_bytes_per_launch"]
+                traffic_source = f"profiles/{name} (committed rocprofv3 --pmc pass over the same kernel and shape; not measured in this run)"
+                break
+            except Exception:
+                pass
         kernel_names = {"qkv": "int4_gemm_wide_kernel (q|k|v: RMSNorm prologue)", "o_proj": "int4_gemm_resid_kernel (o_proj: residual epilogue)",
                         "gate_up": "int4_gemm_wide_kernel<GLU> (gate|up: RMSNorm prologue, SiLU*mul epilogue)",
                         "down_proj": "int4_gemm_resid_kernel (down_proj: residual epilogue)"}
-        d = kinds[dom]
-        roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
-                    "traffic": traffic, "launches_per_step": d["launches_per_step"], "avg_launch_us": d["avg_launch_us"],
-                    "alg_bytes_per_launch": d["alg_bytes_per_launch"], "linears": kinds}
+        k = kinds[dom]
+        roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": k["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"],
+                    "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": k["launches_per_step"],
+                    "avg_launch_us": k["avg_launch_us"], "alg_bytes_per_launch": k["alg_bytes_per_launch"], "linears": kinds}
 
-    # ---- secondary (rank 0, N = 1 only): BASELINE.json's other headline model, GGUF I-quant decode
+    # ---- secondaries (rank 0, N = 1 only): BASELINE.json's other models
     secondary = None
     secondary_moe = None
     secondary_exl3 = None
     batch_sweep = None
     context_sweep = None
-    if rank == 0 and not dist_on and not args.no_secondary and not args.layers and not exl3:
+    if rank == 0 and not d.on and not args.no_secondary and not args.layers and not exl3:
         model.close()
         del model, graph
         torch.cuda.empty_cache()
@@ -774,33 +884,44 @@ def main():
         context_sweep = context_sweep_secondary(32, 4)
 
     if rank == 0:
-        tok_s = (1 if use_tp else world) * B * K_steps / elapsed
+        tok_s = (1 if mode == "tp" else world) * B * K_steps / elapsed
+        geometry = f"{full_spec.num_layers} layers, hidden {full_spec.hidden_size}, vocabulary {full_spec.vocab_size}"
+        if mode == "tp":
+            parallelism = f"tp{world}: ONE model over {world} ranks, column/row-parallel linears, all-reduce: {allreduce_path}"
+        elif mode == "replicas":
+            parallelism = f"dp{world}: {world} independent replicas (tp1 each), no data-path collective"
+        else:
+            parallelism = "tp1"
         line = {
             "metric": "decode tok/s (greedy, batch=1 per GPU), Qwen3-8B EXL3 4.0 bpw" if exl3 else
-                      "decode tok/s (greedy, batch=1 per GPU) + %HBM-peak of the int4 linear kernel, Qwen3-8B AWQ",
+                      "decode tok/s (greedy, batch=1) + %HBM-peak of the int4 linear kernel, Qwen3-8B AWQ",
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": K_steps, "warmup": W_steps,
-            "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if use_tp else "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": plan["scaling"], "vs_baseline": None,
             "dtype": "4-bit trellis weights x fp16 activations, f32 accumulate" if exl3 else "int4 weights x bf16 activations, f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": (f"Qwen3-8B EXL3 4.0 bpw greedy decode, batch=1, {args.prompt}-token prompt then timed tokens, bf16 KV" if exl3 else
-                                    f"Qwen3-8B AWQ int4 (g128) greedy decode, batch=1, {args.prompt}-token prompt (native prefill) then timed tokens, bf16 KV"),
-                       "layers": spec.num_layers, "hidden": spec.hidden_size, "vocab": spec.vocab_size,
-                       "parallelism": "tp1" if world == 1 else (f"tp{world} ({allreduce_path})" if use_tp else f"dp{world} replicas (tp1 each)"),
-                       "weights": "seeded random-init AWQ checkpoint of the Qwen3-8B architecture",
+            "config": {"workload": (f"Qwen3-8B EXL3 4.0 bpw ({geometry}) greedy decode, batch=1, {args.prompt}-token prompt then timed tokens, bf16 KV" if exl3 else
+                                    f"Qwen3-8B AWQ int4 g128 ({geometry}) greedy decode, batch=1, {args.prompt}-token prompt (native prefill) then timed tokens, bf16 KV"),
+                       "parallelism": parallelism,
+                       "weights": "seeded random-init checkpoint of the Qwen3-8B architecture" + (" (every rank slices the same one)" if mode == "tp" else ""),
                        "execution": "one hipGraph per step (decode + device-side bookkeeping)"},
-            "prefill": prefill_block(args.prompt, prefill_s, spec),
+            "prefill": prefill_block(args.prompt, prefill_s, full_spec if mode != "tp" else spec),
             "roofline": roofline,
-            "cpu_baseline": None if (args.no_cpu_baseline or exl3) else cpu_baseline(spec),
+            "cpu_baseline": None if (args.no_cpu_baseline or exl3 or d.on) else cpu_baseline(full_spec),
             "secondary": secondary,
             "secondary_moe": secondary_moe,
             "secondary_exl3": secondary_exl3,
             "batch_sweep": batch_sweep,
             "context_sweep": context_sweep,
         }
+        if d.on:
+            line["comm"] = {"state": comm_state, "note": comm_note}
+            line["replicas"] = replicas
         print(json.dumps(line), flush=True)
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+    if d.on:
+        d.barrier()
+    if comm is not None:
+        comm.close()
+    d.finish()
 
 
 if __name__ == "__main__":

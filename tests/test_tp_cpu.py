@@ -163,3 +163,23 @@ def test_gemma4_shard_spec_and_iq_block_slices():
     assert torch.equal(torch.cat(cols, 0).reshape(-1), raw)
     rows = [shard_iq_blocks(raw, L_DOWN, N, K, ts, r, 2).reshape(N, K // 512, ts) for r in range(2)]
     assert torch.equal(torch.cat(rows, 1).reshape(-1), raw)
+
+
+def test_bench_job_plan_needs_no_gpu():
+    """bench.py's argument logic: N = 1 is the single-GPU job; N > 1 measures ONE model tensor-parallel over the N ranks (the
+    metric's TP curve) with the replicas as a secondary, --replicas restores the weak-scaling job; the Qwen3-8B geometry
+    divides for 2, 4 and 8 ranks and every rank gets whole KV heads and whole quantisation groups."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert bench.plan_job(1, 1, False, "awq", False)["mode"] == "single"
+    for n in (2, 4, 8):
+        p = bench.plan_job(n, n, False, "awq", False)
+        assert (p["mode"], p["scaling"], p["tp"], p["secondary"]) == ("tp", "strong", n, "replicas")
+        assert p["shards"] == [(32 // n, 8 // n, 12288 // n, r) for r in range(n)]
+        assert (12288 // n) % 128 == 0 and (32 // n * 128) % 128 == 0
+        q = bench.plan_job(n, n, True, "awq", False)
+        assert (q["mode"], q["scaling"], q["tp"]) == ("replicas", "weak", 1)
+    with pytest.raises(ValueError):
+        bench.plan_job(3, 3, False, "awq", False)          # 8 KV heads do not divide
+    with pytest.raises(ValueError):
+        bench.plan_job(4, 2, False, "awq", False)          # --gpus must match the launcher's world size

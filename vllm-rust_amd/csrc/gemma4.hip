@@ -1139,30 +1139,59 @@ extern "C" int vmx_gemma4_mmvq_only(vmx_gemma4 *m, int batch, void *stream) {
     const vmx_gemma4_config &c = m->cfg;
     float *proj = (float *)m->proj.p, *out = (float *)m->out.p;
     const int H = c.hidden_size, mask = m->mmvq_mask;
+    uint16_t *h = (uint16_t *)m->h.p, *h2 = (uint16_t *)m->h2.p;
+    // The launches are the ones a decode step makes, in its variants: with one row the q|k|v launch of a layer behind a
+    // norm-fused gate|up carries the layer-boundary norms in its prologue, and gate|up carries the post-attention /
+    // pre-feedforward norms, the GeGLU and q8_1 (run_layers above).  Buffers hold whatever the last step left: only time is read.
+    const G4Layer *prev = nullptr;
+    bool prev_norm_in_mlp = false;
     for (const G4Layer &L : m->layers) {
         const int nseg = L.kv_shared ? 1 : (L.k_eq_v ? 2 : 3), I = L.inter;
         const int NQ = c.num_heads * L.hd, NKV = L.kvh * L.hd, ntot = NQ + (nseg - 1) * NKV;
         const IqLin *qkv[3] = {&L.lin[VMX_L_Q], &L.lin[VMX_L_K], &L.lin[VMX_L_V]};
         const int qoffs[3] = {0, NQ, NQ + NKV};
-        if (mask & 1)
-            if (int rc = mmvq_group(m, qkv, qoffs, nseg, proj, ntot, batch, st)) return rc;
+        if (mask & 1) {
+            bool done = false;
+            if (batch == 1 && prev && prev_norm_in_mlp && !prev->ple) {
+                VmxMmvqSeg pk[3];
+                for (int i = 0; i < nseg; i++)
+                    pk[i] = VmxMmvqSeg{L.lin[VMX_L_Q + i].packed.p, L.lin[VMX_L_Q + i].ggml_type, L.lin[VMX_L_Q + i].out_features, qoffs[i]};
+                if (vmx_iq_packed_norm_multi_ok(pk, nseg, H, batch)) {
+                    if (int rc = vmx_iq_mmvq_packed_norm_multi(pk, nseg, out, h2, h, (const uint16_t *)prev->post_ffn_ln.p,
+                                                               (const uint16_t *)prev->scalar.p, (const uint16_t *)L.input_ln.p, c.rms_norm_eps,
+                                                               proj, H, st))
+                        return rc;
+                    done = true;
+                }
+            }
+            if (!done)
+                if (int rc = mmvq_group(m, qkv, qoffs, nseg, proj, ntot, batch, st)) return rc;
+        }
         if (mask & 2)
             if (int rc = mmvq(m, L.lin[VMX_L_O], out, H, batch, st)) return rc;
         const IqLin *gu[2] = {&L.lin[VMX_L_GATE], &L.lin[VMX_L_UP]};
         const int goffs[2] = {0, I};
-        if (mask & 4) {   // what the step launches: the fused gate|up + GeGLU form where it applies
-            const VmxMmvqSeg gate_pk = {L.lin[VMX_L_GATE].packed.p, L.lin[VMX_L_GATE].ggml_type, L.lin[VMX_L_GATE].out_features, 0};
-            const VmxMmvqSeg up_pk = {L.lin[VMX_L_UP].packed.p, L.lin[VMX_L_UP].ggml_type, L.lin[VMX_L_UP].out_features, 0};
-            if (batch == 1 && vmx_iq_packed_geglu_ok(&gate_pk, &up_pk, H, batch)) {
+        const VmxMmvqSeg gate_pk = {L.lin[VMX_L_GATE].packed.p, L.lin[VMX_L_GATE].ggml_type, L.lin[VMX_L_GATE].out_features, 0};
+        const VmxMmvqSeg up_pk = {L.lin[VMX_L_UP].packed.p, L.lin[VMX_L_UP].ggml_type, L.lin[VMX_L_UP].out_features, 0};
+        const bool norm_in_mlp = batch == 1 && !L.ple && vmx_iq_packed_norm_geglu_ok(&gate_pk, &up_pk, H, batch);
+        if (mask & 4) {
+            int8_t *aq_b = (int8_t *)m->q8b.p;
+            float *ad_b = (float *)((char *)m->q8b.p + (((size_t)I + 255) & ~(size_t)255));
+            if (norm_in_mlp) {
+                if (int rc = vmx_iq_mmvq_packed_norm_geglu(&gate_pk, &up_pk, out, h, h2, (const uint16_t *)L.post_attn_ln.p,
+                                                           (const uint16_t *)L.pre_ffn_ln.p, c.rms_norm_eps, (uint16_t *)m->act.p, aq_b, ad_b, H, st))
+                    return rc;
+            } else if (batch == 1 && vmx_iq_packed_geglu_ok(&gate_pk, &up_pk, H, batch)) {
                 if (int rc = vmx_iq_mmvq_packed_geglu(&gate_pk, &up_pk, (const int8_t *)m->q8.p,
                                                       (const float *)((const char *)m->q8.p + (((size_t)H + 255) & ~(size_t)255)),
-                                                      (uint16_t *)m->act.p, (int8_t *)m->q8b.p,
-                                                      (float *)((char *)m->q8b.p + (((size_t)I + 255) & ~(size_t)255)), H, st))
+                                                      (uint16_t *)m->act.p, aq_b, ad_b, H, st))
                     return rc;
             } else if (int rc = mmvq_group(m, gu, goffs, 2, proj, 2 * I, batch, st)) return rc;
         }
         if (mask & 8)
             if (int rc = mmvq(m, L.lin[VMX_L_DOWN], out, H, batch, st)) return rc;
+        prev = &L;
+        prev_norm_in_mlp = norm_in_mlp;
     }
     return VMX_OK;
 }
