@@ -30,6 +30,21 @@ def test_detection_from_config_json():
     assert ckp.detect_from_json(None, None).method == "none"
 
 
+def test_detection_modelopt_follows_quant_algo():
+    """quant_method "modelopt" (detection.rs:143-160 and its tests :386-500): recognised for MXFP8 / FP8 / FP8_PER_CHANNEL_PER_TOKEN /
+    FP8_PB_WO / NVFP4, nested under "quantization" or flat, case-insensitive; any other or a missing quant_algo is "not detected" and
+    the search falls through to quantize_config.json."""
+    mo = lambda inner: json.dumps({"quantization_config": dict({"quant_method": "modelopt"}, **inner)})
+    for algo in ("MXFP8", "FP8", "FP8_PER_CHANNEL_PER_TOKEN", "FP8_PB_WO", "fp8"):
+        d = ckp.detect_from_json(mo({"quantization": {"quant_algo": algo, "kv_cache_quant_algo": "FP8"}}))
+        assert (d.method, d.method_name) == ("other", "modelopt"), algo
+    assert ckp.detect_from_json(mo({"quant_algo": "NVFP4"})).method == "other"                      # flat layout
+    assert ckp.detect_from_json(mo({"quantization": {"quant_algo": "INT8_SQ"}})).method == "none"   # unknown algorithm
+    assert ckp.detect_from_json(mo({})).method == "none"                                            # no quantization block
+    # not detected in config.json: quantize_config.json is consulted next
+    assert ckp.detect_from_json(mo({"quantization": {"quant_algo": "INT8_SQ"}}), json.dumps({"w_bit": 4, "q_group_size": 128})).method == "awq"
+
+
 def test_detection_from_quantize_config_and_directory(tmp_path):
     d = ckp.detect_from_json(None, json.dumps({"bits": 4, "group_size": 128, "desc_act": False, "sym": True, "damp_percent": 0.01}))
     assert (d.method, d.bits, d.group_size, d.desc_act) == ("gptq", 4, 128, False)

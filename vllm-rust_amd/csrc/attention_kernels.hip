@@ -1010,7 +1010,7 @@ int launch_part(dim3 grid, hipStream_t st, float *tmp_out, float *exp_sums, floa
     // four waves per partition from four tiles per partition on (contexts of 4096 tokens and more); 64- and 128-wide heads,
     // bf16 / FP8 cache, up to 8 query heads per KV head
     if constexpr ((HD == 64 || HD == 128) && (FP8 == 0 || FP8 == 1) && QPK <= 8) {
-        static const bool off = getenv("VMX_NO_PARTITION4") && atoi(getenv("VMX_NO_PARTITION4"));
+        static const bool off = vmx_tune("VMX_NO_PARTITION4", 0) != 0;
         if (tiles_per_part >= 4 && !off && hsplit == 1) {
             hipLaunchKernelGGL((paged_attn_partition4_kernel<HD, QPK, FP8>), grid, dim3(256), 0, st, tmp_out, exp_sums, max_logits, q, kc, vc,
                                bt, sl, scale, H, KVH, mbps, bs, max_parts, window, ks, vs, tiles_per_part, H / KVH);
@@ -1239,7 +1239,7 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
                               const float *k_scale, const float *v_scale, void *workspace, VmxAttnParts *out, hipStream_t st) {
     const int P = parts_for_impl(max_seq_len);
     // wide heads, many query heads per KV head, few waves: the query heads of a KV head are dealt to four waves
-    static const bool no_hsplit = getenv("VMX_NO_ATTN_HEAD_SPLIT") && atoi(getenv("VMX_NO_ATTN_HEAD_SPLIT"));
+    static const bool no_hsplit = vmx_tune("VMX_NO_ATTN_HEAD_SPLIT", 0) != 0;
     const int ratio = num_heads / num_kv_heads;
     const int hsplit = (!no_hsplit && head_dim >= 256 && ratio >= 8 && ratio % 4 == 0 && (int64_t)num_kv_heads * num_seqs * P < 1024) ? 4 : 1;
     const int qpk = qpk_capacity(ratio / hsplit);
@@ -1316,7 +1316,7 @@ extern "C" int vmx_debug_set_fused_attention(int enable) {
 }
 
 bool vmx_fused_decode_attention_ok(int head_dim, int qpk, int rot_dim, int max_seq_len, int window) {
-    if (g_fused_attn_enabled < 0) g_fused_attn_enabled = (getenv("VMX_NO_FUSED_ATTN") && atoi(getenv("VMX_NO_FUSED_ATTN"))) ? 0 : 1;
+    if (g_fused_attn_enabled < 0) g_fused_attn_enabled = (vmx_tune("VMX_NO_FUSED_ATTN", 0) != 0) ? 0 : 1;
     if (!g_fused_attn_enabled) return false;
     // 256-wide heads were measured slower here than the three-launch path (8 waves, 3+ tiles each): not covered
     if (head_dim != 64 && head_dim != 128) return false;
@@ -1362,12 +1362,12 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
 // partitions the consuming linear merges (VMX_SPLIT_LONG_MIN_CTX overrides, for measurement)
 static int split_long_min_ctx() {
     // Qwen3-8B AWQ, one row, same box: 300 tokens 563 (few partitions) vs 554 tok/s (many), 600 tokens 540 vs 551, 900 tokens 531 vs 550
-    static const int v = getenv("VMX_SPLIT_LONG_MIN_CTX") ? atoi(getenv("VMX_SPLIT_LONG_MIN_CTX")) : 512;
+    static const int v = vmx_tune("VMX_SPLIT_LONG_MIN_CTX", 512);
     return v;
 }
 static int split_parts_impl(int head_dim, int qpk, int rot_dim, int max_seq_len, int window, bool wide_heads) {
-    static const bool off = getenv("VMX_NO_SPLIT_ATTN") && atoi(getenv("VMX_NO_SPLIT_ATTN"));
-    static const int p_env = getenv("VMX_SPLIT_ATTN_P") ? atoi(getenv("VMX_SPLIT_ATTN_P")) : 0;
+    static const bool off = vmx_tune("VMX_NO_SPLIT_ATTN", 0) != 0;
+    static const int p_env = vmx_tune("VMX_SPLIT_ATTN_P", 0);
     const bool hd_ok = head_dim == 64 || head_dim == 128 || (wide_heads && head_dim == 256 && qpk <= 2);
     if (off || !hd_ok || qpk < 1 || qpk > 8) return 0;
     const int half = rot_dim / 2;
@@ -1403,13 +1403,13 @@ size_t vmx_split_decode_attention_workspace_bytes(int num_seqs, int num_heads, i
 // chip for 24 us per layer (Qwen3-8B, one row).  Returns the partition count, 0 = not covered.  VMX_NO_SPLIT_ATTN_LONG=1
 // switches the form off.
 int vmx_split_decode_attention_long_parts(int head_dim, int qpk, int rot_dim, int max_seq_len, int window, int num_kv_heads, int num_seqs) {
-    static const bool off = getenv("VMX_NO_SPLIT_ATTN_LONG") && atoi(getenv("VMX_NO_SPLIT_ATTN_LONG"));
+    static const bool off = vmx_tune("VMX_NO_SPLIT_ATTN_LONG", 0) != 0;
     if (off || !(head_dim == 64 || head_dim == 128) || qpk < 1 || qpk > 8) return 0;
     const int half = rot_dim / 2;
     if (rot_dim <= 0 || rot_dim > head_dim || !((half % 64) == 0 || (half == 32 && head_dim == 64))) return 0;
     const int ctx = window > 0 && window < max_seq_len ? window : max_seq_len;
     if (ctx <= split_long_min_ctx()) return 0;
-    static const int p_env = getenv("VMX_SPLIT_LONG_P") ? atoi(getenv("VMX_SPLIT_LONG_P")) : 0;   // measurement: force the count
+    static const int p_env = vmx_tune("VMX_SPLIT_LONG_P", 0);   // measurement: force the count
     if (p_env >= 8 && p_env <= 64) return p_env;
     // one workgroup per compute unit: measured on Qwen3-8B (8 KV heads, one row) at 1024 ... 32768 tokens, 32 partitions beat
     // 12 / 16 / 24 / 64 at every length (8192 tokens: 420 / 440 / 475 / 441 against 478 tok/s; 33 partitions = 264 workgroups

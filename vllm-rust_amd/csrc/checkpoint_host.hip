@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <new>
+#include <ctype.h>
 #include <string>
 #include <vector>
 
@@ -211,10 +212,25 @@ int method_from_name(const std::string &m, const Json *cfg) {
         if (m == e.name) return e.id;
     // the methods the reference names but this library has no kernels for (bitsandbytes, compressed-tensors, modelopt, ...)
     static const char *known[] = {"bitsandbytes", "squeezellm", "compressed-tensors", "torchao", "experts_int8", "moe_wna16", "fbgemm_fp8",
-                                  "ptpc_fp8", "mxfp4", "cpu_awq", "cpu_wna16", "inc", "auto-round", "fp_quant", "quark", "modelopt"};
-    (void)cfg;
+                                  "ptpc_fp8", "mxfp4", "cpu_awq", "cpu_wna16", "inc", "auto-round", "fp_quant", "quark"};
     for (const char *k : known)
         if (m == k) return VMX_QM_OTHER;
+    if (m == "modelopt") {
+        // detection.rs:143-160: recognised only with quant_algo MXFP8 / FP8 / FP8_PER_CHANNEL_PER_TOKEN / FP8_PB_WO / NVFP4
+        // (case-insensitive), nested under "quantization" or flat; anything else is "not detected" and the search goes on
+        const Json *algo = nullptr;
+        if (cfg) {
+            const Json *nested = cfg->get("quantization");
+            if (nested && nested->kind == Json::Obj) algo = nested->get("quant_algo");
+            if (!algo) algo = cfg->get("quant_algo");
+        }
+        if (!algo || algo->kind != Json::Str) return VMX_QM_NONE;
+        std::string a = algo->str;
+        for (char &ch : a) ch = (char)toupper((unsigned char)ch);
+        for (const char *ok : {"MXFP8", "FP8", "FP8_PER_CHANNEL_PER_TOKEN", "FP8_PB_WO", "NVFP4"})
+            if (a == ok) return VMX_QM_OTHER;
+        return VMX_QM_NONE;
+    }
     return VMX_QM_NONE;
 }
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ void sum_partials8(const float *__restrict__ partial,
     float4 a[SMAX], b[SMAX];
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {   // branch-free: a slice past the end re-reads the last one and is not added
-        const float *src = partial + min(s, splits - 1) * slice_stride + idx;
+        const float *src = partial + max(min(s, splits - 1), 0) * slice_stride + idx;   // splits == 0: slice 0 is read, nothing is added
         a[s] = *reinterpret_cast<const float4 *>(src);
         b[s] = *reinterpret_cast<const float4 *>(src + 4);
     }
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void exl3_gateup_act_kernel(const float *__res
 
 // EXL3 decode rows: h += transform(partial) and the block sums the next linear's prologue normalises with (no x row)
 bool exl3_resid_stats_ok(int tokens, int splits, int hidden) {
-    static const bool off = getenv("VMX_EXL3_NO_NORM_FUSION") && atoi(getenv("VMX_EXL3_NO_NORM_FUSION"));
+    static const bool off = vmx_tune("VMX_EXL3_NO_NORM_FUSION", 0) != 0;
     return !off && tokens <= 4 && splits > 0 && hidden % 128 == 0 && hidden <= 8192;
 }
 void launch_exl3_resid_stats(hipStream_t st, uint16_t *h, const float *partial, int splits, int tokens, int hidden, const uint16_t *had_svh,
@@ -1236,7 +1236,7 @@ bool layer_ready(const vmx_qwen3 *m, const Layer &L) {
 
 // VMX_NO_FOLDED_LAYERS=1 keeps the seven-launch layer (norm kernels of their own) for A/B measurements
 bool folded_layers_enabled() {
-    static const bool on = !(getenv("VMX_NO_FOLDED_LAYERS") && atoi(getenv("VMX_NO_FOLDED_LAYERS")));
+    static const bool on = !(vmx_tune("VMX_NO_FOLDED_LAYERS", 0) != 0);
     return on;
 }
 
@@ -1263,7 +1263,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     if (int rc = vmx_comm_check_health(m->comm, "qwen3 forward")) return rc;   // an earlier collective of this group failed
 
     // the lookup is folded into the first layer's norm kernel (VMX_NO_EMBED_FUSION=1: its own launch)
-    static const bool no_embed_fusion = getenv("VMX_NO_EMBED_FUSION") && atoi(getenv("VMX_NO_EMBED_FUSION"));
+    static const bool no_embed_fusion = vmx_tune("VMX_NO_EMBED_FUSION", 0) != 0;
     bool embed_pending = !no_embed_fusion;
     if (!embed_pending) hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
     const float *pending = nullptr;  // down-projection output (f32 slices in PB) not yet folded into the residual stream
@@ -1322,11 +1322,11 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                 return rc;
         } else if (ex && B <= 4 && L.ex_svh_qkv.p) {
             // a 128-wide head is one Hadamard block: the fused attention kernel applies the output transform of q|k|v itself
-            static const bool no_had_fusion = getenv("VMX_EXL3_NO_HAD_FUSION") && atoi(getenv("VMX_EXL3_NO_HAD_FUSION"));
+            static const bool no_had_fusion = vmx_tune("VMX_EXL3_NO_HAD_FUSION", 0) != 0;
             const bool in_attn = !no_had_fusion && hd == 128 && prefill_offset < 0 && !m->rows_share_cache &&
                                  vmx_fused_decode_attention_ok(hd, Hq / Hkv, hd, max_seq_len, 0);
             // ... and so does the attention spread over several workgroups per KV head, whose partitions o_proj merges in its prologue
-            static const bool no_ex_split = getenv("VMX_EXL3_NO_SPLIT_ATTN") && atoi(getenv("VMX_EXL3_NO_SPLIT_ATTN"));
+            static const bool no_ex_split = vmx_tune("VMX_EXL3_NO_SPLIT_ATTN", 0) != 0;
             const int ex_p = vmx_split_decode_attention_parts(hd, Hq / Hkv, hd, max_seq_len, 0);
             ex_split = in_attn && !no_ex_split && !tp && H % 128 == 0 && I % 128 == 0 && L.ex_svh_gu.p && ex_p >= 1 && ex_p <= 4;
             if (in_attn) {
@@ -1423,7 +1423,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             if (split_attn) {
                 if (int rc = vmx_int4_gemm_resid_attn(L.o.packed.p, &sparts, hd, h, ssq, B, H, NQ, L.o.group, st)) return rc;
             } else if (int rc = vmx_int4_gemm_resid(L.o.packed.p, attn, h, ssq, B, H, NQ, L.o.group, st)) return rc;
-            static const bool router_fused = !(getenv("VMX_NO_ROUTER_FUSION") && atoi(getenv("VMX_NO_ROUTER_FUSION")));
+            static const bool router_fused = !(vmx_tune("VMX_NO_ROUTER_FUSION", 0) != 0);
             if (router_fused && c.num_experts <= 8 && c.experts_per_tok <= c.num_experts && H <= 4096) {
                 // post_attention_layernorm, the dense router and the top-k softmax in one launch
                 if (H <= 2048)
@@ -1520,7 +1520,7 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         } else if (L.gate_up.glu) {  // act comes out of the GEMM epilogue
             if (int rc = L.gate_up.forward_glu(x, act, B, st)) return rc;
         } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
-        static const bool no_ex_act = getenv("VMX_EXL3_NO_WAVE_ACT") && atoi(getenv("VMX_EXL3_NO_WAVE_ACT"));
+        static const bool no_ex_act = vmx_tune("VMX_EXL3_NO_WAVE_ACT", 0) != 0;
         if (ex_fold && gu_svh && !no_ex_act) {
             hipLaunchKernelGGL(exl3_gateup_act_kernel, dim3((I / 128 + 3) / 4, B), dim3(256), 0, st, gu_src, gu_splits, B, act, I, gu_svh);
         } else if (one || !L.gate_up.glu) {

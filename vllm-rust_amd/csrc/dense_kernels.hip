@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void embedding_lookup_kernel(uint16_t *__restr
 
 int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
                           hipStream_t st) {
-    static const int mfma_min_m = getenv("VMX_DENSE_MFMA_MIN_M") ? atoi(getenv("VMX_DENSE_MFMA_MIN_M")) : 5;   // 0 disables
+    static const int mfma_min_m = vmx_tune("VMX_DENSE_MFMA_MIN_M", 5);   // 0 disables
     if (mfma_min_m > 0 && M >= mfma_min_m && K % 128 == 0) {   // GEMM-shaped: matrix cores, activations staged in k-passes
         int g16 = ((N + 15) / 16 + 3) / 4;   // 4 waves x one 16-row tile of W per round
         if (g16 > 2048) g16 = 2048;

@@ -1150,10 +1150,7 @@ constexpr int SPLIT_MAX = 4;  // consumers that fold the split-K sum into their 
 
 struct GemmPlan { int upw; int splits; };
 
-inline int tune(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+inline int tune(const char *name, int dflt) { return vmx_tune(name, dflt); }
 
 // Units per wave (-> k-blocks per workgroup, split-K slices).  One work item per workgroup and every
 // weight byte requested at kernel start: the chip streams fastest with the whole matrix in flight,
@@ -1173,7 +1170,7 @@ inline GemmPlan plan_gemm(int N, int K) {
 
 // rows from which the activation staging is looped (VMX_INT4_LOOPED_MIN_M overrides for measurement; 0 disables)
 inline bool use_looped(int M, int upw) {
-    static const int min_m = getenv("VMX_INT4_LOOPED_MIN_M") ? atoi(getenv("VMX_INT4_LOOPED_MIN_M")) : 5;
+    static const int min_m = vmx_tune("VMX_INT4_LOOPED_MIN_M", 5);
     return min_m > 0 && M >= min_m && upw >= 4;
 }
 inline size_t gemm_lds_bytes_looped(int M, int upw) {
@@ -1305,9 +1302,9 @@ extern "C" int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K,
 
 // rows beyond one MFMA row tile and whole 128-column groups: the tiled kernel (VMX_INT4_NO_TILED=1 keeps the 16-row passes)
 static bool tiled_ok(int M, int N) {
-    static const bool off = getenv("VMX_INT4_NO_TILED") && atoi(getenv("VMX_INT4_NO_TILED"));
+    static const bool off = vmx_tune("VMX_INT4_NO_TILED", 0) != 0;
     // rows from which the tiled kernel takes over (VMX_INT4_TILED_MIN_M overrides, for measurement)
-    static const int min_m = getenv("VMX_INT4_TILED_MIN_M") ? atoi(getenv("VMX_INT4_TILED_MIN_M")) : 17;
+    static const int min_m = vmx_tune("VMX_INT4_TILED_MIN_M", 17);
     return !off && M >= min_m && N % 128 == 0;
 }
 
@@ -1350,7 +1347,7 @@ bool plan_wide(int N, int K, bool glu, WidePlan *out) {
     static const int min_items = tune("VMX_INT4_MIN_ITEMS", 768);
     const int n_tiles = N / NT, kblocks = K / KB;
     int f_nwv = 0, f_upw = 0, f_ntw = 0;
-    if (const char *e = getenv(glu ? "VMX_INT4_WIDE_GLU" : "VMX_INT4_WIDE")) sscanf(e, "%d,%d,%d", &f_nwv, &f_upw, &f_ntw);
+    if (const char *e = vmx_tune_str(glu ? "VMX_INT4_WIDE_GLU" : "VMX_INT4_WIDE")) sscanf(e, "%d,%d,%d", &f_nwv, &f_upw, &f_ntw);
     bool found = false;
     for (const auto &cfg : cfgs) {
         const int nwv = cfg[0], upw = cfg[1], kbs = nwv * upw, ntw = f_nwv ? f_ntw : 1;
@@ -1374,7 +1371,7 @@ int launch_wide_m(const WidePlan &p, const uint4 *W, const uint32_t *SZ, const u
         VMX_CHECK_HIP(hipFuncSetAttribute((const void *)int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
     // VMX_INT4_DOT2=1: the one-row kernel with v_dot2c_f32_bf16 on the vector ALU instead of the matrix cores (A/B measurement)
-    static const bool dot2 = getenv("VMX_INT4_DOT2") && atoi(getenv("VMX_INT4_DOT2"));
+    static const bool dot2 = vmx_tune("VMX_INT4_DOT2", 0) != 0;
     if constexpr (MR == 1 && NTW == 1 && NWV == 4) {
         if (dot2) {
             hipLaunchKernelGGL((int4_gemm_wide_kernel<NWV, UPW, NTW, GLU, MR, true>), dim3((unsigned)((N / NT) / NTW * p.splits)), dim3(64 * NWV), lds,

@@ -646,7 +646,7 @@ template <int PPW, bool DBG, int ABL = 0, bool GLU = false, bool NORM = false> i
         }
         attr_set = true;
     }
-    static const int issue_barrier = getenv("VMX_IQ_ISSUE_BARRIER") ? atoi(getenv("VMX_IQ_ISSUE_BARRIER")) : 1;
+    static const int issue_barrier = vmx_tune("VMX_IQ_ISSUE_BARRIER", 1);
     hipLaunchKernelGGL((iq_pk_mmvq_kernel<PPW, DBG, ABL, GLU, NORM>), dim3(wgs), dim3(64 * W), lds + 512 + 8192, st, a, aq, ad, n_in, S, dbg, lds, issue_barrier);
     VMX_CHECK_LAUNCH("iq_mmvq(packed)");
     return VMX_OK;
@@ -674,7 +674,7 @@ int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
         lds = l > lds ? l : lds;
     }
     // row pairs per wave: whole units where that already gives every SIMD several waves, fewer rows per wave for small tensors
-    static const int force_ppw = getenv("VMX_IQ_PPW") ? atoi(getenv("VMX_IQ_PPW")) : 0;
+    static const int force_ppw = vmx_tune("VMX_IQ_PPW", 0);
     int ppw = units_total >= 2048 ? 4 : (units_total >= 1024 ? 2 : 1);
     if (force_ppw == 1 || force_ppw == 2 || force_ppw == 4) ppw = force_ppw;
     if (dbg) ppw = 4;
@@ -683,7 +683,7 @@ int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
     const int cus = vmx_num_cus();
     int W = (units_total * cpu_ + cus - 1) / cus;
     W = W < 1 ? 1 : (W > 16 ? 16 : W);
-    static const int force_w = getenv("VMX_IQ_W") ? atoi(getenv("VMX_IQ_W")) : 0;   // measurement only
+    static const int force_w = vmx_tune("VMX_IQ_W", 0);   // measurement only
     if (force_w >= 1 && force_w <= 16) W = force_w;
     W = ((W + S - 1) / S) * S;
     if (W > 16) W = (16 / S) * S;
@@ -707,7 +707,7 @@ int pk_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
         return pk_launch_ppw<1, false, 0, false, true>(a, wg, W, lds, nullptr, nullptr, n_in, S, nullptr, st);
     }
     if (dbg) return pk_launch_ppw<4, true>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
-    static const int abl = getenv("VMX_IQ_ABL") ? atoi(getenv("VMX_IQ_ABL")) : 0;   // measurement only: 1 = stream alone, 2 = decode alone
+    static const int abl = vmx_tune("VMX_IQ_ABL", 0);   // measurement only: 1 = stream alone, 2 = decode alone
     if (abl == 1 && ppw == 4) return pk_launch_ppw<4, false, 1>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
     if (abl == 2 && ppw == 4) return pk_launch_ppw<4, false, 2>(a, wg, W, lds, aq, ad, n_in, S, dbg, st);
     if (g_pk_stamps && ppw == 4) return pk_launch_ppw<4, false, 3>(a, wg, W, lds, aq, ad, n_in, S, (int32_t *)g_pk_stamps, st);
@@ -767,7 +767,7 @@ extern "C" int vmx_iq_pack(int ggml_type, const void *raw, void *packed, int n_o
 // at least ~2000 8-row units of one K-slice; smaller launches are bound by the launch prologue either way, and rows cut
 // into several K-slices pay an LDS combine).  VMX_IQ_PACKED_MIN_UNITS overrides the threshold (0 = always, -1 = never).
 bool vmx_iq_packed_preferred(const VmxMmvqSeg *segs, int nseg, int n_in, int m) {
-    static const int min_units = getenv("VMX_IQ_PACKED_MIN_UNITS") ? atoi(getenv("VMX_IQ_PACKED_MIN_UNITS")) : 2048;
+    static const int min_units = vmx_tune("VMX_IQ_PACKED_MIN_UNITS", 2048);
     if (m != 1 || min_units < 0 || n_in % 256) return false;
     const int S = pk_num_slices(n_in / 256);
     int units = 0;
@@ -796,7 +796,7 @@ int vmx_iq_mmvq_packed_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq,
 // Whether the gate|up pair can go through the fused GeGLU launch: one activation row, both tensors packed in the same type,
 // whole rows in one K-slice, 64 columns per workgroup, and a launch large enough for the packed kernel to be the faster one.
 bool vmx_iq_packed_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, int n_in, int m) {
-    static const int off = getenv("VMX_IQ_NO_GEGLU_FUSION") ? atoi(getenv("VMX_IQ_NO_GEGLU_FUSION")) : 0;
+    static const int off = vmx_tune("VMX_IQ_NO_GEGLU_FUSION", 0);
     if (off || gate->ggml_type != up->ggml_type || gate->n_out != up->n_out || gate->n_out % 64) return false;
     const VmxMmvqSeg both[2] = {*gate, *up};
     return vmx_iq_packed_preferred(both, 2, n_in, m);
@@ -831,7 +831,7 @@ int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const
 int vmx_iq_mmvq_packed_norm_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const float *o, const uint16_t *h_in, uint16_t *h_out,
                                   const uint16_t *w_post, const uint16_t *w_next, float eps, uint16_t *act, int8_t *aq_out, float *ad_out,
                                   int n_in, hipStream_t st) {
-    static const int off = getenv("VMX_IQ_NO_NORM_FUSION") ? atoi(getenv("VMX_IQ_NO_NORM_FUSION")) : 0;
+    static const int off = vmx_tune("VMX_IQ_NO_NORM_FUSION", 0);
     if (off || !vmx_iq_packed_geglu_ok(gate, up, n_in, 1) || n_in % 32 || n_in > 4096 || h_in == h_out) {
         vmx_set_error("iq_mmvq(packed, norm + GeGLU): not eligible (n_in %d)", n_in);
         return VMX_EUNSUPPORTED;
@@ -858,7 +858,7 @@ int vmx_iq_mmvq_packed_norm_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, 
 }
 
 bool vmx_iq_packed_norm_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, int n_in, int m) {
-    static const int off = getenv("VMX_IQ_NO_NORM_FUSION") ? atoi(getenv("VMX_IQ_NO_NORM_FUSION")) : 0;
+    static const int off = vmx_tune("VMX_IQ_NO_NORM_FUSION", 0);
     return !off && n_in % 32 == 0 && n_in <= 4096 && vmx_iq_packed_geglu_ok(gate, up, n_in, m);
 }
 
@@ -867,7 +867,7 @@ bool vmx_iq_packed_norm_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, i
 // computed by every workgroup from the previous layer's down-projection output o and the residual stream; h_out (!= h_in)
 // receives h'.  One activation row, whole rows in one K-slice, n_in <= 4096, workgroups of at least n_in / 8 threads.
 bool vmx_iq_packed_norm_multi_ok(const VmxMmvqSeg *segs, int nseg, int n_in, int m) {
-    static const int off = getenv("VMX_IQ_NO_QKV_NORM_FUSION") ? atoi(getenv("VMX_IQ_NO_QKV_NORM_FUSION")) : 0;
+    static const int off = vmx_tune("VMX_IQ_NO_QKV_NORM_FUSION", 0);
     if (off || m != 1 || nseg < 1 || nseg > 3 || n_in % 256 || n_in > 4096) return false;
     if (pk_num_slices(n_in / 256) != 1) return false;
     int units = 0;
@@ -883,7 +883,7 @@ bool vmx_iq_packed_norm_multi_ok(const VmxMmvqSeg *segs, int nseg, int n_in, int
     // 6.9 + 5.5 us for the raw-layout launch behind a norm kernel; the 9-wave plan of the full-attention layers (1 152 units, one
     // workgroup per compute unit) takes 18.1 us against 8.1 + 5.5 us in the kernel trace, so those keep the two launches (on the
     // whole step the two choices measured within noise of each other: 327-330 vs 328 tok/s)
-    static const int max_w = getenv("VMX_IQ_QKV_NORM_MAX_W") ? atoi(getenv("VMX_IQ_QKV_NORM_MAX_W")) : 8;
+    static const int max_w = vmx_tune("VMX_IQ_QKV_NORM_MAX_W", 8);
     return 64 * W * 8 >= n_in && W <= max_w;
 }
 int vmx_iq_mmvq_packed_norm_multi(const VmxMmvqSeg *segs, int nseg, const float *o, const uint16_t *h_in, uint16_t *h_out,

@@ -41,6 +41,21 @@ int vmx_num_cus(void);
 
 static inline hipStream_t vmx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Measurement switches (kernel variants kept for A/B runs, forced shapes, ablations).  The shipped library never looks at the
+// environment: every switch is its default.  `make TUNING=1` builds lib/libvmx_tuning.so, in which the same names are read
+// from the environment; nothing but the profiling scripts under tools/ loads that build.
+#ifdef VMX_TUNING
+#include <stdlib.h>
+static inline int vmx_tune(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static inline const char *vmx_tune_str(const char *name) { return getenv(name); }
+#else
+static inline int vmx_tune(const char *, int dflt) { return dflt; }
+static inline const char *vmx_tune_str(const char *) { return nullptr; }
+#endif
+
 // ---------------------------------------------------------------- device side
 #define VMX_WAVE 64
 
