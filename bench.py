@@ -196,15 +196,16 @@ def time_linear_kinds(model, side, B, reps):
     return kinds
 
 
-def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
+def gemma4_secondary(prompt, steps, warmup, cpu_leg=True, batches=(4, 16)):
     """BASELINE.json configs[2]: decode tok/s of a Gemma-4-12B-shaped GGUF model (UD-IQ3_XXS tensor-type mix, Q3_K tied token
     embedding, FP8 e4m3 KV cache with per-layer sliding/full geometry) through the Gemma 4 executor, plus the roofline of
     its dominant kernel (the q8_1 MMVQ): the step's MMVQ launches alone replayed back to back between two HIP events."""
     from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
     total = prompt + warmup + steps + 8
     n_blocks = (total + 15) // 16 + 1
-    spec = Gemma4Spec.gemma4_12b(sliding_window=1024, max_position=max(4096, total + 1), kv_cache_dtype=1, num_blocks=n_blocks,
-                                 max_batch=1, max_seq_len=total + 1, embed_ggml_type=11, final_logit_softcap=30.0,
+    BM = max((1,) + tuple(batches))
+    spec = Gemma4Spec.gemma4_12b(sliding_window=1024, max_position=max(4096, total + 1), kv_cache_dtype=1, num_blocks=n_blocks * BM,
+                                 max_batch=BM, max_seq_len=total + 1, embed_ggml_type=11, final_logit_softcap=30.0,
                                  max_prefill_tokens=prompt)   # prompt passes of more than 16 rows: dequantise once + matrix-core GEMM
     model = QuantizedGemma4ForCausalLM(spec)
     model.load_synthetic(seed=99)
@@ -270,6 +271,40 @@ def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
             kinds[name] = {"launches_per_step": launches, "avg_launch_us": round(us / launches, 3), "alg_bytes_per_launch": round(alg / launches),
                            "GB_s": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4), "us_per_step": round(us, 1)}
         model.mmvq_select(15)
+    # concurrent sequences: from five rows on the I-quant linears run on the int8 matrix cores (one decode of a sub-block for all rows)
+    by_batch = {"1": {"tok_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}}
+    bsteps = max(8, steps // 2)
+    for B in batches:
+        btb = torch.arange(n_blocks * B, dtype=torch.int32, device=dev).reshape(B, n_blocks).contiguous()
+        g7 = torch.Generator(device=dev).manual_seed(11)
+        idb = torch.empty(B, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(side):
+            for b in range(B):
+                pids = torch.randint(0, spec.vocab_size, (prompt,), dtype=torch.int32, device=dev, generator=g7)
+                model.prefill(pids, 0, btb[b], out_id=idb[b:b + 1])
+            posb = torch.full((B,), prompt, dtype=torch.int32, device=dev)
+            slotb = (btb[:, prompt // 16] * 16 + prompt % 16).to(torch.int32).contiguous()
+            slb = torch.full((B,), prompt + 1, dtype=torch.int32, device=dev)
+            outb = torch.empty(B, dtype=torch.int32, device=dev)
+
+            def stepb():
+                model.forward_decode_batch(idb, posb, slotb, btb, slb, max_seq_len=spec.max_seq_len, out_ids=outb)
+                model.advance(idb, outb, posb, slotb, slb, btb)
+            stepb()
+            gb = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gb, stream=side):
+                stepb()
+            for _ in range(warmup):
+                gb.replay()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(bsteps):
+                gb.replay()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            del gb
+        by_batch[str(B)] = {"tok_s": round(B * bsteps / tb, 1), "ms_per_step": round(tb / bsteps * 1e3, 4)}
     dom = max(("qkv", "o_proj", "gate_up", "down_proj"), key=lambda k: kinds[k]["us_per_step"])
     # the launches are the variants the step makes (vmx_gemma4_mmvq_only mirrors run_layers): norms in the prologues included
     mmvq_kernel = {"qkv": "iq_pk_mmvq_kernel<NORM> (q|k|v, three packed I-quant tensors in one launch, layer-boundary norms + q8_1 in the prologue; "
@@ -304,6 +339,7 @@ def gemma4_secondary(prompt, steps, warmup, cpu_leg=True):
                                    "token embedding), 48 layers (40 sliding 8x256 window 1024, 8 full 1x512), FP8 e4m3 KV, soft-cap 30",
                        "weights": "seeded random-init blocks of the architecture", "execution": "one hipGraph per step"},
             "weight_bytes_per_token": wbytes + embed_bytes,
+            "batch_sweep": by_batch,
             "roofline": {"bound": "hbm", "kernel": mmvq_kernel[dom], "achieved": kinds[dom]["GB_s"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kinds[dom]["frac"], "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": kinds[dom]["launches_per_step"], "avg_launch_us": kinds[dom]["avg_launch_us"],

@@ -117,6 +117,21 @@ int vmx_iq_mmvq_packed_geglu_bf16(int ggml_type, const void *gate_packed, const 
 /* Parity aid: the integer sub-dots of the packed kernel, out[o * (n_in/32) + g] (the layout of vmx_iq_subdots_i32 at m = 1). */
 int vmx_iq_subdots_packed_i32(int ggml_type, const void *packed, const int8_t *aq, int32_t *out, int n_out, int n_in, void *stream);
 
+/* mmvq_iq*_f32 for 2 .. 16 activation rows (the M <= 16 accumulators of iq_dequant.cu:388-423; batched decode) on the int8
+ * matrix cores: a sub-block is decoded once into signed int8 bytes and v_mfma_i32_16x16x32_i8 forms its dot with all rows; the
+ * integer sub-dots are the reference's bit for bit (vmx_iq_subdots_mma_i32: out[(o * m + mi) * (n_in / 32) + g], the layout of
+ * vmx_iq_subdots_i32), the f32 sums run in another order.  The weight is the 16-row-tile form vmx_iq_mma_pack makes at load
+ * time (IQ3_XXS, IQ3_S, IQ2_S; the same bytes, rows rounded up to a multiple of 16; vmx_iq_mma_packed_bytes = 0 for other
+ * types).  packed 16-byte aligned, aq 8-byte aligned, aq [m, n_in], ad [m, n_in / 32], y [m, n_out]. */
+size_t vmx_iq_mma_packed_bytes(int ggml_type, int n_out, int n_in);
+int vmx_iq_mma_pack(int ggml_type, const void *raw, void *packed, int n_out, int n_in, void *stream);
+int vmx_iq_mmvq_mma_f32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m,
+                        void *stream);
+int vmx_iq_subdots_mma_i32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, int32_t *out, int n_out, int n_in,
+                           int m, void *stream);
+/* Parity / measurement aid: rows from which the Gemma 4 executor's I-quant linears take the matrix-core form (default 5: up to four rows the per-row kernels are faster; 17 = never). */
+int vmx_debug_iq_mma_min_rows(int rows);
+
 /* Measurement aid: while buf != NULL, vmx_iq_mmvq_packed_f32 launches that work on whole 8-row units record per wave 8
  * shader-clock stamps (u64: entry, loads issued, tables built, after each of the four row pairs, end) at
  * buf[(workgroup * 16 + wave) * 10 ..]; buf must hold 160 u64 per workgroup. */

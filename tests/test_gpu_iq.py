@@ -205,6 +205,42 @@ def test_packed_mmvq_subdots_bit_exact_and_sums(gpu, name, tid, ts, n_out, n_in)
     assert np.abs(got - raw_y).max() <= 1e-5 * np.abs(raw_y).max() + 1e-6
 
 
+@pytest.mark.parametrize("name,tid,ts", PACKED_TYPES)
+@pytest.mark.parametrize("m,n_out,n_in", [(16, 6, 256), (2, 13, 768), (16, 64, 3840), (5, 40, 15360), (16, 33, 11008), (9, 2050, 512), (1, 70, 1024),
+                                           (16, 600, 4096)])
+def test_mma_mmvq_subdots_bit_exact_and_sums(gpu, name, tid, ts, m, n_out, n_in):
+    """2 .. 16 activation rows on the int8 matrix cores over the 16-row-tile form: integer sub-dots of every (row, activation
+    row, sub-block) bit for bit those of the CPU oracle, sums within the reference's MMVQ gate (rel-L2 1e-3,
+    cuda_tests.rs:100-104, M in {1, 4, 16}) and equal to the per-row kernel's up to f32 summation order.  Shapes: one
+    super-block (the reference's real blocks), ragged row counts (not a multiple of 16 or 32), Gemma's 3840 and 15360, uneven
+    K slices, more rows than one workgroup holds."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(m + n_out + n_in + tid)
+    if n_in == 256 and n_out == 6:
+        _, w_raw, _ = load_iq_fixture(name)
+    else:
+        w_raw = random_iq_blocks(rng, ts, n_out * (n_in // 256))
+    x = (rng.standard_normal((m, n_in)) * 2).astype(np.float32)
+    x[0, :64] = 0.0                                             # all-zero q8_1 blocks
+    if m > 2:
+        x[2, 5] = 300.0                                         # an outlier: the rest of its block quantises to 0 / +-1
+    aq, ad = orc.quantize_q8_1(x)
+    wd = _dev(torch, w_raw)
+    packed = vmx.iq_mma_pack(tid, wd, n_out, n_in)
+    assert packed.numel() == (n_out + 15) // 16 * 16 * (n_in // 256) * ts
+    full = (n_out // 16) * 16 * (n_in // 256) * ts              # a permutation of the same bytes (plus zero rows up to a multiple of 16)
+    assert np.array_equal(np.sort(packed.cpu().numpy()[:full]), np.sort(w_raw[:full]))
+    aqd, add = _dev(torch, aq), _dev(torch, ad)
+    got_sub = vmx.iq_subdots_mma(tid, packed, aqd, add, n_out, n_in).cpu().numpy()
+    assert np.array_equal(got_sub, orc.iq_subdots(tid, w_raw, aq, n_out, n_in))
+    got = vmx.iq_mmvq_mma(tid, packed, aqd, add, n_out, n_in).cpu().numpy()
+    ref = orc.iq_mmvq_q8(tid, w_raw, aq, ad, n_out, n_in)
+    assert np.isfinite(got).all() and rel_l2(got, ref) <= 1e-3
+    raw_y = vmx.iq_mmvq(tid, wd, aqd, add, n_out, n_in).cpu().numpy()
+    assert np.abs(got - raw_y).max() <= 1e-5 * np.abs(raw_y).max() + 1e-6
+
+
 def test_packed_rejects_types_without_packed_form(gpu):
     from vllm_rust_amd._lib import lib
     assert lib.vmx_iq_packed_bytes(17, 8, 256) == 0 and lib.vmx_iq_packed_bytes(18, 9, 512) == 16 * 2 * 98

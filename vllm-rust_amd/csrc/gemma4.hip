@@ -351,7 +351,9 @@ struct Buf {
 struct IqLin {
     int ggml_type = 0, in_features = 0, out_features = 0;
     Buf raw;
-    Buf packed;   // load-time repack for the one-row decode kernel (IQ3_XXS, IQ3_S, IQ2_S); the raw blocks stay for m > 1
+    Buf packed;   // load-time repack for the one-row decode kernel (IQ3_XXS, IQ3_S, IQ2_S)
+    Buf mma;      // 16-row-tile form of the same types for 2 .. 16 rows on the int8 matrix cores (only when max_batch > 1);
+                  // the raw blocks stay for the other types, the dequantising prompt path and the parity aids
     bool loaded = false;
     double alg_bytes(int m) const {
         return (double)out_features * (in_features / 256) * vmx_iq_type_size(ggml_type) + (double)m * in_features * (1.0 + 4.0 / 32.0) +
@@ -409,6 +411,8 @@ int8_t *aq_of(vmx_gemma4 *m) { return (int8_t *)(m->q8_alt ? m->q8_alt : m->q8.p
 float *ad_of(vmx_gemma4 *m, int tokens, int k) { return (float *)((char *)aq_of(m) + (((size_t)tokens * k + 255) & ~(size_t)255)); }
 
 // Projections that share the q8_1 activations (1..3 of them: q|k|v, gate|up, or a single one), outputs at y + off[i]
+int g_mma_min_rows = 5;   // rows from which the matrix-core MMVQ takes over from the per-row kernels (tests: vmx_debug_iq_mma_min_rows)
+
 int mmvq_group(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, float *y, int ldy, int tokens, hipStream_t st) {
     VmxMmvqSeg raw[3], pk[3];
     const int k = lins[0]->in_features;
@@ -417,6 +421,14 @@ int mmvq_group(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, 
         pk[i] = VmxMmvqSeg{lins[i]->packed.p, lins[i]->ggml_type, lins[i]->out_features, offs[i]};
     }
     if (vmx_iq_packed_preferred(pk, n, k, tokens)) return vmx_iq_mmvq_packed_multi(pk, n, aq_of(m), ad_of(m, tokens, k), y, k, st);
+    // several rows: one decode of a sub-block for all of them on the int8 matrix cores, where every tensor has that form
+    bool all_mma = tokens >= g_mma_min_rows;
+    VmxMmvqSeg mm[3];
+    for (int i = 0; i < n; i++) {
+        mm[i] = VmxMmvqSeg{lins[i]->mma.p, lins[i]->ggml_type, lins[i]->out_features, offs[i]};
+        all_mma = all_mma && lins[i]->mma.p != nullptr;
+    }
+    if (all_mma) return vmx_iq_mmvq_mma_multi(mm, n, aq_of(m), ad_of(m, tokens, k), y, k, tokens, ldy, st);
     return vmx_iq_mmvq_multi(raw, n, aq_of(m), ad_of(m, tokens, k), y, k, tokens, ldy, st);
 }
 
@@ -427,6 +439,7 @@ int mmvq(vmx_gemma4 *m, const IqLin &l, float *y, int ldy, int tokens, hipStream
         const VmxMmvqSeg pk = {l.packed.p, l.ggml_type, l.out_features, 0};
         if (vmx_iq_packed_preferred(&pk, 1, l.in_features, tokens)) return mmvq_group(m, one, off, 1, y, ldy, tokens, st);
     }
+    if (l.mma.p && tokens >= g_mma_min_rows) return mmvq_group(m, one, off, 1, y, ldy, tokens, st);
     return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq_of(m), ad_of(m, tokens, l.in_features), y, l.out_features, l.in_features, tokens, ldy, st);
 }
 
@@ -759,6 +772,12 @@ extern "C" int vmx_gemma4_load_iq_linear(vmx_gemma4 *m, int layer, int slot, int
         if (int rc = l.packed.alloc(pb)) return rc;
         if (int rc = vmx_iq_pack(ggml_type, l.raw.p, l.packed.p, l.out_features, l.in_features, stream)) return rc;
     }
+    l.mma.release();
+    if (m->cfg.max_batch > 1)
+        if (const size_t mb = vmx_iq_mma_packed_bytes(ggml_type, l.out_features, l.in_features)) {
+            if (int rc = l.mma.alloc(mb)) return rc;
+            if (int rc = vmx_iq_mma_pack(ggml_type, l.raw.p, l.mma.p, l.out_features, l.in_features, stream)) return rc;
+        }
     l.loaded = true;
     return VMX_OK;
 }
@@ -1214,5 +1233,13 @@ extern "C" int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t
     Buf *src = which == 0 ? &m->h : which == 1 ? &m->x : nullptr;
     VMX_REQUIRE(src && bytes <= src->bytes, "gemma4_debug_read: bad request");
     VMX_CHECK_HIP(hipMemcpyAsync(dst, src->p, bytes, hipMemcpyDefault, vmx_stream(stream)));
+    return VMX_OK;
+}
+
+// Parity / measurement aid: rows from which the Gemma executor's I-quant linears run on the int8 matrix cores (default 5;
+// 17 = never, i.e. the per-row kernels for every batch size).
+extern "C" int vmx_debug_iq_mma_min_rows(int rows) {
+    VMX_REQUIRE(rows >= 2 && rows <= 17, "debug_iq_mma_min_rows: %d (2 .. 17)", rows);
+    g_mma_min_rows = rows;
     return VMX_OK;
 }

@@ -335,15 +335,21 @@ extern "C" int vmx_kquant_gemv_f32(int ggml_type, const void *w, const float *x,
     VMX_REQUIRE(n_out > 0 && n_in > 0 && n_in % vmx_ggml_block_elems(ggml_type) == 0, "kquant_gemv: n_in (%d) not a multiple of the block size",
                 n_in);
     hipStream_t st = vmx_stream(stream);
-    if (ggml_type == 11 && m == 1 && n_in <= 4096) {   // lm_head-sized Q3_K x vector
+    if (ggml_type == 11 && n_in <= 4096 && (m == 1 || n_out >= 65536)) {
+        // lm_head-sized Q3_K: the one-row kernel (activations resident in registers, every weight byte fetched once), one launch
+        // per activation row -- for a vocabulary-sized table m passes of it are several times faster than the generic m-row kernel
         const int nb = n_in / 256;
         int g = (n_out + 3) / 4;
         const int cap = vmx_num_cus() * 3;
         if (g > cap) g = cap;
         const int rpw = (n_out + g * 4 - 1) / (g * 4);
         g = (n_out + rpw * 4 - 1) / (rpw * 4);
-        if (nb <= 8) hipLaunchKernelGGL((q3k_gemv_m1_kernel<1, 3>), dim3(g), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, nb, rpw);
-        else hipLaunchKernelGGL((q3k_gemv_m1_kernel<2, 3>), dim3(g), dim3(256), 0, st, (const uint8_t *)w, x, y, n_out, nb, rpw);
+        for (int r = 0; r < m; r++) {
+            const float *xr = x + (int64_t)r * n_in;
+            float *yr = y + (int64_t)r * n_out;
+            if (nb <= 8) hipLaunchKernelGGL((q3k_gemv_m1_kernel<1, 3>), dim3(g), dim3(256), 0, st, (const uint8_t *)w, xr, yr, n_out, nb, rpw);
+            else hipLaunchKernelGGL((q3k_gemv_m1_kernel<2, 3>), dim3(g), dim3(256), 0, st, (const uint8_t *)w, xr, yr, n_out, nb, rpw);
+        }
         VMX_CHECK_LAUNCH("kquant_gemv(q3_k)");
         return VMX_OK;
     }

@@ -16,14 +16,18 @@ typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x32_bf16.  Lane (i = lane & 15, g = lane >> 4) feeds row i of a 16-row block with the 8 values k0 + 8 g .. + 7,
 // read straight from global memory as one 16-byte load per operand block (the four waves of a workgroup re-read the A rows
 // through the vector L1).  No LDS, no barriers: out-of-range rows and columns read a clamped address and are not stored.
-template <bool LO>
+// KSPLIT: few output tiles (down_proj, o_proj: N = hidden) would leave most compute units idle, so the four waves of a workgroup
+// share ONE 64 x 64 tile and take a quarter of K each; the quarters are added through LDS in wave order (deterministic).
+template <bool LO, bool KSPLIT>
 __global__ __launch_bounds__(256) void split_gemm_kernel(const uint16_t *__restrict__ A, const uint16_t *__restrict__ Bhi,
                                                           const uint16_t *__restrict__ Blo, float *__restrict__ C, int M, int N, int K,
                                                           int ldc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 256 + wave * 64;
-    if (n0 >= N) return;
+    const int m0 = blockIdx.y * 64, n0 = KSPLIT ? blockIdx.x * 64 : blockIdx.x * 256 + wave * 64;
+    if (!KSPLIT && n0 >= N) return;
+    const int kq = K / 4;   // KSPLIT: K % 128 == 0
+    const int k_begin = KSPLIT ? wave * kq : 0, k_end = KSPLIT ? k_begin + kq : K;
     int64_t arow[4], brow[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(const uint16_t *__restr
     for (int rb = 0; rb < 4; rb++)
 #pragma unroll
         for (int cb = 0; cb < 4; cb++) acc[rb][cb] = sg_f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
         uint4 a[4], bh[4], bl[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -53,6 +57,32 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(const uint16_t *__restr
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, a[rb]),
                                                                           __builtin_bit_cast(vmx_bf16x8, bl[cb]), acc[rb][cb], 0, 0, 0);
             }
+    }
+    if constexpr (KSPLIT) {
+        // wave w keeps row block w: it adds the four waves' sums of that block in wave order
+        __shared__ sg_f32x4 red[4][4][4][64];   // [source wave][row block][column block][lane]: 64 KiB
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) red[wave][rb][cb][lane] = acc[rb][cb];
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            sg_f32x4 t = red[0][wave][cb][lane];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                const sg_f32x4 o = red[w][wave][cb][lane];
+                t[0] += o[0]; t[1] += o[1]; t[2] += o[2]; t[3] += o[3];
+            }
+            const int col = n0 + cb * 16 + i;
+            if (col >= N) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = m0 + wave * 16 + 4 * g + j;
+                if (row < M) C[(int64_t)row * ldc + col] = t[j];
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int rb = 0; rb < 4; rb++)
@@ -83,7 +113,12 @@ int vmx_iq_dequant_split(int ggml_type, const void *blocks, void *workspace, int
 int vmx_split_gemm_f32(const uint16_t *A, const void *workspace, float *C, int M, int N, int K, int ldc, hipStream_t st) {
     const int64_t n = (int64_t)N * K;
     const uint16_t *hi = (const uint16_t *)workspace, *lo = hi + n;
-    hipLaunchKernelGGL(split_gemm_kernel<true>, dim3((N + 255) / 256, (M + 63) / 64), dim3(256), 0, st, A, hi, lo, C, M, N, K, ldc);
+    // under about two workgroups per compute unit the four waves of a workgroup split K over one 64 x 64 tile instead
+    const int wide_wgs = ((N + 255) / 256) * ((M + 63) / 64);
+    if (wide_wgs < 2 * vmx_num_cus() && K % 128 == 0 && K >= 1024)
+        hipLaunchKernelGGL((split_gemm_kernel<true, true>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, hi, lo, C, M, N, K, ldc);
+    else
+        hipLaunchKernelGGL((split_gemm_kernel<true, false>), dim3((N + 255) / 256, (M + 63) / 64), dim3(256), 0, st, A, hi, lo, C, M, N, K, ldc);
     VMX_CHECK_LAUNCH("split_gemm");
     return VMX_OK;
 }

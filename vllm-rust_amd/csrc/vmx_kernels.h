@@ -134,6 +134,10 @@ int vmx_iq_mmvq_packed_norm_multi(const VmxMmvqSeg *segs_packed, int nseg, const
 int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up_packed, const int8_t *aq, const float *ad, uint16_t *act,
                              int8_t *aq_out, float *ad_out, int n_in, hipStream_t st);
 
+// iq_mma.hip: the same MMVQ for 2 .. 16 activation rows on the int8 matrix cores over the 16-row-tile form (vmx_iq_mma_pack)
+bool vmx_iq_mma_supported(int ggml_type);
+int vmx_iq_mmvq_mma_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int m, int ldy, hipStream_t st);
+
 // kquant_kernels.hip
 int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_t *ids, uint16_t *out, int tokens, int dim, int vocab,
                                   float scale, hipStream_t st);

@@ -11,7 +11,7 @@ import torch
 from ._lib import check, lib
 
 __all__ = [
-    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_mmvq_packed_geglu", "iq_subdots_packed",
+    "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_mmvq_packed_geglu", "iq_subdots_packed", "iq_mma_pack", "iq_mmvq_mma", "iq_subdots_mma",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
     "rms_norm", "rope_neox", "rope_gptj", "reshape_and_cache_hnd", "copy_blocks", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_f16", "paged_attention_static", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
@@ -88,6 +88,29 @@ def iq_mmvq_packed_geglu(ggml_type: int, gate_packed: torch.Tensor, up_packed: t
 def iq_subdots_packed(ggml_type: int, packed: torch.Tensor, aq: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
     out = torch.zeros((n_out, 1, n_in // 32), dtype=torch.int32, device=packed.device)
     check(lib.vmx_iq_subdots_packed_i32(ggml_type, _ptr(packed), _ptr(aq), _ptr(out), n_out, n_in, _stream()))
+    return out
+
+
+def iq_mma_pack(ggml_type: int, raw: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
+    """Load-time repack of raw I-quant blocks [n_out, n_in] into 16-row tiles for the matrix-core MMVQ (iq_mmvq_mma)."""
+    need = lib.vmx_iq_mma_packed_bytes(ggml_type, n_out, n_in)
+    packed = torch.empty(max(need, 16), dtype=torch.uint8, device=raw.device)
+    check(lib.vmx_iq_mma_pack(ggml_type, _ptr(raw), _ptr(packed), n_out, n_in, _stream()))
+    return packed
+
+
+def iq_mmvq_mma(ggml_type: int, packed: torch.Tensor, aq: torch.Tensor, ad: torch.Tensor, n_out: int, n_in: int):
+    """1 .. 16 activation rows (aq int8 [m, n_in], ad f32 [m, n_in / 32]) against 16-row-tile weights -> f32 [m, n_out]."""
+    m = aq.shape[0]
+    y = torch.empty((m, n_out), dtype=torch.float32, device=packed.device)
+    check(lib.vmx_iq_mmvq_mma_f32(ggml_type, _ptr(packed), _ptr(aq), _ptr(ad), _ptr(y), n_out, n_in, m, _stream()))
+    return y
+
+
+def iq_subdots_mma(ggml_type: int, packed: torch.Tensor, aq: torch.Tensor, ad: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
+    m = aq.shape[0]
+    out = torch.zeros((n_out, m, n_in // 32), dtype=torch.int32, device=packed.device)
+    check(lib.vmx_iq_subdots_mma_i32(ggml_type, _ptr(packed), _ptr(aq), _ptr(ad), _ptr(out), n_out, n_in, m, _stream()))
     return out
 
 
