@@ -45,6 +45,9 @@ extern "C" {
 #define VMX_KV_FP8_E4M3 1
 #define VMX_KV_INT8 2     /* symmetric int8 stored as value + 128 (quantize_int8, kv_cache/quantization.rs:330-345): the standalone cache
                            * write and decode attention take it; the whole-token executors keep bf16 / FP8 e4m3 caches */
+#define VMX_KV_FP8_E5M2 4  /* FP8 e5m2 bytes (KVCacheDtype::Fp8E5m2; read side load_kv_to_f32<fp8_e5m2_byte>, kernels/paged_attention.cu:77-82):
+                           * standalone cache write and decode attention.  The write encodes e5m2 (round to nearest even, clamp to
+                           * +-57344); the reference's own write path still stores e4m3 bytes in this mode (cache_engine.rs:218-224) */
 
 /* ------------------------------------------------------------------ runtime */
 
@@ -352,6 +355,19 @@ int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cac
                              int num_heads, int num_kv_heads, int max_blocks_per_seq, int max_seq_len,
                              int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
                              const float *v_scale, void *workspace, size_t workspace_bytes, void *stream);
+/* AttentionBackend::batched_decode_attention_with_lse (crates/core/src/layers/attention/backend.rs:99-137): the same decode
+ * attention, also returning lse [seqs, heads] f32 = ln sum_i exp(scale * q . k_i) over each head's (windowed) context: what a
+ * decode-context-parallel group exchanges to merge the ranks' partial outputs (distributed/context_parallel.rs). */
+int vmx_paged_attention_bf16_with_lse(uint16_t *out, float *lse, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                      const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs,
+                                      int num_heads, int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim,
+                                      int block_size, int window, int kv_dtype, const float *k_scale, const float *v_scale,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+/* The local half of lse_correct_and_reduce (crates/core/src/distributed/context_parallel.rs:281-315): with the ranks'
+ * statistics gathered as lse_all [ranks][rows] (rows = seqs * heads), out [rows, head_dim] f32 = attn_out (bf16) *
+ * exp(lse_all[rank] - logsumexp_r lse_all[r]); the caller's all-reduce (sum) over the group gives the merged attention. */
+int vmx_lse_correct_f32(float *out, const uint16_t *attn_out, const float *lse_all, int ranks, int rank, int64_t rows,
+                        int head_dim, void *stream);
 /* The fp16 variants of the same kernels (paged_attention_v2_f16 / _reduce_f16, crates/core/kernels/paged_attention.cu;
  * load_kv_to_f32<__half> :59-61): q, both caches and out are fp16; no quantised cache in this form. */
 int vmx_paged_attention_f16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,

@@ -226,9 +226,42 @@ static inline uint8_t orc_kv_int8_quant(uint16_t x_bf16, float scale) {
     return (uint8_t)((int)roundf(a) + 128); /* Tensor::round = round half away from zero */
 }
 
+/* FP8 e5m2 is the top byte of an IEEE half: decode through fp16 (load_kv_to_f32<fp8_e5m2_byte>, paged_attention.cu:77-82).
+ * Encode: x / scale clamped to the largest finite value 57344 and rounded through bf16 as the e4m3 writer does, then
+ * round-to-nearest-even on the 8 dropped bits of the half (exact: bf16 -> half is exact inside e5m2's range except for
+ * values under half's normal range, where the double rounding is avoided by rounding from the float directly). */
+float orc_fp8_e5m2_decode(uint8_t b) { return orc_f16_to_f32((uint16_t)((uint16_t)b << 8)); }
+
+uint8_t orc_fp8_e5m2_encode_rne(float v) {
+    uint32_t u; memcpy(&u, &v, 4);
+    uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    float a = fabsf(v);
+    if (a != a) return (uint8_t)(sign | 0x7Fu);
+    if (a > 57344.0f) a = 57344.0f;
+    /* e5m2 grid: normals 2^e * (1 + m/4), e in [-14, 15]; subnormals m * 2^-16 */
+    int e; float fr = frexpf(a, &e);          /* a = fr * 2^e, fr in [0.5, 1) */
+    if (a == 0.0f) return sign;
+    int ex = e - 1;                            /* a = (2 fr) * 2^ex, 2 fr in [1, 2) */
+    if (ex < -14) ex = -14;                    /* subnormal spacing */
+    float step = ldexpf(1.0f, ex - 2);
+    float q = a / step;                        /* exact: power-of-two scaling */
+    float r = nearbyintf(q);                   /* default rounding mode: ties to even */
+    float val = r * step;
+    (void)fr;
+    /* val is on the grid (possibly the next binade); read its bits back through half */
+    uint16_t h = orc_f32_to_f16(val);
+    return (uint8_t)(sign | (uint8_t)(h >> 8));
+}
+
+static inline uint8_t orc_kv_e5m2_quant(uint16_t x_bf16, float scale) {
+    float a = orc_bf16_to_f32(x_bf16) / scale;
+    a = a < -57344.0f ? -57344.0f : (a > 57344.0f ? 57344.0f : a);
+    return orc_fp8_e5m2_encode_rne(orc_bf16_to_f32(orc_f32_to_bf16(a)));
+}
+
 /* Scatter K/V rows [tokens, kv_heads*head_dim] into the paged cache
  * [blocks, block_size, kv_heads, head_dim]; slot < 0 skips.  kv_dtype 0 = bf16
- * copy, 1 = FP8 e4m3 with per-tensor scales. */
+ * copy, 1 = FP8 e4m3 with per-tensor scales, 2 = INT8 + 128, 4 = FP8 e5m2. */
 void orc_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
                            const int32_t *slots, int64_t tokens, int kv_heads, int head_dim,
                            int block_size, int kv_dtype, float k_scale, float v_scale) {
@@ -245,6 +278,9 @@ void orc_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_c
             } else if (kv_dtype == 2) { /* quantize_int8 (kv_cache/quantization.rs:330-345): clamp(x / scale, +-127), round, + 128 */
                 ((uint8_t *)k_cache)[dst + i] = orc_kv_int8_quant(key[t * row + i], k_scale);
                 ((uint8_t *)v_cache)[dst + i] = orc_kv_int8_quant(value[t * row + i], v_scale);
+            } else if (kv_dtype == 4) {
+                ((uint8_t *)k_cache)[dst + i] = orc_kv_e5m2_quant(key[t * row + i], k_scale);
+                ((uint8_t *)v_cache)[dst + i] = orc_kv_e5m2_quant(value[t * row + i], v_scale);
             } else {
                 ((uint8_t *)k_cache)[dst + i] = orc_kv_fp8_quant(key[t * row + i], k_scale);
                 ((uint8_t *)v_cache)[dst + i] = orc_kv_fp8_quant(value[t * row + i], v_scale);
@@ -257,6 +293,7 @@ static inline float kv_load(const void *cache, int64_t idx, int kv_dtype, float 
     if (kv_dtype == 0) return orc_bf16_to_f32(((const uint16_t *)cache)[idx]);
     if (kv_dtype == 2) return ((float)((const uint8_t *)cache)[idx] - 128.0f) * scale; /* paged_attention.cu:83-95 */
     if (kv_dtype == 3) return orc_f16_to_f32(((const uint16_t *)cache)[idx]);               /* the _f16 kernel variants, :59-61 */
+    if (kv_dtype == 4) return orc_fp8_e5m2_decode(((const uint8_t *)cache)[idx]) * scale;   /* :77-82 */
     return orc_fp8_e4m3_decode(((const uint8_t *)cache)[idx]) * scale;
 }
 
@@ -337,6 +374,37 @@ void orc_paged_attention_v2(const uint16_t *q, const void *k_cache, const void *
                 }
             }
             free(all_tmp); free(all_sum); free(all_max); free(logits);
+        }
+    }
+}
+
+/* per_seq_decode_with_lse (crates/core/src/layers/attention/naive.rs:151-205): lse[s][h] = max + ln sum exp(scores - max) over
+ * the (windowed) context, scores = scale * q . k; double accumulation here, the test carries the tolerance.  An empty
+ * context gives -inf. */
+void orc_paged_attention_lse(const uint16_t *q, const void *k_cache, const int32_t *block_tables, const int32_t *seq_lens, float scale,
+                             int64_t num_seqs, int num_heads, int num_kv_heads, int max_blocks_per_seq, int head_dim, int block_size,
+                             int window, int kv_dtype, float k_scale, double *lse) {
+    int qpk = num_heads / num_kv_heads;
+    int64_t tok_stride = (int64_t)num_kv_heads * head_dim;
+    for (int64_t s = 0; s < num_seqs; s++) {
+        int seq_len = seq_lens[s];
+        int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
+        for (int h = 0; h < num_heads; h++) {
+            int kvh = h / qpk;
+            const uint16_t *qv = q + (s * num_heads + h) * head_dim;
+            double m = -INFINITY, sum = 0.0;
+            double *sc = (double *)malloc(sizeof(double) * (size_t)(seq_len > 0 ? seq_len : 1));
+            for (int t = start; t < seq_len; t++) {
+                int blk = block_tables[s * max_blocks_per_seq + t / block_size];
+                int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * head_dim;
+                double qk = 0.0;
+                for (int d = 0; d < head_dim; d++) qk += (double)orc_bf16_to_f32(qv[d]) * (double)kv_load(k_cache, base + d, kv_dtype, k_scale);
+                sc[t] = qk * (double)scale;
+                if (sc[t] > m) m = sc[t];
+            }
+            for (int t = start; t < seq_len; t++) sum += exp(sc[t] - m);
+            lse[s * num_heads + h] = seq_len > start ? m + log(sum) : -INFINITY;
+            free(sc);
         }
     }
 }

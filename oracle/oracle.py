@@ -73,6 +73,9 @@ for _name, _res, _args in [
     ("orc_copy_blocks", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     ("orc_reshape_and_cache", None, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
     ("orc_paged_attention_v2", None, [C.c_void_p] * 5 + [C.c_float, C.c_int64] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
+    ("orc_paged_attention_lse", None, [C.c_void_p] * 4 + [C.c_float, C.c_int64] + [C.c_int] * 7 + [C.c_float, C.c_void_p]),
+    ("orc_fp8_e5m2_decode", C.c_float, [C.c_uint8]),
+    ("orc_fp8_e5m2_encode_rne", C.c_uint8, [C.c_float]),
     ("orc_q6k_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_q4_0_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
     ("orc_q8_0_dequant", None, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -379,6 +382,24 @@ def paged_attention_v2(q_bf16, k_cache, v_cache, block_tables, seq_lens, scale: 
                                 num_kv_heads, bt.shape[1], head_dim, block_size, partition_size, window, kv_dtype,
                                 k_scale, v_scale, _p(out))
     return out
+
+
+def paged_attention_lse(q_bf16, k_cache, block_tables, seq_lens, scale: float, num_heads: int, num_kv_heads: int, head_dim: int,
+                        block_size: int, window: int = 0, kv_dtype: int = 0, k_scale: float = 1.0) -> np.ndarray:
+    """float64 [seqs, heads]: ln sum exp(scale * q . k) per head over its (windowed) context."""
+    q, bt, sl = _c(q_bf16, np.uint16), _c(block_tables, np.int32), _c(seq_lens, np.int32)
+    out = np.empty((sl.size, num_heads), np.float64)
+    _lib.orc_paged_attention_lse(_p(q), _p(k_cache), _p(bt), _p(sl), scale, sl.size, num_heads, num_kv_heads, bt.shape[1], head_dim,
+                                 block_size, window, kv_dtype, k_scale, _p(out))
+    return out
+
+
+def fp8_e5m2_decode(b: int) -> float:
+    return float(_lib.orc_fp8_e5m2_decode(b))
+
+
+def fp8_e5m2_encode_rne(v: float) -> int:
+    return int(_lib.orc_fp8_e5m2_encode_rne(v))
 
 
 def q6k_dequant(data) -> np.ndarray:

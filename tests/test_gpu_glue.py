@@ -359,6 +359,109 @@ def test_paged_attention_int8_kv(gpu, H, KVH, D):
         assert np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum()) <= 1e-3 + 2 ** -8
 
 
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (4, 4, 64)])
+def test_paged_attention_fp8_e5m2_kv(gpu, H, KVH, D):
+    """FP8 e5m2 KV cache (KVCacheDtype::Fp8E5m2; the read side is load_kv_to_f32<fp8_e5m2_byte>, kernels/paged_attention.cu:77-82):
+    the bytes vmx_reshape_and_cache writes are the oracle's round-to-nearest-even e5m2 of clamp(x / scale, +-57344), and decode
+    attention over them matches the oracle within the floating-point bar.  (The reference's own cache engine still writes
+    e4m3 bytes in this mode, cache_engine.rs:217-223; a caller that wants those passes VMX_KV_FP8_E4M3 to the write.)"""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(H + D + 11)
+    BS, NB, MB = 16, 48, 24
+    seq_lens = np.array([1, 37, 300], np.int32)
+    S = len(seq_lens)
+    T = NB * BS
+    k = orc.f32_to_bf16((rng.standard_normal((T, KVH * D)) * np.exp(rng.uniform(-12, 3, (T, 1)))).astype(np.float32))   # down into subnormals
+    v = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    ks = 1.0
+    vs = float(np.abs(orc.bf16_to_f32(v)).max() * 0.5 / 57344.0)    # half the range: exercises the clamp
+    slots = rng.permutation(T).astype(np.int32)
+    kc = np.zeros((NB, BS, KVH, D), np.uint8); vc = np.zeros_like(kc)
+    orc.reshape_and_cache(k, v, kc, vc, slots, KVH, D, BS, 4, ks, vs)
+    assert (vc & 0x7F).max() == 0x7B and (kc & 0x7F).min() == 0 and 0 < (kc & 0x7F)[(kc & 0x7F) > 0].min() < 4
+    kcd = torch.zeros((NB, BS, KVH, D), dtype=torch.uint8, device="cuda"); vcd = torch.zeros_like(kcd)
+    sk = torch.tensor([ks], dtype=torch.float32, device="cuda"); sv = torch.tensor([vs], dtype=torch.float32, device="cuda")
+    vmx.reshape_and_cache(_bf(torch, k), _bf(torch, v), kcd, vcd, torch.from_numpy(slots).cuda(), KVH, D, BS, 4, sk, sv)
+    assert np.array_equal(kcd.cpu().numpy(), kc) and np.array_equal(vcd.cpu().numpy(), vc)
+    # attention over a cache of ordinary magnitudes
+    k2 = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    ks2 = float(np.abs(orc.bf16_to_f32(k2)).max() / 57344.0)
+    orc.reshape_and_cache(k2, v, kc, vc, slots, KVH, D, BS, 4, ks2, vs)
+    kcd, vcd = torch.from_numpy(kc).cuda(), torch.from_numpy(vc).cuda()
+    sk = torch.tensor([ks2], dtype=torch.float32, device="cuda")
+    bt = np.stack([rng.permutation(NB)[:MB] for _ in range(S)]).astype(np.int32)
+    q = orc.f32_to_bf16(rng.standard_normal((S, H * D)).astype(np.float32))
+    scale = float(1.0 / np.sqrt(D))
+    for window in (0, 100):
+        got = _u16(torch, vmx.paged_attention(_bf(torch, q), kcd, vcd, torch.from_numpy(bt).cuda(), torch.from_numpy(seq_lens).cuda(),
+                                              scale, H, KVH, D, BS, int(seq_lens.max()), window, 4, sk, sv))
+        ref = orc.paged_attention_v2(q, kc, vc, bt, seq_lens, scale, H, KVH, D, BS, 256, window, 4, ks2, vs)
+        g, r = orc.bf16_to_f32(got), orc.bf16_to_f32(ref)
+        assert np.abs(g - r).max() <= (1e-3 + 2 ** -7) * np.abs(r).max(), window
+        assert np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum()) <= 1e-3 + 2 ** -8
+
+
+@pytest.mark.parametrize("H,KVH,D,kvt", [(32, 8, 128, 0), (16, 8, 256, 0), (4, 4, 64, 1), (32, 8, 128, 1), (16, 1, 512, 0)])
+def test_paged_attention_with_lse_and_context_parallel_merge(gpu, H, KVH, D, kvt):
+    """batched_decode_attention_with_lse (layers/attention/backend.rs:113, naive.rs:151-205): the output is the plain entry point's
+    bit for bit and lse = ln sum exp(scale * q . k) within 1e-4 of the oracle's float64 value (absolute; the statistic is O(1..10)),
+    -inf for an empty context.  Then the use it exists for (lse_correct_and_reduce, distributed/context_parallel.rs:281-315): the
+    context dealt to 3 ranks in interleaved blocks, each rank's attention over its own slice corrected with the gathered
+    statistics, and the shares summed -- equal to attention over the whole context within the bf16 bar."""
+    from oracle import oracle as orc
+    vmx, torch = gpu
+    rng = np.random.default_rng(H + D + kvt)
+    BS, NB, MB = 16, 160, 130
+    seq_lens = np.array([0, 1, 37, 300, 2050], np.int32)
+    S = len(seq_lens)
+    T = NB * BS
+    k = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    v = orc.f32_to_bf16(rng.standard_normal((T, KVH * D)).astype(np.float32))
+    ks, vs = (float(np.abs(orc.bf16_to_f32(k)).max() / 448.0), float(np.abs(orc.bf16_to_f32(v)).max() / 448.0)) if kvt else (1.0, 1.0)
+    kc = np.zeros((NB, BS, KVH, D), np.uint8 if kvt else np.uint16); vc = np.zeros_like(kc)
+    orc.reshape_and_cache(k, v, kc, vc, np.arange(T, dtype=np.int32), KVH, D, BS, kvt, ks, vs)
+    dev = lambda a: torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).cuda()
+    kcd, vcd = dev(kc), dev(vc)
+    if not kvt:
+        kcd, vcd = kcd.view(torch.bfloat16), vcd.view(torch.bfloat16)
+    sk = torch.tensor([ks], dtype=torch.float32, device="cuda"); sv = torch.tensor([vs], dtype=torch.float32, device="cuda")
+    bt = np.stack([rng.permutation(NB)[:MB] for _ in range(S)]).astype(np.int32)
+    q = orc.f32_to_bf16(rng.standard_normal((S, H * D)).astype(np.float32))
+    scale = float(1.0 / np.sqrt(D))
+    btd, sld = torch.from_numpy(bt).cuda(), torch.from_numpy(seq_lens).cuda()
+    for window in (0, 100):
+        plain = vmx.paged_attention(_bf(torch, q), kcd, vcd, btd, sld, scale, H, KVH, D, BS, int(seq_lens.max()), window, kvt, sk, sv)
+        out, lse = vmx.paged_attention_with_lse(_bf(torch, q), kcd, vcd, btd, sld, scale, H, KVH, D, BS, int(seq_lens.max()), window, kvt, sk, sv)
+        assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+        want = orc.paged_attention_lse(q, kc, bt, seq_lens, scale, H, KVH, D, BS, window, kvt, ks)
+        got = lse.cpu().numpy().astype(np.float64)
+        assert np.all(np.isneginf(got[0])) and np.all(np.isneginf(want[0]))
+        assert np.abs(got[1:] - want[1:]).max() <= 1e-4, (window, np.abs(got[1:] - want[1:]).max())
+    # ---- context-parallel merge: rank r holds the context's blocks r, r + R, ... (interleave = one cache block)
+    R = 3
+    full = orc.bf16_to_f32(_u16(torch, vmx.paged_attention(_bf(torch, q), kcd, vcd, btd, sld, scale, H, KVH, D, BS, int(seq_lens.max()), 0, kvt, sk, sv)))
+    outs, lses = [], []
+    for r in range(R):
+        nblk = (seq_lens + BS - 1) // BS
+        bt_r = np.zeros_like(bt); sl_r = np.zeros_like(seq_lens)
+        for s in range(S):
+            mine = [b for b in range(nblk[s]) if b % R == r]
+            bt_r[s, :len(mine)] = bt[s, mine]
+            sl_r[s] = sum(min(BS, seq_lens[s] - b * BS) for b in mine)
+        o, l = vmx.paged_attention_with_lse(_bf(torch, q), kcd, vcd, torch.from_numpy(bt_r).cuda(), torch.from_numpy(sl_r).cuda(), scale,
+                                            H, KVH, D, BS, int(max(sl_r.max(), 1)), 0, kvt, sk, sv)
+        outs.append(o); lses.append(l)
+    lse_all = torch.stack(lses).contiguous()                      # [R, S, H]: what the all-gather hands every rank
+    merged = sum(vmx.lse_correct(outs[r], lse_all, r, D) for r in range(R)).cpu().numpy().reshape(S, H * D)
+    assert np.all(merged[0] == 0)
+    assert np.abs(merged[1:] - full[1:]).max() <= (1e-3 + 2 ** -7) * np.abs(full[1:]).max()
+    assert np.sqrt(((merged[1:] - full[1:]) ** 2).sum() / (full[1:] ** 2).sum()) <= 1e-3 + 2 ** -8
+    from vllm_rust_amd._lib import lib
+    assert lib.vmx_lse_correct_f32(None, None, None, 1, 0, 1, 64, None) != 0
+    assert lib.vmx_lse_correct_f32(merged.ctypes.data, merged.ctypes.data, merged.ctypes.data, 2, 2, 1, 64, None) != 0
+
+
 @pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (16, 8, 256), (4, 4, 64), (16, 1, 512)])
 def test_paged_attention_f16(gpu, H, KVH, D):
     """The fp16 kernel variants (paged_attention_v2_f16 / _reduce_f16): fp16 q, cache and output against the oracle's fp16 form."""

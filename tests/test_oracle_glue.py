@@ -217,3 +217,37 @@ def test_int8_kv_quantiser_known_values():
     orc.reshape_and_cache(k, k, kc, vc, np.array([0], np.int32), 1, 8, 1, 2, 1.0, 0.5)
     assert kc.reshape(-1).tolist() == [128, 129, 127, 129, 127, 130, 255, 1]
     assert vc.reshape(-1).tolist() == [128, 130, 126, 129, 127, 131, 255, 1]
+
+
+def test_fp8_e5m2_is_the_top_byte_of_a_half_and_rounds_to_nearest_even():
+    """load_kv_to_f32<fp8_e5m2_byte> (kernels/paged_attention.cu:77-82): the byte is the high half of an IEEE fp16."""
+    vals = [orc.fp8_e5m2_decode(b) for b in range(0x7C)]         # 0 .. 57344, increasing; 0x7C is inf
+    assert vals[0x3C] == 1.0 and vals[0x7B] == 57344.0 and vals[1] == 2.0 ** -16
+    for b, v in enumerate(vals):
+        assert v == float(np.array([b << 8], np.uint16).view(np.float16)[0])
+        assert orc.fp8_e5m2_encode_rne(v) == b and orc.fp8_e5m2_encode_rne(-v) == (b | 0x80)
+    for b in range(0x7B):
+        mid = (vals[b] + vals[b + 1]) / 2.0
+        assert orc.fp8_e5m2_encode_rne(mid) == (b if b % 2 == 0 else b + 1)
+        assert orc.fp8_e5m2_encode_rne(np.nextafter(np.float32(mid), np.float32(1e9))) == b + 1
+        assert orc.fp8_e5m2_encode_rne(np.nextafter(np.float32(mid), np.float32(-1e9))) == b
+    assert orc.fp8_e5m2_encode_rne(1e9) == 0x7B and orc.fp8_e5m2_encode_rne(-1e9) == 0xFB     # clamp, never inf
+
+
+def test_paged_attention_lse_matches_dense_logsumexp():
+    """per_seq_decode_with_lse (layers/attention/naive.rs:151-205) on a paged cache against float64 numpy."""
+    rng = np.random.default_rng(5)
+    H, KVH, D, BS, NB, MB = 4, 2, 64, 16, 8, 4
+    seq_lens = np.array([0, 1, 37], np.int32)
+    kc = orc.f32_to_bf16(rng.standard_normal((NB, BS, KVH, D)).astype(np.float32))
+    q = orc.f32_to_bf16(rng.standard_normal((3, H * D)).astype(np.float32))
+    bt = np.stack([rng.permutation(NB)[:MB] for _ in range(3)]).astype(np.int32)
+    lse = orc.paged_attention_lse(q, kc, bt, seq_lens, 0.125, H, KVH, D, BS, window=20)
+    assert np.all(np.isneginf(lse[0]))
+    kf, qf = orc.bf16_to_f32(kc).astype(np.float64), orc.bf16_to_f32(q).astype(np.float64).reshape(3, H, D)
+    for s in (1, 2):
+        n = int(seq_lens[s]); start = max(n - 20, 0)
+        for h in range(H):
+            keys = np.stack([kf[bt[s, t // BS], t % BS, h // (H // KVH)] for t in range(start, n)])
+            sc = keys @ qf[s, h] * 0.125
+            assert abs(lse[s, h] - (sc.max() + np.log(np.exp(sc - sc.max()).sum()))) < 1e-12

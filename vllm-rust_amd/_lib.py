@@ -104,6 +104,8 @@ _SIGS = {
     "vmx_reshape_and_cache": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vmx_paged_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vmx_paged_attention_bf16": (_i, [_p] * 6 + [_f] + [_i] * 9 + [_p, _p, _p, _sz, _p]),
+    "vmx_paged_attention_bf16_with_lse": (_i, [_p] * 7 + [_f] + [_i] * 9 + [_p, _p, _p, _sz, _p]),
+    "vmx_lse_correct_f32": (_i, [_p, _p, _p, _i, _i, _i64, _i, _p]),
     "vmx_paged_attention_f16": (_i, [_p] * 6 + [_f] + [_i] * 8 + [_p, _sz, _p]),
     "vmx_paged_attention_static_max_bytes": (_sz, []),
     "vmx_paged_attention_bf16_static": (_i, [_p] * 6 + [_f] + [_i] * 9 + [_p, _p, _p]),

@@ -44,7 +44,8 @@ namespace {
 // Raw (unconverted) cache accesses, so that many rows can wait in registers cheaply.
 // FP8: the cache's element type as a template value -- 0 bf16, 1 FP8 e4m3 bytes, 2 INT8 bytes stored as value + 128
 // (load_kv_to_f32<int8_t>, crates/core/kernels/paged_attention.cu:83-95), 3 fp16 with fp16 queries (the paged_attention_*_f16
-// variants: load_kv_to_f32<__half>, :59-61); callers that know only bf16 / e4m3 pass false / true.
+// variants: load_kv_to_f32<__half>, :59-61), 4 FP8 e5m2 bytes (load_kv_to_f32<fp8_e5m2_byte>, :77-82); callers that know only
+// bf16 / e4m3 pass false / true.
 template <int FP8> struct Raw8 { using T = uint2; };
 template <> struct Raw8<0> { using T = uint4; };
 template <> struct Raw8<3> { using T = uint4; };
@@ -75,6 +76,15 @@ template <int FP8> __device__ __forceinline__ void cvt8(const typename Raw8<FP8>
         const uint32_t w[2] = {v.x, v.y};
 #pragma unroll
         for (int j = 0; j < 8; j++) f[j] = ((float)((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) - 128.0f) * scale;
+    } else if constexpr (FP8 == 4) {
+        f[0] = __builtin_amdgcn_cvt_f32_bf8(v.x, 0) * scale;
+        f[1] = __builtin_amdgcn_cvt_f32_bf8(v.x, 1) * scale;
+        f[2] = __builtin_amdgcn_cvt_f32_bf8(v.x, 2) * scale;
+        f[3] = __builtin_amdgcn_cvt_f32_bf8(v.x, 3) * scale;
+        f[4] = __builtin_amdgcn_cvt_f32_bf8(v.y, 0) * scale;
+        f[5] = __builtin_amdgcn_cvt_f32_bf8(v.y, 1) * scale;
+        f[6] = __builtin_amdgcn_cvt_f32_bf8(v.y, 2) * scale;
+        f[7] = __builtin_amdgcn_cvt_f32_bf8(v.y, 3) * scale;
     } else {
         f[0] = __builtin_amdgcn_cvt_f32_fp8(v.x, 0) * scale;
         f[1] = __builtin_amdgcn_cvt_f32_fp8(v.x, 1) * scale;
@@ -102,6 +112,9 @@ template <int FP8> __device__ __forceinline__ void cvt2(uint32_t w, float scale,
     } else if constexpr (FP8 == 2) {
         a = ((float)(w & 0xFFu) - 128.0f) * scale;
         b = ((float)((w >> 8) & 0xFFu) - 128.0f) * scale;
+    } else if constexpr (FP8 == 4) {
+        a = __builtin_amdgcn_cvt_f32_bf8(w, 0) * scale;
+        b = __builtin_amdgcn_cvt_f32_bf8(w, 1) * scale;
     } else {
         a = __builtin_amdgcn_cvt_f32_fp8(w, 0) * scale;
         b = __builtin_amdgcn_cvt_f32_fp8(w, 1) * scale;
@@ -411,13 +424,18 @@ __global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__rest
                                                                  const float *__restrict__ max_logits,
                                                                  const int32_t *__restrict__ seq_lens, int num_heads, int head_dim,
                                                                  int max_parts, int window, int part_tokens, int8_t *__restrict__ aq,
-                                                                 float *__restrict__ ad, int out_f16) {
+                                                                 float *__restrict__ ad, int out_f16, float *__restrict__ lse = nullptr) {
+    // lse (optional) [seqs][heads]: natural-log sum of exp of the head's scaled logits over its whole context, the statistic
+    // batched_decode_attention_with_lse hands to the decode-context-parallel merge (layers/attention/backend.rs:99-137)
     __shared__ float w_s[64];
     __shared__ float inv_s;
     __shared__ float acc_s[512];
     const int head = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
     const int seq_len = seq_lens[seq];
-    if (seq_len == 0) return;
+    if (seq_len == 0) {   // no context: the output row stays as the caller left it; the statistic of an empty sum is -inf
+        if (lse && tid == 0) lse[(int64_t)seq * num_heads + head] = -INFINITY;
+        return;
+    }
     const int eff = (window > 0 && seq_len > window) ? window : seq_len;
     // part_tokens == 0: the producer dealt the tiles to max_parts balanced ranges (split_decode_attn_kernel; a range without
     // tokens carries sum 0 and weighs nothing)
@@ -444,7 +462,10 @@ __global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__rest
             const float w = tid < np ? sm * __expf(mx - gmax) : 0.f;
             const float gsum = vmx_wave_sum(w);
             w_s[tid] = w;
-            if (tid == 0) inv_s = 1.0f / (gsum + 1e-6f);
+            if (tid == 0) {
+                inv_s = 1.0f / (gsum + 1e-6f);
+                if (lse) lse[(int64_t)seq * num_heads + head] = gmax + logf(gsum);
+            }
         }
         __syncthreads();
         inv = inv_s;
@@ -466,6 +487,7 @@ __global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__rest
         float val;
         if (np == 1) {
             val = tp[d];
+            if (lse && d == 0) lse[(int64_t)seq * num_heads + head] = max_logits[mo] + logf(exp_sums[mo]);
         } else {
             float acc = 0.f;
             for (int k = 0; k < G; k++) acc += acc_s[k * head_dim + d];
@@ -1253,12 +1275,12 @@ int vmx_paged_attention_parts(const uint16_t *q, const void *k_cache, const void
     const int tpp = tiles_per_part_for(max_seq_len);
     out->part_tokens = tpp * 16;
     const dim3 grid(num_kv_heads * hsplit, num_seqs, P);
-    const int kvt = kv_dtype == VMX_KV_F16_INTERNAL ? 3 : (kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0));
+    const int kvt = kv_dtype == VMX_KV_F16_INTERNAL ? 3 : (kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : (kv_dtype == VMX_KV_FP8_E5M2 ? 4 : 0)));
     int rc = VMX_EUNSUPPORTED;
 #define ARGS grid, st, tmp_out, exp_sums, max_logits, q, k_cache, v_cache, block_tables, seq_lens, scale, num_heads, num_kv_heads, \
              max_blocks_per_seq, block_size, P, window, k_scale, v_scale, tpp, hsplit
 #define BY_KV(HD, Q)                                                                                                       \
-    rc = kvt == 3 ? launch_part<HD, Q, 3>(ARGS)                                                                            \
+    rc = kvt == 4 ? launch_part<HD, Q, 4>(ARGS) : kvt == 3 ? launch_part<HD, Q, 3>(ARGS)                                     \
                   : (kvt == 2 ? launch_part<HD, Q, 2>(ARGS) : (kvt == 1 ? launch_part<HD, Q, 1>(ARGS) : launch_part<HD, Q, 0>(ARGS)))
 #define BY_QPK(HD)                                                                                                         \
     switch (qpk) {                                                                                                         \
@@ -1473,12 +1495,12 @@ static int paged_attention_impl(uint16_t *out, const uint16_t *q, const void *k_
                                 const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs, int num_heads,
                                 int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim, int block_size,
                                 int window, int kv_dtype, const float *k_scale, const float *v_scale, void *workspace,
-                                size_t workspace_bytes, void *stream, int f16) {
+                                size_t workspace_bytes, void *stream, int f16, float *lse = nullptr) {
     VMX_REQUIRE(out && q && k_cache && v_cache && block_tables && seq_lens && workspace, "paged_attention: null pointer");
     VMX_REQUIRE(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
                 "paged_attention: num_heads (%d) must be a multiple of num_kv_heads (%d)", num_heads, num_kv_heads);
     VMX_REQUIRE(block_size > 0 && max_blocks_per_seq > 0 && window >= 0, "paged_attention: bad cache geometry");
-    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || (!f16 && (kv_dtype == VMX_KV_FP8_E4M3 || kv_dtype == VMX_KV_INT8)),
+    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || (!f16 && (kv_dtype == VMX_KV_FP8_E4M3 || kv_dtype == VMX_KV_INT8 || kv_dtype == VMX_KV_FP8_E5M2)),
                 "paged_attention: unsupported kv dtype %d%s", kv_dtype, f16 ? " (the fp16 form takes an fp16 cache only)" : "");
     VMX_REQUIRE(workspace_bytes >= vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len),
                 "paged_attention: workspace too small");
@@ -1491,7 +1513,7 @@ static int paged_attention_impl(uint16_t *out, const uint16_t *q, const void *k_
         return rc;
     hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3(num_heads, num_seqs), dim3(512), 0, st, out, parts.tmp_out, parts.exp_sums,
                        parts.max_logits, seq_lens, num_heads, head_dim, parts.max_parts, window, parts.part_tokens, (int8_t *)nullptr,
-                       (float *)nullptr, f16);
+                       (float *)nullptr, f16, lse);
     VMX_CHECK_LAUNCH("paged_attention(reduce)");
     return VMX_OK;
 }
@@ -1503,6 +1525,49 @@ extern "C" int vmx_paged_attention_bf16(uint16_t *out, const uint16_t *q, const 
                                         size_t workspace_bytes, void *stream) {
     return paged_attention_impl(out, q, k_cache, v_cache, block_tables, seq_lens, scale, num_seqs, num_heads, num_kv_heads, max_blocks_per_seq,
                                 max_seq_len, head_dim, block_size, window, kv_dtype, k_scale, v_scale, workspace, workspace_bytes, stream, 0);
+}
+
+// AttentionBackend::batched_decode_attention_with_lse (layers/attention/backend.rs:99-137): the same decode attention, plus
+// lse [seqs, heads] f32 = log sum_i exp(scale * q . k_i) over each head's context (natural log)
+extern "C" int vmx_paged_attention_bf16_with_lse(uint16_t *out, float *lse, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                                 const int32_t *block_tables, const int32_t *seq_lens, float scale, int num_seqs,
+                                                 int num_heads, int num_kv_heads, int max_blocks_per_seq, int max_seq_len, int head_dim,
+                                                 int block_size, int window, int kv_dtype, const float *k_scale, const float *v_scale,
+                                                 void *workspace, size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(lse, "paged_attention_with_lse: null pointer");
+    return paged_attention_impl(out, q, k_cache, v_cache, block_tables, seq_lens, scale, num_seqs, num_heads, num_kv_heads, max_blocks_per_seq,
+                                max_seq_len, head_dim, block_size, window, kv_dtype, k_scale, v_scale, workspace, workspace_bytes, stream, 0, lse);
+}
+
+// lse_correct_and_reduce, the local half (crates/core/src/distributed/context_parallel.rs:281-315): every decode-context-parallel
+// rank holds attention over its own slice of the context plus that slice's log-sum-exp; with the statistics of all ranks gathered
+// (lse_all [ranks][rows], rows = seqs * heads) the rank's share of the full result is attn * exp(lse_local - logsumexp_r lse_r).
+// The shares are then summed by an all-reduce.  f32 out so that the sum over ranks rounds once; a row whose every rank is
+// empty (-inf everywhere) gives zeros.  grid (rows), block 64.
+__global__ __launch_bounds__(64) void lse_correct_kernel(float *__restrict__ out, const uint16_t *__restrict__ attn,
+                                                        const float *__restrict__ lse_all, int ranks, int rank, int64_t rows, int head_dim) {
+    const int64_t row = blockIdx.x;
+    float mx = -INFINITY;
+    for (int r = 0; r < ranks; r++) mx = fmaxf(mx, lse_all[(int64_t)r * rows + row]);
+    float c = 0.0f;
+    if (mx != -INFINITY) {
+        float sum = 0.0f;
+        for (int r = 0; r < ranks; r++) sum += expf(lse_all[(int64_t)r * rows + row] - mx);
+        c = expf(lse_all[(int64_t)rank * rows + row] - (mx + logf(sum)));
+    }
+    for (int d = threadIdx.x; d < head_dim; d += 64) out[row * head_dim + d] = c != 0.0f ? vmx_bf16_to_f32(attn[row * head_dim + d]) * c : 0.0f;
+}
+
+extern "C" int vmx_lse_correct_f32(float *out, const uint16_t *attn_out, const float *lse_all, int ranks, int rank, int64_t rows,
+                                   int head_dim, void *stream) {
+    VMX_REQUIRE(out && attn_out && lse_all, "lse_correct: null pointer");
+    VMX_REQUIRE(ranks > 0 && rank >= 0 && rank < ranks && rows >= 0 && head_dim > 0, "lse_correct: rank %d of %d, %lld rows of %d", rank, ranks,
+                (long long)rows, head_dim);
+    if (rows == 0) return VMX_OK;
+    hipLaunchKernelGGL(lse_correct_kernel, dim3((unsigned)rows), dim3(64), 0, vmx_stream(stream), out, attn_out, lse_all, ranks, rank, rows,
+                       head_dim);
+    VMX_CHECK_LAUNCH("lse_correct");
+    return VMX_OK;
 }
 
 // paged_attention_v2_f16 + paged_attention_v2_reduce_f16 (crates/core/kernels/paged_attention.cu): fp16 queries, fp16 cache, fp16 output

@@ -252,6 +252,15 @@ __global__ __launch_bounds__(256) void reshape_and_cache_kernel(const uint16_t *
             ((uint8_t *)k_cache)[dst + i] = (uint8_t)((int)roundf(a) + 128);
             ((uint8_t *)v_cache)[dst + i] = (uint8_t)((int)roundf(b) + 128);
         }
+    } else if (fp8 == 3) {   // FP8 e5m2 (max finite 57344): x / scale, clamped, through bf16 like the e4m3 path, round to nearest even
+        const float ksc = k_scale ? *k_scale : 1.0f, vsc = v_scale ? *v_scale : 1.0f;
+        for (int i = threadIdx.x; i < row_elems; i += 256) {
+            float a = vmx_bf16_to_f32(ks[i]) / ksc, b = vmx_bf16_to_f32(vs[i]) / vsc;
+            a = vmx_bf16_to_f32(vmx_f32_to_bf16(fminf(fmaxf(a, -57344.0f), 57344.0f)));
+            b = vmx_bf16_to_f32(vmx_f32_to_bf16(fminf(fmaxf(b, -57344.0f), 57344.0f)));
+            ((uint8_t *)k_cache)[dst + i] = (uint8_t)(__builtin_amdgcn_cvt_pk_bf8_f32(a, a, 0, false) & 0xFFu);
+            ((uint8_t *)v_cache)[dst + i] = (uint8_t)(__builtin_amdgcn_cvt_pk_bf8_f32(b, b, 0, false) & 0xFFu);
+        }
     } else {
         const float ksc = k_scale ? *k_scale : 1.0f, vsc = v_scale ? *v_scale : 1.0f;
         for (int i = threadIdx.x; i < row_elems; i += 256) {
@@ -375,11 +384,12 @@ extern "C" int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value,
                                      const float *k_scale, const float *v_scale, void *stream) {
     VMX_REQUIRE(key && value && k_cache && v_cache && slot_mapping, "reshape_and_cache: null pointer");
     VMX_REQUIRE(kv_heads > 0 && head_dim > 0 && (kv_heads * head_dim) % 8 == 0 && block_size > 0, "reshape_and_cache: bad geometry");
-    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3 || kv_dtype == VMX_KV_INT8, "reshape_and_cache: unsupported kv dtype %d",
-                kv_dtype);
+    VMX_REQUIRE(kv_dtype == VMX_KV_AUTO || kv_dtype == VMX_KV_FP8_E4M3 || kv_dtype == VMX_KV_INT8 || kv_dtype == VMX_KV_FP8_E5M2,
+                "reshape_and_cache: unsupported kv dtype %d", kv_dtype);
     if (tokens <= 0) return VMX_OK;
     hipLaunchKernelGGL(reshape_and_cache_kernel, dim3(tokens), dim3(256), 0, vmx_stream(stream), key, value, k_cache, v_cache,
-                       slot_mapping, kv_heads * head_dim, kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0), k_scale, v_scale);
+                       slot_mapping, kv_heads * head_dim, kv_dtype == VMX_KV_FP8_E5M2 ? 3 : (kv_dtype == VMX_KV_INT8 ? 2 : (kv_dtype == VMX_KV_FP8_E4M3 ? 1 : 0)),
+                       k_scale, v_scale);
     VMX_CHECK_LAUNCH("reshape_and_cache");
     return VMX_OK;
 }

@@ -13,7 +13,7 @@ from ._lib import check, lib
 __all__ = [
     "init", "iq_type_size", "iq_dequantize", "quantize_q8_1", "iq_mmvq", "iq_matmul", "iq_gemm", "iq_subdots", "iq_pack", "iq_mmvq_packed", "iq_mmvq_packed_geglu", "iq_subdots_packed", "iq_mma_pack", "iq_mmvq_mma", "iq_subdots_mma",
     "gather_dequant_q6k", "awq_to_gptq_qweight", "awq_repack_nibbles", "int4_pack", "int4_gemm", "int4_dequant",
-    "rms_norm", "rope_neox", "rope_gptj", "reshape_and_cache_hnd", "copy_blocks", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_f16", "paged_attention_static", "dense_gemv",
+    "rms_norm", "rope_neox", "rope_gptj", "reshape_and_cache_hnd", "copy_blocks", "silu_and_mul", "argmax", "KVScales", "reshape_and_cache", "paged_attention", "paged_attention_f16", "paged_attention_static", "paged_attention_with_lse", "lse_correct", "dense_gemv",
     "embedding_lookup", "fp8_gemm", "fp8_dequant", "fp8_quant", "fp8_scaled_mm", "fp8_dequant_block", "fp8_block_gemm", "fused_rmsnorm_fp8",
     "topk_softmax", "moe_align_block_size", "moe_int4_forward", "moe_ep_int4_forward",
 ]
@@ -291,6 +291,31 @@ def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, scale: float, n
                                        scale, num_seqs, num_heads, num_kv_heads, block_tables.shape[1], max_seq_len, head_dim,
                                        block_size, window, kv_dtype, _ptr(k_scale), _ptr(v_scale), _ptr(ws), ws.numel(),
                                        _stream()))
+    return out
+
+
+def paged_attention_with_lse(q, k_cache, v_cache, block_tables, seq_lens, scale: float, num_heads: int, num_kv_heads: int,
+                             head_dim: int, block_size: int, max_seq_len: int, window: int = 0, kv_dtype: int = 0, k_scale=None,
+                             v_scale=None, workspace=None):
+    """Decode attention plus lse f32 [seqs, heads] = ln sum_i exp(scale * q . k_i) per head (-inf for an empty context)."""
+    num_seqs = seq_lens.numel()
+    need = lib.vmx_paged_attention_workspace_bytes(num_seqs, num_heads, head_dim, max_seq_len)
+    ws = workspace if workspace is not None else torch.empty(max(need, 8), dtype=torch.uint8, device=q.device)
+    out = torch.zeros((num_seqs, num_heads * head_dim), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((num_seqs, num_heads), dtype=torch.float32, device=q.device)
+    check(lib.vmx_paged_attention_bf16_with_lse(_ptr(out), _ptr(lse), _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(block_tables),
+                                                _ptr(seq_lens), scale, num_seqs, num_heads, num_kv_heads, block_tables.shape[1],
+                                                max_seq_len, head_dim, block_size, window, kv_dtype, _ptr(k_scale), _ptr(v_scale),
+                                                _ptr(ws), ws.numel(), _stream()))
+    return out, lse
+
+
+def lse_correct(attn_out: torch.Tensor, lse_all: torch.Tensor, rank: int, head_dim: int) -> torch.Tensor:
+    """This rank's share of the context-parallel merge: attn_out bf16 [rows * head_dim], lse_all f32 [ranks, rows] -> f32
+    [rows, head_dim] = attn_out * exp(lse_all[rank] - logsumexp over ranks); summing the shares over the ranks merges them."""
+    ranks, rows = lse_all.shape[0], lse_all[0].numel()
+    out = torch.empty((rows, head_dim), dtype=torch.float32, device=attn_out.device)
+    check(lib.vmx_lse_correct_f32(_ptr(out), _ptr(attn_out), _ptr(lse_all), ranks, rank, rows, head_dim, _stream()))
     return out
 
 
