@@ -155,6 +155,13 @@ int vmx_ggml_block_elems(int ggml_type);  /* 32 or 256 */
 int vmx_kquant_dequantize_f32(int ggml_type, const void *blocks, float *out, int64_t n_blocks, void *stream);
 /* qmm.forward for small m (gguf/mod.rs:197): y[m, n_out] = x[m, n_in] @ dequant(W)^T, f32 in/out, 1 <= m <= 8. */
 int vmx_kquant_gemv_f32(int ggml_type, const void *w, const float *x, float *y, int n_out, int n_in, int m, void *stream);
+/* The same product for any m (the reference's QMatMul leaves the vector kernels past 8 rows and multiplies the dequantised
+ * dense weight with the f32 activations; QuantizedLinear / GgufWeightLoader, crates/core/src/quantization/gguf/mod.rs): weight
+ * and activations are each split into two bf16 terms and multiplied on the bf16 matrix cores (hi.hi + lo.hi + hi.lo), so the
+ * result is the f32 GEMM to about 2^-16 relative per product.  workspace >= vmx_kquant_gemm_workspace_bytes. */
+size_t vmx_kquant_gemm_workspace_bytes(int m, int n_out, int n_in);
+int vmx_kquant_gemm_f32(int ggml_type, const void *w, const float *x, float *y, int m, int n_out, int n_in, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------- AWQ / GPTQ int4 */
 
@@ -315,6 +322,13 @@ int vmx_temperature_scale_bf16(uint16_t *logits, float inv_temperature, int rows
 int vmx_softmax_to_probs(float *probs, const void *logits, int logits_dtype, int rows, int vocab, void *stream);
 int vmx_top_k_top_p_sample(int32_t *out_ids, const float *probs, const float *rand_vals, const int32_t *top_k_per_seq,
                            const float *top_p_per_seq, int top_k, float top_p, int rows, int vocab, void *stream);
+/* Replaces temperature_scale_f32_per_seq (crates/core/kernels/sampling.cu:529-543): f32 logits [rows, vocab] in place, row r
+ * times inv_temps[r] (device f32 [rows]). */
+int vmx_temperature_scale_f32_per_seq(float *logits, const float *inv_temps, int rows, int vocab, void *stream);
+/* Replaces multinomial_sample_no_filter_parallel (sampling.cu:566-631): the top_k = 0, top_p = 1 fast path.  Same chunking
+ * (256 contiguous chunks of ceil(vocab / 256)) and the same order of f32 additions, so the drawn token is the reference's for
+ * the same probs and rand_vals; a draw that overruns the last chunk gives vocab - 1. */
+int vmx_multinomial_sample_no_filter(int32_t *out_ids, const float *probs, const float *rand_vals, int rows, int vocab, void *stream);
 
 /* KVScales (kv_cache/quantization.rs:80-277) as device-resident state of vmx_kv_scales_state_bytes() = 32 bytes whose first two
  * f32 are k_scale and v_scale, so `state` and `(float *)state + 1` are the k_scale / v_scale arguments of every entry point here.

@@ -290,9 +290,13 @@ def test_gemma4_rejects_bad_config():
     assert b"hidden_size" in lib.vmx_last_error()
 
 
-def test_gemma4_load_from_gguf_file_equals_direct_load(tmp_path):
+@pytest.mark.parametrize("ple", [False, True])
+def test_gemma4_load_from_gguf_file_equals_direct_load(tmp_path, ple):
     """Write the synthetic checkpoint as a GGUF v3 file (llama.cpp tensor names, on-disk dims reversed, F32 norms, Q3_K
-    token_embd), load it through the library's container parser and compare a decode step with the directly loaded model."""
+    token_embd), load it through the library's container parser and compare a decode step with the directly loaded model.
+    ple: the per-layer-input variant (E2B / E4B) with its tensors under the names to_llama_cpp_prefixes gives them
+    (quantization/gguf/mod.rs:1421-1424,1450-1453): blk.N.inp_gate / proj / post_norm, per_layer_token_embd (Q6_K),
+    per_layer_model_proj, per_layer_proj_norm."""
     import torch
     import vllm_rust_amd as vmx
     from tests.test_gguf_host import build_gguf
@@ -301,11 +305,12 @@ def test_gemma4_load_from_gguf_file_equals_direct_load(tmp_path):
     vmx.init(0)
     spec = Gemma4Spec(256, 2, 4, 512, 512, head_dim_sliding=64, head_dim_full=128, kv_heads_sliding=2, kv_heads_full=1,
                       sliding_window=16, full_every=2, max_position=64, kv_cache_dtype=1, num_blocks=4, max_batch=1, max_seq_len=32,
-                      embed_ggml_type=11)
+                      embed_ggml_type=11, **(dict(hidden_size_per_layer_input=256, vocab_size_per_layer_input=512,
+                                                  ple_embed_ggml_type=14) if ple else {}))
     a = QuantizedGemma4ForCausalLM(spec)
     ck = a.load_synthetic(seed=5, keep_host_copy=True)
     # checkpoint -> GGUF tensors
-    names = {0: "attn_q", 1: "attn_k", 2: "attn_v", 3: "attn_output", 4: "ffn_gate", 5: "ffn_up", 6: "ffn_down"}
+    names = {0: "attn_q", 1: "attn_k", 2: "attn_v", 3: "attn_output", 4: "ffn_gate", 5: "ffn_up", 6: "ffn_down", 7: "inp_gate", 8: "proj"}
     norms = {"input_ln": "attn_norm", "post_attn_ln": "post_attention_norm", "pre_ffn_ln": "ffn_norm", "post_ffn_ln": "post_ffw_norm",
              "q_norm": "attn_q_norm", "k_norm": "attn_k_norm", "scalar": "layer_output_scale"}
     tensors, payload = [], {}
@@ -318,6 +323,19 @@ def test_gemma4_load_from_gguf_file_equals_direct_load(tmp_path):
         for slot, (K, N) in spec.linear_shapes(li).items():
             t, raw = ck[f"{li}.{slot}.iq"]
             tensors.append((f"blk.{li}.{names[slot]}.weight", [K, N], t)); payload[f"blk.{li}.{names[slot]}.weight"] = raw.numpy().tobytes()
+        if ple:
+            w = ck[f"{li}.post_ple_norm"].float().numpy()
+            tensors.append((f"blk.{li}.post_norm.weight", [w.size], 0)); payload[f"blk.{li}.post_norm.weight"] = w.tobytes()
+    extra = 0
+    if ple:
+        LP = spec.hidden_size_per_layer_input * spec.num_layers
+        t, raw = ck["0.9.iq"]
+        tensors.append(("per_layer_model_proj.weight", [spec.hidden_size, LP], t)); payload["per_layer_model_proj.weight"] = raw.numpy().tobytes()
+        w = ck["ple_proj_norm"].float().numpy()
+        tensors.append(("per_layer_proj_norm.weight", [w.size], 0)); payload["per_layer_proj_norm.weight"] = w.tobytes()
+        tensors.append(("per_layer_token_embd.weight", [LP, spec.vocab_size_per_layer_input], 14))
+        payload["per_layer_token_embd.weight"] = ck["ple_embed"].numpy().tobytes()
+        extra = spec.num_layers + 3
     data, blobs = build_gguf(3, [("general.architecture", 8, "gemma4")], tensors)
     hdr = go.parse(data)
     buf = bytearray(data)
@@ -327,7 +345,7 @@ def test_gemma4_load_from_gguf_file_equals_direct_load(tmp_path):
     path = tmp_path / "tiny-gemma4.gguf"
     path.write_bytes(bytes(buf))
     b = QuantizedGemma4ForCausalLM(spec)
-    assert b.load_gguf(path) == 2 + spec.num_layers * 7 + sum(len(spec.linear_shapes(li)) for li in range(spec.num_layers))
+    assert b.load_gguf(path) == 2 + spec.num_layers * 7 + sum(len(spec.linear_shapes(li)) for li in range(spec.num_layers)) + extra
     ids = torch.tensor([17], dtype=torch.int32, device="cuda"); pos = torch.zeros(1, dtype=torch.int32, device="cuda")
     slots = torch.zeros(1, dtype=torch.int32, device="cuda"); bt = torch.zeros((1, 4), dtype=torch.int32, device="cuda")
     sl = torch.ones(1, dtype=torch.int32, device="cuda")

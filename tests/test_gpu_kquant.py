@@ -53,6 +53,20 @@ def test_dequant_bit_exact_and_gemv(gpu, t):
         exp = x.astype(np.float64) @ ref.reshape(n_out, n_in).astype(np.float64).T
         got = y.cpu().numpy()
         assert np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum()) <= 1e-5
+    # past 8 rows: dense product of the dequantised weight with the f32 activations (ragged row counts, both tile forms)
+    for m in (9, 70, 200):
+        x = rng.standard_normal((m, n_in)).astype(np.float32)
+        y = torch.full((m, n_out), 7.0, dtype=torch.float32, device="cuda")
+        xd = torch.from_numpy(x).cuda()
+        need = lib.vmx_kquant_gemm_workspace_bytes(m, n_out, n_in)
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        check(lib.vmx_kquant_gemm_f32(t, w.data_ptr(), xd.data_ptr(), y.data_ptr(), m, n_out, n_in, ws.data_ptr(), need, st))
+        exp = x.astype(np.float64) @ ref.reshape(n_out, n_in).astype(np.float64).T
+        got = y.cpu().numpy()
+        assert np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum()) <= 1e-5
+        assert np.abs(got - exp).max() <= 2e-5 * np.abs(exp).max()
+        assert lib.vmx_kquant_gemm_f32(t, w.data_ptr(), xd.data_ptr(), y.data_ptr(), m, n_out, n_in, ws.data_ptr(), need - 1, st) != 0
+    assert lib.vmx_kquant_gemm_f32(18, w.data_ptr(), xd.data_ptr(), y.data_ptr(), 9, n_out, n_in, ws.data_ptr(), need, st) != 0
 
 
 def test_q6k_matches_reference_gather_kernel_path(gpu):

@@ -91,3 +91,56 @@ def test_softmax_temperature_and_sampling(gpu):
         sel, below, above = ref_sample(pn[r], rv[r], int(tk[r]), float(tp[r]))
         if min(below, above) > 1e-5:
             assert got[r] == sel
+
+
+def ref_multinomial_no_filter(p, rnd):
+    """multinomial_sample_no_filter_parallel (sampling.cu:566-631) with its order of f32 additions: np.add.accumulate is a
+    strict left-to-right sum."""
+    V = p.size
+    chunk = (V + 255) // 256
+    ser = lambda a, start=np.float32(0): np.add.accumulate(np.concatenate([[start], a]).astype(np.float32), dtype=np.float32)
+    sums = np.array([ser(p[min(c * chunk, V):min((c + 1) * chunk, V)])[-1] for c in range(256)], np.float32)
+    target = np.float32(np.float32(rnd) * ser(sums)[-1])
+    pre = ser(sums)                       # pre[c] = cdf before chunk c, pre[c + 1] after it
+    hit = np.nonzero(pre[1:] > target)[0]
+    tc = int(hit[0]) if hit.size else 255
+    cdf = pre[tc] if hit.size else pre[256]    # without a hit the walk has added every chunk and the last chunk is scanned on top
+    lo, hi = min(tc * chunk, V), min((tc + 1) * chunk, V)
+    run = ser(p[lo:hi], cdf)[1:]
+    inner = np.nonzero(run > target)[0]
+    return lo + int(inner[0]) if inner.size else V - 1
+
+
+@pytest.mark.parametrize("V", [100, 5000, 151936])
+def test_per_seq_temperature_and_parallel_multinomial_bit_exact(gpu, V):
+    """temperature_scale_f32_per_seq and multinomial_sample_no_filter_parallel (sampling.cu:529-631): the scaled logits are the
+    f32 products bit for bit, and the drawn token ids are the reference's for the same probabilities and uniforms (integer
+    result, same addition order, so exact) -- over ordinary draws, rand = 0, rand just under 1 and a peaked distribution."""
+    from vllm_rust_amd._lib import lib, check
+    vmx, torch = gpu
+    rng = np.random.default_rng(V)
+    rows = 8
+    lg = (rng.standard_normal((rows, V)) * 2).astype(np.float32)
+    lg[3, V // 3] = 40.0                                                    # one token holds nearly all the mass
+    inv_t = (1.0 / rng.uniform(0.3, 1.5, rows)).astype(np.float32)
+    t = torch.from_numpy(lg.copy()).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.vmx_temperature_scale_f32_per_seq(t.data_ptr(), torch.from_numpy(inv_t).cuda().data_ptr(), rows, V, st))
+    assert np.array_equal(t.cpu().numpy(), lg * inv_t[:, None])
+    probs = torch.empty((rows, V), dtype=torch.float32, device="cuda")
+    check(lib.vmx_softmax_to_probs(probs.data_ptr(), t.data_ptr(), 0, rows, V, st))
+    pn = probs.cpu().numpy()
+    out = torch.empty(rows, dtype=torch.int32, device="cuda")
+    for trial in range(4):
+        rv = rng.random(rows).astype(np.float32)
+        if trial == 1:
+            rv[:] = 0.0
+        if trial == 2:
+            rv[:] = np.nextafter(np.float32(1.0), np.float32(0.0))
+        check(lib.vmx_multinomial_sample_no_filter(out.data_ptr(), probs.data_ptr(), torch.from_numpy(rv).cuda().data_ptr(), rows, V, st))
+        got = out.cpu().numpy()
+        want = np.array([ref_multinomial_no_filter(pn[r], rv[r]) for r in range(rows)])
+        assert np.array_equal(got, want), (trial, got, want)
+        if trial == 1:
+            assert np.array_equal(got, [int(np.nonzero(pn[r] > 0)[0][0]) for r in range(rows)])
+    assert lib.vmx_multinomial_sample_no_filter(None, None, None, 1, 8, None) != 0 and lib.vmx_temperature_scale_f32_per_seq(None, None, 1, 8, None) != 0

@@ -57,6 +57,8 @@ _SIGS = {
     "vmx_ggml_block_elems": (_i, [_i]),
     "vmx_kquant_dequantize_f32": (_i, [_i, _p, _p, _i64, _p]),
     "vmx_kquant_gemv_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_kquant_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "vmx_kquant_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vmx_awq_to_gptq_qweight": (_i, [_p, _p, _i, _i, _p]),
     "vmx_awq_repack_nibbles": (_i, [_p, _p, _i64, _p]),
     "vmx_int4_packed_bytes": (_sz, [_i, _i, _i]),
@@ -88,6 +90,8 @@ _SIGS = {
     "vmx_temperature_scale_bf16": (_i, [_p, _f, _i, _i, _p]),
     "vmx_softmax_to_probs": (_i, [_p, _p, _i, _i, _i, _p]),
     "vmx_top_k_top_p_sample": (_i, [_p, _p, _p, _p, _p, _i, _f, _i, _i, _p]),
+    "vmx_temperature_scale_f32_per_seq": (_i, [_p, _p, _i, _i, _p]),
+    "vmx_multinomial_sample_no_filter": (_i, [_p, _p, _p, _i, _i, _p]),
     "vmx_rms_norm_bf16": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _p]),
     "vmx_rope_neox_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vmx_rope_gptj_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -168,7 +168,70 @@ __global__ __launch_bounds__(256) void top_k_top_p_kernel(int32_t *__restrict__ 
     }
 }
 
+// temperature_scale_f32_per_seq (crates/core/kernels/sampling.cu:529-543): row r of the f32 logits times inv_temps[r], in place.
+// grid (column tiles, rows): a whole vocabulary row per workgroup would leave most of the chip idle at small batches.
+__global__ __launch_bounds__(256) void temperature_per_seq_kernel(float *__restrict__ logits, const float *__restrict__ inv_temps, int vocab) {
+    const float inv_t = inv_temps[blockIdx.y];
+    float *row = logits + (int64_t)blockIdx.y * vocab;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < vocab; i += gridDim.x * 256) row[i] *= inv_t;
+}
+
+// multinomial_sample_no_filter_parallel (sampling.cu:566-631): inverse-CDF sample of an unfiltered distribution.  The token
+// depends on the order of the f32 additions, so the order is the reference's: 256 contiguous chunks of ceil(vocab / 256)
+// probabilities, each summed front to back; the chunk sums added front to back for the total and again for the prefix
+// walk; the chosen chunk re-added element by element on top of the prefix.  One workgroup of 256 per row.  Thread t reads
+// its chunk as a stream of its own (a cache line serves 16 consecutive steps of one lane); the serial part is one lane.
+__global__ __launch_bounds__(256) void multinomial_no_filter_kernel(int32_t *__restrict__ out, const float *__restrict__ probs,
+                                                                    const float *__restrict__ rand_vals, int vocab) {
+    __shared__ float chunk_sums[256];
+    const int seq = blockIdx.x, tid = threadIdx.x;
+    const float *p = probs + (int64_t)seq * vocab;
+    const int chunk = (vocab + 255) / 256;
+    const int lo = min(tid * chunk, vocab), hi = min(lo + chunk, vocab);
+    float s = 0.0f;
+    for (int i = lo; i < hi; i++) s += p[i];
+    chunk_sums[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float total = 0.0f;
+        for (int c = 0; c < 256; c++) total += chunk_sums[c];
+        const float target = rand_vals[seq] * total;
+        float cdf = 0.0f;
+        int tc = 255;
+        for (int c = 0; c < 256; c++) {
+            const float next = cdf + chunk_sums[c];
+            if (next > target) { tc = c; break; }
+            cdf = next;
+        }
+        const int c0 = min(tc * chunk, vocab), c1 = min(c0 + chunk, vocab);
+        int sel = vocab - 1;
+        for (int i = c0; i < c1; i++) {
+            cdf += p[i];
+            if (cdf > target) { sel = i; break; }
+        }
+        out[seq] = sel;
+    }
+}
+
 }  // namespace
+
+extern "C" int vmx_temperature_scale_f32_per_seq(float *logits, const float *inv_temps, int rows, int vocab, void *stream) {
+    VMX_REQUIRE(logits && inv_temps && rows >= 0 && vocab > 0, "temperature_scale_per_seq: bad arguments");
+    if (rows == 0) return VMX_OK;
+    int tiles = (vocab + 2047) / 2048;   // eight elements per lane
+    hipLaunchKernelGGL(temperature_per_seq_kernel, dim3(tiles, rows), dim3(256), 0, vmx_stream(stream), logits, inv_temps, vocab);
+    VMX_CHECK_LAUNCH("temperature_scale_per_seq");
+    return VMX_OK;
+}
+
+extern "C" int vmx_multinomial_sample_no_filter(int32_t *out_ids, const float *probs, const float *rand_vals, int rows, int vocab,
+                                                void *stream) {
+    VMX_REQUIRE(out_ids && probs && rand_vals && rows >= 0 && vocab > 0, "multinomial_sample_no_filter: bad arguments");
+    if (rows == 0) return VMX_OK;
+    hipLaunchKernelGGL(multinomial_no_filter_kernel, dim3(rows), dim3(256), 0, vmx_stream(stream), out_ids, probs, rand_vals, vocab);
+    VMX_CHECK_LAUNCH("multinomial_sample_no_filter");
+    return VMX_OK;
+}
 
 extern "C" int vmx_temperature_scale_bf16(uint16_t *logits, float inv_temperature, int rows, int vocab, void *stream) {
     VMX_REQUIRE(logits && rows >= 0 && vocab > 0, "temperature_scale: bad arguments");

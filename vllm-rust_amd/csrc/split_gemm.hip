@@ -4,6 +4,7 @@
 // and a dequantised weight w = d * scale * grid needs at most ~16 mantissa bits, so w is split as hi = bf16(w), lo = bf16(w - hi) and
 // the product is two bf16 MFMA passes into one f32 accumulator: x * hi and x * lo are exact in f32, and hi + lo reproduces w to
 // 2^-17 relative -- below the f32 summation noise of a dot over thousands of terms.
+#include <algorithm>
 #include "vmx_internal.h"
 #include "vmx_kernels.h"
 
@@ -98,7 +99,61 @@ __global__ __launch_bounds__(256) void split_gemm_kernel(const uint16_t *__restr
         }
 }
 
+// f32 rows [rows, K] -> bf16 rows [rows, 3K]: v = hi + lo with hi = bf16(v), lo = bf16(v - hi).  WEIGHT rows are laid out
+// hi | hi | lo and ACTIVATION rows hi | lo | hi, so that one bf16 GEMM over 3K computes xhi.whi + xlo.whi + xhi.wlo: the
+// f32 product short of the lo.lo term (2^-16 relative per factor pair, below the f32 summation noise of a long dot).
+template <bool WEIGHT>
+__global__ __launch_bounds__(256) void split3_rows_kernel(uint16_t *__restrict__ out, const float *__restrict__ in, int64_t rows, int K) {
+    const int64_t n = rows * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / K;
+        const int k = (int)(i - r * K);
+        const float v = in[i];
+        const uint16_t hi = vmx_f32_to_bf16(v), lo = vmx_f32_to_bf16(v - vmx_bf16_to_f32(hi));
+        uint16_t *o = out + r * 3 * K;
+        o[k] = hi;
+        o[K + k] = WEIGHT ? hi : lo;
+        o[2 * K + k] = WEIGHT ? lo : hi;
+    }
+}
+
 }  // namespace
+
+// QMatMul::forward beyond the 8-row vector kernels (candle's dequantize-and-matmul path behind QuantizedLinear,
+// crates/core/src/quantization/gguf/mod.rs): the K-quant / legacy-block weight dequantised to dense f32, times f32 activations.
+// workspace: f32 weight [N*K] | bf16 weight thirds [N, 3K] | bf16 activation thirds [M, 3K]
+extern "C" size_t vmx_kquant_gemm_workspace_bytes(int m, int n_out, int n_in) {
+    if (m <= 0 || n_out <= 0 || n_in <= 0) return 0;
+    return (size_t)n_out * n_in * 4 + (size_t)n_out * n_in * 6 + (size_t)m * n_in * 6;
+}
+
+extern "C" int vmx_kquant_gemm_f32(int ggml_type, const void *w, const float *x, float *y, int m, int n_out, int n_in, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    VMX_REQUIRE(w && x && y && workspace, "kquant_gemm: null pointer");
+    VMX_REQUIRE(vmx_ggml_type_size(ggml_type) > 0 && vmx_iq_type_size(ggml_type) <= 0, "kquant_gemm: ggml type %d is not a K-quant / legacy block type",
+                ggml_type);
+    VMX_REQUIRE(m >= 0 && n_out > 0 && n_in > 0 && n_in % vmx_ggml_block_elems(ggml_type) == 0,
+                "kquant_gemm: n_in (%d) must be a positive multiple of the block size", n_in);
+    if (m == 0) return VMX_OK;
+    VMX_REQUIRE(workspace_bytes >= vmx_kquant_gemm_workspace_bytes(m, n_out, n_in), "kquant_gemm: workspace of %zu bytes, need %zu",
+                workspace_bytes, vmx_kquant_gemm_workspace_bytes(m, n_out, n_in));
+    hipStream_t st = vmx_stream(stream);
+    const int64_t nk = (int64_t)n_out * n_in;
+    float *wf = (float *)workspace;
+    uint16_t *w3 = (uint16_t *)(wf + nk), *x3 = w3 + 3 * nk;
+    if (int rc = vmx_kquant_dequantize_f32(ggml_type, w, wf, nk / vmx_ggml_block_elems(ggml_type), stream)) return rc;
+    const int gw = (int)std::min<int64_t>((nk + 255) / 256, 16384), gx = (int)std::min<int64_t>(((int64_t)m * n_in + 255) / 256, 16384);
+    hipLaunchKernelGGL((split3_rows_kernel<true>), dim3(gw), dim3(256), 0, st, w3, wf, (int64_t)n_out, n_in);
+    hipLaunchKernelGGL((split3_rows_kernel<false>), dim3(gx), dim3(256), 0, st, x3, x, (int64_t)m, n_in);
+    const int K3 = 3 * n_in;
+    const int wide_wgs = ((n_out + 255) / 256) * ((m + 63) / 64);
+    if (wide_wgs < 2 * vmx_num_cus() && K3 % 128 == 0)
+        hipLaunchKernelGGL((split_gemm_kernel<false, true>), dim3((n_out + 63) / 64, (m + 63) / 64), dim3(256), 0, st, x3, w3, w3, y, m, n_out, K3, n_out);
+    else
+        hipLaunchKernelGGL((split_gemm_kernel<false, false>), dim3((n_out + 255) / 256, (m + 63) / 64), dim3(256), 0, st, x3, w3, w3, y, m, n_out, K3, n_out);
+    VMX_CHECK_LAUNCH("kquant_gemm");
+    return VMX_OK;
+}
 
 size_t vmx_iq_gemm_workspace(int N, int K) { return (size_t)N * K * 4; }   // the two bf16 halves
 

@@ -305,8 +305,11 @@ class QuantizedGemma4ForCausalLM:
             self.load_tensor(T_PLE_EMBED, 0, pe); keep("ple_embed", pe)
         return ck
 
+    # the per-layer-input tensors: blk.N.inp_gate / proj / post_norm and the top-level per_layer_token_embd / per_layer_model_proj /
+    # per_layer_proj_norm (to_llama_cpp_prefixes, crates/core/src/quantization/gguf/mod.rs:1421-1424,1450-1453)
     GGUF_SLOT_NAMES = {L_Q: "self_attn.q_proj", L_K: "self_attn.k_proj", L_V: "self_attn.v_proj", L_O: "self_attn.o_proj",
-                       L_GATE: "mlp.gate_proj", L_UP: "mlp.up_proj", L_DOWN: "mlp.down_proj"}
+                       L_GATE: "mlp.gate_proj", L_UP: "mlp.up_proj", L_DOWN: "mlp.down_proj",
+                       L_PLE_GATE: "per_layer_input_gate", L_PLE_PROJ: "per_layer_projection"}
     GGUF_NORM_NAMES = {T_INPUT_LN: "input_layernorm", T_POST_ATTN_LN: "post_attention_layernorm", T_PRE_FFN_LN: "pre_feedforward_layernorm",
                        T_POST_FFN_LN: "post_feedforward_layernorm", T_Q_NORM: "self_attn.q_norm", T_K_NORM: "self_attn.k_norm",
                        T_LAYER_SCALAR: "layer_scalar"}
@@ -318,8 +321,6 @@ class QuantizedGemma4ForCausalLM:
         HF -> llama.cpp map in priority order (gguf/mod.rs:1416-1479).  Returns the number of tensors loaded."""
         from ._lib import GgufTensor
         s = self.spec
-        if s.hidden_size_per_layer_input > 0:
-            raise NotImplementedError("per-layer-input tensors have no GGUF name map here: load them with load_iq_linear / load_tensor")
         h = C.c_void_p()
         check(lib.vmx_gguf_open(str(path).encode(), C.byref(h)))
         try:
@@ -379,6 +380,37 @@ class QuantizedGemma4ForCausalLM:
                     if list(t.shape[:t.n_dims]) != [N, K]:
                         raise ValueError(f"{t.name.decode()}: shape {list(t.shape[:t.n_dims])}, expected {[N, K]}")
                     self.load_iq_linear(li, slot, t.ggml_type, raw.to(self.device)); n += 1
+                if s.hidden_size_per_layer_input > 0:
+                    idx = find(f"model.layers.{li}.post_per_layer_input_norm")
+                    if idx < 0:
+                        raise KeyError(f"layer {li}: post_per_layer_input_norm not found")
+                    self.load_tensor(T_POST_PLE_NORM, li, dense_bf16(idx).reshape(-1).to(self.device)); n += 1
+            if s.hidden_size_per_layer_input > 0:
+                LP = s.hidden_size_per_layer_input * s.num_layers
+                idx = find("model.per_layer_model_projection")
+                if idx < 0:
+                    raise KeyError("per_layer_model_proj.weight not found")
+                t, raw = read(idx)
+                if list(t.shape[:t.n_dims]) != [LP, s.hidden_size]:
+                    raise ValueError(f"{t.name.decode()}: shape {list(t.shape[:t.n_dims])}, expected {[LP, s.hidden_size]}")
+                self.load_iq_linear(0, L_PLE_MODEL_PROJ, t.ggml_type, raw.to(self.device)); n += 1
+                idx = find("model.per_layer_projection_norm")
+                if idx < 0:
+                    raise KeyError("per_layer_proj_norm.weight not found")
+                self.load_tensor(T_PLE_PROJ_NORM, 0, dense_bf16(idx).reshape(-1).to(self.device)); n += 1
+                idx = find("model.embed_tokens_per_layer")
+                if idx < 0:
+                    raise KeyError("per_layer_token_embd.weight not found")
+                t, raw = read(idx)
+                if list(t.shape[:t.n_dims]) != [s.vocab_size_per_layer_input, LP]:
+                    raise ValueError(f"{t.name.decode()}: shape {list(t.shape[:t.n_dims])}, expected {[s.vocab_size_per_layer_input, LP]}")
+                if s.ple_embed_ggml_type == 0:
+                    self.load_tensor(T_PLE_EMBED, 0, dense_bf16(idx).to(self.device))
+                else:
+                    if t.ggml_type != s.ple_embed_ggml_type:
+                        raise ValueError(f"per_layer_token_embd is GGML type {t.ggml_type}, the model was created for {s.ple_embed_ggml_type}")
+                    self.load_tensor(T_PLE_EMBED, 0, raw.to(self.device))
+                n += 1
             return n
         finally:
             lib.vmx_gguf_close(h)
