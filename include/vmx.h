@@ -134,6 +134,9 @@ int vmx_iq_subdots_mma_i32(int ggml_type, const void *packed, const int8_t *aq, 
                            int m, void *stream);
 /* Parity / measurement aid: rows from which the Gemma 4 executor's I-quant linears take the matrix-core form (default 5: up to four rows the per-row kernels are faster; 17 = never). */
 int vmx_debug_iq_mma_min_rows(int rows);
+/* Measurement / test aid: on != 0 sends the Gemma 4 executor's prompt-sized linears through the two-term bf16 split even for
+ * the types that have the exact one-pass integer form (A/B runs and the test that compares the two). */
+int vmx_debug_gemma4_split_always(int on);
 
 /* Measurement aid: while buf != NULL, vmx_iq_mmvq_packed_f32 launches that work on whole 8-row units record per wave 8
  * shader-clock stamps (u64: entry, loads issued, tables built, after each of the four row pairs, end) at

@@ -249,11 +249,13 @@ def test_packed_rejects_types_without_packed_form(gpu):
 
 
 @pytest.mark.parametrize("name", IQ_NAMES)
-@pytest.mark.parametrize("m,n_out,n_in", [(17, 203, 3840), (64, 512, 256), (130, 300, 1024)])
+@pytest.mark.parametrize("m,n_out,n_in", [(17, 203, 3840), (64, 512, 256), (130, 300, 1024), (300, 64, 512), (256, 1024, 2048)])
 def test_iq_gemm_prompt_sized_rows(gpu, name, m, n_out, n_in):
     """More than 16 rows: the reference dequantises the weight to dense f32 and multiplies the unquantised activations
-    (gguf/mod.rs:358-365).  Checked against the oracle's dequantised weight times the bf16 activations in float64: the only
-    differences left are the 2^-17 split of the weight and f32 summation order (1e-3 is the stated bar; measured ~1e-6)."""
+    (gguf/mod.rs:358-365).  Checked against the oracle's dequantised weight times the bf16 activations in float64.  IQ2_XS,
+    IQ2_S, IQ3_XXS and IQ3_S run the exact one-pass form (fp16 integer x f32 super-block scale: only f32 summation order
+    differs); IQ4_XS, and any call whose workspace cannot also hold the fp16 copy of the rows (m > n_out here), the two-term
+    bf16 split (2^-17 per weight).  1e-3 is the stated bar; measured ~1e-6."""
     from oracle import oracle as orc
     vmx, torch = gpu
     tid = orc.IQ_TYPES[name]; ts = orc.IQ_TYPE_SIZE[tid]

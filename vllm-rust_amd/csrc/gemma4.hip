@@ -399,6 +399,7 @@ struct vmx_gemma4 {
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     float kv_headroom = 1.5f;   // DEFAULT_KV_HEADROOM_FACTOR (kv_cache/quantization.rs:108)
     Buf gemm_ws;                // dequantised weight of one projection (f32 + bf16 halves) for passes of more than 16 rows
+    Buf a16;                    // fp16 copy of the rows a prompt-sized linear multiplies (the one-pass integer form)
     Buf kv_stage;               // bf16 K | V rows of one pass, used by an FP8 cache's first (calibrating) write
     int mmvq_mask = 15;         // measurement: which projections vmx_gemma4_mmvq_only launches (1 q|k|v, 2 o, 4 gate|up, 8 down)
     IqLin ple_model_proj;
@@ -443,6 +444,8 @@ int mmvq(vmx_gemma4 *m, const IqLin &l, float *y, int ldy, int tokens, hipStream
     return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq_of(m), ad_of(m, tokens, l.in_features), y, l.out_features, l.in_features, tokens, ldy, st);
 }
 
+bool g_split_always = false;   // measurement: prompt-sized linears always through the two-term bf16 split (vmx_debug_gemma4_split_always)
+
 // A linear on `rows` token rows: the q8_1 MMVQ up to IQ_GEMV_MAX_M = 16 rows (activations already quantised in m->q8), beyond that
 // the reference's large-M form (gguf/mod.rs:358-365): dequantise the weight once, multiply the unquantised bf16 rows `a`.
 int g4_linears(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, const uint16_t *a, float *y, int ldy, int rows,
@@ -451,8 +454,21 @@ int g4_linears(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, 
         if (n == 1 && offs[0] == 0) return mmvq(m, *lins[0], y, ldy, rows, st);
         return mmvq_group(m, lins, offs, n, y, ldy, rows, st);
     }
+    // types whose dequantised weight is (f32 scale per super-block) x (integer that fp16 holds exactly) take one matrix-core pass
+    // over fp16 activations; the others (IQ4_XS) the exact two-term bf16 split
+    bool a16_ready = false;
     for (int i = 0; i < n; i++) {
         const IqLin &l = *lins[i];
+        if (vmx_iq_int_form_ok(l.ggml_type) && !g_split_always) {
+            if (!a16_ready) {
+                if (int rc = vmx_bf16_rows_to_f16(a, (uint16_t *)m->a16.p, (int64_t)rows * l.in_features, st)) return rc;
+                a16_ready = true;
+            }
+            if (int rc = vmx_iq_dequant_int(l.ggml_type, l.raw.p, m->gemm_ws.p, l.out_features, l.in_features, st)) return rc;
+            if (int rc = vmx_int_gemm_f32((const uint16_t *)m->a16.p, m->gemm_ws.p, y + offs[i], rows, l.out_features, l.in_features, ldy, st))
+                return rc;
+            continue;
+        }
         if (int rc = vmx_iq_dequant_split(l.ggml_type, l.raw.p, m->gemm_ws.p, l.out_features, l.in_features, st)) return rc;
         if (int rc = vmx_split_gemm_f32(a, m->gemm_ws.p, y + offs[i], rows, l.out_features, l.in_features, ldy, st)) return rc;
     }
@@ -652,6 +668,10 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
             wmax = w > wmax ? w : wmax;
         }
         TRY(m->gemm_ws.alloc(wmax));
+        int kmax = H;
+        for (const G4Layer &L : m->layers)
+            for (const IqLin &l : L.lin) kmax = l.in_features > kmax ? l.in_features : kmax;
+        TRY(m->a16.alloc((size_t)c.max_prefill_tokens * kmax * 2));
     }
     TRY(m->red_bf16.alloc((size_t)R * H * 2));
     TRY(m->keys.alloc((size_t)R * 8));
@@ -702,7 +722,7 @@ extern "C" void vmx_gemma4_destroy(vmx_gemma4 *m) {
     }
     m->ple_model_proj.raw.release();
     m->ple_model_proj.packed.release();
-    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage, &m->red_bf16, &m->keys, &m->gemm_ws}) b->release();
+    for (Buf *b : {&m->ple_embed, &m->ple_proj_norm, &m->ple_e, &m->ple_p, &m->pli, &m->kv_stage, &m->red_bf16, &m->keys, &m->gemm_ws, &m->a16}) b->release();
     for (Buf *b : {&m->embed, &m->final_norm, &m->cos_sin_s, &m->cos_sin_f, &m->positions, &m->h, &m->x, &m->q, &m->attn, &m->act, &m->proj, &m->out,
                    &m->logits, &m->logits_f32, &m->x_f32, &m->attn_ws, &m->argmax_ws, &m->q8, &m->q8b, &m->h2})
         b->release();
@@ -1118,6 +1138,11 @@ extern "C" int vmx_gemma4_kv_scales_get(vmx_gemma4 *m, int layer, float *k_scale
     memcpy(k_scale, &w[0], 4);
     memcpy(v_scale, &w[1], 4);
     *calibrated = (int)w[2];
+    return VMX_OK;
+}
+
+extern "C" int vmx_debug_gemma4_split_always(int on) {
+    g_split_always = on != 0;
     return VMX_OK;
 }
 

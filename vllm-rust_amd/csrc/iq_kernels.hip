@@ -126,6 +126,59 @@ __global__ __launch_bounds__(256) void iq_dequant_split_kernel(const uint8_t *__
     }
 }
 
+// Dequantise into the EXACT integer form of the prompt-sized GEMM.  A dequantised I-quant weight is d * c * I with d the f16
+// super-block scale, c a power of two and I = (2 ls + 1) * (signed codebook byte) an integer of at most 11 bits (IQ3_XXS: 31 * 62),
+// so I is exact in fp16 and the f32 product the reference forms (iq_dequant.cu: db * grid byte, no rounding: 11 + 5 + 6 bits)
+// equals (d * c) * I.  Q [rows][K] fp16 = I, Dt [K / 256][rows] f32 = d * c (transposed: a wave reads the scales of 16
+// neighbouring columns in one line).  Same LDS staging of the stores as the split kernel.  Not for IQ4_XS (its integers need 13 bits).
+template <int T>
+__global__ __launch_bounds__(256) void iq_dequant_int_kernel(const uint8_t *__restrict__ blocks, uint16_t *__restrict__ Q,
+                                                              float *__restrict__ Dt, int64_t n_blocks, int rows, int nsb) {
+    __shared__ uint32_t cb[IqTraits<T>::LDS_WORDS];
+    __shared__ uint2 sg[SignLut<T>::N];
+    __shared__ __align__(16) uint16_t stage[256 * 32];
+    load_tables<T>(cb, sg);
+    const int64_t total = n_blocks * 8;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {   // uniform per workgroup
+        const int64_t s = base + threadIdx.x;
+        if (s < total) {
+            const int64_t blk = s >> 3;
+            const int ib = (int)(s & 7);
+            const uint8_t *b = blocks + blk * IqTraits<T>::TS;
+            int q[8];
+            SubScale sc;
+            decode_sub<T>(b, ib, cb, sg, q, sc);
+            const int m0 = 2 * sc.ls0 + 1, m1 = (T == 17 || T == 22) ? 2 * sc.ls1 + 1 : m0;
+            uint32_t h[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int mul = k < 4 ? m0 : m1, w = q[k];
+                uint16_t hh[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) hh[j] = __builtin_bit_cast(uint16_t, (_Float16)(float)(mul * (int)(int8_t)((w >> (8 * j)) & 0xFF)));
+                h[2 * k] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+                h[2 * k + 1] = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+            }
+            uint4 *dh = reinterpret_cast<uint4 *>(stage + threadIdx.x * 32);
+#pragma unroll
+            for (int r = 0; r < 4; r++) dh[r] = make_uint4(h[4 * r], h[4 * r + 1], h[4 * r + 2], h[4 * r + 3]);
+            if (ib == 0) {
+                const float d = vmx_f16_to_f32((uint16_t)ld16(b));
+                const float c = (T == 17 || T == 22) ? 0.125f : (T == 18 ? 0.25f : 1.0f);
+                Dt[(blk % nsb) * rows + blk / nsb] = d * c;
+            }
+        }
+        __syncthreads();
+        const int64_t live = (total - base < 256 ? total - base : 256) * 4;   // 16-byte pieces of this chunk
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = r * 256 + threadIdx.x;
+            if (i < live) reinterpret_cast<uint4 *>(Q + base * 32)[i] = reinterpret_cast<const uint4 *>(stage)[i];
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ q8_1
 // 8 lanes per 32-value block: one float4 load, one packed int8x4 store per lane.
 __global__ __launch_bounds__(256) void quantize_q8_1_kernel(const float *__restrict__ x, int8_t *__restrict__ aq,
@@ -596,6 +649,25 @@ int vmx_iq_dequantize_split_bf16(int ggml_type, const void *blocks, uint16_t *hi
     IQ_DISPATCH(ggml_type, CALL)
 #undef CALL
     VMX_CHECK_LAUNCH("iq_dequantize_split");
+    return VMX_OK;
+}
+
+bool vmx_iq_int_form_ok(int ggml_type) { return ggml_type == 17 || ggml_type == 18 || ggml_type == 21 || ggml_type == 22; }
+
+int vmx_iq_dequantize_int_f16(int ggml_type, const void *blocks, uint16_t *Q, float *Dt, int rows, int nsb, hipStream_t st) {
+    const int64_t n_blocks = (int64_t)rows * nsb;
+    if (n_blocks <= 0) return VMX_OK;
+    const int grid = grid_for(n_blocks * 8, 256, 16384);
+#define CALL(T) hipLaunchKernelGGL((iq_dequant_int_kernel<T>), dim3(grid), dim3(256), 0, st, (const uint8_t *)blocks, Q, Dt, n_blocks, rows, nsb)
+    switch (ggml_type) {
+        case 17: CALL(17); break;
+        case 18: CALL(18); break;
+        case 21: CALL(21); break;
+        case 22: CALL(22); break;
+        default: vmx_set_error("iq_dequantize_int: GGML type %d has no exact fp16 integer form", ggml_type); return VMX_EUNSUPPORTED;
+    }
+#undef CALL
+    VMX_CHECK_LAUNCH("iq_dequantize_int");
     return VMX_OK;
 }
 

@@ -148,6 +148,13 @@ size_t vmx_iq_gemm_workspace(int N, int K);
 int vmx_iq_dequantize_split_bf16(int ggml_type, const void *blocks, uint16_t *hi, uint16_t *lo, int64_t n_blocks, hipStream_t st);
 int vmx_iq_dequant_split(int ggml_type, const void *blocks, void *workspace, int N, int K, hipStream_t st);
 int vmx_split_gemm_f32(const uint16_t *A, const void *workspace, float *C, int M, int N, int K, int ldc, hipStream_t st);
+// the exact one-pass form (weights = f32 super-block scale x fp16 integer; IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S)
+bool vmx_iq_int_form_ok(int ggml_type);
+int vmx_iq_dequantize_int_f16(int ggml_type, const void *blocks, uint16_t *Q, float *Dt, int rows, int nsb, hipStream_t st);
+size_t vmx_iq_gemm_int_workspace(int M, int N, int K);
+int vmx_iq_dequant_int(int ggml_type, const void *blocks, void *workspace, int N, int K, hipStream_t st);
+int vmx_bf16_rows_to_f16(const uint16_t *A, uint16_t *a16, int64_t n, hipStream_t st);
+int vmx_int_gemm_f32(const uint16_t *a16, const void *workspace, float *C, int M, int N, int K, int ldc, hipStream_t st);
 int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st);
 // bf16 matrix-core GEMM y = bf16(bf16(x @ W^T) + bias), W [N, K] bf16 (fp8_kernels.hip)
 int vmx_bf16_gemm_nt(uint16_t *y, const uint16_t *x, const uint16_t *w, const uint16_t *bias, int M, int N, int K, hipStream_t st);
