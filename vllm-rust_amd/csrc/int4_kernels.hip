@@ -1067,6 +1067,210 @@ __global__ __launch_bounds__(256) void int4_gemm_tiled_kernel(const uint4 *__res
             }
 }
 
+// The same product with a 64-row x 256-column workgroup tile, built around what bounds the 64 x 128 form on gfx950 (its vector
+// ALU: staging, row sums and the per-k-block epilogue cost twice the cycles of its matrix instructions):
+//   * a wave owns FOUR column tiles (64 x 64 outputs): one A-fragment read from LDS feeds four matrix instructions;
+//   * the activation tile goes from global memory straight into LDS (global_load_lds, no registers, no vector-ALU work).
+//     Rows are 256 bytes unpadded; lane l of a 1 KiB request fills slot (row l / 16, position l % 16) with the row's 16-byte
+//     chunk  position ^ (row & 15), so the 16 rows a fragment read touches lie in 16 different bank groups;
+//   * the row sums of the zero-point term come from the matrix cores: wave w multiplies row tile w by a matrix of ones
+//     (4 extra instructions per k-block), leaves the 16 sums in LDS, and every wave applies  -(s (128 + zp)) * sum  one
+//     k-block later, after the barrier it needs anyway; the epilogue per k-block is two fused multiply-adds per element.
+// 1-D grid, ordered so that the row tiles of one column block are neighbours in time AND run on the same XCD (workgroup i
+// runs on XCD i % 8): the block's weights come from HBM once and from that XCD's L2 for the other row tiles.  N % 256 == 0.
+// (w & 0x000F000F) | base in one instruction (the compiler emits v_and + v_or: VOP3 takes no second literal)
+__device__ __forceinline__ uint32_t nib_pair(uint32_t w, uint32_t base) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(0x000F000Fu), "v"(base));
+    return r;
+}
+
+template <bool GLU, bool GROUPED = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void int4_gemm_tiled4_kernel(
+    const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ, const uint16_t *__restrict__ x, float *__restrict__ partial,
+    uint16_t *__restrict__ act, int M, int N, int K, int group, int kb_per_split, int slice_rows, Int4GroupedArgs ga, int row_tiles,
+    uint16_t *__restrict__ ybf, const uint16_t *__restrict__ bias) {
+    // ybf (one split only): the finished bf16 output y = bf16(sum + bias) instead of f32 slices
+    __shared__ __align__(16) uint16_t xs[2][PF_BM * KB];
+    __shared__ __align__(16) float sumx[2][PF_BM];
+    __shared__ int32_t prow_s[PF_BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 15, h = lane >> 4;
+    const int kblocks = K / KB, G = K / group;
+    const int col_blocks = N >> 8, cbg = (col_blocks + 7) >> 3;
+    // id -> (split, group of 8 column blocks, row tile, column block inside the group)
+    const int per_split = cbg * 8 * row_tiles;
+    const int ks = (int)blockIdx.x / per_split, rid = (int)blockIdx.x % per_split;
+    const int g8 = rid / (8 * row_tiles), rem = rid % (8 * row_tiles);
+    const int rt = rem >> 3, cb = g8 * 8 + (rem & 7);
+    if (cb >= col_blocks) return;
+    const int row0 = rt * PF_BM;
+    const int nt0 = cb * 16 + wave * 4;   // this wave's four column tiles
+    const int kb_begin = ks * kb_per_split, kb_end = min(kblocks, kb_begin + kb_per_split);
+    if constexpr (GROUPED) {
+        if (row0 >= ga.total_post_pad[0]) return;
+        int e = ga.block_expert[rt];
+        e = e < 0 ? 0 : (e >= ga.num_experts ? ga.num_experts - 1 : e);
+        const char *packed = static_cast<const char *>(ga.table[e]);
+        if (!packed) return;
+        W = reinterpret_cast<const uint4 *>(packed);
+        SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
+        if (tid < PF_BM) {
+            const int p = ga.sorted[row0 + tid];
+            prow_s[tid] = p >= 0 && p < ga.numel ? p : -1;
+        }
+        __syncthreads();
+    }
+    // The four 1 KiB pieces of the activation tile this wave requests per k-block: piece q = rows 16 wave + 4 q .. + 3.  A row
+    // past the end (or a padding pair) reads row 0: its outputs are never stored.
+    const uint16_t *xsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = wave * 16 + q * 4 + (lane >> 4);
+        int64_t grow;
+        if constexpr (GROUPED) {
+            const int p = prow_s[r];
+            grow = p < 0 ? 0 : p / ga.x_row_div;
+        } else {
+            grow = row0 + r < M ? row0 + r : 0;
+        }
+        xsrc[q] = x + grow * K + (((lane & 15) ^ (r & 15)) << 3);
+    }
+
+    vmx_f32x4 fin[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) fin[mt][c] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 wr[4];
+    uint32_t szr[4];
+    auto fetch = [&](int kb, int b) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xsrc[q] + kb * KB),
+                                             (__attribute__((address_space(3))) void *)(&xs[b][(wave * 16 + q * 4) * KB]), 16, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            wr[c] = W[((int64_t)(nt0 + c) * kblocks + kb) * 64 + lane];
+            szr[c] = SZ[((int64_t)(nt0 + c) * G + (kb * KB) / group) * 16 + nl];
+        }
+    };
+    if (kb_begin < kb_end) fetch(kb_begin, 0);
+    int buf = 0;
+    float nsz_prev[4] = {0.f, 0.f, 0.f, 0.f};   // -(s (128 + zp)) of the previous k-block
+    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    uint32_t base = 0x43004300u;
+    asm volatile("" : "+v"(base));   // kept in a vector register: the third operand of v_and_or_b32
+    // byte offset of this lane's A fragments inside a tile: row (mt * 16 + nl), chunk (4 i + h) at position chunk ^ nl
+    for (int kb = kb_begin; kb < kb_end; kb++) {
+        const uint4 wc[4] = {wr[0], wr[1], wr[2], wr[3]};
+        float sc[4], nsz[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            sc[c] = __uint_as_float(szr[c] << 16);
+            nsz[c] = -sc[c] * __uint_as_float(szr[c] & 0xFFFF0000u);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile requested one iteration ago has landed in LDS
+        __syncthreads();
+        if (kb + 1 < kb_end) fetch(kb + 1, buf ^ 1);   // next block's loads fly under this block's matrix work
+        const uint16_t *xb = xs[buf];
+
+        // zero-point term of the previous k-block (its row sums became visible with the barrier above)
+        if (kb > kb_begin) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const float4 sx = *reinterpret_cast<const float4 *>(&sumx[buf ^ 1][mt * 16 + 4 * h]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    fin[mt][c][0] = fmaf(nsz_prev[c], sx.x, fin[mt][c][0]);
+                    fin[mt][c][1] = fmaf(nsz_prev[c], sx.y, fin[mt][c][1]);
+                    fin[mt][c][2] = fmaf(nsz_prev[c], sx.z, fin[mt][c][2]);
+                    fin[mt][c][3] = fmaf(nsz_prev[c], sx.w, fin[mt][c][3]);
+                }
+            }
+        }
+        vmx_f32x4 acc[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[mt][c] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+        vmx_f32x4 rs = {0.f, 0.f, 0.f, 0.f};   // row sums of row tile `wave`
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint4 bu[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t w = i == 0 ? wc[c].x : (i == 1 ? wc[c].y : (i == 2 ? wc[c].z : wc[c].w));
+                bu[c].x = nib_pair(w, base);
+                bu[c].y = nib_pair(w >> 4, base);
+                bu[c].z = nib_pair(w >> 8, base);
+                bu[c].w = nib_pair(w >> 12, base);
+            }
+            {
+                const uint4 aw = *reinterpret_cast<const uint4 *>(xb + (wave * 16 + nl) * KB + (((4 * i + h) ^ nl) << 3));
+                rs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, aw), __builtin_bit_cast(vmx_bf16x8, ones), rs, 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const uint4 au = *reinterpret_cast<const uint4 *>(xb + (mt * 16 + nl) * KB + (((4 * i + h) ^ nl) << 3));
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, bu[c]),
+                                                                         acc[mt][c], 0, 0, 0);
+            }
+        }
+        if (nl == 0) *reinterpret_cast<float4 *>(&sumx[buf][wave * 16 + 4 * h]) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) fin[mt][c][r] = fmaf(sc[c], acc[mt][c][r], fin[mt][c][r]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) nsz_prev[c] = nsz[c];
+        buf ^= 1;
+    }
+    if (kb_begin < kb_end) {   // zero-point term of the last k-block
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const float4 sx = *reinterpret_cast<const float4 *>(&sumx[buf ^ 1][mt * 16 + 4 * h]);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                fin[mt][c][0] = fmaf(nsz_prev[c], sx.x, fin[mt][c][0]);
+                fin[mt][c][1] = fmaf(nsz_prev[c], sx.y, fin[mt][c][1]);
+                fin[mt][c][2] = fmaf(nsz_prev[c], sx.z, fin[mt][c][2]);
+                fin[mt][c][3] = fmaf(nsz_prev[c], sx.w, fin[mt][c][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = row0 + mt * 16 + 4 * h + r;
+                if constexpr (GROUPED) {
+                    const int p = prow_s[mt * 16 + 4 * h + r];
+                    row = p < 0 ? M : p;   // padding rows fail the bound check below (M = numel)
+                }
+                if constexpr (GLU) {
+                    const float up = __shfl_xor(fin[mt][c][r], 8, 64);
+                    if (row < M && nl < 8) {
+                        const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(fin[mt][c][r]));
+                        const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
+                        act[(int64_t)row * (N >> 1) + (nt0 + c) * 8 + nl] = vmx_f32_to_bf16((gg / (1.0f + expf(-gg))) * uu);
+                    }
+                } else if (row < M) {
+                    const int n = (nt0 + c) * 16 + nl;
+                    if (ybf) ybf[(int64_t)row * N + n] = vmx_f32_to_bf16(bias ? fin[mt][c][r] + vmx_bf16_to_f32(bias[n]) : fin[mt][c][r]);
+                    else partial[((int64_t)ks * slice_rows + row) * N + n] = fin[mt][c][r];
+                }
+            }
+}
+
 // Token-grouped form for a handful of rows per expert (decode batches): row block blockIdx.y = 16 sorted (token, slot) pairs
 // of one expert (moe_align_block_size with block_size 16); the expert's tile stream is read once for all of them, at the rate of
 // the small-M kernel.  GLU: act [pairs][N/2]; else partial [splits][pairs][N].
@@ -1308,6 +1512,26 @@ static bool tiled_ok(int M, int N) {
     return !off && M >= min_m && N % 128 == 0;
 }
 
+// Launch of the prompt-shaped kernel: 64 x 256 workgroup tiles where N allows (VMX_INT4_TILED_WIDE=0 keeps 64 x 128 for A/B runs)
+static bool tiled_wide_ok(int N) {
+    static const bool wide = vmx_tune("VMX_INT4_TILED_WIDE", 1) != 0;
+    return wide && N % 256 == 0;
+}
+
+template <bool GLU, bool GROUPED>
+static void launch_tiled(const uint4 *W, const uint32_t *SZ, const uint16_t *x, float *partial, uint16_t *act, int M, int N, int K, int group,
+                         int kbs, int slice_rows, const Int4GroupedArgs &ga, int row_tiles, int splits, hipStream_t st,
+                         uint16_t *ybf = nullptr, const uint16_t *bias = nullptr) {
+    if (tiled_wide_ok(N)) {
+        const int cbg = ((N >> 8) + 7) >> 3;
+        hipLaunchKernelGGL((int4_gemm_tiled4_kernel<GLU, GROUPED>), dim3(cbg * 8 * row_tiles * splits), dim3(256), 0, st, W, SZ, x, partial, act, M, N,
+                           K, group, kbs, slice_rows, ga, row_tiles, ybf, bias);
+    } else {
+        hipLaunchKernelGGL((int4_gemm_tiled_kernel<GLU, GROUPED>), dim3(N / 128, row_tiles, splits), dim3(256), 0, st, W, SZ, x, partial, act, M, N,
+                           K, group, kbs, slice_rows, ga);
+    }
+}
+
 // ---- internal (C++) entry points used by the decoder ---------------------------------------
 int vmx_int4_splits(int N, int K) { return plan_gemm(N, K).splits; }
 
@@ -1318,8 +1542,7 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
     if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, the same split-K slices as the small-M plan
         const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
-        hipLaunchKernelGGL(int4_gemm_tiled_kernel<false>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, p.splits), dim3(256), 0, st, W, SZ, x, partial,
-                           (uint16_t *)nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{});
+        launch_tiled<false, false>(W, SZ, x, partial, nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{}, (M + PF_BM - 1) / PF_BM, p.splits, st);
         VMX_CHECK_LAUNCH("int4_gemm(tiled)");
         return VMX_OK;
     }
@@ -1535,8 +1758,7 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
     if (tiled_ok(M, N)) {
-        hipLaunchKernelGGL(int4_gemm_tiled_kernel<true>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, 1), dim3(256), 0, st, W, SZ, x, (float *)nullptr,
-                           act, M, N, K, group, K / KB, M, Int4GroupedArgs{});
+        launch_tiled<true, false>(W, SZ, x, nullptr, act, M, N, K, group, K / KB, M, Int4GroupedArgs{}, (M + PF_BM - 1) / PF_BM, 1, st);
         VMX_CHECK_LAUNCH("int4_gemm(tiled glu)");
         return VMX_OK;
     }
@@ -1655,13 +1877,10 @@ int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *
         return VMX_OK;
     }
     VMX_REQUIRE(N % 128 == 0, "int4_gemm_token_grouped: N (%d) must be a multiple of 128", N);
-    const dim3 grid(N / 128, max_blocks, act ? 1 : p.splits);
     if (act)
-        hipLaunchKernelGGL((int4_gemm_tiled_kernel<true, true>), grid, dim3(256), 0, st, (const uint4 *)nullptr, (const uint32_t *)nullptr, x,
-                           (float *)nullptr, act, pairs, N, K, group, kblocks, pairs, ga);
+        launch_tiled<true, true>(nullptr, nullptr, x, nullptr, act, pairs, N, K, group, kblocks, pairs, ga, max_blocks, 1, st);
     else
-        hipLaunchKernelGGL((int4_gemm_tiled_kernel<false, true>), grid, dim3(256), 0, st, (const uint4 *)nullptr, (const uint32_t *)nullptr, x,
-                           partial, (uint16_t *)nullptr, pairs, N, K, group, kbs, pairs, ga);
+        launch_tiled<false, true>(nullptr, nullptr, x, partial, nullptr, pairs, N, K, group, kbs, pairs, ga, max_blocks, p.splits, st);
     VMX_CHECK_LAUNCH("int4_gemm(token grouped)");
     return VMX_OK;
 }
@@ -1703,12 +1922,23 @@ extern "C" int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *pa
     float *partial = (float *)workspace;
     (void)mc;
     if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, then the slices are summed (+ bias) into bf16
-        const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
-        hipLaunchKernelGGL(int4_gemm_tiled_kernel<false>, dim3(N / 128, (M + PF_BM - 1) / PF_BM, p.splits), dim3(256), 0, st, W, SZ, x, partial,
-                           (uint16_t *)nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{});
+        const int kblocks = K / KB, row_tiles = (M + PF_BM - 1) / PF_BM;
+        // split-K only while the tiles alone leave compute units idle (the plan's slice count is sized for one row tile)
+        int splits = p.splits;
+        if (tiled_wide_ok(N)) {
+            const int tiles = (N >> 8) * row_tiles, want = (2 * vmx_num_cus() + tiles - 1) / tiles;
+            splits = want < splits ? (want < 1 ? 1 : want) : splits;
+        }
+        const int kbs = (kblocks + splits - 1) / splits;
+        if (splits == 1 && tiled_wide_ok(N)) {   // one slice: the kernel writes the bf16 output itself
+            launch_tiled<false, false>(W, SZ, x, nullptr, nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{}, row_tiles, 1, st, y, bias);
+            VMX_CHECK_LAUNCH("int4_gemm(tiled)");
+            return VMX_OK;
+        }
+        launch_tiled<false, false>(W, SZ, x, partial, nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{}, row_tiles, splits, st);
         VMX_CHECK_LAUNCH("int4_gemm(tiled)");
         const int64_t total = (int64_t)M * N;
-        hipLaunchKernelGGL(int4_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, bias, y, M, N, p.splits);
+        hipLaunchKernelGGL(int4_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, bias, y, M, N, splits);
         VMX_CHECK_LAUNCH("int4_reduce");
         return VMX_OK;
     }
