@@ -398,12 +398,13 @@ def exl3_secondary(reps=8):
 
 def exl3_decode_secondary(prompt, steps, warmup):
     """BASELINE.json configs[3] at TP=1: decode tok/s of a Qwen3-8B-shaped model whose 252 projections are EXL3 4.0 bpw
-    trellis-coded linears (bf16 model; each linear casts to fp16 and back as the reference's Exl3Linear does)."""
+    trellis-coded linears, run in fp16 end to end as the reference runs an EXL3 checkpoint (fp16 embedding, norms, lm_head,
+    activations and KV cache; weight_loader.rs:453-461)."""
     from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
     total = prompt + warmup + steps + 8
     n_blocks = (total + 15) // 16 + 1
     spec = Qwen3Spec.qwen3_8b(max_position=max(4096, total + 1), num_blocks=n_blocks, max_batch=1, max_seq_len=total + 1,
-                              max_prefill_tokens=prompt)
+                              max_prefill_tokens=prompt, act_dtype="f16")
     model = QuantizedQwen3ForCausalLM(spec)
     model.load_synthetic_exl3(bits=4, codebook=0, seed=9)
     dev = model.device
@@ -445,7 +446,7 @@ def exl3_decode_secondary(prompt, steps, warmup):
     model.close()
     return {"metric": "decode tok/s (greedy, batch=1), Qwen3-8B EXL3 4.0 bpw, TP=1", "value": round(steps / dt, 2), "unit": "tok/s",
             "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-            "config": {"workload": "Qwen3-8B-shaped: 36 layers, 252 EXL3 4.0 bpw projections (default codebook), bf16 lm_head and KV",
+            "config": {"workload": "Qwen3-8B-shaped: 36 layers, 252 EXL3 4.0 bpw projections (default codebook), fp16 activations, lm_head and KV",
                        "weights": "seeded random trellis words and sign/scale vectors", "execution": "one hipGraph per step"},
             "weight_bytes_per_token": int(per_tok), "GBps_weights_only": round(per_tok / (dt / steps) / 1e9, 1),
             "roofline": {"bound": "valu (trellis decode: 7 vector-ALU slots per weight); shown against HBM", "kernel": "exl3_gemm_kernel<4 bpw>",
@@ -825,6 +826,8 @@ def main():
     if args.layers:
         full_spec.num_layers = args.layers
     exl3 = args.weights == "exl3"
+    if exl3:   # an EXL3 checkpoint runs in fp16 end to end (weight_loader.rs:453-461)
+        full_spec.act_dtype = "f16"
     B = 1
 
     # ---- the primary job
@@ -935,7 +938,7 @@ def main():
             "ms_per_step": round(elapsed / K_steps * 1e3, 4), "higher_is_better": True, "scaling": plan["scaling"], "vs_baseline": None,
             "dtype": "4-bit trellis weights x fp16 activations, f32 accumulate" if exl3 else "int4 weights x bf16 activations, f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": (f"Qwen3-8B EXL3 4.0 bpw ({geometry}) greedy decode, batch=1, {args.prompt}-token prompt then timed tokens, bf16 KV" if exl3 else
+            "config": {"workload": (f"Qwen3-8B EXL3 4.0 bpw ({geometry}) greedy decode, batch=1, {args.prompt}-token prompt then timed tokens, fp16 activations and KV" if exl3 else
                                     f"Qwen3-8B AWQ int4 g128 ({geometry}) greedy decode, batch=1, {args.prompt}-token prompt (native prefill) then timed tokens, bf16 KV"),
                        "parallelism": parallelism,
                        "weights": "seeded random-init checkpoint of the Qwen3-8B architecture" + (" (every rank slices the same one)" if mode == "tp" else ""),

@@ -314,6 +314,9 @@ int vmx_silu_and_mul_bf16(uint16_t *out, const uint16_t *gate, const uint16_t *u
 size_t vmx_argmax_workspace_bytes(int rows, int vocab);
 int vmx_argmax_bf16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace,
                     size_t workspace_bytes, void *stream);
+/* The same over fp16 logits: the dtype-generic argmax of sampling/gpu.rs (greedy path) on a model that runs in fp16. */
+int vmx_argmax_f16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace,
+                   size_t workspace_bytes, void *stream);
 
 /* Replace temperature_scale_bf16, softmax_to_probs(_f32) and top_k_top_p_sample(_per_seq)
  * (crates/core/kernels/sampling.cu:102-190,197-293,351-520; callers sampling/gpu.rs:834-1094).
@@ -414,7 +417,11 @@ int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_c
                                const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
                                int num_kv_heads, int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
                                const float *v_scale, void *stream);
-
+/* The same for a model that runs in fp16 (EXL3 checkpoints, crates/core/src/quantization/weight_loader.rs:453-461): q, the
+ * cache and out hold fp16; fp16 forms of the matrix instructions, softmax weights rounded to fp16. */
+int vmx_prefill_attention_f16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                              const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
+                              int num_kv_heads, int head_dim, int block_size, int window, void *stream);
 
 /* Replaces the cuBLAS half_matmul_pooled used for the (tied) lm_head on the decode path
  * (crates/core/src/models/qwen3_quantized.rs:1258-1302; cuda_kernels.rs half_matmul_pooled):
@@ -422,6 +429,9 @@ int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_c
  * The reference's arithmetic lives in a third-party library, so parity is tolerance-only. */
 int vmx_dense_gemv_bf16(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N,
                         int K, void *stream);
+/* The same product over fp16 x, W, bias and y (the lm_head of a model that runs in fp16; same call site). */
+int vmx_dense_gemv_f16(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N,
+                       int K, void *stream);
 
 /* Replaces embedding_lookup_bf16 (crates/core/kernels/activations.cu embedding_lookup_*):
  * out[t, :] = table[ids[t], :]; out-of-range ids give a zero row. */
@@ -510,6 +520,7 @@ int vmx_comm_world(const vmx_comm *c);
  * linear outputs (parallel_layers.rs:296) and Max of the 64-bit argmax keys of the vocabulary-parallel head. */
 int vmx_comm_all_reduce(vmx_comm *c, void *buf, size_t count, int dtype, int op, void *stream);
 int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t count, void *stream);
+int vmx_comm_all_reduce_sum_f16(vmx_comm *c, uint16_t *buf, size_t count, void *stream);   /* fp16 rows: models that run in fp16 */
 int vmx_comm_all_reduce_max_u64(vmx_comm *c, unsigned long long *buf, size_t count, void *stream);
 /* all_gather along dimension 0 (communicator.rs:44; ColumnParallelLinear's gather_output, parallel_layers.rs:152):
  * out [world][bytes_per_rank]. */
@@ -707,6 +718,14 @@ int vmx_debug_set_fused_attention(int enable);
  * engine/helpers.rs:1076).  on != 0: the rows are consecutive tokens of one sequence over a shared block table (a prompt fed
  * through the decode path); the executor then writes every row's K/V before any row's attention starts. */
 int vmx_qwen3_set_rows_share_cache(vmx_qwen3 *m, int on);
+
+/* The 16-bit type the model runs in: VMX_BF16 (default) or VMX_F16.  The reference's Exl3WeightLoader forces fp16 on the
+ * activation path whatever dtype was configured -- embedding, norms and lm_head of published EXL3 checkpoints are fp16 too
+ * (crates/core/src/quantization/weight_loader.rs:453-461), and Exl3Linear::forward casts to fp16 and back on any other
+ * dtype (exl3.rs:222-277).  With VMX_F16 every 16-bit tensor handed to vmx_qwen3_load_tensor (embedding, lm_head, norm
+ * weights), the logits and the KV cache hold fp16, and every rounding point of the bf16 form rounds to fp16.  Call before
+ * loading tensors; needs kv_cache_dtype VMX_KV_AUTO, a dense MLP, and every projection loaded as an EXL3 linear. */
+int vmx_qwen3_set_activation_dtype(vmx_qwen3 *m, int dtype);
 
 /* Attach the tensor-parallel group of a model created with tp_size > 1 (not owned by the model). */
 int vmx_qwen3_set_comm(vmx_qwen3 *m, vmx_comm *comm);

@@ -105,8 +105,80 @@ class OracleQwen3:
             out[t] = orc.f32_to_bf16(acc)
         return out
 
+    # ---- a model that runs in fp16 (EXL3 checkpoints: weight_loader.rs:453-461): the same operator order with fp16 tensors.
+    # The reference's own vector kernels are bf16-only, so on this path its norms / rotary / activation go through the
+    # third-party tensor library (absent here): f32 arithmetic with one rounding to fp16 per operator is assumed -- parity unpinned.
+    @staticmethod
+    def _f(u16):
+        return u16.view(np.float16).astype(np.float32)
+
+    @staticmethod
+    def _h(f32):
+        return np.asarray(f32, np.float32).astype(np.float16).view(np.uint16)
+
+    def _rms_f16(self, x_u16, w_u16, eps):
+        x = self._f(x_u16)
+        inv = (np.float32(1.0) / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + eps)).astype(np.float32)
+        return self._h(x * inv * self._f(w_u16)[None, :])
+
+    def decode_f16(self, ids, positions, slots, block_tables, seq_lens):
+        s = self.s
+        B, hd, Hq, Hkv = len(ids), s.head_dim, s.num_heads, s.num_kv_heads
+        f, hh = self._f, self._h
+        h = self.ck["embed"][ids]                                           # [B, H] fp16 bits
+        cs = self.cos_sin                                                   # f32 [max_pos, hd], values already rounded to fp16
+        for li in range(s.num_layers):
+            x = self._rms_f16(h, self.ck[f"{li}.input_ln"], s.rms_norm_eps)
+            q, k, v = (self.linear_f16(li, sl, x) for sl in (0, 1, 2))
+            if s.qk_norm:
+                q = self._rms_f16(q.reshape(B * Hq, hd), self.ck[f"{li}.q_norm"], s.rms_norm_eps).reshape(B, -1)
+                k = self._rms_f16(k.reshape(B * Hkv, hd), self.ck[f"{li}.k_norm"], s.rms_norm_eps).reshape(B, -1)
+
+            def rope(t_u16, nh):
+                t = f(t_u16).reshape(B, nh, hd)
+                c, sn = cs[positions][:, None, :hd // 2], cs[positions][:, None, hd // 2:]
+                a, b = t[..., :hd // 2], t[..., hd // 2:]
+                return hh(np.concatenate([a * c - b * sn, b * c + a * sn], -1)).reshape(B, nh * hd)
+            q, k = rope(q, Hq), rope(k, Hkv)
+            for b in range(B):
+                if slots[b] >= 0:
+                    self.k_cache[li].reshape(-1, Hkv, hd)[slots[b]] = k[b].reshape(Hkv, hd)
+                    self.v_cache[li].reshape(-1, Hkv, hd)[slots[b]] = v[b].reshape(Hkv, hd)
+            attn = np.zeros((B, Hq * hd), np.uint16)
+            for b in range(B):
+                n = int(seq_lens[b])
+                if n == 0:
+                    continue
+                rows = np.array([block_tables[b, t // s.block_size] * s.block_size + t % s.block_size for t in range(n)])
+                K = f(self.k_cache[li].reshape(-1, Hkv, hd)[rows]).astype(np.float64)    # [n, Hkv, hd]
+                V = f(self.v_cache[li].reshape(-1, Hkv, hd)[rows]).astype(np.float64)
+                qb = f(q[b]).reshape(Hq, hd).astype(np.float64)
+                for hq in range(Hq):
+                    kv = hq // (Hq // Hkv)
+                    lg = (K[:, kv, :] @ qb[hq]) / np.sqrt(hd)
+                    p = np.exp(lg - lg.max())
+                    attn[b, hq * hd:(hq + 1) * hd] = hh(((p / p.sum()) @ V[:, kv, :]).astype(np.float32))
+            h = hh(f(self.linear_f16(li, 3, attn)) + f(h))
+            x = self._rms_f16(h, self.ck[f"{li}.post_ln"], s.rms_norm_eps)
+            g, u = f(self.linear_f16(li, 4, x)), f(self.linear_f16(li, 5, x))
+            a = hh((g / (np.float32(1.0) + np.exp(-g))) * u)
+            h = hh(f(h) + f(self.linear_f16(li, 6, a)))
+        x = self._rms_f16(h, self.ck["final_norm"], s.rms_norm_eps)
+        if getattr(self, "_head64", None) is None:
+            head = self.ck["embed"] if s.tie_word_embeddings else self.ck["lm_head"]
+            self._head64 = f(head).astype(np.float64).T.copy()
+        logits = hh((f(x).astype(np.float64) @ self._head64).astype(np.float32))
+        return logits, h, x
+
+    def linear_f16(self, li, slot, x_u16):
+        """Exl3Linear::forward on fp16 rows (exl3.rs:216-286): no casts either side."""
+        bits, cb, tr, K, N, suh, svh = self.ex[(li, slot)]
+        return orc.exl3_gemm(x_u16, tr, suh, svh, K, N, bits, cb)
+
     def decode(self, ids, positions, slots, block_tables, seq_lens):
         s = self.s
+        if getattr(s, "act_dtype", "bf16") == "f16":
+            return self.decode_f16(ids, positions, slots, block_tables, seq_lens)
         B = len(ids)
         h = self.ck["embed"][ids]                                           # [B, H] bf16
         for li in range(s.num_layers):

@@ -88,7 +88,7 @@ def _decode_logits(torch, model, spec):
     bt = torch.tensor([[0, 1], [2, 3]], dtype=torch.int32, device="cuda")
     slots = torch.tensor([0, 32], dtype=torch.int32, device="cuda")
     sl = torch.tensor([1, 1], dtype=torch.int32, device="cuda")
-    out = torch.empty((2, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+    out = torch.empty((2, spec.vocab_size), dtype=getattr(model, "act_torch_dtype", torch.bfloat16), device="cuda")
     model.forward_decode_batch(ids, pos, slots, bt, sl, logits=out)
     torch.cuda.synchronize()
     return out
@@ -167,33 +167,36 @@ def test_gptq_safetensors_directory_matches_the_same_weights_in_awq_form(tmp_pat
             b.close()
 
 
-def test_exl3_safetensors_directory_round_trip(tmp_path):
+@pytest.mark.parametrize("act_dtype", ["bf16", "f16"])
+def test_exl3_safetensors_directory_round_trip(tmp_path, act_dtype):
     """An ExLlamaV3-format directory (trellis / suh / svh per projection, the mcg flag tensor for the second codebook, fp16 backbone)
-    loads into the same executor as the same tensors handed over directly."""
+    loads into the same executor as the same tensors handed over directly -- a bf16 model converts the fp16 backbone, a model
+    that runs in fp16 takes it as stored."""
     import torch
     from safetensors.torch import save_file
     import vllm_rust_amd as vmx
     from vllm_rust_amd import checkpoint as ckp
     from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, Qwen3Spec
     vmx.init(0)
-    spec = Qwen3Spec(512, 2, 4, 2, 128, 1024, 2048, max_position=128, num_blocks=8, max_batch=2, max_seq_len=64)
+    spec = Qwen3Spec(512, 2, 4, 2, 128, 1024, 2048, max_position=128, num_blocks=8, max_batch=2, max_seq_len=64, act_dtype=act_dtype)
     a = QuantizedQwen3ForCausalLM(spec)
     b = QuantizedQwen3ForCausalLM(spec)
+    adt = a.act_torch_dtype
     try:
         ck = a.load_synthetic_exl3(bits=3, codebook=1, seed=6, keep_host_copy=True)
         # fp16 backbone, as published EXL3 checkpoints have it: give model `a` the same fp16-rounded values
         f16 = lambda t: t.to(torch.float16)
         from vllm_rust_amd.qwen3 import T_EMBED, T_FINAL_NORM, T_INPUT_LN, T_K_NORM, T_LM_HEAD, T_POST_LN, T_Q_NORM
         out = {"model.embed_tokens.weight": f16(ck["embed"]), "lm_head.weight": f16(ck["lm_head"]), "model.norm.weight": f16(ck["final_norm"])}
-        a.load_tensor(T_EMBED, 0, f16(ck["embed"]).to(torch.bfloat16).cuda())
-        a.load_tensor(T_LM_HEAD, 0, f16(ck["lm_head"]).to(torch.bfloat16).cuda())
-        a.load_tensor(T_FINAL_NORM, 0, f16(ck["final_norm"]).to(torch.bfloat16).cuda())
+        a.load_tensor(T_EMBED, 0, f16(ck["embed"]).to(adt).cuda())
+        a.load_tensor(T_LM_HEAD, 0, f16(ck["lm_head"]).to(adt).cuda())
+        a.load_tensor(T_FINAL_NORM, 0, f16(ck["final_norm"]).to(adt).cuda())
         for li in range(spec.num_layers):
             pre = f"model.layers.{li}."
             for name, key, tid in (("input_layernorm", "input_ln", T_INPUT_LN), ("post_attention_layernorm", "post_ln", T_POST_LN),
                                    ("self_attn.q_norm", "q_norm", T_Q_NORM), ("self_attn.k_norm", "k_norm", T_K_NORM)):
                 out[f"{pre}{name}.weight"] = f16(ck[f"{li}.{key}"])
-                a.load_tensor(tid, li, f16(ck[f"{li}.{key}"]).to(torch.bfloat16).cuda())
+                a.load_tensor(tid, li, f16(ck[f"{li}.{key}"]).to(adt).cuda())
             for slot, p in enumerate(ckp._PROJ):
                 bits, cb, tr, suh, svh = ck[f"{li}.{slot}.exl3"]
                 out[f"{pre}{p}.trellis"], out[f"{pre}{p}.suh"], out[f"{pre}{p}.svh"] = tr, suh, svh

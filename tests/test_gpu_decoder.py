@@ -266,6 +266,49 @@ def test_exl3_decoder_matches_oracle(gpu, bits, cb):
     model.close()
 
 
+def test_exl3_decoder_fp16_matches_oracle(gpu):
+    """An EXL3 model run in fp16 end to end (vmx_qwen3_set_activation_dtype: fp16 embedding / norms / lm_head, fp16 activations,
+    logits and cache) against the composed fp16 oracle; then the native prompt pass against the decode path on the same model."""
+    from tests.model_oracle import OracleQwen3
+    from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache
+    vmx, torch = gpu
+    spec = _tiny_spec(hidden_size=256, intermediate_size=512, act_dtype="f16", max_prefill_tokens=64)
+    model = QuantizedQwen3ForCausalLM(spec)
+    ck = model.load_synthetic_exl3(bits=4, codebook=0, seed=6, keep_host_copy=True)
+    ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta, "f16"))
+    B, MB = 2, 8
+    bt = np.arange(B * MB, dtype=np.int32).reshape(B, MB)
+    ids = np.array([5, 731], np.int32)
+    f32 = lambda u: u.view(np.float16).astype(np.float32)
+    for step in range(4):
+        pos = np.full(B, step, np.int32)
+        slots = (bt[:, 0] * spec.block_size + pos).astype(np.int32)
+        sl = pos + 1
+        logits = torch.empty((B, spec.vocab_size), dtype=torch.float16, device="cuda")
+        out = model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, pos, slots, bt, sl)), logits=logits)
+        torch.cuda.synchronize()
+        exp, _, _ = ref.decode(ids, pos, slots, bt, sl)
+        got = f32(_u16(torch, logits)); exp = f32(exp)
+        assert np.isfinite(got).all()
+        rel = np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum())
+        assert rel <= 1e-2, (step, rel)
+        ids = out.cpu().numpy().astype(np.int32)
+    model.close()
+    # prompt pass (fp16 prefill attention, 16-row EXL3 passes) == the same tokens through the decode path
+    prompt = torch.tensor([3, 500, 42, 42, 7, 999, 1, 250, 13, 77, 600, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17], dtype=torch.int32, device="cuda")
+    btp = torch.tensor([9, 2, 5, 11], dtype=torch.int32, device="cuda")
+    a = QuantizedQwen3ForCausalLM(spec); a.load_synthetic_exl3(bits=4, seed=21)
+    lg_a = torch.empty(spec.vocab_size, dtype=torch.float16, device="cuda")
+    id_a = a.prefill(prompt, 0, btp, logits_last=lg_a)
+    b = QuantizedQwen3ForCausalLM(spec); b.load_synthetic_exl3(bits=4, seed=21)
+    ids_b, lg_b = b.forward(prompt, 0, btp)
+    torch.cuda.synchronize()
+    ga, gb = lg_a.float().cpu().numpy(), lg_b[-1].float().cpu().numpy()
+    assert np.sqrt(((ga - gb) ** 2).sum() / (gb ** 2).sum()) <= 1e-2
+    assert gb[int(id_a[0])] >= gb.max() - abs(gb.max()) * 2 ** -8
+    a.close(); b.close()
+
+
 def test_prefill_forward_equals_token_by_token_decode(gpu):
     """forward() over a prompt (chunks of max_batch pseudo-sequences) must give the logits of feeding the same
     tokens one at a time: rows of the small-M linears and the per-sequence attention are independent."""

@@ -46,6 +46,18 @@ def _allreduce_worker(rank, world, conns, result_q):
                 if not torch.equal(buf.cpu().view(torch.int16), _expected(xs).view(torch.int16)):
                     bad.append(("eager", rep, n))
                 it += 1
+        # fp16 rows (a model that runs in fp16): the same protocol, sum rounded to fp16
+        for n in SIZES[:3]:
+            xs = [x.float().to(torch.float16) for x in _inputs(it, n, world)]
+            buf = xs[rank].cuda()
+            comm.all_reduce_sum_f16(buf)
+            torch.cuda.synchronize()
+            acc = torch.zeros(n, dtype=torch.float32)
+            for x in xs:
+                acc = acc + x.float()
+            if not torch.equal(buf.cpu().view(torch.int16), acc.to(torch.float16).view(torch.int16)):
+                bad.append(("eager fp16", n))
+            it += 1
         # the same call replayed from a graph with fresh inputs each time
         n = 4096
         buf = torch.zeros(n, dtype=torch.bfloat16, device="cuda")

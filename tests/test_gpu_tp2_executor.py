@@ -25,8 +25,10 @@ def _spec(moe, world=2):
     kw = dict(hidden_size=256, num_layers=2, num_heads=max(4, 2 * world), num_kv_heads=max(2, world), head_dim=64,
               intermediate_size=max(512, 128 * world), vocab_size=1024, group_size=128, max_position=64, num_blocks=8, block_size=16,
               max_batch=2, max_seq_len=64)
-    if moe == "exl3":   # every shard must hold whole 128-wide Hadamard blocks: 128-wide heads
+    if moe in ("exl3", "exl3_f16"):   # every shard must hold whole 128-wide Hadamard blocks: 128-wide heads
         kw.update(head_dim=128, num_heads=max(4, world))
+        if moe == "exl3_f16":   # the model runs in fp16 end to end: fp16 rows through the all-reduce
+            kw.update(act_dtype="f16")
     elif moe:
         kw.update(num_experts=max(4, world), experts_per_tok=2, qk_norm=False)
     return Qwen3Spec(**kw)
@@ -91,13 +93,13 @@ def _worker(rank, world, conns, result_q, moe):
                     for mdl in (shard, ref):
                         if mdl is not None:
                             mdl.load_tensor(which, li, w)
-        elif moe in ("exl3", "exl3_true"):
+        elif moe in ("exl3", "exl3_f16", "exl3_true"):
             full = _spec(moe, world)
             whole = QuantizedQwen3ForCausalLM(full)   # every rank draws the one seeded checkpoint; rank 0 keeps it as the reference
             ck = whole.load_synthetic_exl3(bits=4, codebook=0, seed=7, keep_host_copy=True)
             shard = QuantizedQwen3ForCausalLM(shard_spec(full, rank, world))
             _load_exl3_shard(shard, ck, full, rank, world)
-            if rank == 0 and moe == "exl3":
+            if rank == 0 and moe in ("exl3", "exl3_f16"):
                 ref = whole
             else:
                 whole.close()
@@ -132,11 +134,12 @@ def _worker(rank, world, conns, result_q, moe):
             pos = torch.full((B,), p, dtype=torch.int32, device="cuda")
             slots = (bt[:, p // full.block_size] * full.block_size + p % full.block_size).to(torch.int32)
             sl = pos + 1
-            lg = torch.empty((B, VL), dtype=torch.bfloat16, device="cuda")
+            adt = getattr(shard, "act_torch_dtype", torch.bfloat16)
+            lg = torch.empty((B, VL), dtype=adt, device="cuda")
             out = shard.forward_decode_batch(ids, pos, slots, bt, sl, logits=lg)
             torch.cuda.synchronize()
             if ref is not None:
-                lr = torch.empty((B, V), dtype=torch.bfloat16, device="cuda")
+                lr = torch.empty((B, V), dtype=adt, device="cuda")
                 out_ref = ref.forward_decode_batch(ref_ids, pos, slots, bt, sl, logits=lr)
                 torch.cuda.synchronize()
                 compare(p, lr.float().cpu().numpy(), out_ref.cpu().numpy().tolist(), lg.float().cpu().numpy(), out.cpu().numpy())
@@ -161,7 +164,7 @@ def _worker(rank, world, conns, result_q, moe):
         result_q.put((rank, ([("exception", repr(e), traceback.format_exc())], None, -1)))
 
 
-CASES = [(False, 2), (True, 2), ("gemma", 2), ("exl3", 2), (False, 4), (False, 8), (True, 8), ("gemma", 4), ("exl3", 4), ("exl3_true", 2)]
+CASES = [(False, 2), (True, 2), ("gemma", 2), ("exl3", 2), (False, 4), (False, 8), (True, 8), ("gemma", 4), ("exl3", 4), ("exl3_true", 2), ("exl3_f16", 2)]
 
 
 @pytest.mark.parametrize("moe,world", CASES, ids=[f"{'dense' if m is False else 'moe' if m is True else m}-tp{w}" for m, w in CASES])

@@ -32,6 +32,12 @@ def _rel(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
 
 
+def _act_f32(spec, u16):
+    """16-bit activation bits of the model's dtype (bf16, or fp16 for spec.act_dtype == "f16") as f32."""
+    from oracle import oracle as orc
+    return u16.view(np.float16).astype(np.float32) if getattr(spec, "act_dtype", "bf16") == "f16" else orc.bf16_to_f32(u16)
+
+
 def _fill_kv(torch, model, ref, num_layers, shapes, kv_dtype, seed, k_std=1.0):
     """Same random cache rows in the model and in the oracle; shapes[li] = (blocks, block_size, kv_heads, head_dim).
     k_std: standard deviation of the bf16 K rows (Gemma attends with scale 1.0 over 256 / 512 dims: unit-variance keys would
@@ -40,7 +46,8 @@ def _fill_kv(torch, model, ref, num_layers, shapes, kv_dtype, seed, k_std=1.0):
     for li in range(num_layers):
         for which, cache in ((0, ref.k_cache), (1, ref.v_cache)):
             if kv_dtype == 0:
-                t = (torch.randn(shapes[li], device="cuda", generator=g) * (k_std if which == 0 else 1.0)).to(torch.bfloat16)
+                t = (torch.randn(shapes[li], device="cuda", generator=g) * (k_std if which == 0 else 1.0)).to(
+                    getattr(model, "act_torch_dtype", torch.bfloat16))
                 host = _u16(torch, t)
             else:   # finite e4m3 bytes of moderate magnitude (exponent field <= 5: |x| < 0.5, so that softmax rows stay spread), random sign
                 mag = torch.randint(0, 0x30, shapes[li], device="cuda", generator=g, dtype=torch.int32)
@@ -70,12 +77,12 @@ def _decode_and_compare(torch, model, ref, spec, start_lens, steps, first_ids, b
         msl = int(sl.max())
         if fused_switch is not None:
             lib.vmx_debug_set_fused_attention(int(fused_switch(step)))
-        logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+        logits = torch.empty((B, spec.vocab_size), dtype=getattr(model, "act_torch_dtype", torch.bfloat16), device="cuda")
         out = model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, pos, slots, bt, sl)), max_seq_len=msl, logits=logits)
         torch.cuda.synchronize()
         exp, exp_h, _ = ref.decode(ids, pos, slots, bt, sl)
-        got = orc.bf16_to_f32(_u16(torch, logits)); expf = orc.bf16_to_f32(exp)
-        got_h = orc.bf16_to_f32(_u16(torch, model.debug_read(0, (B, spec.hidden_size)))); exp_hf = orc.bf16_to_f32(exp_h)
+        got = _act_f32(spec, _u16(torch, logits)); expf = _act_f32(spec, exp)
+        got_h = _act_f32(spec, _u16(torch, model.debug_read(0, (B, spec.hidden_size)))); exp_hf = _act_f32(spec, exp_h)
         assert np.isfinite(got).all()
         rh, rl = _rel(got_h, exp_hf), _rel(got, expf)
         print(f"step {step} seq_lens {sl.tolist()} rel-L2 h {rh:.4f} logits {rl:.4f}")
@@ -97,7 +104,7 @@ def _qwen3_case(gpu, spec, loader, start_lens, steps, first_ids, fused_switch=No
     model = QuantizedQwen3ForCausalLM(spec)
     try:
         ck = getattr(model, loader)(seed=13, keep_host_copy=True, **loader_kw)
-        ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta))
+        ref = OracleQwen3(spec, ck, rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta, spec.act_dtype))
         shape = (spec.num_blocks, spec.block_size, spec.num_kv_heads, spec.head_dim)
         _fill_kv(torch, model, ref, spec.num_layers, [shape] * spec.num_layers, spec.kv_cache_dtype, seed=99)
         return _decode_and_compare(torch, model, ref, spec, start_lens, steps, first_ids, bar, fused_switch)
@@ -175,6 +182,30 @@ def test_qwen3_8b_exl3_decode_rows(gpu):
     _qwen3_case(gpu, _spec_8b(max_batch=1, num_layers=3), "load_synthetic_exl3", start_lens=[41], steps=2, first_ids=[5], bar=3e-2, bits=4)
     _qwen3_case(gpu, _spec_8b(max_batch=4), "load_synthetic_exl3", start_lens=[0, 16, 511, 1020], steps=1, first_ids=[1, 22, 333, 4444],
                 bar=3e-2, bits=4)
+
+
+def test_qwen3_8b_exl3_fp16_activations(gpu):
+    """The same EXL3 geometry run in fp16 end to end (what the reference does with an EXL3 checkpoint: fp16 embedding, norms,
+    lm_head, activations and cache): the fused one-row layer at a short context (three layers), four rows across the attention
+    regimes (spread attention merged by o_proj, the many-partition form past 512 tokens), and two rows at 15 / 1023 tokens.
+    The oracle is the composed fp16 model of tests/model_oracle.py (parity unpinned: the reference's fp16 norms / rotary /
+    activation run in its third-party tensor library)."""
+    _qwen3_case(gpu, _spec_8b(max_batch=1, num_layers=3, act_dtype="f16"), "load_synthetic_exl3", start_lens=[41], steps=2, first_ids=[5],
+                bar=2e-2, bits=4)
+    _qwen3_case(gpu, _spec_8b(max_batch=4, act_dtype="f16"), "load_synthetic_exl3", start_lens=[0, 16, 511, 1020], steps=1,
+                first_ids=[1, 22, 333, 4444], bar=2e-2, bits=4)
+    _qwen3_case(gpu, _spec_8b(max_batch=2, act_dtype="f16"), "load_synthetic_exl3", start_lens=[15, 1023], steps=2, first_ids=[5, 6],
+                bar=2e-2, bits=4)
+
+
+def test_qwen3_8b_exl3_fp16_unfused_rows(gpu):
+    """fp16 activations on the launch sequences without the decode-row fusions: eight rows (per-projection EXL3 launches with
+    their own Hadamard kernels, q/k/v post-processing, one-launch or partitioned attention + merge, SiLU kernel) and the
+    three-launch attention forced at two rows."""
+    _qwen3_case(gpu, _spec_8b(max_batch=8, num_blocks=8 * 40, act_dtype="f16"), "load_synthetic_exl3",
+                start_lens=[0, 1, 15, 16, 100, 300, 511, 600], steps=1, first_ids=list(range(50, 58)), bar=2e-2, bits=4)
+    _qwen3_case(gpu, _spec_8b(max_batch=2, act_dtype="f16"), "load_synthetic_exl3", start_lens=[33, 700], steps=1, first_ids=[5, 6],
+                fused_switch=lambda step: False, bar=2e-2, bits=4)
 
 
 def test_mixtral_8x7b_moe_layers(gpu):

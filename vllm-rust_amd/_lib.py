@@ -103,6 +103,7 @@ _SIGS = {
     "vmx_silu_and_mul_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "vmx_argmax_workspace_bytes": (_sz, [_i, _i]),
     "vmx_argmax_bf16": (_i, [_p, _p, _i, _i, _p, _sz, _p]),
+    "vmx_argmax_f16": (_i, [_p, _p, _i, _i, _p, _sz, _p]),
     "vmx_kv_scales_state_bytes": (_sz, []),
     "vmx_kv_scales_init": (_i, [_p, _f, _f, _i, _p]),
     "vmx_kv_scales_calibrate_if_needed": (_i, [_p, _p, _i64, _p, _i64, _f, _p]),
@@ -115,6 +116,7 @@ _SIGS = {
     "vmx_paged_attention_static_max_bytes": (_sz, []),
     "vmx_paged_attention_bf16_static": (_i, [_p] * 6 + [_f] + [_i] * 9 + [_p, _p, _p]),
     "vmx_dense_gemv_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_dense_gemv_f16": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "vmx_embedding_lookup_bf16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "vmx_comm_unique_id": (_i, [_p]),
     "vmx_comm_create": (_i, [_p, _i, _i, _p]),
@@ -122,6 +124,7 @@ _SIGS = {
     "vmx_comm_rank": (_i, [_p]),
     "vmx_comm_world": (_i, [_p]),
     "vmx_comm_all_reduce_sum_bf16": (_i, [_p, _p, _sz, _p]),
+    "vmx_comm_all_reduce_sum_f16": (_i, [_p, _p, _sz, _p]),
     "vmx_comm_all_reduce_max_u64": (_i, [_p, _p, _sz, _p]),
     "vmx_comm_all_reduce": (_i, [_p, _p, _sz, _i, _i, _p]),
     "vmx_comm_all_gather": (_i, [_p, _p, _p, _sz, _p]),
@@ -150,6 +153,7 @@ _SIGS = {
     "vmx_qwen3_load_iq_linear": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "vmx_qwen3_load_dense_linear": (_i, [_p, _i, _i, _p, _sz, _p]),
     "vmx_qwen3_set_rows_share_cache": (_i, [_p, _i]),
+    "vmx_qwen3_set_activation_dtype": (_i, [_p, _i]),
     "vmx_qwen3_load_exl3_linear": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vmx_qwen3_decode": (_i, [_p] * 6 + [_i, _i, _i, _p, _p, _p]),
     "vmx_debug_set_fused_attention": (_i, [_i]),
@@ -164,6 +168,7 @@ _SIGS = {
     "vmx_qwen3_linears_select": (_i, [_p, _i]),
     "vmx_qwen3_linears_info": (_i, [_p, _i, _p, _p]),
     "vmx_prefill_attention_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "vmx_prefill_attention_f16": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _i, _i, _p]),
     "vmx_quant_detect_json": (_i, [C.c_char_p, C.c_char_p, _p]),
     "vmx_quant_detect_dir": (_i, [C.c_char_p, _p]),
     "vmx_safetensors_open": (_i, [C.c_char_p, _p]),

@@ -175,35 +175,38 @@ def load_qwen3_awq_checkpoint(model, model_dir):
     return det
 
 
-def _backbone_bf16(ck, name):
-    """A norm / embedding / lm_head tensor as torch bf16: bf16 checkpoints as stored, fp16 ones (EXL3 backbones) converted."""
+def _backbone_bf16(ck, name, want=None):
+    """A norm / embedding / lm_head tensor in the model's 16-bit dtype `want` (torch.bfloat16 by default): tensors stored in
+    that dtype go in as they are (the fp16 backbone of an EXL3 checkpoint into a model that runs in fp16), others are converted."""
     import torch
+    want = want or torch.bfloat16
     a = ck.get(name)
     f = ck._file(ck.where[name])
     dtype = f.info(lib.vmx_safetensors_find(f._h, name.encode()))[1]
     if dtype == "BF16":
-        return torch.from_numpy(a.view(np.int16)).view(torch.bfloat16)
+        return torch.from_numpy(a.view(np.int16)).view(torch.bfloat16).to(want)
     if dtype == "F16":
-        return torch.from_numpy(a.view(np.int16)).view(torch.float16).to(torch.bfloat16)
+        return torch.from_numpy(a.view(np.int16)).view(torch.float16).to(want)
     if dtype == "F32":
-        return torch.from_numpy(a).to(torch.bfloat16)
+        return torch.from_numpy(a).to(want)
     raise ValueError(f"{name}: backbone tensor of dtype {dtype}")
 
 
 def _load_backbone(model, ck):
     from .qwen3 import T_EMBED, T_FINAL_NORM, T_INPUT_LN, T_K_NORM, T_LM_HEAD, T_POST_LN, T_Q_NORM
     s = model.spec
-    model.load_tensor(T_EMBED, 0, _backbone_bf16(ck, "model.embed_tokens.weight").cuda())
+    want = getattr(model, "act_torch_dtype", None)
+    model.load_tensor(T_EMBED, 0, _backbone_bf16(ck, "model.embed_tokens.weight", want).cuda())
     if not s.tie_word_embeddings:
-        model.load_tensor(T_LM_HEAD, 0, _backbone_bf16(ck, "lm_head.weight").cuda())
-    model.load_tensor(T_FINAL_NORM, 0, _backbone_bf16(ck, "model.norm.weight").cuda())
+        model.load_tensor(T_LM_HEAD, 0, _backbone_bf16(ck, "lm_head.weight", want).cuda())
+    model.load_tensor(T_FINAL_NORM, 0, _backbone_bf16(ck, "model.norm.weight", want).cuda())
     for li in range(s.num_layers):
         pre = f"model.layers.{li}."
-        model.load_tensor(T_INPUT_LN, li, _backbone_bf16(ck, pre + "input_layernorm.weight").cuda())
-        model.load_tensor(T_POST_LN, li, _backbone_bf16(ck, pre + "post_attention_layernorm.weight").cuda())
+        model.load_tensor(T_INPUT_LN, li, _backbone_bf16(ck, pre + "input_layernorm.weight", want).cuda())
+        model.load_tensor(T_POST_LN, li, _backbone_bf16(ck, pre + "post_attention_layernorm.weight", want).cuda())
         if s.qk_norm:
-            model.load_tensor(T_Q_NORM, li, _backbone_bf16(ck, pre + "self_attn.q_norm.weight").cuda())
-            model.load_tensor(T_K_NORM, li, _backbone_bf16(ck, pre + "self_attn.k_norm.weight").cuda())
+            model.load_tensor(T_Q_NORM, li, _backbone_bf16(ck, pre + "self_attn.q_norm.weight", want).cuda())
+            model.load_tensor(T_K_NORM, li, _backbone_bf16(ck, pre + "self_attn.k_norm.weight", want).cuda())
 
 
 def load_qwen3_gptq_checkpoint(model, model_dir, use_zeros=None):
@@ -250,8 +253,9 @@ def load_qwen3_exl3_checkpoint(model, model_dir):
     """Fill a QuantizedQwen3ForCausalLM from an ExLlamaV3 directory (Exl3WeightLoader::load_linear, quantization/
     weight_loader.rs:470-559): per projection "<prefix>.trellis" i16 [in/16, out/16, 16 * bpw] (bits per weight from the last
     dimension, 2..8, may differ between tensors), ".suh" f16 [in], ".svh" f16 [out], and the codebook from the presence of the
-    flag tensors ".mcg" / ".mul1" (exl3.rs:90-152).  Backbone tensors of such checkpoints are fp16; this executor keeps its
-    residual stream in bf16, so they are converted on the way in."""
+    flag tensors ".mcg" / ".mul1" (exl3.rs:90-152).  Backbone tensors of such checkpoints are fp16: a model built with
+    act_dtype "f16" takes them as stored and runs in fp16 end to end, as the reference does (weight_loader.rs:453-461); a
+    bf16 model converts them on the way in."""
     import torch
     det = detect_from_directory(model_dir)
     if det.method != "exl3":

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
         }
 #pragma unroll
         for (int j = 0; j < EPL; j++) {
-            v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j]));
+            v[j] = vmx_rnd16<FP8 == 3>((v[j]));
             ss += v[j] * v[j];
         }
         const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
             const float inv = rsqrtf(ss / (float)HD + eps);
 #pragma unroll
             for (int j = 0; j < EPL; j++)
-                v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j] * inv * (nw ? vmx_bf16_to_f32(nw[lane + 64 * j]) : 1.0f)));
+                v[j] = vmx_rnd16<FP8 == 3>((v[j] * inv * (nw ? vmx_ld16<FP8 == 3>(nw[lane + 64 * j]) : 1.0f)));
         }
         if (is_q || is_k) {   // NeoX rotation of the first rot_dim dims: pairs (i, i + rot_dim/2)
             const int half = rot_dim >> 1;
@@ -675,28 +675,28 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
                     if (j < hj) {
                         const int i = lane + 64 * j;
                         const float xv = v[j], yv = v[j + hj], c = cs[i], sn = cs[half + i];
-                        v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(xv * c - yv * sn));
-                        v[j + hj] = vmx_bf16_to_f32(vmx_f32_to_bf16(yv * c + xv * sn));
+                        v[j] = vmx_rnd16<FP8 == 3>((xv * c - yv * sn));
+                        v[j + hj] = vmx_rnd16<FP8 == 3>((yv * c + xv * sn));
                     }
                 }
             } else {                  // half == 32 (checked on the host): partner is lane ^ 32 of element 0
                 const float other = __shfl_xor(v[0], 32, 64);
                 const int i = lane & 31;
                 const float c = cs[i], sn = cs[32 + i];
-                v[0] = vmx_bf16_to_f32(vmx_f32_to_bf16(lane < 32 ? v[0] * c - other * sn : v[0] * c + other * sn));
+                v[0] = vmx_rnd16<FP8 == 3>((lane < 32 ? v[0] * c - other * sn : v[0] * c + other * sn));
             }
         }
         if (is_q) {
 #pragma unroll
-            for (int j = 0; j < EPL; j++) qs[wave * HD + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+            for (int j = 0; j < EPL; j++) qs[wave * HD + lane + 64 * j] = vmx_st16<FP8 == 3>(v[j]);
         } else {
             const int slot = slots[seq];
             if (slot >= 0) {
                 const int64_t dst = ((int64_t)slot * Hkv + kvh) * HD;
                 void *cache = is_k ? k_cache : v_cache;
-                if constexpr (!FP8) {
+                if constexpr (kv16<FP8>()) {
 #pragma unroll
-                    for (int j = 0; j < EPL; j++) ((uint16_t *)cache)[dst + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+                    for (int j = 0; j < EPL; j++) ((uint16_t *)cache)[dst + lane + 64 * j] = vmx_st16<FP8 == 3>(v[j]);
                 } else {
                     const float sc = is_k ? ksc : vsc;
 #pragma unroll
@@ -763,10 +763,10 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
             val = acc * (1.0f / (gsum + 1e-6f));
         }
         const int64_t ob = ((int64_t)seq * Hq + kvh * nq + h) * HD + d;
-        const uint16_t vb = vmx_f32_to_bf16(val);
+        const uint16_t vb = vmx_st16<FP8 == 3>(val);
         out[ob] = vb;
         if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block
-            const float vq = vmx_bf16_to_f32(vb);
+            const float vq = vmx_ld16<FP8 == 3>(vb);
             float amax = fabsf(vq);
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
         const int64_t slice = (int64_t)tokens * ntot, base = (int64_t)seq * ntot + (int64_t)(has_head ? head : 0) * HD;
         const uint16_t *nw = is_q ? q_norm_w : (is_k ? k_norm_w : nullptr);
 #pragma unroll
-        for (int j = 0; j < EPL; j++) nwf[j] = nw ? vmx_bf16_to_f32(nw[lane + 64 * j]) : 1.0f;
+        for (int j = 0; j < EPL; j++) nwf[j] = nw ? vmx_ld16<FP8 == 3>(nw[lane + 64 * j]) : 1.0f;
         attn_sum_splits<EPL>(partial + base + lane, splits, slice, v);
     }
     // rotation factors of this lane's pairs (position known after the first round trip)
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < EPL; j++) {
-            v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j]));
+            v[j] = vmx_rnd16<FP8 == 3>((v[j]));
             ss += v[j] * v[j];
         }
         const bool normed = is_q ? q_norm_w != nullptr : (is_k ? k_norm_w != nullptr : v_norm != 0);
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
             ss = vmx_wave_sum(ss);
             const float inv = rsqrtf(ss / (float)HD + eps);
 #pragma unroll
-            for (int j = 0; j < EPL; j++) v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(v[j] * inv * nwf[j]));
+            for (int j = 0; j < EPL; j++) v[j] = vmx_rnd16<FP8 == 3>((v[j] * inv * nwf[j]));
         }
         if (is_q || is_k) {   // NeoX rotation of the first rot_dim dims: pairs (i, i + rot_dim/2)
             if ((half & 63) == 0) {   // partner in the same lane: element j pairs with j + half/64
@@ -895,24 +895,24 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
                 for (int j = 0; j < EPL / 2; j++) {
                     if (j < hj) {
                         const float xv = v[j], yv = v[j + hj];
-                        v[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(xv * rc[j] - yv * rs[j]));
-                        v[j + hj] = vmx_bf16_to_f32(vmx_f32_to_bf16(yv * rc[j] + xv * rs[j]));
+                        v[j] = vmx_rnd16<FP8 == 3>((xv * rc[j] - yv * rs[j]));
+                        v[j + hj] = vmx_rnd16<FP8 == 3>((yv * rc[j] + xv * rs[j]));
                     }
                 }
             } else {                  // half == 32 (checked on the host): partner is lane ^ 32 of element 0
                 const float other = __shfl_xor(v[0], 32, 64);
-                v[0] = vmx_bf16_to_f32(vmx_f32_to_bf16(lane < 32 ? v[0] * rc[0] - other * rs[0] : v[0] * rc[0] + other * rs[0]));
+                v[0] = vmx_rnd16<FP8 == 3>((lane < 32 ? v[0] * rc[0] - other * rs[0] : v[0] * rc[0] + other * rs[0]));
             }
         }
         if (is_q) {
 #pragma unroll
-            for (int j = 0; j < EPL; j++) qs[wave * HD + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+            for (int j = 0; j < EPL; j++) qs[wave * HD + lane + 64 * j] = vmx_st16<FP8 == 3>(v[j]);
         } else if (slot >= 0) {
             const int64_t dst = ((int64_t)slot * Hkv + kvh) * HD;
             void *cache = is_k ? k_cache : v_cache;
-            if constexpr (!FP8) {
+            if constexpr (kv16<FP8>()) {
 #pragma unroll
-                for (int j = 0; j < EPL; j++) ((uint16_t *)cache)[dst + lane + 64 * j] = vmx_f32_to_bf16(v[j]);
+                for (int j = 0; j < EPL; j++) ((uint16_t *)cache)[dst + lane + 64 * j] = vmx_st16<FP8 == 3>(v[j]);
             } else {
                 const float sc = is_k ? ksc : vsc;
 #pragma unroll
@@ -1071,6 +1071,8 @@ static int parts_for_impl(int max_seq_len) {
 //   O^T += V^T P^T   exactly the B fragment of v_mfma_f32_16x16x16_bf16 (k = token); A = V^T from LDS (row = head dim).
 // O^T keeps a query row in one accumulator column, so the online-softmax rescale is a per-lane multiply.
 typedef short vmx_s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vmx_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vmx_f16x8 __attribute__((ext_vector_type(8)));
 
 template <int HD, int QPK, int FP8>
 __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ q,
@@ -1125,6 +1127,13 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
             const int t = min(t0 + tok, hi - 1);    // rows past the end repeat the last valid row (their weights are 0)
             const int blk = block_table[t / block_size];
             const int64_t base = ((int64_t)blk * block_size + t % block_size) * tok_stride + (int64_t)kvh * HD + dc * 8;
+            if constexpr (FP8 == 3) {   // fp16 cache, fp16 matrix instructions: the bits go to LDS as they are
+                const uint4 kr = load8_raw<FP8>(k_cache, base), vr = load8_raw<FP8>(v_cache, base);
+                *reinterpret_cast<uint4 *>(&Ks[tok * KROW + dc * 8]) = kr;
+                const uint32_t vw[4] = {vr.x, vr.y, vr.z, vr.w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VROW + tok] = (uint16_t)(e & 1 ? vw[e >> 1] >> 16 : vw[e >> 1] & 0xFFFFu);
+            } else {
             float kf[8], vf[8];
             cvt8<FP8>(load8_raw<FP8>(k_cache, base), 1.0f, kf);
             cvt8<FP8>(load8_raw<FP8>(v_cache, base), 1.0f, vf);
@@ -1134,6 +1143,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
             *reinterpret_cast<uint4 *>(&Ks[tok * KROW + dc * 8]) = make_uint4(kw[0], kw[1], kw[2], kw[3]);
 #pragma unroll
             for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VROW + tok] = (uint16_t)(__float_as_uint(vf[e]) >> 16);
+            }
         }
         __syncthreads();
         // wave-uniform: does this KV tile intersect the wave's causal / window range at all
@@ -1143,6 +1153,9 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
 #pragma unroll
             for (int c = 0; c < KSTEPS; c++) {
                 const uint4 ka = *reinterpret_cast<const uint4 *>(&Ks[n * KROW + 32 * c + 8 * g]);
+                if constexpr (FP8 == 3)
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vmx_f16x8, ka), __builtin_bit_cast(vmx_f16x8, qb[c]), sacc, 0, 0, 0);
+                else
                 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, ka), __builtin_bit_cast(vmx_bf16x8, qb[c]), sacc, 0, 0, 0);
             }
             float sv[4], tmax = -FLT_MAX;
@@ -1168,11 +1181,14 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
             l_part = l_part * alpha + psum;
             vmx_s16x4 pb;
 #pragma unroll
-            for (int i = 0; i < 4; i++) pb[i] = (short)vmx_f32_to_bf16(p[i]);
+            for (int i = 0; i < 4; i++) pb[i] = (short)vmx_st16<FP8 == 3>(p[i]);
 #pragma unroll
             for (int d = 0; d < DT; d++) {
                 acc[d] *= alpha;
                 const vmx_s16x4 va = *reinterpret_cast<const vmx_s16x4 *>(&Vt[(16 * d + n) * VROW + 4 * g]);
+                if constexpr (FP8 == 3)
+                    acc[d] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(vmx_f16x4, va), __builtin_bit_cast(vmx_f16x4, pb), acc[d], 0, 0, 0);
+                else
                 acc[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, acc[d], 0, 0, 0);
             }
         }
@@ -1184,8 +1200,8 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
         uint16_t *o = out + ((int64_t)qi * num_heads + head) * HD;
 #pragma unroll
         for (int d = 0; d < DT; d++) {   // acc[d][i] = O[query row n][dim 16 d + 4 g + i]
-            const uint32_t w0 = (uint32_t)vmx_f32_to_bf16(acc[d][0] * inv) | ((uint32_t)vmx_f32_to_bf16(acc[d][1] * inv) << 16);
-            const uint32_t w1 = (uint32_t)vmx_f32_to_bf16(acc[d][2] * inv) | ((uint32_t)vmx_f32_to_bf16(acc[d][3] * inv) << 16);
+            const uint32_t w0 = (uint32_t)vmx_st16<FP8 == 3>(acc[d][0] * inv) | ((uint32_t)vmx_st16<FP8 == 3>(acc[d][1] * inv) << 16);
+            const uint32_t w1 = (uint32_t)vmx_st16<FP8 == 3>(acc[d][2] * inv) | ((uint32_t)vmx_st16<FP8 == 3>(acc[d][3] * inv) << 16);
             *reinterpret_cast<uint2 *>(o + 16 * d + 4 * g) = make_uint2(w0, w1);
         }
     }
@@ -1203,10 +1219,10 @@ int launch_prefill(hipStream_t st, uint16_t *out, const uint16_t *q, const void 
 }
 }  // namespace
 
-extern "C" int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
-                                          const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
-                                          int num_kv_heads, int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
-                                          const float *v_scale, void *stream) {
+static int prefill_attention_impl(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                  const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
+                                  int num_kv_heads, int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
+                                  const float *v_scale, void *stream, bool f16) {
     VMX_REQUIRE(out && q && k_cache && v_cache && block_table, "prefill_attention: null pointer");
     VMX_REQUIRE(q_len >= 0 && seqlen_offset >= 0, "prefill_attention: q_len %d / seqlen_offset %d", q_len, seqlen_offset);
     VMX_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
@@ -1219,13 +1235,14 @@ extern "C" int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, cons
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
     int rc = VMX_EUNSUPPORTED;
 #define ARGS st, out, q, k_cache, v_cache, block_table, q_len, seqlen_offset, scale, num_heads, num_kv_heads, block_size, window, k_scale, v_scale
+#define PF_ONE(HD, Q) rc = f16 ? launch_prefill<HD, Q, 3>(ARGS) : fp8 ? launch_prefill<HD, Q, 1>(ARGS) : launch_prefill<HD, Q, 0>(ARGS)
 #define BY_QPK(HD)                                                                                                          \
     switch (qpk) {                                                                                                          \
-        case 1: rc = fp8 ? launch_prefill<HD, 1, true>(ARGS) : launch_prefill<HD, 1, false>(ARGS); break;                   \
-        case 2: rc = fp8 ? launch_prefill<HD, 2, true>(ARGS) : launch_prefill<HD, 2, false>(ARGS); break;                   \
-        case 4: rc = fp8 ? launch_prefill<HD, 4, true>(ARGS) : launch_prefill<HD, 4, false>(ARGS); break;                   \
-        case 8: rc = fp8 ? launch_prefill<HD, 8, true>(ARGS) : launch_prefill<HD, 8, false>(ARGS); break;                   \
-        case 16: rc = fp8 ? launch_prefill<HD, 16, true>(ARGS) : launch_prefill<HD, 16, false>(ARGS); break;                \
+        case 1: PF_ONE(HD, 1); break;                                                                                       \
+        case 2: PF_ONE(HD, 2); break;                                                                                       \
+        case 4: PF_ONE(HD, 4); break;                                                                                       \
+        case 8: PF_ONE(HD, 8); break;                                                                                       \
+        case 16: PF_ONE(HD, 16); break;                                                                                     \
         default: vmx_set_error("prefill_attention: %d query heads per KV head unsupported (1..16)", num_heads / num_kv_heads); return VMX_EUNSUPPORTED; \
     }
     switch (head_dim) {
@@ -1238,13 +1255,27 @@ extern "C" int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, cons
             return VMX_EUNSUPPORTED;
     }
 #undef BY_QPK
+#undef PF_ONE
 #undef ARGS
     return rc;
 }
 
-namespace {
-// (re-opened for the decode helpers below)
-}  // namespace
+extern "C" int vmx_prefill_attention_bf16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                          const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
+                                          int num_kv_heads, int head_dim, int block_size, int window, int kv_dtype, const float *k_scale,
+                                          const float *v_scale, void *stream) {
+    return prefill_attention_impl(out, q, k_cache, v_cache, block_table, q_len, seqlen_offset, scale, num_heads, num_kv_heads, head_dim,
+                                  block_size, window, kv_dtype, k_scale, v_scale, stream, false);
+}
+
+// The same over fp16 queries and an fp16 cache, fp16 out (models that run in fp16): the fp16 forms of the matrix instructions,
+// softmax weights rounded to fp16 where the bf16 form rounds them to bf16.
+extern "C" int vmx_prefill_attention_f16(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache,
+                                         const int32_t *block_table, int q_len, int seqlen_offset, float scale, int num_heads,
+                                         int num_kv_heads, int head_dim, int block_size, int window, void *stream) {
+    return prefill_attention_impl(out, q, k_cache, v_cache, block_table, q_len, seqlen_offset, scale, num_heads, num_kv_heads, head_dim,
+                                  block_size, window, VMX_KV_AUTO, nullptr, nullptr, stream, true);
+}
 
 
 extern "C" size_t vmx_paged_attention_workspace_bytes(int num_seqs, int num_heads, int head_dim, int max_seq_len) {
@@ -1357,17 +1388,17 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
                                const float *v_scale, int8_t *aq, float *ad, int v_norm, hipStream_t st, const uint16_t *had_svh) {
     const int qpk = qpk_capacity(num_heads / num_kv_heads);
     const dim3 grid(num_kv_heads, num_seqs);
-    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
+    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3, f16 = kv_dtype == VMX_KV_F16_INTERNAL;   // f16: fp16 activations and cache
     VMX_REQUIRE(!had_svh || head_dim == 128, "fused_decode_attention: the output Hadamard form needs 128-wide heads");
     int rc = VMX_EUNSUPPORTED;
 #define FARGS grid, st, out, qkv_partial, splits, num_seqs, k_cache, v_cache, q_norm_w, k_norm_w, eps, cos_sin, positions, slots, block_tables, \
               seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size, window, k_scale, v_scale, aq, ad, v_norm, had_svh
 #define F_QPK(HD)                                                                                         \
     switch (qpk) {                                                                                        \
-        case 1: rc = fp8 ? launch_fused<HD, 1, true>(FARGS) : launch_fused<HD, 1, false>(FARGS); break;   \
-        case 2: rc = fp8 ? launch_fused<HD, 2, true>(FARGS) : launch_fused<HD, 2, false>(FARGS); break;   \
-        case 4: rc = fp8 ? launch_fused<HD, 4, true>(FARGS) : launch_fused<HD, 4, false>(FARGS); break;   \
-        case 8: rc = fp8 ? launch_fused<HD, 8, true>(FARGS) : launch_fused<HD, 8, false>(FARGS); break;   \
+        case 1: rc = f16 ? launch_fused<HD, 1, 3>(FARGS) : fp8 ? launch_fused<HD, 1, 1>(FARGS) : launch_fused<HD, 1, 0>(FARGS); break;   \
+        case 2: rc = f16 ? launch_fused<HD, 2, 3>(FARGS) : fp8 ? launch_fused<HD, 2, 1>(FARGS) : launch_fused<HD, 2, 0>(FARGS); break;   \
+        case 4: rc = f16 ? launch_fused<HD, 4, 3>(FARGS) : fp8 ? launch_fused<HD, 4, 1>(FARGS) : launch_fused<HD, 4, 0>(FARGS); break;   \
+        case 8: rc = f16 ? launch_fused<HD, 8, 3>(FARGS) : fp8 ? launch_fused<HD, 8, 1>(FARGS) : launch_fused<HD, 8, 0>(FARGS); break;   \
         default: break;                                                                                   \
     }
     if (head_dim == 64) { F_QPK(64) } else if (head_dim == 128) { F_QPK(128) }
@@ -1463,14 +1494,16 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
     out->max_parts = P;
     out->part_tokens = 0;
     const dim3 grid(num_kv_heads, num_seqs, P);
-    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
+    const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3, f16 = kv_dtype == VMX_KV_F16_INTERNAL;   // f16: fp16 activations and cache
     int rc = VMX_EUNSUPPORTED;
 #define SARGS grid, st, out->tmp_out, out->exp_sums, out->max_logits, qkv_partial, splits, num_seqs, k_cache, v_cache, q_norm_w, k_norm_w, eps, \
               cos_sin, positions, slots, block_tables, seq_lens, scale, num_heads, num_kv_heads, rot_dim, max_blocks_per_seq, block_size,     \
               window, k_scale, v_scale, v_norm, had_svh
 #define S_ONE(HD, Q)                                                                                                          \
-    rc = wide ? (fp8 ? launch_split<HD, Q, true, 16>(SARGS) : launch_split<HD, Q, false, 16>(SARGS))                           \
-              : (fp8 ? launch_split<HD, Q, true, (Q + 2 > 8 ? 16 : 8)>(SARGS) : launch_split<HD, Q, false, (Q + 2 > 8 ? 16 : 8)>(SARGS))
+    rc = wide ? (f16 ? launch_split<HD, Q, 3, 16>(SARGS) : fp8 ? launch_split<HD, Q, 1, 16>(SARGS) : launch_split<HD, Q, 0, 16>(SARGS))       \
+              : (f16   ? launch_split<HD, Q, 3, (Q + 2 > 8 ? 16 : 8)>(SARGS)                                                                 \
+                 : fp8 ? launch_split<HD, Q, 1, (Q + 2 > 8 ? 16 : 8)>(SARGS)                                                                 \
+                       : launch_split<HD, Q, 0, (Q + 2 > 8 ? 16 : 8)>(SARGS))
 #define S_QPK(HD)                       \
     switch (qpk) {                      \
         case 1: S_ONE(HD, 1); break;    \
@@ -1480,7 +1513,7 @@ int vmx_split_decode_attention(VmxAttnParts *out, void *workspace, const float *
         default: break;                 \
     }
     if (head_dim == 64) { S_QPK(64) } else if (head_dim == 128) { S_QPK(128) }
-    else if (head_dim == 256 && !wide) {   // 8 waves only: the 16-wave form would spill at 128 registers per lane
+    else if (head_dim == 256 && !wide && !f16) {   // 8 waves only: the 16-wave form would spill at 128 registers per lane
         if (qpk == 1) rc = fp8 ? launch_split<256, 1, true, 8>(SARGS) : launch_split<256, 1, false, 8>(SARGS);
         else if (qpk == 2) rc = fp8 ? launch_split<256, 2, true, 8>(SARGS) : launch_split<256, 2, false, 8>(SARGS);
     }

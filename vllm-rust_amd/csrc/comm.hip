@@ -144,7 +144,8 @@ __device__ __forceinline__ bool p2p_wait(const P2PArgs &a, const uint32_t *f, ui
     }
 }
 
-// OP 0: bf16 sum of `count` elements (count % 8 == 0); OP 1: u64 max of `count` elements (the vocab-parallel argmax keys)
+// OP 0: bf16 sum of `count` elements (count % 8 == 0); OP 1: u64 max of `count` elements (the vocab-parallel argmax keys);
+// OP 2: fp16 sum (as OP 0: f32 accumulation in rank order, one rounding)
 template <int OP>
 __global__ __launch_bounds__(256) void p2p_all_reduce_kernel(P2PArgs a, void *__restrict__ buf_v, int count) {
     __shared__ uint32_t epoch_s, bad_s;
@@ -161,13 +162,15 @@ __global__ __launch_bounds__(256) void p2p_all_reduce_kernel(P2PArgs a, void *__
     // 16-byte chunk of this thread: 8 bf16 or 2 u64; idx = its offset in 2-byte units
     const int64_t chunk = (int64_t)wg * 256 + tid;
     const int64_t idx = chunk * 8;
-    const int64_t nchunks = OP == 0 ? count / 8 : (count + 1) / 2;
+    constexpr bool SUM = OP == 0 || OP == 2;
+    const int64_t nchunks = SUM ? count / 8 : (count + 1) / 2;
     const bool live = chunk < nchunks;
     const bool odd_tail = OP == 1 && live && 2 * chunk + 1 >= count;   // odd u64 count: the last chunk holds one element
     uint16_t *buf = static_cast<uint16_t *>(buf_v);
-    const uint4 nan4 = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
+    const uint32_t nan2 = OP == 2 ? 0x7E007E00u : 0x7FC07FC0u;   // two quiet NaNs of the element type
+    const uint4 nan4 = make_uint4(nan2, nan2, nan2, nan2);
     if (bad_s != 0u) {   // a failed rank takes no further part; a sum becomes NaN, the keys keep the local maximum
-        if (OP == 0 && live) *reinterpret_cast<uint4 *>(buf + idx) = nan4;
+        if (SUM && live) *reinterpret_cast<uint4 *>(buf + idx) = nan4;
         return;
     }
     uint4 mine = make_uint4(0, 0, 0, 0);
@@ -196,23 +199,23 @@ __global__ __launch_bounds__(256) void p2p_all_reduce_kernel(P2PArgs a, void *__
     __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (system scope by default in HIP device code) peers' slices are read afresh
     if (!live) return;
     if (bad_s != 0u) {
-        if (OP == 0) *reinterpret_cast<uint4 *>(buf + idx) = nan4;
+        if (SUM) *reinterpret_cast<uint4 *>(buf + idx) = nan4;
         return;
     }
-    if (OP == 0) {
+    if (SUM) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < a.world; r++) {   // rank order: identical bits on every rank
             const uint4 v = r == a.rank ? mine : *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(a.stage[r] + par * a.ar_slot) + idx);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                acc[2 * j] += __uint_as_float(w[j] << 16);
-                acc[2 * j + 1] += __uint_as_float(w[j] & 0xFFFF0000u);
+                acc[2 * j] += vmx_ld16<OP == 2>((uint16_t)(w[j] & 0xFFFFu));
+                acc[2 * j + 1] += vmx_ld16<OP == 2>((uint16_t)(w[j] >> 16));
             }
         }
         uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = (uint32_t)vmx_f32_to_bf16(acc[2 * j]) | ((uint32_t)vmx_f32_to_bf16(acc[2 * j + 1]) << 16);
+        for (int j = 0; j < 4; j++) o[j] = (uint32_t)vmx_st16<OP == 2>(acc[2 * j]) | ((uint32_t)vmx_st16<OP == 2>(acc[2 * j + 1]) << 16);
         *reinterpret_cast<uint4 *>(buf + idx) = make_uint4(o[0], o[1], o[2], o[3]);
     } else {
         unsigned long long m0 = ((unsigned long long)mine.y << 32) | mine.x, m1 = ((unsigned long long)mine.w << 32) | mine.z;
@@ -605,7 +608,7 @@ extern "C" void vmx_comm_destroy(vmx_comm *c) {
 extern "C" int vmx_comm_rank(const vmx_comm *c) { return c ? c->rank : 0; }
 extern "C" int vmx_comm_world(const vmx_comm *c) { return c ? c->world : 1; }
 
-extern "C" int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t count, void *stream) {
+static int all_reduce_sum16(vmx_comm *c, uint16_t *buf, size_t count, void *stream, bool f16) {
     VMX_REQUIRE(c && buf, "comm_all_reduce: null pointer");
     if (int rc = comm_check(c, "comm_all_reduce")) return rc;
     if (c->world == 1 && !c->comm) return VMX_OK;
@@ -613,12 +616,23 @@ extern "C" int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t c
     if (c->p2p.ready && count > 0 && count % 8 == 0 && count * 2 <= c->p2p.ar_slot) {
         VMX_REQUIRE(((uintptr_t)buf & 15) == 0, "comm_all_reduce: the buffer must be 16-byte aligned");
         const int grid = (int)((count + P2P_WG_ELEMS - 1) / P2P_WG_ELEMS);
-        hipLaunchKernelGGL(p2p_all_reduce_kernel<0>, dim3(grid), dim3(256), 0, vmx_stream(stream), c->p2p.args, (void *)buf, (int)count);
+        if (f16) hipLaunchKernelGGL(p2p_all_reduce_kernel<2>, dim3(grid), dim3(256), 0, vmx_stream(stream), c->p2p.args, (void *)buf, (int)count);
+        else hipLaunchKernelGGL(p2p_all_reduce_kernel<0>, dim3(grid), dim3(256), 0, vmx_stream(stream), c->p2p.args, (void *)buf, (int)count);
         VMX_CHECK_LAUNCH("p2p_all_reduce");
         return VMX_OK;
     }
     VMX_REQUIRE(c->comm, "comm_all_reduce: %zu elements do not fit the peer-mapped transport and this communicator has no RCCL side", count);
-    return check_rccl(rccl().AllReduce(buf, buf, count, NCCL_BF16, NCCL_SUM, c->comm, vmx_stream(stream)), "ncclAllReduce(bf16,sum)");
+    return check_rccl(rccl().AllReduce(buf, buf, count, f16 ? VMX_COMM_F16 : NCCL_BF16, NCCL_SUM, c->comm, vmx_stream(stream)),
+                      f16 ? "ncclAllReduce(f16,sum)" : "ncclAllReduce(bf16,sum)");
+}
+
+extern "C" int vmx_comm_all_reduce_sum_bf16(vmx_comm *c, uint16_t *buf, size_t count, void *stream) {
+    return all_reduce_sum16(c, buf, count, stream, false);
+}
+
+// The same sum over fp16 elements: the row-parallel outputs of a model that runs in fp16 (EXL3 checkpoints)
+extern "C" int vmx_comm_all_reduce_sum_f16(vmx_comm *c, uint16_t *buf, size_t count, void *stream) {
+    return all_reduce_sum16(c, buf, count, stream, true);
 }
 
 extern "C" int vmx_comm_all_reduce_max_u64(vmx_comm *c, unsigned long long *buf, size_t count, void *stream) {
@@ -643,6 +657,7 @@ extern "C" int vmx_comm_all_reduce(vmx_comm *c, void *buf, size_t count, int dty
     if (int rc = comm_check(c, "comm_all_reduce")) return rc;
     if (c->world == 1 && !c->comm) return VMX_OK;
     if (dtype == VMX_COMM_BF16 && op == VMX_COMM_SUM) return vmx_comm_all_reduce_sum_bf16(c, (uint16_t *)buf, count, stream);
+    if (dtype == VMX_COMM_F16 && op == VMX_COMM_SUM) return vmx_comm_all_reduce_sum_f16(c, (uint16_t *)buf, count, stream);
     if (dtype == VMX_COMM_U64 && op == VMX_COMM_MAX) return vmx_comm_all_reduce_max_u64(c, (unsigned long long *)buf, count, stream);
     VMX_REQUIRE(c->comm, "comm_all_reduce: dtype %d / op %d needs the RCCL side of the communicator", dtype, op);
     return check_rccl(rccl().AllReduce(buf, buf, count, dtype, op, c->comm, vmx_stream(stream)), "ncclAllReduce");

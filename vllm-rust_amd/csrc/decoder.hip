@@ -17,9 +17,6 @@
 #include <new>
 #include <vector>
 
-int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
-                          hipStream_t st);
-
 namespace {
 
 __device__ __forceinline__ float round_bf16(float v) { return vmx_bf16_to_f32(vmx_f32_to_bf16(v)); }
@@ -130,12 +127,12 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float f[8]) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// One workgroup per token.  h (bf16 residual stream, in/out), optional incoming linear output as
+// One workgroup per token.  h (residual stream in the activation dtype -- bf16, or fp16 with F16 --, in/out), optional incoming linear output as
 // f32 partials [splits][tokens][hidden] (splits < 0: `partial` is instead a bf16 [tokens][hidden] tensor,
 // the all-reduced output of a row-parallel linear):  o = bf16(sum partials); h = bf16(h + o);
 // x = bf16(h * rsqrt(mean(h^2) + eps) * w)   (add_bf16 then rms_norm_bf16: variance over the ROUNDED h).
 // Thread t owns the 8-element chunks t, t+256, ... (CH of them, hidden <= CH*2048) in registers.
-template <int CH>
+template <int CH, bool F16>
 __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ h, uint16_t *__restrict__ x,
                                                           const float *__restrict__ partial, int splits, int tokens,
                                                           const uint16_t *__restrict__ w, float eps, int hidden,
@@ -165,23 +162,23 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
             float o[8];
             exl3_out_transform8(partial, splits, slice, row + 8 * min(ci, nchunk - 1), had_svh, 8 * min(ci, nchunk - 1), o);
             if (ci < nchunk) {
-                unpack_bf16x8(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
+                vmx_unpack16x8<F16>(*reinterpret_cast<const uint4 *>(h + row + 8 * ci), hv[c]);
 #pragma unroll
-                for (int j = 0; j < 8; j++) hv[c][j] = round_bf16(hv[c][j] + round_bf16(o[j]));
-                *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack_bf16x8(hv[c]);
+                for (int j = 0; j < 8; j++) hv[c][j] = vmx_rnd16<F16>(hv[c][j] + vmx_rnd16<F16>(o[j]));
+                *reinterpret_cast<uint4 *>(h + row + 8 * ci) = vmx_pack16x8<F16>(hv[c]);
 #pragma unroll
                 for (int j = 0; j < 8; j++) var += hv[c][j] * hv[c][j];
             }
         } else if (ci < nchunk) {
-            unpack_bf16x8(emb_table && !emb_ok ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(hsrc + 8 * ci), hv[c]);
-            if (emb_table) *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack_bf16x8(hv[c]);
+            vmx_unpack16x8<F16>(emb_table && !emb_ok ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(hsrc + 8 * ci), hv[c]);
+            if (emb_table) *reinterpret_cast<uint4 *>(h + row + 8 * ci) = vmx_pack16x8<F16>(hv[c]);
             if (partial) {
                 float o[8];
-                if (splits < 0) unpack_bf16x8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(partial) + row + 8 * ci), o);
+                if (splits < 0) vmx_unpack16x8<F16>(*reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(partial) + row + 8 * ci), o);
                 else sum_partials8(partial, splits, slice, row + 8 * ci, o);
 #pragma unroll
-                for (int j = 0; j < 8; j++) hv[c][j] = round_bf16(hv[c][j] + round_bf16(o[j]));
-                *reinterpret_cast<uint4 *>(h + row + 8 * ci) = pack_bf16x8(hv[c]);
+                for (int j = 0; j < 8; j++) hv[c][j] = vmx_rnd16<F16>(hv[c][j] + vmx_rnd16<F16>(o[j]));
+                *reinterpret_cast<uint4 *>(h + row + 8 * ci) = vmx_pack16x8<F16>(hv[c]);
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) var += hv[c][j] * hv[c][j];
@@ -194,14 +191,14 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
         const int ci = threadIdx.x + 256 * c;
         if (ci < nchunk) {
             float wv[8], o[8];
-            unpack_bf16x8(wraw[c], wv);
+            vmx_unpack16x8<F16>(wraw[c], wv);
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = hv[c][j] * inv * wv[j];
-            const uint4 packed = pack_bf16x8(o);
+            const uint4 packed = vmx_pack16x8<F16>(o);
             *reinterpret_cast<uint4 *>(x + row + 8 * ci) = packed;
             if (aq) {  // q8_1 of the (bf16-rounded) normed row for an I-quant consumer; hidden % 32 == 0
                 float xr[8];
-                unpack_bf16x8(packed, xr);
+                vmx_unpack16x8<F16>(packed, xr);
                 vmx_q8_1_emit8(xr, aq + row + 8 * ci, ad + (row >> 5) + (ci >> 2), (ci & 3) == 0);
             }
         }
@@ -213,6 +210,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(uint16_t *__restrict__ 
 // 128-column Hadamard block: all its split-K loads are requested at once (two columns per lane), then the transform (same
 // stage order and arithmetic as exl3_out_transform8), h = bf16(h + bf16(o)) and the block's sum of squares of the new h
 // into blk_ssq [tokens][hidden / 128].  The consuming linear normalises its rows itself from those sums.
+template <bool F16>
 __global__ __launch_bounds__(256) void exl3_resid_stats_kernel(uint16_t *__restrict__ h, const float *__restrict__ partial, int splits,
                                                                 int tokens, int hidden, const uint16_t *__restrict__ had_svh,
                                                                 float *__restrict__ blk_ssq) {
@@ -246,9 +244,9 @@ __global__ __launch_bounds__(256) void exl3_resid_stats_kernel(uint16_t *__restr
     }
     const float o0 = (float)((_Float16)(e0 * 0.088388347648f) * __builtin_bit_cast(_Float16, (uint16_t)(sv & 0xffffu)));
     const float o1 = (float)((_Float16)(e1 * 0.088388347648f) * __builtin_bit_cast(_Float16, (uint16_t)(sv >> 16)));
-    const float h0 = round_bf16(__uint_as_float(hraw << 16) + round_bf16(o0));
-    const float h1 = round_bf16(__uint_as_float(hraw & 0xffff0000u) + round_bf16(o1));
-    *reinterpret_cast<uint32_t *>(h + row + col) = (__float_as_uint(h0) >> 16) | (__float_as_uint(h1) & 0xffff0000u);
+    const float h0 = vmx_rnd16<F16>(vmx_ld16<F16>((uint16_t)(hraw & 0xffffu)) + vmx_rnd16<F16>(o0));
+    const float h1 = vmx_rnd16<F16>(vmx_ld16<F16>((uint16_t)(hraw >> 16)) + vmx_rnd16<F16>(o1));
+    *reinterpret_cast<uint32_t *>(h + row + col) = (uint32_t)vmx_st16<F16>(h0) | ((uint32_t)vmx_st16<F16>(h1) << 16);
     const float var = vmx_wave_sum(h0 * h0 + h1 * h1);
     if (lane == 0) blk_ssq[t * nblk + blk] = var;
 }
@@ -349,6 +347,7 @@ __global__ __launch_bounds__(256) void norm_router_topk_kernel(const uint16_t *_
 // grid (heads_q + 2*heads_kv, tokens), block 64.  Takes the merged qkv linear output as f32
 // partials [splits][tokens][(Hq + 2*Hkv) * hd]; per head: bf16 round, optional per-head RMSNorm
 // (bf16 round), NeoX RoPE (bf16 round); q -> q_out, k and v -> paged cache (bf16 or FP8 e4m3).
+template <bool F16>
 __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ partial, int splits, int tokens,
                                                        uint16_t *__restrict__ q_out, void *__restrict__ k_cache,
                                                        void *__restrict__ v_cache, const uint16_t *__restrict__ q_norm_w,
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ 
     const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
     float ss = 0.f;
     for (int i = lane; i < hd; i += 64) {
-        const float v = round_bf16(sum_partials(partial, splits, slice, base + i));
+        const float v = vmx_rnd16<F16>(sum_partials(partial, splits, slice, base + i));
         vals[i] = v;
         ss += v * v;
     }
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ 
     if (nw) {  // per-head RMSNorm, output rounded to bf16 (rms_norm_bf16 on the [.., hd] view)
         ss = vmx_wave_sum(ss);
         const float inv = rsqrtf(ss / (float)hd + eps);
-        for (int i = lane; i < hd; i += 64) vals[i] = round_bf16(vals[i] * inv * vmx_bf16_to_f32(nw[i]));
+        for (int i = lane; i < hd; i += 64) vals[i] = vmx_rnd16<F16>(vals[i] * inv * vmx_ld16<F16>(nw[i]));
     }
     __syncthreads();
     if (is_q || is_k) {  // NeoX rotation of the first rot_dim dims
@@ -380,13 +379,13 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ 
         const float *cs = cos_sin + (int64_t)positions[t] * rot_dim;
         for (int i = lane; i < half; i += 64) {
             const float xv = vals[i], yv = vals[half + i], c = cs[i], s = cs[half + i];
-            vals[i] = round_bf16(xv * c - yv * s);
-            vals[half + i] = round_bf16(yv * c + xv * s);
+            vals[i] = vmx_rnd16<F16>(xv * c - yv * s);
+            vals[half + i] = vmx_rnd16<F16>(yv * c + xv * s);
         }
         __syncthreads();
     }
     if (is_q) {
-        for (int i = lane; i < hd; i += 64) q_out[((int64_t)t * Hq + head) * hd + i] = vmx_f32_to_bf16(vals[i]);
+        for (int i = lane; i < hd; i += 64) q_out[((int64_t)t * Hq + head) * hd + i] = vmx_st16<F16>(vals[i]);
         return;
     }
     const int slot = slots[t];
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ 
     const int64_t dst = ((int64_t)slot * Hkv + kvh) * hd;
     void *cache = is_k ? k_cache : v_cache;
     if (!fp8) {
-        for (int i = lane; i < hd; i += 64) ((uint16_t *)cache)[dst + i] = vmx_f32_to_bf16(vals[i]);
+        for (int i = lane; i < hd; i += 64) ((uint16_t *)cache)[dst + i] = vmx_st16<F16>(vals[i]);
     } else {
         const float sc = is_k ? (k_scale ? *k_scale : 1.f) : (v_scale ? *v_scale : 1.f);
         for (int i = lane; i < hd; i += 64) {
@@ -410,6 +409,7 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(const float *__restrict__ 
 // a[t, i] = bf16(silu(bf16(gate)) * bf16(up)) from the merged gate|up linear output (f32 partials
 // [splits][tokens][2*inter], gate columns first); 8 elements per thread.  Optionally also the q8_1 form of the
 // result for an I-quant down projection (inter % 32 == 0).
+template <bool F16>
 __global__ __launch_bounds__(256) void gateup_act_kernel(const float *__restrict__ partial, int splits, int tokens,
                                                           uint16_t *__restrict__ act, int inter, int8_t *__restrict__ aq,
                                                           float *__restrict__ ad, const uint16_t *__restrict__ had_svh) {
@@ -432,14 +432,14 @@ __global__ __launch_bounds__(256) void gateup_act_kernel(const float *__restrict
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float gg = round_bf16(g[j]);
-                g[j] = (gg / (1.0f + expf(-gg))) * round_bf16(u[j]);
+                const float gg = vmx_rnd16<F16>(g[j]);
+                g[j] = (gg / (1.0f + expf(-gg))) * vmx_rnd16<F16>(u[j]);
             }
-            const uint4 packed = pack_bf16x8(g);
+            const uint4 packed = vmx_pack16x8<F16>(g);
             *reinterpret_cast<uint4 *>(act + c * 8) = packed;
             if (aq) {
                 float r[8];
-                unpack_bf16x8(packed, r);
+                vmx_unpack16x8<F16>(packed, r);
                 vmx_q8_1_emit8(r, aq + c * 8, ad + (c >> 2), (c & 3) == 0);
             }
         }
@@ -447,10 +447,11 @@ __global__ __launch_bounds__(256) void gateup_act_kernel(const float *__restrict
 }
 
 // y[i] = bf16(sum of split-K slices): the local output of a row-parallel linear before the all-reduce
+template <bool F16>
 __global__ __launch_bounds__(256) void slices_to_bf16_kernel(const float *__restrict__ partial, int splits, int64_t n,
                                                               uint16_t *__restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) y[i] = vmx_f32_to_bf16(sum_partials(partial, splits, n, i));
+    if (i < n) y[i] = vmx_st16<F16>(sum_partials(partial, splits, n, i));
 }
 
 __global__ __launch_bounds__(256) void f16_to_bf16_into_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int64_t n,
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(256) void embed_kernel(uint16_t *__restrict__ out, 
 // requests the split-K slices of its gate and up columns in one go (two columns per lane), applies both output transforms
 // (stage order and arithmetic of exl3_out_transform8) and writes act = bf16(silu(bf16 gate) * bf16 up).
 // partial: [splits][tokens][2 * inter], gate columns first; svh: the merged gate|up scale vector.  grid (inter / 512, tokens).
+template <bool F16>
 __global__ __launch_bounds__(256) void exl3_gateup_act_kernel(const float *__restrict__ partial, int splits, int tokens,
                                                                uint16_t *__restrict__ act, int inter, const uint16_t *__restrict__ svh) {
     const int t = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -510,9 +512,9 @@ __global__ __launch_bounds__(256) void exl3_gateup_act_kernel(const float *__res
     }
     const uint32_t sc[4] = {svg & 0xffffu, svg >> 16, svu & 0xffffu, svu >> 16};
 #pragma unroll
-    for (int j = 0; j < 4; j++) e[j] = round_bf16((float)((_Float16)(e[j] * 0.088388347648f) * __builtin_bit_cast(_Float16, (uint16_t)sc[j])));
+    for (int j = 0; j < 4; j++) e[j] = vmx_rnd16<F16>((float)((_Float16)(e[j] * 0.088388347648f) * __builtin_bit_cast(_Float16, (uint16_t)sc[j])));
     const float a0 = (e[0] / (1.0f + expf(-e[0]))) * e[2], a1 = (e[1] / (1.0f + expf(-e[1]))) * e[3];
-    *reinterpret_cast<uint32_t *>(act + (int64_t)t * inter + col) = (uint32_t)vmx_f32_to_bf16(a0) | ((uint32_t)vmx_f32_to_bf16(a1) << 16);
+    *reinterpret_cast<uint32_t *>(act + (int64_t)t * inter + col) = (uint32_t)vmx_st16<F16>(a0) | ((uint32_t)vmx_st16<F16>(a1) << 16);
 }
 
 // EXL3 decode rows: h += transform(partial) and the block sums the next linear's prologue normalises with (no x row)
@@ -521,18 +523,27 @@ bool exl3_resid_stats_ok(int tokens, int splits, int hidden) {
     return !off && tokens <= 4 && splits > 0 && hidden % 128 == 0 && hidden <= 8192;
 }
 void launch_exl3_resid_stats(hipStream_t st, uint16_t *h, const float *partial, int splits, int tokens, int hidden, const uint16_t *had_svh,
-                             float *blk_ssq) {
-    hipLaunchKernelGGL(exl3_resid_stats_kernel, dim3((hidden / 128 + 3) / 4, tokens), dim3(256), 0, st, h, partial, splits, tokens, hidden,
-                       had_svh, blk_ssq);
+                             float *blk_ssq, bool f16 = false) {
+    const dim3 grid((hidden / 128 + 3) / 4, tokens);
+    if (f16) hipLaunchKernelGGL(exl3_resid_stats_kernel<true>, grid, dim3(256), 0, st, h, partial, splits, tokens, hidden, had_svh, blk_ssq);
+    else hipLaunchKernelGGL(exl3_resid_stats_kernel<false>, grid, dim3(256), 0, st, h, partial, splits, tokens, hidden, had_svh, blk_ssq);
+}
+
+template <bool F16>
+void launch_resid_norm_t(hipStream_t st, uint16_t *h, uint16_t *x, const float *partial, int splits, int tokens, const uint16_t *w,
+                         float eps, int hidden, int8_t *aq, float *ad, const uint16_t *had_svh, const uint16_t *emb_table,
+                         const int32_t *emb_ids, int vocab) {
+    if (hidden <= 2048) hipLaunchKernelGGL((resid_norm_kernel<1, F16>), dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+    else if (hidden <= 4096) hipLaunchKernelGGL((resid_norm_kernel<2, F16>), dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+    else if (hidden <= 8192) hipLaunchKernelGGL((resid_norm_kernel<4, F16>), dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+    else hipLaunchKernelGGL((resid_norm_kernel<8, F16>), dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
 }
 
 void launch_resid_norm(hipStream_t st, uint16_t *h, uint16_t *x, const float *partial, int splits, int tokens, const uint16_t *w,
                        float eps, int hidden, int8_t *aq = nullptr, float *ad = nullptr, const uint16_t *had_svh = nullptr,
-                       const uint16_t *emb_table = nullptr, const int32_t *emb_ids = nullptr, int vocab = 0) {
-    if (hidden <= 2048) hipLaunchKernelGGL(resid_norm_kernel<1>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
-    else if (hidden <= 4096) hipLaunchKernelGGL(resid_norm_kernel<2>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
-    else if (hidden <= 8192) hipLaunchKernelGGL(resid_norm_kernel<4>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
-    else hipLaunchKernelGGL(resid_norm_kernel<8>, dim3(tokens), dim3(256), 0, st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+                       const uint16_t *emb_table = nullptr, const int32_t *emb_ids = nullptr, int vocab = 0, bool f16 = false) {
+    if (f16) launch_resid_norm_t<true>(st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
+    else launch_resid_norm_t<false>(st, h, x, partial, splits, tokens, w, eps, hidden, aq, ad, had_svh, emb_table, emb_ids, vocab);
 }
 
 struct DevBuf {
@@ -629,6 +640,7 @@ struct vmx_qwen3 {
     vmx_comm *comm = nullptr;  // tensor-parallel group (not owned); NULL = single GPU
     int lin_mask = 15;  // measurement aid: which linears vmx_qwen3_linears_only launches (1 q|k|v, 2 o, 4 gate|up, 8 down)
     bool rows_share_cache = false;  // rows of a decode batch attend to K/V rows written by other rows of the same call
+    bool act_f16 = false;   // activations, norm weights, embedding / lm_head tables and the KV cache are fp16 (EXL3 checkpoints); else bf16
     int vocab_local() const { return cfg.tp_size > 1 ? cfg.vocab_size / cfg.tp_size : cfg.vocab_size; }
     int qkv_n() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
 };
@@ -671,7 +683,7 @@ int iq_forward(vmx_qwen3 *m, const IqLinear &l, float *y, int ldy, int tokens, h
 // Exl3Linear::forward on the rows of a bf16 activation tensor; the result (fp16 cast back to bf16, exl3.rs:272-277) lands
 // as f32 in y[row * ldy + col], the form the vector kernels take with splits == 1.
 int exl3_forward(vmx_qwen3 *m, const Exl3Lin &l, const uint16_t *x, float *y, int ldy, int tokens, hipStream_t st) {
-    return vmx_exl3_forward_f32(x, 1, l.trellis.p, (const uint16_t *)l.suh.p, (const uint16_t *)l.svh.p, y, ldy, tokens, l.in_features,
+    return vmx_exl3_forward_f32(x, m->act_f16 ? 0 : 1, l.trellis.p, (const uint16_t *)l.suh.p, (const uint16_t *)l.svh.p, y, ldy, tokens, l.in_features,
                                 l.out_features, l.bits, l.codebook, m->exl3_ws.p, m->exl3_ws.bytes, st);
 }
 
@@ -688,7 +700,7 @@ int exl3_forward_group(vmx_qwen3 *m, const Layer &L, std::initializer_list<int> 
         n_out[n++] = L.ex[sl].out_features;
     }
     const Exl3Lin &f = L.ex[*slots.begin()];
-    return vmx_exl3_forward_multi_f32(x, 1, n, tr, suh, n_out, (const uint16_t *)svh.p, y, ldy, tokens, f.in_features, f.bits, f.codebook,
+    return vmx_exl3_forward_multi_f32(x, m->act_f16 ? 0 : 1, n, tr, suh, n_out, (const uint16_t *)svh.p, y, ldy, tokens, f.in_features, f.bits, f.codebook,
                                       m->exl3_ws.p, m->exl3_ws.bytes, st, partial_out, splits_out, norm_w, blk_ssq, eps, attn_parts);
 }
 
@@ -716,7 +728,13 @@ int dense_forward(vmx_qwen3 *m, const void *W, const uint16_t *x, float *y, int 
 // reference's RowParallelLinear (distributed/parallel_layers.rs:275-305) with a quantized linear computes.
 int tp_reduce(vmx_qwen3 *m, const float *partial, int splits, int tokens, int hidden, hipStream_t st) {
     const int64_t n = (int64_t)tokens * hidden;
-    hipLaunchKernelGGL(slices_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, splits, n,
+    if (m->act_f16) {
+        hipLaunchKernelGGL(slices_to_bf16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, splits, n,
+                           (uint16_t *)m->red_bf16.p);
+        VMX_CHECK_LAUNCH("slices_to_f16");
+        return vmx_comm_all_reduce_sum_f16(m->comm, (uint16_t *)m->red_bf16.p, (size_t)n, st);
+    }
+    hipLaunchKernelGGL(slices_to_bf16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, splits, n,
                        (uint16_t *)m->red_bf16.p);
     VMX_CHECK_LAUNCH("slices_to_bf16");
     return vmx_comm_all_reduce_sum_bf16(m->comm, (uint16_t *)m->red_bf16.p, (size_t)n, st);
@@ -1261,6 +1279,13 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
     const bool tp = c.tp_size > 1 || m->comm != nullptr;  // a 1-rank communicator still exercises the collective path
     VMX_REQUIRE(!tp || m->comm, "qwen3_decode: tp_size %d but no communicator attached (vmx_qwen3_set_comm)", c.tp_size);
     if (int rc = vmx_comm_check_health(m->comm, "qwen3 forward")) return rc;   // an earlier collective of this group failed
+    // fp16 activations (EXL3 checkpoints): every tensor the bf16 form rounds to bf16 is rounded to fp16 instead, the cache holds fp16
+    const bool f16 = m->act_f16;
+    const int kvd = f16 ? VMX_KV_F16_INTERNAL : c.kv_cache_dtype;
+    if (f16)
+        for (const Layer &L : m->layers)
+            VMX_REQUIRE(L.exl3_ready() && !L.int4_ready() && c.num_experts == 0,
+                        "qwen3 forward: fp16 activations are built for models whose projections are all EXL3 linears");
 
     // the lookup is folded into the first layer's norm kernel (VMX_NO_EMBED_FUSION=1: its own launch)
     static const bool no_embed_fusion = vmx_tune("VMX_NO_EMBED_FUSION", 0) != 0;
@@ -1304,11 +1329,11 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, h, (const uint16_t *)m->embed.p, input_ids, H, c.vocab_size);
             embed_pending = false;
         }
-        if (ex_norm_in) launch_exl3_resid_stats(st, h, pending, pending_splits, B, H, pending_svh, ssq);
+        if (ex_norm_in) launch_exl3_resid_stats(st, h, pending, pending_splits, B, H, pending_svh, ssq, f16);
         else if (!fold_in)
             launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)L.input_ln.p, c.rms_norm_eps, H,
                               iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, H) : nullptr, pending_svh,
-                              embed_pending ? (const uint16_t *)m->embed.p : nullptr, input_ids, c.vocab_size);
+                              embed_pending ? (const uint16_t *)m->embed.p : nullptr, input_ids, c.vocab_size, f16);
         embed_pending = false;
         pending_svh = nullptr;
         have_ssq = false;
@@ -1364,47 +1389,54 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
                                                     c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
-                                                    Hkv, hd, hd, max_blocks_per_seq, max_seq_len, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, 0,
+                                                    Hkv, hd, hd, max_blocks_per_seq, max_seq_len, c.block_size, 0, kvd, ks, ks + 1, 0,
                                                     st, qkv_svh, long_p))
                 return rc;
             if (int rc = vmx_paged_attention_merge(attn, &sparts, seq_lens, B, Hq, hd, 0, st, iq ? q8_aq(m) : nullptr,
-                                                   iq ? q8_ad(m, B, NQ) : nullptr))
+                                                   iq ? q8_ad(m, B, NQ) : nullptr, f16 ? 1 : 0))
                 return rc;
         } else if (split_attn) {
             if (int rc = vmx_split_decode_attention(&sparts, m->attn_ws.p, qkv_src, s_qkv, L.k_cache.p, L.v_cache.p,
                                                     c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
-                                                    Hkv, hd, hd, max_blocks_per_seq, max_seq_len, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, 0,
+                                                    Hkv, hd, hd, max_blocks_per_seq, max_seq_len, c.block_size, 0, kvd, ks, ks + 1, 0,
                                                     st, qkv_svh))
                 return rc;
         } else if (fused_attn) {
             if (int rc = vmx_fused_decode_attention(attn, qkv_src, s_qkv, L.k_cache.p, L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                                                     c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps,
                                                     (const float *)m->cos_sin.p, positions, slot_mapping, block_tables, seq_lens, scale, B, Hq,
-                                                    Hkv, hd, hd, max_blocks_per_seq, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
+                                                    Hkv, hd, hd, max_blocks_per_seq, c.block_size, 0, kvd, ks, ks + 1,
                                                     iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, NQ) : nullptr, 0, st, qkv_svh))
                 return rc;
-        } else
-        hipLaunchKernelGGL(qkv_post_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, s_qkv, B, q, L.k_cache.p,
+        } else if (f16)
+            hipLaunchKernelGGL(qkv_post_kernel<true>, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, s_qkv, B, q, L.k_cache.p,
+                               L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
+                               c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
+                               slot_mapping, Hq, Hkv, hd, hd, 0, ks, ks + 1);
+        else
+        hipLaunchKernelGGL(qkv_post_kernel<false>, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, PA, s_qkv, B, q, L.k_cache.p,
                            L.v_cache.p, c.qk_norm ? (const uint16_t *)L.q_norm.p : nullptr,
                            c.qk_norm ? (const uint16_t *)L.k_norm.p : nullptr, c.rms_norm_eps, (const float *)m->cos_sin.p, positions,
                            slot_mapping, Hq, Hkv, hd, hd, fp8, ks, ks + 1);
         if (fused_attn || split_attn || long_p > 0) {
         } else if (prefill_offset >= 0) {
-            if (int rc = vmx_prefill_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, scale, Hq, Hkv, hd,
-                                                    c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, st))
+            if (int rc = f16 ? vmx_prefill_attention_f16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, scale, Hq, Hkv,
+                                                         hd, c.block_size, 0, st)
+                             : vmx_prefill_attention_bf16(attn, q, L.k_cache.p, L.v_cache.p, block_tables, B, prefill_offset, scale, Hq, Hkv,
+                                                          hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1, st))
                 return rc;
             if (iq)
                 if (int rc = iq_quantize(m, attn, B, NQ, st)) return rc;
         } else {
             VmxAttnParts ap;
             if (int rc = vmx_paged_attention_parts(q, L.k_cache.p, L.v_cache.p, block_tables, seq_lens, scale, B, Hq, Hkv,
-                                                   max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, c.kv_cache_dtype, ks, ks + 1,
+                                                   max_blocks_per_seq, max_seq_len, hd, c.block_size, 0, kvd, ks, ks + 1,
                                                    m->attn_ws.p, &ap, st))
                 return rc;
             if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, 0, st, iq ? q8_aq(m) : nullptr,
-                                                   iq ? q8_ad(m, B, NQ) : nullptr))
+                                                   iq ? q8_ad(m, B, NQ) : nullptr, f16 ? 1 : 0))
                 return rc;
         }
         if (fold) {   // h += o_proj(attn);  act = glu(gate|up(rms_norm(h)));  h += down(act)
@@ -1472,10 +1504,10 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             o_splits = -1;
         }
         const bool ex_norm_gu = ex_fold && o_svh && exl3_resid_stats_ok(B, o_splits, H);
-        if (ex_norm_gu) launch_exl3_resid_stats(st, h, o_src, o_splits, B, H, o_svh, ssq);
+        if (ex_norm_gu) launch_exl3_resid_stats(st, h, o_src, o_splits, B, H, o_svh, ssq, f16);
         else
         launch_resid_norm(st, h, x, o_src, o_splits, B, (const uint16_t *)L.post_ln.p, c.rms_norm_eps, H, iq ? q8_aq(m) : nullptr,
-                          iq ? q8_ad(m, B, H) : nullptr, o_svh);
+                          iq ? q8_ad(m, B, H) : nullptr, o_svh, nullptr, nullptr, 0, f16);
         if (moe) {
             // QuantizedMoELayer::forward (models/mixtral_quantized.rs:138-195): dense router, softmax (bf16) -> top-k -> renormalise,
             // out = sum_j bf16(expert_j(x) * w_j), experts = down(silu(gate x) * up x); no host read of the routing
@@ -1522,10 +1554,15 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
         } else if (int rc = run_linear(m, L.gate_up, x, PA, B, st)) return rc;
         static const bool no_ex_act = vmx_tune("VMX_EXL3_NO_WAVE_ACT", 0) != 0;
         if (ex_fold && gu_svh && !no_ex_act) {
-            hipLaunchKernelGGL(exl3_gateup_act_kernel, dim3((I / 128 + 3) / 4, B), dim3(256), 0, st, gu_src, gu_splits, B, act, I, gu_svh);
+            if (f16) hipLaunchKernelGGL(exl3_gateup_act_kernel<true>, dim3((I / 128 + 3) / 4, B), dim3(256), 0, st, gu_src, gu_splits, B, act, I, gu_svh);
+            else hipLaunchKernelGGL(exl3_gateup_act_kernel<false>, dim3((I / 128 + 3) / 4, B), dim3(256), 0, st, gu_src, gu_splits, B, act, I, gu_svh);
         } else if (one || !L.gate_up.glu) {
             int64_t blocks = ((int64_t)B * I / 8 + 255) / 256;
-            hipLaunchKernelGGL(gateup_act_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, gu_src, gu_splits, B, act, I,
+            if (f16)
+                hipLaunchKernelGGL(gateup_act_kernel<true>, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, gu_src, gu_splits, B, act,
+                                   I, (int8_t *)nullptr, (float *)nullptr, gu_svh);
+            else
+            hipLaunchKernelGGL(gateup_act_kernel<false>, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, gu_src, gu_splits, B, act, I,
                                iq ? q8_aq(m) : nullptr, iq ? q8_ad(m, B, I) : nullptr, gu_svh);
         }
         if (ex_fold) {
@@ -1549,7 +1586,8 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             pending_splits = -1;
         }
     }
-    launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr, pending_svh);
+    launch_resid_norm(st, h, x, pending, pending_splits, B, (const uint16_t *)m->final_norm.p, c.rms_norm_eps, H, nullptr, nullptr, pending_svh,
+                      nullptr, nullptr, 0, f16);
     VMX_CHECK_LAUNCH("qwen3 layers");
     return VMX_OK;
 }
@@ -1564,13 +1602,16 @@ int run_head(vmx_qwen3 *m, const uint16_t *x, int rows, int32_t *out_ids, uint16
     const int VL = m->vocab_local();
     const int64_t v0 = tp ? (int64_t)c.tp_rank * VL : 0;  // first vocabulary row of this rank's lm_head slice
     const uint16_t *head = m->lm_head_tied ? (const uint16_t *)m->embed.p + v0 * H : (const uint16_t *)m->lm_head.p;
-    if (int rc = vmx_dense_gemv_launch(logits, x, head, nullptr, B, VL, H, st)) return rc;
+    const int f16 = m->act_f16 ? 1 : 0;   // fp16 table, fp16 logits
+    if (int rc = vmx_dense_gemv_launch(logits, x, head, nullptr, B, VL, H, st, f16)) return rc;
     if (out_ids) {
         if (!tp) {
-            if (int rc = vmx_argmax_bf16(out_ids, logits, B, VL, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;
+            if (int rc = f16 ? vmx_argmax_f16(out_ids, logits, B, VL, m->argmax_ws.p, m->argmax_ws.bytes, stream)
+                             : vmx_argmax_bf16(out_ids, logits, B, VL, m->argmax_ws.p, m->argmax_ws.bytes, stream))
+                return rc;
         } else {  // vocab-parallel: best (value, global index) key per rank, max over ranks
             unsigned long long *keys = (unsigned long long *)m->keys.p;
-            if (int rc = vmx_argmax_keys(keys, logits, B, VL, (uint32_t)v0, m->argmax_ws.p, st)) return rc;
+            if (int rc = vmx_argmax_keys(keys, logits, B, VL, (uint32_t)v0, m->argmax_ws.p, st, f16)) return rc;
             if (int rc = vmx_comm_all_reduce_max_u64(m->comm, keys, B, stream)) return rc;
             if (int rc = vmx_argmax_keys_to_ids(keys, out_ids, B, st)) return rc;
         }
@@ -1625,6 +1666,20 @@ extern "C" int vmx_qwen3_prefill(vmx_qwen3 *m, const int32_t *input_ids, int seq
 extern "C" int vmx_qwen3_set_rows_share_cache(vmx_qwen3 *m, int on) {
     VMX_REQUIRE(m, "qwen3_set_rows_share_cache: null model");
     m->rows_share_cache = on != 0;
+    return VMX_OK;
+}
+
+// The 16-bit type of activations, norm weights, the embedding / lm_head tables, logits and an un-quantized KV cache: VMX_BF16
+// (default) or VMX_F16.  The reference runs EXL3 checkpoints in fp16 whatever the configured dtype
+// (crates/core/src/quantization/weight_loader.rs:453-461; Exl3Linear::forward casts to fp16 and back otherwise,
+// exl3.rs:222-277): with VMX_F16 every tensor the bf16 form rounds to bf16 is rounded to fp16 instead and 16-bit tensors are
+// loaded as fp16 bits.  Call before loading tensors; fp16 needs every projection to be an EXL3 linear and a 16-bit KV cache.
+extern "C" int vmx_qwen3_set_activation_dtype(vmx_qwen3 *m, int dtype) {
+    VMX_REQUIRE(m, "qwen3_set_activation_dtype: null model");
+    VMX_REQUIRE(dtype == VMX_BF16 || dtype == VMX_F16, "qwen3_set_activation_dtype: dtype %d (VMX_BF16 or VMX_F16)", dtype);
+    VMX_REQUIRE(dtype == VMX_BF16 || (m->cfg.kv_cache_dtype == VMX_KV_AUTO && m->cfg.num_experts == 0),
+                "qwen3_set_activation_dtype: fp16 activations take a 16-bit KV cache and a dense MLP");
+    m->act_f16 = dtype == VMX_F16;
     return VMX_OK;
 }
 

@@ -3,19 +3,23 @@
 // cuda_kernels.rs half_matmul_pooled): y[m, n] = bf16(sum_k x[m, k] * W[n, k]), f32 accumulation.
 // gfx950 form: one wave per output row, the row streamed with 16-byte loads (1 KiB per
 // wave-instruction), v_dot2c_f32_bf16 on packed pairs, x rows held in LDS, wave64 butterfly.
-#include "vmx_internal.h"
+#include "vmx_kernels.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
-__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+// F16: the operands are fp16 pairs (v_dot2_f32_f16), else bf16 pairs (v_dot2_f32_bf16); f32 accumulation either way
+template <bool F16> __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    if constexpr (F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
+    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
 
 // grid-stride over rows: wave w of workgroup b takes rows (b*4 + w) * R + r.  K % 512 == 0 is not
 // required: the tail is handled with a bounds check on the 8-element chunk index.
-template <int MT, int R>
+template <int MT, int R, bool F16>
 __global__ __launch_bounds__(256) void dense_gemv_kernel(uint16_t *__restrict__ y, const uint16_t *__restrict__ x,
                                                           const uint16_t *__restrict__ W, const uint16_t *__restrict__ bias, int M,
                                                           int N, int K) {
@@ -46,10 +50,10 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(uint16_t *__restrict__ 
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         float a = acc[r][m];
-                        a = dot2(wv[r].x, xv.x, a);
-                        a = dot2(wv[r].y, xv.y, a);
-                        a = dot2(wv[r].z, xv.z, a);
-                        a = dot2(wv[r].w, xv.w, a);
+                        a = dot2<F16>(wv[r].x, xv.x, a);
+                        a = dot2<F16>(wv[r].y, xv.y, a);
+                        a = dot2<F16>(wv[r].z, xv.z, a);
+                        a = dot2<F16>(wv[r].w, xv.w, a);
                         acc[r][m] = a;
                     }
                 }
@@ -61,8 +65,8 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(uint16_t *__restrict__ 
             for (int m = 0; m < MT; m++) {
                 float v = vmx_wave_sum(acc[r][m]);
                 if (lane == 0 && m < M && row0 + r < N) {
-                    if (bias) v += vmx_bf16_to_f32(bias[row0 + r]);
-                    y[(int64_t)m * N + row0 + r] = vmx_f32_to_bf16(v);
+                    if (bias) v += vmx_ld16<F16>(bias[row0 + r]);
+                    y[(int64_t)m * N + row0 + r] = vmx_st16<F16>(v);
                 }
             }
     }
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(uint16_t *__restrict__ 
 // A fragment of step j is read from LDS at the matching k (x[m][128 b + 32 g + 8 j .. + 8]): the matrix instruction only needs
 // A and B to agree on which k sits where.  Activations are staged PK = 1024 k at a time (33 KB at 16 rows).  f32 accumulation
 // in k order within a lane group, groups summed by the MFMA: re-associated against the kernel above, same products.
-template <bool DUMMY = false>
+template <bool F16>
 __global__ __launch_bounds__(256) void dense_gemm16_kernel(uint16_t *__restrict__ y, const uint16_t *__restrict__ x,
                                                             const uint16_t *__restrict__ W, const uint16_t *__restrict__ bias, int M,
                                                             int N, int K) {
@@ -110,6 +114,9 @@ __global__ __launch_bounds__(256) void dense_gemm16_kernel(uint16_t *__restrict_
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint4 au = *reinterpret_cast<const uint4 *>(xs + nl * XROW + b + 32 * g + 8 * j);
+                    if constexpr (F16)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, au), __builtin_bit_cast(f16x8_t, wv[j]), acc, 0, 0, 0);
+                    else
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, wv[j]), acc,
                                                                   0, 0, 0);
                 }
@@ -118,11 +125,11 @@ __global__ __launch_bounds__(256) void dense_gemm16_kernel(uint16_t *__restrict_
         // lane holds activation rows m = 4 g + r of output column (W row) tile * 16 + nl
         const int col = tile * 16 + nl;
         if (tile < tiles && col < N) {
-            const float bv = bias ? vmx_bf16_to_f32(bias[col]) : 0.f;
+            const float bv = bias ? vmx_ld16<F16>(bias[col]) : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int m = 4 * g + r;
-                if (m < M) y[(int64_t)m * N + col] = vmx_f32_to_bf16(acc[r] + bv);
+                if (m < M) y[(int64_t)m * N + col] = vmx_st16<F16>(acc[r] + bv);
             }
         }
     }
@@ -140,13 +147,13 @@ __global__ __launch_bounds__(256) void embedding_lookup_kernel(uint16_t *__restr
 
 }  // namespace
 
-int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
-                          hipStream_t st) {
+template <bool F16>
+static int dense_gemv_launch_t(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st) {
     static const int mfma_min_m = vmx_tune("VMX_DENSE_MFMA_MIN_M", 5);   // 0 disables
     if (mfma_min_m > 0 && M >= mfma_min_m && K % 128 == 0) {   // GEMM-shaped: matrix cores, activations staged in k-passes
         int g16 = ((N + 15) / 16 + 3) / 4;   // 4 waves x one 16-row tile of W per round
         if (g16 > 2048) g16 = 2048;
-        hipLaunchKernelGGL((dense_gemm16_kernel<false>), dim3(g16), dim3(256), 0, st, y, x, W, bias, M, N, K);
+        hipLaunchKernelGGL((dense_gemm16_kernel<F16>), dim3(g16), dim3(256), 0, st, y, x, W, bias, M, N, K);
         VMX_CHECK_LAUNCH("dense_gemm16");
         return VMX_OK;
     }
@@ -156,9 +163,9 @@ int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, con
 #define DL(MT, R)                                                                                                        \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
-            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)dense_gemv_kernel<MT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)dense_gemv_kernel<MT, R, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)lds));                                                                \
-        hipLaunchKernelGGL((dense_gemv_kernel<MT, R>), dim3(grid), dim3(256), lds, st, y, x, W, bias, M, N, K);          \
+        hipLaunchKernelGGL((dense_gemv_kernel<MT, R, F16>), dim3(grid), dim3(256), lds, st, y, x, W, bias, M, N, K);     \
     } while (0)
     if (M == 1) DL(1, 2);
     else if (M == 2) DL(2, 2);
@@ -170,13 +177,28 @@ int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, con
     return VMX_OK;
 }
 
+int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
+                          hipStream_t st, int f16) {
+    return f16 ? dense_gemv_launch_t<true>(y, x, W, bias, M, N, K, st) : dense_gemv_launch_t<false>(y, x, W, bias, M, N, K, st);
+}
+
 extern "C" int vmx_dense_gemv_bf16(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
                                    void *stream) {
     VMX_REQUIRE(y && x && W, "dense_gemv: null pointer");
     VMX_REQUIRE(M >= 1 && M <= 16, "dense_gemv: M (%d) must be in 1..16", M);
     VMX_REQUIRE(N > 0 && K > 0 && K % 8 == 0, "dense_gemv: K (%d) must be a positive multiple of 8", K);
     VMX_REQUIRE((size_t)M * K * 2 <= 160 * 1024, "dense_gemv: M*K too large for LDS staging");
-    return vmx_dense_gemv_launch(y, x, W, bias, M, N, K, vmx_stream(stream));
+    return vmx_dense_gemv_launch(y, x, W, bias, M, N, K, vmx_stream(stream), 0);
+}
+
+// The same product over fp16 operands (fp16 models: the lm_head of an EXL3 checkpoint), fp16 out
+extern "C" int vmx_dense_gemv_f16(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K,
+                                  void *stream) {
+    VMX_REQUIRE(y && x && W, "dense_gemv: null pointer");
+    VMX_REQUIRE(M >= 1 && M <= 16, "dense_gemv: M (%d) must be in 1..16", M);
+    VMX_REQUIRE(N > 0 && K > 0 && K % 8 == 0, "dense_gemv: K (%d) must be a positive multiple of 8", K);
+    VMX_REQUIRE((size_t)M * K * 2 <= 160 * 1024, "dense_gemv: M*K too large for LDS staging");
+    return vmx_dense_gemv_launch(y, x, W, bias, M, N, K, vmx_stream(stream), 1);
 }
 
 extern "C" int vmx_embedding_lookup_bf16(uint16_t *out, const uint16_t *table, const int32_t *ids, int tokens, int hidden, int vocab,

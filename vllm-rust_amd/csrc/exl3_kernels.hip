@@ -104,8 +104,9 @@ __global__ __launch_bounds__(64) void exl3_had_f16_kernel(const uint16_t *__rest
 }
 
 // Output side: sum of f32 split-K slices -> Hadamard in f32 -> * 1/sqrt(128) -> fp16 -> * svh (fp16).  grid (N/128, M)
-// y32 != NULL: instead of fp16 into y, the value cast to bf16 (the model dtype of a bf16 model, exl3.rs:272-277) is written
-// as f32 at y32[row * ld32 + col] for consumers that take f32 linear outputs.
+// y32 != NULL: instead of fp16 into y, the fp16 value is written as f32 at y32[row * ld32 + col] for consumers that take f32
+// linear outputs; every such consumer rounds to the model dtype first (the cast back of exl3.rs:272-277 on a bf16 model,
+// nothing on an fp16 model).
 __global__ __launch_bounds__(64) void exl3_out_had_kernel(const float *__restrict__ partial, int splits, int64_t slice,
                                                            const uint16_t *__restrict__ svh, uint16_t *__restrict__ y, int N,
                                                            float *__restrict__ y32, int ld32) {
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64) void exl3_out_had_kernel(const float *__restric
     }
     if (y32) {
         float *d = y32 + (int64_t)blockIdx.y * ld32 + blockIdx.x * 128 + 2 * lane;
-        *reinterpret_cast<float2 *>(d) = make_float2(vmx_bf16_to_f32(vmx_f32_to_bf16((float)o0)), vmx_bf16_to_f32(vmx_f32_to_bf16((float)o1)));
+        *reinterpret_cast<float2 *>(d) = make_float2((float)o0, (float)o1);
     } else {
         *reinterpret_cast<uint32_t *>(y + base) = (uint32_t)half_to_bits(o0) | ((uint32_t)half_to_bits(o1) << 16);
     }
@@ -305,13 +306,21 @@ __global__ __launch_bounds__(256) void exl3_gemm_kernel(Exl3Segs segs, const uin
                         a1 += pt[i][p].y * wt;
                     }
                     const float ginv = 1.0f / (gsum + 1e-6f);
-                    in = (uint32_t)vmx_f32_to_bf16(a0 * ginv) | ((uint32_t)vmx_f32_to_bf16(a1 * ginv) << 16);
+                    // the merged attention row in the activation dtype (what the separate merge kernel would have stored)
+                    in = x_bf16 ? ((uint32_t)vmx_f32_to_bf16(a0 * ginv) | ((uint32_t)vmx_f32_to_bf16(a1 * ginv) << 16))
+                                : ((uint32_t)vmx_st16<true>(a0 * ginv) | ((uint32_t)vmx_st16<true>(a1 * ginv) << 16));
                 }
-                if (segs.norm_w) {
+                if (segs.norm_w) {   // rows and norm weights in the activation dtype (bf16, or fp16 when !x_bf16)
                     const float inv = rsqrtf(vmx_wave_sum(lane < (K >> 7) ? hss[i] : 0.f) / (float)K + segs.eps);
-                    const float x0 = __uint_as_float(in << 16) * inv * __uint_as_float(hnw[i] << 16);
-                    const float x1 = __uint_as_float(in & 0xffff0000u) * inv * __uint_as_float(hnw[i] & 0xffff0000u);
-                    in = (uint32_t)vmx_f32_to_bf16(x0) | ((uint32_t)vmx_f32_to_bf16(x1) << 16);
+                    if (x_bf16) {
+                        const float x0 = __uint_as_float(in << 16) * inv * __uint_as_float(hnw[i] << 16);
+                        const float x1 = __uint_as_float(in & 0xffff0000u) * inv * __uint_as_float(hnw[i] & 0xffff0000u);
+                        in = (uint32_t)vmx_f32_to_bf16(x0) | ((uint32_t)vmx_f32_to_bf16(x1) << 16);
+                    } else {
+                        const float x0 = vmx_ld16<true>((uint16_t)(in & 0xffffu)) * inv * vmx_ld16<true>((uint16_t)(hnw[i] & 0xffffu));
+                        const float x1 = vmx_ld16<true>((uint16_t)(in >> 16)) * inv * vmx_ld16<true>((uint16_t)(hnw[i] >> 16));
+                        in = (uint32_t)vmx_st16<true>(x0) | ((uint32_t)vmx_st16<true>(x1) << 16);
+                    }
                 }
                 half_t a, b;
                 if (x_bf16) { a = (half_t)__uint_as_float(in << 16); b = (half_t)__uint_as_float(in & 0xffff0000u); }
@@ -557,7 +566,7 @@ int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const vo
                                void *workspace, size_t workspace_bytes, hipStream_t st, const float **partial_out, int *splits_out,
                                const uint16_t *norm_w, const float *blk_ssq, float eps, const VmxAttnParts *attn_parts) {
     VMX_REQUIRE(nseg >= 1 && nseg <= 3 && M >= 1 && M <= 4, "exl3_forward_multi: %d tensors / %d rows unsupported", nseg, M);
-    VMX_REQUIRE(!norm_w || (x_bf16 && blk_ssq && K <= 8192), "exl3_forward_multi: the norm form takes bf16 rows of at most 8192 columns");
+    VMX_REQUIRE(!norm_w || (blk_ssq && K <= 8192), "exl3_forward_multi: the norm form takes rows of at most 8192 columns");
     int N = 0;
     Exl3Segs sg;
     for (int i = 0; i < 3; i++) {
@@ -574,7 +583,7 @@ int vmx_exl3_forward_multi_f32(const uint16_t *x, int x_bf16, int nseg, const vo
     sg.blk_ssq = blk_ssq;
     sg.eps = eps;
     if (attn_parts) {
-        VMX_REQUIRE(x_bf16 && !norm_w && K % 128 == 0 && attn_parts->max_parts >= 1 && attn_parts->max_parts <= 4 && attn_parts->part_tokens == 0,
+        VMX_REQUIRE(!norm_w && K % 128 == 0 && attn_parts->max_parts >= 1 && attn_parts->max_parts <= 4 && attn_parts->part_tokens == 0,
                     "exl3_forward_multi: attention partitions (%d) not mergeable here", attn_parts->max_parts);
         sg.attn_tmp = attn_parts->tmp_out;
         sg.attn_mx = attn_parts->max_logits;

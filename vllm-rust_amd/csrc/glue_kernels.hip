@@ -171,6 +171,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 // grid (chunks, rows): each workgroup reduces one slice of a row to a key in part[row][chunk].
+template <bool F16>
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t *__restrict__ logits, unsigned long long *__restrict__ part,
                                                               int vocab, uint32_t index_offset) {
     __shared__ unsigned long long red[4];
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t *__r
     int i = lo + threadIdx.x * 8;
     for (; vec_ok && i + 8 <= hi; i += 256 * 8) {
         float f[8];
-        unpack8(*reinterpret_cast<const uint4 *>(lg + i), f);
+        vmx_unpack16x8<F16>(*reinterpret_cast<const uint4 *>(lg + i), f);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const unsigned long long k = argmax_key(f[j], index_offset + (uint32_t)(i + j));
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t *__r
     if (!vec_ok) i = lo + threadIdx.x * 8;
     for (; i < hi; i += 256 * 8)  // tail (or unaligned row): scalar
         for (int j = i; j < min(i + 8, hi); j++) {
-            const unsigned long long k = argmax_key(vmx_bf16_to_f32(lg[j]), index_offset + (uint32_t)j);
+            const unsigned long long k = argmax_key(vmx_ld16<F16>(lg[j]), index_offset + (uint32_t)j);
             best = k > best ? k : best;
         }
     best = wave_max_u64(best);
@@ -363,20 +364,35 @@ extern "C" size_t vmx_argmax_workspace_bytes(int rows, int vocab) {
     return (size_t)rows * argmax_chunks(vocab) * sizeof(unsigned long long);
 }
 
-extern "C" int vmx_argmax_bf16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+static int argmax_impl(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace, size_t workspace_bytes, void *stream,
+                       bool f16) {
     VMX_REQUIRE(out_ids && logits && workspace, "argmax: null pointer");
     VMX_REQUIRE(rows >= 0 && vocab > 0, "argmax: bad shape");
     VMX_REQUIRE(workspace_bytes >= vmx_argmax_workspace_bytes(rows, vocab), "argmax: workspace too small");
     if (rows == 0) return VMX_OK;
     const int chunks = argmax_chunks(vocab);
-    hipLaunchKernelGGL(argmax_partial_kernel, dim3(chunks, rows), dim3(256), 0, vmx_stream(stream), logits,
-                       (unsigned long long *)workspace, vocab, 0u);
+    if (f16)
+        hipLaunchKernelGGL(argmax_partial_kernel<true>, dim3(chunks, rows), dim3(256), 0, vmx_stream(stream), logits,
+                           (unsigned long long *)workspace, vocab, 0u);
+    else
+        hipLaunchKernelGGL(argmax_partial_kernel<false>, dim3(chunks, rows), dim3(256), 0, vmx_stream(stream), logits,
+                           (unsigned long long *)workspace, vocab, 0u);
     VMX_CHECK_LAUNCH("argmax(partial)");
     hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, vmx_stream(stream), (const unsigned long long *)workspace, out_ids,
                        (unsigned long long *)nullptr, chunks);
     VMX_CHECK_LAUNCH("argmax(final)");
     return VMX_OK;
+}
+
+extern "C" int vmx_argmax_bf16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+    return argmax_impl(out_ids, logits, rows, vocab, workspace, workspace_bytes, stream, false);
+}
+
+// The same over fp16 logits (models that run in fp16)
+extern "C" int vmx_argmax_f16(int32_t *out_ids, const uint16_t *logits, int rows, int vocab, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+    return argmax_impl(out_ids, logits, rows, vocab, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int vmx_reshape_and_cache(const uint16_t *key, const uint16_t *value, void *k_cache, void *v_cache,
@@ -475,10 +491,14 @@ __global__ void argmax_keys_to_ids_kernel(const unsigned long long *__restrict__
 // Vocab-parallel argmax, step 1: per-row winning key over this rank's logits slice (global index =
 // index_offset + local index).  keys: u64 [rows]; workspace as vmx_argmax_bf16, plus the keys.
 int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,
-                    hipStream_t st) {
+                    hipStream_t st, int f16) {
     const int chunks = argmax_chunks(vocab);
-    hipLaunchKernelGGL(argmax_partial_kernel, dim3(chunks, rows), dim3(256), 0, st, logits, (unsigned long long *)workspace, vocab,
-                       index_offset);
+    if (f16)
+        hipLaunchKernelGGL(argmax_partial_kernel<true>, dim3(chunks, rows), dim3(256), 0, st, logits, (unsigned long long *)workspace, vocab,
+                           index_offset);
+    else
+        hipLaunchKernelGGL(argmax_partial_kernel<false>, dim3(chunks, rows), dim3(256), 0, st, logits, (unsigned long long *)workspace, vocab,
+                           index_offset);
     hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, (const unsigned long long *)workspace, (int32_t *)nullptr, keys,
                        chunks);
     VMX_CHECK_LAUNCH("argmax(keys)");

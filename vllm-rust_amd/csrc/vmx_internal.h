@@ -74,6 +74,33 @@ __device__ __forceinline__ float vmx_f16_to_f32(uint16_t h) {
     return static_cast<float>(__builtin_bit_cast(_Float16, h));
 }
 
+// One 16-bit activation element in the model's activation dtype: bf16 (F16 = false) or IEEE fp16 (EXL3 checkpoints run in
+// fp16 end to end, crates/core/src/quantization/weight_loader.rs:453-461).  Both stores round to nearest even.
+template <bool F16> __device__ __forceinline__ float vmx_ld16(uint16_t b) {
+    if constexpr (F16) return vmx_f16_to_f32(b);
+    else return vmx_bf16_to_f32(b);
+}
+template <bool F16> __device__ __forceinline__ uint16_t vmx_st16(float v) {
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
+    else return vmx_f32_to_bf16(v);
+}
+template <bool F16> __device__ __forceinline__ float vmx_rnd16(float v) { return vmx_ld16<F16>(vmx_st16<F16>(v)); }
+// eight consecutive elements <-> f32
+template <bool F16> __device__ __forceinline__ void vmx_unpack16x8(const uint4 v, float f[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f[2 * j] = vmx_ld16<F16>((uint16_t)(w[j] & 0xFFFFu));
+        f[2 * j + 1] = vmx_ld16<F16>((uint16_t)(w[j] >> 16));
+    }
+}
+template <bool F16> __device__ __forceinline__ uint4 vmx_pack16x8(const float f[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = (uint32_t)vmx_st16<F16>(f[2 * j]) | ((uint32_t)vmx_st16<F16>(f[2 * j + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __device__ __forceinline__ float vmx_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

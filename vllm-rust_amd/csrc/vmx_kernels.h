@@ -100,7 +100,7 @@ int vmx_comm_check_health(const vmx_comm *c, const char *what);
 
 // glue_kernels.hip
 int vmx_argmax_keys(unsigned long long *keys, const uint16_t *logits, int rows, int vocab, uint32_t index_offset, void *workspace,
-                    hipStream_t st);
+                    hipStream_t st, int f16 = 0);   // f16: the logits are fp16
 int vmx_argmax_keys_to_ids(const unsigned long long *keys, int32_t *out_ids, int rows, hipStream_t st);
 
 // iq_kernels.hip
@@ -155,7 +155,8 @@ size_t vmx_iq_gemm_int_workspace(int M, int N, int K);
 int vmx_iq_dequant_int(int ggml_type, const void *blocks, void *workspace, int N, int K, hipStream_t st);
 int vmx_bf16_rows_to_f16(const uint16_t *A, uint16_t *a16, int64_t n, hipStream_t st);
 int vmx_int_gemm_f32(const uint16_t *a16, const void *workspace, float *C, int M, int N, int K, int ldc, hipStream_t st);
-int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st);
+int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st,
+                          int f16 = 0);   // f16: x, W, bias and y hold fp16 (same f32 accumulation, fp16 matrix / dot instructions)
 // bf16 matrix-core GEMM y = bf16(bf16(x @ W^T) + bias), W [N, K] bf16 (fp8_kernels.hip)
 int vmx_bf16_gemm_nt(uint16_t *y, const uint16_t *x, const uint16_t *w, const uint16_t *bias, int M, int N, int K, hipStream_t st);
 

@@ -125,6 +125,11 @@ class Communicator:
         assert t.dtype == torch.bfloat16 and t.is_contiguous()
         check(lib.vmx_comm_all_reduce_sum_bf16(self.handle, t.data_ptr(), t.numel(), self._st()))
 
+    def all_reduce_sum_f16(self, t: torch.Tensor) -> None:
+        """The same sum over fp16 rows (models that run in fp16): f32 accumulation in rank order, one rounding to fp16."""
+        assert t.dtype == torch.float16 and t.is_contiguous()
+        check(lib.vmx_comm_all_reduce_sum_f16(self.handle, t.data_ptr(), t.numel(), self._st()))
+
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         """all_gather along dimension 0 (DeviceCommunicator::all_gather, communicator.rs:44)."""
         assert t.is_contiguous()

@@ -46,6 +46,8 @@ class Qwen3Spec:
     max_prefill_tokens: int = 0   # rows per native prefill call (0: prompts go through the decode path in max_batch chunks)
     num_experts: int = 0          # > 0: mixture-of-experts MLP (Mixtral: 8 experts, 2 per token); intermediate_size = expert width
     experts_per_tok: int = 0
+    act_dtype: str = "bf16"       # "f16": the model runs in fp16 (EXL3 checkpoints, weight_loader.rs:453-461): fp16 embedding /
+                                  # norm / lm_head tensors, fp16 activations, logits and KV cache
 
     @staticmethod
     def qwen3_8b(**kw):
@@ -62,9 +64,9 @@ class Qwen3Spec:
         return Qwen3Spec(1024, 28, 16, 8, 128, 3072, 151936, tie_word_embeddings=True, **kw)
 
 
-def rope_cos_sin_cache(head_dim: int, max_position: int, theta: float) -> np.ndarray:
+def rope_cos_sin_cache(head_dim: int, max_position: int, theta: float, dtype: str = "bf16") -> np.ndarray:
     """cos|sin table as the reference builds it (layers/rotary.rs:84-103): f32 inv_freq and
-    angles, cos/sin rounded to bf16 (the model dtype) and widened back to f32."""
+    angles, cos/sin rounded to the model dtype (bf16, or fp16 with dtype "f16") and widened back to f32."""
     i = np.arange(0, head_dim, 2, dtype=np.float32)
     inv_freq = (np.float32(1.0) / np.power(np.float32(theta), i / np.float32(head_dim))).astype(np.float32)
     t = np.arange(max_position, dtype=np.float32)[:, None]
@@ -75,6 +77,8 @@ def rope_cos_sin_cache(head_dim: int, max_position: int, theta: float) -> np.nda
         u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
         return u.view(np.float32)
 
+    if dtype == "f16":
+        return np.concatenate([np.cos(freqs).astype(np.float16), np.sin(freqs).astype(np.float16)], axis=1).astype(np.float32)
     return np.concatenate([bf16_round(np.cos(freqs)), bf16_round(np.sin(freqs))], axis=1).astype(np.float32)
 
 
@@ -89,7 +93,11 @@ class QuantizedQwen3ForCausalLM:
                           spec.num_experts, spec.experts_per_tok)
         self._h = C.c_void_p()
         check(lib.vmx_qwen3_create(C.byref(cfg), C.byref(self._h)))
-        cs = torch.from_numpy(rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta)).to(self.device)
+        assert spec.act_dtype in ("bf16", "f16")
+        self.act_torch_dtype = torch.float16 if spec.act_dtype == "f16" else torch.bfloat16
+        if spec.act_dtype == "f16":
+            check(lib.vmx_qwen3_set_activation_dtype(self._h, 2))   # VMX_F16
+        cs = torch.from_numpy(rope_cos_sin_cache(spec.head_dim, spec.max_position, spec.rope_theta, spec.act_dtype)).to(self.device)
         self.load_tensor(T_COS_SIN, 0, cs)
 
     def set_comm(self, comm) -> None:
@@ -335,7 +343,7 @@ class QuantizedQwen3ForCausalLM:
         return ck
 
     def _load_synthetic_dense(self, seed: int, keep_host_copy: bool):
-        """Embedding, lm_head and norm weights (bf16)."""
+        """Embedding, lm_head and norm weights (in the model's 16-bit dtype)."""
         s = self.spec
         g = torch.Generator(device=self.device).manual_seed(seed)
         ck = {}
@@ -344,20 +352,20 @@ class QuantizedQwen3ForCausalLM:
             if keep_host_copy:
                 ck[name] = t.cpu()
 
-        emb = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.5).to(torch.bfloat16)
+        emb = (torch.randn((s.vocab_size, s.hidden_size), device=self.device, generator=g) * 0.5).to(self.act_torch_dtype)
         self.load_tensor(T_EMBED, 0, emb); keep("embed", emb)
         if not s.tie_word_embeddings:
             rows = s.vocab_size // s.tp_size if s.tp_size > 1 else s.vocab_size
-            head = (torch.randn((rows, s.hidden_size), device=self.device, generator=g) * 0.05).to(torch.bfloat16)
+            head = (torch.randn((rows, s.hidden_size), device=self.device, generator=g) * 0.05).to(self.act_torch_dtype)
             self.load_tensor(T_LM_HEAD, 0, head); keep("lm_head", head)
             del head
         del emb
-        fn = (1.0 + 0.1 * torch.randn(s.hidden_size, device=self.device, generator=g)).to(torch.bfloat16)
+        fn = (1.0 + 0.1 * torch.randn(s.hidden_size, device=self.device, generator=g)).to(self.act_torch_dtype)
         self.load_tensor(T_FINAL_NORM, 0, fn); keep("final_norm", fn)
         for li in range(s.num_layers):
             for which, n, name in ((T_INPUT_LN, s.hidden_size, "input_ln"), (T_POST_LN, s.hidden_size, "post_ln"),
                                    (T_Q_NORM, s.head_dim, "q_norm"), (T_K_NORM, s.head_dim, "k_norm")):
-                w = (1.0 + 0.1 * torch.randn(n, device=self.device, generator=g)).to(torch.bfloat16)
+                w = (1.0 + 0.1 * torch.randn(n, device=self.device, generator=g)).to(self.act_torch_dtype)
                 self.load_tensor(which, li, w); keep(f"{li}.{name}", w)
         return ck
 
@@ -397,7 +405,7 @@ class QuantizedQwen3ForCausalLM:
         S = input_ids.numel()
         bt1 = block_table.reshape(1, -1).to(torch.int32)
         ids_out = torch.empty(S, dtype=torch.int32, device=self.device)
-        logits = torch.empty((S, s.vocab_size), dtype=torch.bfloat16, device=self.device) if return_logits else None
+        logits = torch.empty((S, s.vocab_size), dtype=self.act_torch_dtype, device=self.device) if return_logits else None
         check(lib.vmx_qwen3_set_rows_share_cache(self._h, 1))
         try:
             self._forward_chunks(input_ids, seqlen_offset, bt1, ids_out, logits)
@@ -422,7 +430,7 @@ class QuantizedQwen3ForCausalLM:
         torch.cuda.current_stream().synchronize()
 
     def debug_read(self, which: int, shape) -> torch.Tensor:
-        t = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
+        t = torch.empty(shape, dtype=self.act_torch_dtype, device=self.device)
         check(lib.vmx_qwen3_debug_read(self._h, which, t.data_ptr(), t.numel() * 2, self._stream()))
         torch.cuda.current_stream().synchronize()
         return t
