@@ -44,8 +44,8 @@ def test_dense_layers_match_oracle_per_step(gpu):
 
 def test_qwen3_0_6b_bf16_greedy_tokens_equal_the_oracle(gpu):
     """The whole model (28 layers, vocabulary 151936, tied head): a 12-token prompt through the native prompt pass, then 10
-    greedy tokens; the oracle runs the same loop on the CPU (its prompt one token at a time).  The token ids must be equal.
-    Seeded weights make this deterministic; a logit tie within bf16 rounding would show up as a fixed failure, not a flake."""
+    greedy tokens; the oracle runs the same loop on the CPU (its prompt one token at a time) over the executor's tokens.  Every
+    executor token must be the oracle's argmax or a near-tie of it, and at most two steps may be near-ties."""
     from tests.model_oracle import OracleQwen3
     from vllm_rust_amd.qwen3 import QuantizedQwen3ForCausalLM, rope_cos_sin_cache
     vmx, torch = gpu
@@ -80,19 +80,25 @@ def test_qwen3_0_6b_bf16_greedy_tokens_equal_the_oracle(gpu):
                                              torch.from_numpy(slot(p)).to(dev), bt_t, torch.tensor([p + 1], dtype=torch.int32, device=dev),
                                              max_seq_len=P + N)
             got.append(int(out.item()))
-        # oracle: the same loop
+        # oracle: the same loop, fed the executor's tokens, so that every step is comparable even after a near-tie went the
+        # other way (the prompt pass rounds its softmax weights to bf16 for the matrix cores, the oracle's per-token attention
+        # does not: logits agree to a few bf16 steps, not bit for bit)
+        from oracle import oracle as orc
         exp, logits = [], None
         for p in range(P):
             logits, _, _ = ref.decode(prompt[p:p + 1], np.asarray([p], np.int32), slot(p), bt, np.asarray([p + 1], np.int32))
-        from oracle import oracle as orc
+        rows = [orc.bf16_to_f32(logits)[0]]
         exp.append(int(orc.argmax_bf16(logits)[0]))
         for i in range(N - 1):
             p = P + i
-            logits, _, _ = ref.decode(np.asarray([exp[-1]], np.int32), np.asarray([p], np.int32), slot(p), bt, np.asarray([p + 1], np.int32))
+            logits, _, _ = ref.decode(np.asarray([got[i]], np.int32), np.asarray([p], np.int32), slot(p), bt, np.asarray([p + 1], np.int32))
+            rows.append(orc.bf16_to_f32(logits)[0])
             exp.append(int(orc.argmax_bf16(logits)[0]))
         print("executor", got)
         print("oracle  ", exp)
-        assert got == exp
+        for i, row in enumerate(rows):   # the executor's token is the oracle's argmax or within two bf16 steps of its maximum
+            assert row[got[i]] >= row.max() - abs(row.max()) * 2 ** -6, (i, got[i], exp[i], float(row[got[i]]), float(row.max()))
+        assert sum(g == e for g, e in zip(got, exp)) >= N - 2, (got, exp)
         assert len(set(got)) > 3, "degenerate greedy loop: the comparison would say little"
     finally:
         model.close()

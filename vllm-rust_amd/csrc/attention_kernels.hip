@@ -1233,7 +1233,9 @@ static int prefill_attention_impl(uint16_t *out, const uint16_t *q, const void *
     hipStream_t st = vmx_stream(stream);
     const int qpk = qpk_capacity(num_heads / num_kv_heads);   // any ratio up to 16 runs on the next compiled capacity
     const bool fp8 = kv_dtype == VMX_KV_FP8_E4M3;
-    int rc = VMX_EUNSUPPORTED;
+    int rc = vmx_prefill_attention_tiled(out, q, k_cache, v_cache, block_table, q_len, seqlen_offset, scale, num_heads, num_kv_heads, head_dim,
+                                         block_size, window, f16 ? 3 : (fp8 ? 1 : 0), k_scale, v_scale, st);   // 64- / 128-wide heads
+    if (rc != VMX_EUNSUPPORTED) return rc;
 #define ARGS st, out, q, k_cache, v_cache, block_table, q_len, seqlen_offset, scale, num_heads, num_kv_heads, block_size, window, k_scale, v_scale
 #define PF_ONE(HD, Q) rc = f16 ? launch_prefill<HD, Q, 3>(ARGS) : fp8 ? launch_prefill<HD, Q, 1>(ARGS) : launch_prefill<HD, Q, 0>(ARGS)
 #define BY_QPK(HD)                                                                                                          \

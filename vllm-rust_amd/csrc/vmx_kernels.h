@@ -62,6 +62,12 @@ int vmx_fused_decode_attention(uint16_t *out, const float *qkv_partial, int spli
 int vmx_exl3_forward_f32(const uint16_t *x, int x_bf16, const void *trellis, const uint16_t *suh, const uint16_t *svh, float *y32,
                          int ld, int M, int K, int N, int bits, int codebook, void *workspace, size_t workspace_bytes, hipStream_t st);
 
+// prefill_attn.hip: prompt attention on 32 x 32 matrix-core tiles (64- / 128-wide heads; kv: 0 bf16, 1 FP8 e4m3, 3 fp16 cache with
+// fp16 queries and output); VMX_EUNSUPPORTED (no message) when the geometry is not covered
+int vmx_prefill_attention_tiled(uint16_t *out, const uint16_t *q, const void *k_cache, const void *v_cache, const int32_t *block_table,
+                                int q_len, int seqlen_offset, float scale, int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                int window, int kv, const float *k_scale, const float *v_scale, hipStream_t st);
+
 // attention_kernels.hip
 struct VmxAttnParts {
     float *tmp_out, *exp_sums, *max_logits;  // [S][H][P][hd], [S][H][P], [S][H][P]
