@@ -180,16 +180,30 @@ __device__ __forceinline__ float chunk_sum16(const uint4 v) {
     return s;
 }
 
+template <bool GLU>
+__device__ __forceinline__ void int4_gemm_tile_store(const float *red, const uint16_t *__restrict__ bias, uint16_t *__restrict__ y,
+                                                     float *__restrict__ partial, int64_t slice_stride, int M, int N, int nt, int ks,
+                                                     const int32_t *omap);
+
 // Sum of the 4 waves' accumulators and the store.  Lane holds rows m = 4h + r, column n = nt*16 + nl.
 // omap (token-grouped experts): output row of block row m (LDS), instead of m itself.
 template <bool GLU>
 __device__ __forceinline__ void int4_gemm_epilogue(float *red, const vmx_f32x4 fin, const uint16_t *__restrict__ bias,
                                                    uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride, int M,
                                                    int N, int nt, int ks, const int32_t *omap = nullptr) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = lane & 15, h = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     *reinterpret_cast<float4 *>(red + (wave * 64 + lane) * 4) = make_float4(fin[0], fin[1], fin[2], fin[3]);
     __syncthreads();
     if (wave != 0) return;
+    int4_gemm_tile_store<GLU>(red, bias, y, partial, slice_stride, M, N, nt, ks, omap);
+}
+
+// One wave: sum of the 4 waves' accumulators of one column tile (red [4][64][4]) and the store.
+template <bool GLU>
+__device__ __forceinline__ void int4_gemm_tile_store(const float *red, const uint16_t *__restrict__ bias, uint16_t *__restrict__ y,
+                                                     float *__restrict__ partial, int64_t slice_stride, int M, int N, int nt, int ks,
+                                                     const int32_t *omap) {
+    const int lane = threadIdx.x & 63, nl = lane & 15, h = lane >> 4;
     float4 a = *reinterpret_cast<const float4 *>(red + lane * 4);
 #pragma unroll
     for (int wv = 1; wv < 4; wv++) {
@@ -389,13 +403,16 @@ __device__ __forceinline__ void int4_gemm_body(const uint4 *__restrict__ W, cons
 // staged XS = 8 k-blocks at a time (M = 16: 33 KB, four workgroups per CU).  Every weight unit is still requested at kernel
 // start; units are dealt to the waves round-robin (k-block 4u + wave), so each pass feeds all four waves.  Same arithmetic
 // per k-block; only the order in which a wave meets its k-blocks differs from the body above.
-template <int UPW, bool TAIL, bool GLU>
+template <int UPW, bool TAIL, bool GLU, int CT = 1>
 __device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                       const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
                                                       uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride,
                                                       int M, int N, int K, int group, int block,
                                                       const int32_t *xmap = nullptr, const int32_t *omap = nullptr) {
     // xmap / omap (token-grouped experts, LDS): activation row and output row of block row m
+    // CT: column tiles per workgroup.  A staged activation pass (M x 1024 k, 32 KB at 16 rows) serves one 1 KB weight unit per
+    // k-block and tile: with one tile per workgroup a 16-row launch reads four times as many activation bytes (from L2) as
+    // weight bytes -- 200 MB against 52 MB on the gate|up shape; CT tiles share the staged rows and each A fragment read from LDS.
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int XS = 4 * UPW < 8 ? 4 * UPW : 8;   // k-blocks staged per pass
     static_assert((4 * UPW) % XS == 0 && XS % 4 == 0, "slice must be whole passes, a pass whole rounds of the 4 waves");
@@ -403,94 +420,129 @@ __device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ 
     constexpr int XROW = XS * KB + 8, CPR = XS * KB / 8;
     uint16_t *xs = reinterpret_cast<uint16_t *>(smem);                     // [M][XROW]
     float *sumx = reinterpret_cast<float *>(smem + (size_t)M * XROW * 2);  // [4*UPW][16]
-    float *red = sumx + 4 * UPW * 16;                                      // [4][64][4]
-    uint32_t *szs = reinterpret_cast<uint32_t *>(red + 4 * 64 * 4);        // [4*UPW][16]
+    float *red = sumx + 4 * UPW * 16;                                      // [CT][4][64][4]
+    uint32_t *szs = reinterpret_cast<uint32_t *>(red + CT * 4 * 64 * 4);   // [CT][4*UPW][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = N / NT, kblocks = K / KB, G = K / group;
-    const int nt = block % n_tiles, ks = block / n_tiles;
+    const int n_groups = n_tiles / CT;
+    const int nt0 = (block % n_groups) * CT, ks = block / n_groups;
     const int kb_wg = ks * 4 * UPW;
     const int nl = lane & 15, h = lane >> 4;
     const int total = M * CPR;
 
-    uint32_t szv[(4 * UPW * 16 + 255) / 256];
+    constexpr int NSZ = (CT * 4 * UPW * 16 + 255) / 256;
+    uint32_t szv[NSZ];
 #pragma unroll
-    for (int j = 0; j < (4 * UPW * 16 + 255) / 256; j++) {
-        const int i = tid + 256 * j, kb = kb_wg + (i >> 4);
-        szv[j] = (i < 4 * UPW * 16 && (!TAIL || kb < kblocks)) ? SZ[((int64_t)nt * G + (kb * KB) / group) * 16 + (i & 15)] : 0u;
+    for (int j = 0; j < NSZ; j++) {
+        const int i = tid + 256 * j, t = i / (4 * UPW * 16), r = i % (4 * UPW * 16), kb = kb_wg + (r >> 4);
+        szv[j] = (i < CT * 4 * UPW * 16 && (!TAIL || kb < kblocks)) ? SZ[((int64_t)(nt0 + t) * G + (kb * KB) / group) * 16 + (r & 15)] : 0u;
     }
-    uint4 wreg[UPW];   // unit u of this wave = k-block 4u + wave of the slice
+    uint4 wreg[CT][UPW];   // unit u of this wave = k-block 4u + wave of the slice
 #pragma unroll
     for (int u = 0; u < UPW; u++) {
         const int kb = kb_wg + 4 * u + wave;
-        if (!TAIL || kb < kblocks) wreg[u] = W[((int64_t)nt * kblocks + kb) * 64 + lane];
-        else wreg[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < CT; t++) {
+            if (!TAIL || kb < kblocks) wreg[t][u] = W[((int64_t)(nt0 + t) * kblocks + kb) * 64 + lane];
+            else wreg[t][u] = make_uint4(0, 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < (4 * UPW * 16 + 255) / 256; j++)
-        if (tid + 256 * j < 4 * UPW * 16) szs[tid + 256 * j] = szv[j];
+    for (int j = 0; j < NSZ; j++)
+        if (tid + 256 * j < CT * 4 * UPW * 16) szs[tid + 256 * j] = szv[j];
 
     const uint16_t *xrow = xs + min(nl, M - 1) * XROW + 8 * h;
-    vmx_f32x4 fin = {0.f, 0.f, 0.f, 0.f};
+    vmx_f32x4 fin[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) fin[t] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
         if (p) __syncthreads();   // the previous pass has been read by every wave
         const int kp0 = (kb_wg + p * XS) * KB;
-        for (int c0 = 0; c0 < total; c0 += 256) {
-            const int c = c0 + tid;
-            const bool live = c < total;
-            const int m = live ? c / CPR : 0, cc = live ? c % CPR : 0, k = kp0 + cc * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (live && (!TAIL || k < K)) v = *reinterpret_cast<const uint4 *>(x + (int64_t)(xmap ? xmap[m] : m) * K + k);
-            if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = v;
-            const float sm = chunk_sum16(v);
-            if (live && (tid & 15) == 0) sumx[(p * XS + (cc >> 4)) * 16 + m] = sm;
+        for (int c0 = 0; c0 < total; c0 += 1024) {   // four chunks per thread requested before the first is used (a round trip each otherwise)
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = c0 + 256 * j + tid;
+                const bool live = c < total;
+                const int m = live ? c / CPR : 0, cc = live ? c % CPR : 0, k = kp0 + cc * 8;
+                v[j] = make_uint4(0, 0, 0, 0);
+                if (live && (!TAIL || k < K)) v[j] = *reinterpret_cast<const uint4 *>(x + (int64_t)(xmap ? xmap[m] : m) * K + k);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (c0 + 256 * j < total) {   // workgroup-uniform
+                    const int c = c0 + 256 * j + tid;
+                    const bool live = c < total;
+                    const int m = live ? c / CPR : 0, cc = live ? c % CPR : 0;
+                    if (live) *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = v[j];
+                    const float sm = chunk_sum16(v[j]);
+                    if (live && (tid & 15) == 0) sumx[(p * XS + (cc >> 4)) * 16 + m] = sm;
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < UPP; q++) {
             const int u = p * UPP + q, kbl = 4 * u + wave, kin = kbl - p * XS;   // k-block inside the slice / inside the pass
             if (!TAIL || kb_wg + kbl < kblocks) {  // wave-uniform
-                vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const uint32_t w4[4] = {wreg[u].x, wreg[u].y, wreg[u].z, wreg[u].w};
+                vmx_f32x4 acc[CT];
+#pragma unroll
+                for (int t = 0; t < CT; t++) acc[t] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t w = w4[i];
-                    uint4 bu;
-                    bu.x = (w & 0x000F000Fu) | 0x43004300u;
-                    bu.y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
-                    bu.z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
-                    bu.w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
                     const uint4 au = *reinterpret_cast<const uint4 *>(xrow + kin * KB + 32 * i);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, bu),
-                                                                  acc, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < CT; t++) {
+                        const uint32_t w = i == 0 ? wreg[t][u].x : i == 1 ? wreg[t][u].y : i == 2 ? wreg[t][u].z : wreg[t][u].w;
+                        uint4 bu;
+                        bu.x = (w & 0x000F000Fu) | 0x43004300u;
+                        bu.y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+                        bu.z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+                        bu.w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, bu),
+                                                                         acc[t], 0, 0, 0);
+                    }
                 }
-                const uint32_t szw = szs[kbl * 16 + nl];
-                const float s = __uint_as_float(szw << 16);
-                const float zo = __uint_as_float(szw & 0xFFFF0000u);
                 const float4 sx = *reinterpret_cast<const float4 *>(sumx + kbl * 16 + 4 * h);
-                fin[0] += s * (acc[0] - zo * sx.x);
-                fin[1] += s * (acc[1] - zo * sx.y);
-                fin[2] += s * (acc[2] - zo * sx.z);
-                fin[3] += s * (acc[3] - zo * sx.w);
+#pragma unroll
+                for (int t = 0; t < CT; t++) {
+                    const uint32_t szw = szs[(t * 4 * UPW + kbl) * 16 + nl];
+                    const float s = __uint_as_float(szw << 16);
+                    const float zo = __uint_as_float(szw & 0xFFFF0000u);
+                    fin[t][0] += s * (acc[t][0] - zo * sx.x);
+                    fin[t][1] += s * (acc[t][1] - zo * sx.y);
+                    fin[t][2] += s * (acc[t][2] - zo * sx.z);
+                    fin[t][3] += s * (acc[t][3] - zo * sx.w);
+                }
             }
         }
     }
-    int4_gemm_epilogue<GLU>(red, fin, bias, y, partial, slice_stride, M, N, nt, ks, omap);
+    if constexpr (CT == 1) {
+        int4_gemm_epilogue<GLU>(red, fin[0], bias, y, partial, slice_stride, M, N, nt0, ks, omap);
+    } else {   // every wave leaves its sums of all CT tiles; wave t < CT then adds up and stores tile t
+#pragma unroll
+        for (int t = 0; t < CT; t++)
+            *reinterpret_cast<float4 *>(red + ((t * 4 + wave) * 64 + lane) * 4) = make_float4(fin[t][0], fin[t][1], fin[t][2], fin[t][3]);
+        __syncthreads();
+        for (int t = wave; t < CT; t += 4)
+            int4_gemm_tile_store<GLU>(red + t * 4 * 64 * 4, bias, y, partial, slice_stride, M, N, nt0 + t, ks, omap);
+    }
 }
 
-template <int UPW, bool TAIL>
+template <int UPW, bool TAIL, int CT = 1>
 __global__ __launch_bounds__(256) void int4_gemm_looped_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                                 const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
                                                                 uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N,
                                                                 int K, int group, int slice_rows) {
-    int4_gemm_body_looped<UPW, TAIL, false>(W, SZ, x, bias, y, partial, (int64_t)slice_rows * N, M, N, K, group, blockIdx.x);
+    int4_gemm_body_looped<UPW, TAIL, false, CT>(W, SZ, x, bias, y, partial, (int64_t)slice_rows * N, M, N, K, group, blockIdx.x);
 }
 
-template <int UPW, bool TAIL>
+template <int UPW, bool TAIL, int CT = 1>
 __global__ __launch_bounds__(256) void int4_gemm_glu_looped_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                                     const uint16_t *__restrict__ x, uint16_t *__restrict__ act, int M,
                                                                     int N, int K, int group) {
-    int4_gemm_body_looped<UPW, TAIL, true>(W, SZ, x, nullptr, act, nullptr, 0, M, N, K, group, blockIdx.x);
+    int4_gemm_body_looped<UPW, TAIL, true, CT>(W, SZ, x, nullptr, act, nullptr, 0, M, N, K, group, blockIdx.x);
 }
 
 template <int UPW, bool TAIL>
@@ -1377,8 +1429,16 @@ inline bool use_looped(int M, int upw) {
     static const int min_m = vmx_tune("VMX_INT4_LOOPED_MIN_M", 5);
     return min_m > 0 && M >= min_m && upw >= 4;
 }
-inline size_t gemm_lds_bytes_looped(int M, int upw) {
-    return (size_t)M * ((4 * upw < 8 ? 4 * upw : 8) * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + 4 * 64 * 4 * 4 + (size_t)4 * upw * 16 * 4;
+inline size_t gemm_lds_bytes_looped(int M, int upw, int ct = 1) {
+    return (size_t)M * ((4 * upw < 8 ? 4 * upw : 8) * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + (size_t)ct * 4 * 64 * 4 * 4 +
+           (size_t)ct * 4 * upw * 16 * 4;
+}
+// Column tiles per workgroup of the looped form: two where the tile count allows (Qwen3-8B AWQ, same box, with the staging
+// loads in batches of four: 16 rows 3912 -> 4346 tok/s aggregate, 8 rows 2510 -> 2588; VMX_INT4_LOOPED_CT=1 for A/B runs)
+inline int looped_ct(int M, int N) {
+    static const int ct = vmx_tune("VMX_INT4_LOOPED_CT", 2);
+    (void)M;
+    return (ct == 2 && (N / NT) % 2 == 0) ? 2 : 1;
 }
 
 inline size_t gemm_lds_bytes(int M, int upw) {
@@ -1389,17 +1449,20 @@ int launch_gemm(const GemmPlan &p, const uint4 *W, const uint32_t *SZ, const uin
                 float *partial, int M, int N, int K, int group, hipStream_t st, int slice_rows = 0) {
     if (slice_rows <= 0) slice_rows = M;
     if (use_looped(M, p.upw)) {
-        const size_t ll = gemm_lds_bytes_looped(M, p.upw);
-        const dim3 lgrid((unsigned)((N / NT) * p.splits));
+        const int ct = looped_ct(M, N);
+        const size_t ll = gemm_lds_bytes_looped(M, p.upw, ct);
+        const dim3 lgrid((unsigned)((N / NT / ct) * p.splits));
         const bool ltail = (K / KB) % (4 * p.upw) != 0;
-#define LOOPED(U)                                                                                                                          \
+#define LOOPED_C(U, C)                                                                                                                     \
         do {                                                                                                                               \
-            if (ltail) hipLaunchKernelGGL((int4_gemm_looped_kernel<U, true>), lgrid, dim3(256), ll, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows); \
-            else hipLaunchKernelGGL((int4_gemm_looped_kernel<U, false>), lgrid, dim3(256), ll, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows);      \
+            if (ltail) hipLaunchKernelGGL((int4_gemm_looped_kernel<U, true, C>), lgrid, dim3(256), ll, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows); \
+            else hipLaunchKernelGGL((int4_gemm_looped_kernel<U, false, C>), lgrid, dim3(256), ll, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows);      \
         } while (0)
+#define LOOPED(U) do { if (ct == 2) LOOPED_C(U, 2); else LOOPED_C(U, 1); } while (0)
         if (p.upw == 8) LOOPED(8);
         else LOOPED(4);
 #undef LOOPED
+#undef LOOPED_C
         VMX_CHECK_LAUNCH("int4_gemm(looped)");
         return VMX_OK;
     }
@@ -1769,15 +1832,19 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
         const uint16_t *xc = x + (int64_t)m0 * K;
         uint16_t *ac = act + (int64_t)m0 * (N / 2);
         if (use_looped(mm, p.upw)) {
-            const size_t ll = gemm_lds_bytes_looped(mm, p.upw);
-#define GLOOPED(U)                                                                                                                 \
+            const int ct = looped_ct(mm, N);
+            const size_t ll = gemm_lds_bytes_looped(mm, p.upw, ct);
+            const dim3 lgrid((unsigned)(N / NT / ct));
+#define GLOOPED_C(U, C)                                                                                                            \
             do {                                                                                                                   \
-                if (tail) hipLaunchKernelGGL((int4_gemm_glu_looped_kernel<U, true>), grid, block, ll, st, W, SZ, xc, ac, mm, N, K, group); \
-                else hipLaunchKernelGGL((int4_gemm_glu_looped_kernel<U, false>), grid, block, ll, st, W, SZ, xc, ac, mm, N, K, group);      \
+                if (tail) hipLaunchKernelGGL((int4_gemm_glu_looped_kernel<U, true, C>), lgrid, block, ll, st, W, SZ, xc, ac, mm, N, K, group); \
+                else hipLaunchKernelGGL((int4_gemm_glu_looped_kernel<U, false, C>), lgrid, block, ll, st, W, SZ, xc, ac, mm, N, K, group);      \
             } while (0)
+#define GLOOPED(U) do { if (ct == 2) GLOOPED_C(U, 2); else GLOOPED_C(U, 1); } while (0)
             if (p.upw == 8) GLOOPED(8);
             else GLOOPED(4);
 #undef GLOOPED
+#undef GLOOPED_C
             continue;
         }
         const size_t lds = gemm_lds_bytes(mm, p.upw);
