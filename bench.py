@@ -158,11 +158,13 @@ def prefill_block(tokens, seconds, spec):
     blk = {"tokens": tokens, "ms": round(seconds * 1e3, 3), "tok_s": round(tokens / seconds, 1),
            "linear_TFLOP_s": round(flop / seconds / 1e12, 1), "mfma_peak_TFLOP_s": 2500.0,
            "frac_of_mfma_peak": round(flop / seconds / 1e12 / 2500.0, 4),
-           "note": "one vmx_qwen3_prefill call (64x128-tile MFMA int4 GEMM, MFMA prefill attention); untimed part of the job"}
+           "note": "one vmx_qwen3_prefill call (64x256-tile MFMA int4 GEMM, 32x32-tile MFMA prompt attention); untimed part of the job"}
     try:
-        k = json.loads((ROOT / "profiles" / "r02_pmc_prefill_mfma.json").read_text())["kernels"]
-        blk["mfma_busy_frac"] = {name.split(" (")[0]: v["mfma_busy_frac"] for name, v in k.items()}
-        blk["mfma_busy_source"] = "profiles/r02_pmc_prefill_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES over the same kernels and shapes)"
+        j = json.loads((ROOT / "profiles" / "r03_pmc_prefill_mfma.json").read_text())
+        blk["mfma_busy_frac"] = {f"{tag}: {name.split(' (')[0]}": v["mfma_busy_frac"] for tag in ("prompt_256", "prompt_2048")
+                                 for name, v in j[tag].items()}
+        blk["mfma_busy_source"] = ("profiles/r03_pmc_prefill_mfma.json (committed rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass over the same "
+                                   "kernels at 256- and 2048-token prompts; not measured in this run)")
     except Exception:
         pass
     return blk
