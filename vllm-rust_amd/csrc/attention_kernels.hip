@@ -191,18 +191,10 @@ __device__ __forceinline__ void attn_tile_fold(const AttnTile<HD, FP8> &t, int n
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const float l = tl < ntok ? acc[r] * lscale : -FLT_MAX;
-        float mx = l;
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+        const float mx = vmx_row16_max(l);
         const float m_new = fmaxf(m_run[r], mx);
         const float e = tl < ntok ? __expf(l - m_new) : 0.f;
-        float sm = e;
-        sm += __shfl_xor(sm, 1, 64);
-        sm += __shfl_xor(sm, 2, 64);
-        sm += __shfl_xor(sm, 4, 64);
-        sm += __shfl_xor(sm, 8, 64);
+        const float sm = vmx_row16_sum(e);
         corr[r] = __expf(m_run[r] - m_new);  // 0 on the first tile (m_run = -FLT_MAX)
         s_run[r] = s_run[r] * corr[r] + sm;
         m_run[r] = m_new;
@@ -498,8 +490,7 @@ __global__ __launch_bounds__(512) void paged_attn_reduce_kernel(uint16_t *__rest
         if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block (iq_dequant.cu:253-267)
             const float v = vmx_bf16_to_f32(vb);
             float amax = fabsf(v);
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            amax = vmx_row32_max(amax);
             const float dq = amax / 127.0f;
             aq[obase + d] = amax != 0.0f ? (int8_t)(int)roundf(v / dq) : (int8_t)0;
             if ((d & 31) == 0) ad[(obase + d) >> 5] = dq;
@@ -552,8 +543,7 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_small_kernel(uint16_t *
         if (aq) {
             const float v = vmx_bf16_to_f32(vb);
             float amax = fabsf(v);
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            amax = vmx_row32_max(amax);
             const float dq = amax / 127.0f;
             aq[obase + d] = amax != 0.0f ? (int8_t)(int)roundf(v / dq) : (int8_t)0;
             if ((d & 31) == 0) ad[(obase + d) >> 5] = dq;
@@ -564,14 +554,19 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_small_kernel(uint16_t *
 // Output transform of an EXL3 linear (exl3.rs:256-286) on one 128-wide head held as elements lane, lane + 64: H_128 in f32
 // (element bits 0..5 = lane bits, bit 6 = the in-lane pair, in the stage order of the separate transform kernel),
 // * 1/sqrt(128), round to fp16, * svh in fp16.
+template <int M> __device__ __forceinline__ void attn_had_stage(float v[2], int lane) {
+    const float p0 = vmx_lane_xor<M>(v[0]), p1 = vmx_lane_xor<M>(v[1]);
+    const bool neg = (lane & M) != 0;
+    v[0] = (neg ? -v[0] : v[0]) + p0;
+    v[1] = (neg ? -v[1] : v[1]) + p1;
+}
 __device__ __forceinline__ void attn_exl3_out_transform(float v[2], int lane, uint16_t sv0, uint16_t sv1) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const float p0 = __shfl_xor(v[0], m, 64), p1 = __shfl_xor(v[1], m, 64);
-        const bool neg = (lane & m) != 0;
-        v[0] = (neg ? -v[0] : v[0]) + p0;
-        v[1] = (neg ? -v[1] : v[1]) + p1;
-    }
+    attn_had_stage<1>(v, lane);
+    attn_had_stage<2>(v, lane);
+    attn_had_stage<4>(v, lane);
+    attn_had_stage<8>(v, lane);
+    attn_had_stage<16>(v, lane);
+    attn_had_stage<32>(v, lane);
     const float s0 = v[0] + v[1], d0 = v[0] - v[1];
     v[0] = (float)((_Float16)(s0 * 0.088388347648f) * __builtin_bit_cast(_Float16, sv0));
     v[1] = (float)((_Float16)(d0 * 0.088388347648f) * __builtin_bit_cast(_Float16, sv1));
@@ -680,7 +675,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
                     }
                 }
             } else {                  // half == 32 (checked on the host): partner is lane ^ 32 of element 0
-                const float other = __shfl_xor(v[0], 32, 64);
+                const float other = vmx_lane_xor<32>(v[0]);
                 const int i = lane & 31;
                 const float c = cs[i], sn = cs[32 + i];
                 v[0] = vmx_rnd16<FP8 == 3>((lane < 32 ? v[0] * c - other * sn : v[0] * c + other * sn));
@@ -768,8 +763,7 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
         if (aq) {   // q8_1 of the bf16 output for an I-quant o_proj: 32 consecutive lanes hold one block
             const float vq = vmx_ld16<FP8 == 3>(vb);
             float amax = fabsf(vq);
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+            amax = vmx_row32_max(amax);
             const float dq = amax / 127.0f;
             aq[ob] = amax != 0.0f ? (int8_t)(int)roundf(vq / dq) : (int8_t)0;
             if ((d & 31) == 0) ad[ob >> 5] = dq;
@@ -900,7 +894,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
                     }
                 }
             } else {                  // half == 32 (checked on the host): partner is lane ^ 32 of element 0
-                const float other = __shfl_xor(v[0], 32, 64);
+                const float other = vmx_lane_xor<32>(v[0]);
                 v[0] = vmx_rnd16<FP8 == 3>((lane < 32 ? v[0] * rc[0] - other * rs[0] : v[0] * rc[0] + other * rs[0]));
             }
         }
@@ -1167,8 +1161,8 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
                 sv[i] = sacc[i] * lscale;
                 if (ok[i]) tmax = fmaxf(tmax, sv[i]);
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = fmaxf(tmax, vmx_lane_xor<16>(tmax));
+            tmax = fmaxf(tmax, vmx_lane_xor<32>(tmax));
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __expf(m_run - m_new);   // both -FLT_MAX (nothing seen yet): exp(0) = 1 on zero sums
             m_run = m_new;
@@ -1193,8 +1187,8 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(uint16_t *__restrict_
             }
         }
     }
-    float l = l_part + __shfl_xor(l_part, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l = l_part + vmx_lane_xor<16>(l_part);
+    l += vmx_lane_xor<32>(l);
     if (q_valid) {
         const float inv = vsc / l;
         uint16_t *o = out + ((int64_t)qi * num_heads + head) * HD;

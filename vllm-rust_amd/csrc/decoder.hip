@@ -98,7 +98,7 @@ __device__ __forceinline__ void exl3_out_transform8(const float *__restrict__ pa
         const bool neg = (lane & m) != 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float p = __shfl_xor(o[j], m, 64);
+            const float p = vmx_lane_xor_m(o[j], m);
             o[j] = (neg ? -o[j] : o[j]) + p;
         }
     }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void exl3_resid_stats_kernel(uint16_t *__restr
     e1 = d;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
-        const float p0 = __shfl_xor(e0, m, 64), p1 = __shfl_xor(e1, m, 64);
+        const float p0 = vmx_lane_xor_m(e0, m), p1 = vmx_lane_xor_m(e1, m);
         const bool neg = (lane & m) != 0;
         e0 = (neg ? -e0 : e0) + p0;
         e1 = (neg ? -e1 : e1) + p1;
@@ -332,8 +332,8 @@ __global__ __launch_bounds__(256) void norm_router_topk_kernel(const uint16_t *_
         int bi = lane < E ? lane : 0x7fffffff;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
+            const float ov = vmx_lane_xor_m(bv, off);
+            const int oi = vmx_lane_xor_m(bi, off);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         if (lane == ki) { mine = bv; topk_ids[(int64_t)t * k + ki] = bi; }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void exl3_gateup_act_kernel(const float *__res
         const bool neg = (lane & m) != 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float p = __shfl_xor(e[j], m, 64);
+            const float p = vmx_lane_xor_m(e[j], m);
             e[j] = (neg ? -e[j] : e[j]) + p;
         }
     }

@@ -77,7 +77,7 @@ __device__ __forceinline__ void had128_wave(float &e0, float &e1, int lane) {
     e1 = d;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {     // stride 2m in elements = lane bit m
-        const float p0 = __shfl_xor(e0, m, 64), p1 = __shfl_xor(e1, m, 64);
+        const float p0 = vmx_lane_xor_m(e0, m), p1 = vmx_lane_xor_m(e1, m);
         const bool neg = (lane & m) != 0;
         e0 = (neg ? -e0 : e0) + p0;
         e1 = (neg ? -e1 : e1) + p1;

@@ -164,7 +164,7 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, uint32_t idx) 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off, 64);
+        const unsigned long long o = ((unsigned long long)(unsigned)vmx_lane_xor_m((int)(v >> 32), off) << 32) | (unsigned)vmx_lane_xor_m((int)v, off);
         v = o > v ? o : v;
     }
     return v;

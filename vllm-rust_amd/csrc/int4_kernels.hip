@@ -173,11 +173,7 @@ __device__ __forceinline__ float chunk_sum16(const uint4 v) {
     float f[8];
     bf16x8_to_f32(v, f);
     float s = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
-    return s;
+    return vmx_row16_sum(s);
 }
 
 template <bool GLU>
@@ -217,7 +213,7 @@ __device__ __forceinline__ void int4_gemm_tile_store(const float *red, const uin
         const int mrow = 4 * h + r;
         const int orow = omap ? omap[mrow] : mrow;
         if (GLU) {
-            const float up = __shfl_xor(out4[r], 8, 64);
+            const float up = vmx_lane_xor<8>(out4[r]);
             if (mrow < M && nl < 8) {
                 const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(out4[r]));
                 const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
@@ -676,8 +672,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
             float f8[8];
             bf16x8_to_f32(xn, f8);
             float sh = ((f8[0] + f8[1]) + (f8[2] + f8[3])) + ((f8[4] + f8[5]) + (f8[6] + f8[7]));
-            sh += __shfl_xor(sh, 4, 64);
-            sh += __shfl_xor(sh, 8, 64);
+            sh += vmx_lane_xor<4>(sh);
+            sh += vmx_lane_xor<8>(sh);
             if (live && (tid & 15) < 4) sumx[(cc >> 4) * 4 + (tid & 3)] = sh;
         } else {
             const float sm = chunk_sum16(xn);   // 16 consecutive chunks = one (row, k-block)
@@ -725,8 +721,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(MR == 
         }
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
-            fsum[t] += __shfl_xor(fsum[t], 16, 64);
-            fsum[t] += __shfl_xor(fsum[t], 32, 64);
+            fsum[t] += vmx_lane_xor<16>(fsum[t]);
+            fsum[t] += vmx_lane_xor<32>(fsum[t]);
             if (hh == 0) red[((t * NWV + wave) * 16 + nl) * 4] = fsum[t];
         }
     }
@@ -951,10 +947,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
         if (tid < 16 * M) h[hidx] = hn;
         float sq = vmx_bf16_to_f32(hn);   // sum of squares of the tile's 16 new residual values, for the norm in the next linear
         sq *= sq;
-        sq += __shfl_xor(sq, 1, 64);
-        sq += __shfl_xor(sq, 2, 64);
-        sq += __shfl_xor(sq, 4, 64);
-        sq += __shfl_xor(sq, 8, 64);
+        sq = vmx_row16_sum(sq);
         if (tid < 16 * M && c == 0) ssq[m * (N / NT) + nt] = sq;
     }
 }
@@ -1107,7 +1100,7 @@ __global__ __launch_bounds__(256) void int4_gemm_tiled_kernel(const uint4 *__res
                     row = p < 0 ? M : p;   // padding rows fail the bound check below (M = numel)
                 }
                 if constexpr (GLU) {
-                    const float up = __shfl_xor(fin[mt][c][r], 8, 64);
+                    const float up = vmx_lane_xor<8>(fin[mt][c][r]);
                     if (row < M && nl < 8) {
                         const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(fin[mt][c][r]));
                         const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));
@@ -1309,7 +1302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     row = p < 0 ? M : p;   // padding rows fail the bound check below (M = numel)
                 }
                 if constexpr (GLU) {
-                    const float up = __shfl_xor(fin[mt][c][r], 8, 64);
+                    const float up = vmx_lane_xor<8>(fin[mt][c][r]);
                     if (row < M && nl < 8) {
                         const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(fin[mt][c][r]));
                         const float uu = vmx_bf16_to_f32(vmx_f32_to_bf16(up));

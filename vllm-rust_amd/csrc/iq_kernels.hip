@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256) void quantize_q8_1_kernel(const float *__restr
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) v = reinterpret_cast<const float4 *>(x)[lane4];
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = fmaxf(amax, vmx_lane_xor<1>(amax));
+    amax = fmaxf(amax, vmx_lane_xor<2>(amax));
+    amax = fmaxf(amax, vmx_lane_xor<4>(amax));
     const float d = amax / 127.0f;
     uint32_t packed = 0;
     if (amax != 0.0f) {
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256) void quantize_q8_1_bf16_kernel(const uint16_t 
                         __uint_as_float(p.y & 0xFFFF0000u));
     }
     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = fmaxf(amax, vmx_lane_xor<1>(amax));
+    amax = fmaxf(amax, vmx_lane_xor<2>(amax));
+    amax = fmaxf(amax, vmx_lane_xor<4>(amax));
     const float d = amax / 127.0f;
     uint32_t packed = 0;
     if (amax != 0.0f) {

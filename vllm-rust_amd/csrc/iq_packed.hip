@@ -294,26 +294,26 @@ template <int NR> __device__ __forceinline__ float reduce_rows(const float *v, i
     const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
     if constexpr (NR == 8) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) w[i] = (h5 ? v[i + 4] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 4], 32, 64);
+        for (int i = 0; i < 4; i++) w[i] = (h5 ? v[i + 4] : v[i]) + vmx_lane_xor<32>(h5 ? v[i] : v[i + 4]);
 #pragma unroll
-        for (int i = 0; i < 2; i++) x[i] = (h4 ? w[i + 2] : w[i]) + __shfl_xor(h4 ? w[i] : w[i + 2], 16, 64);
-        z = (h3 ? x[1] : x[0]) + __shfl_xor(h3 ? x[0] : x[1], 8, 64);
+        for (int i = 0; i < 2; i++) x[i] = (h4 ? w[i + 2] : w[i]) + vmx_lane_xor<16>(h4 ? w[i] : w[i + 2]);
+        z = (h3 ? x[1] : x[0]) + vmx_lane_xor<8>(h3 ? x[0] : x[1]);
         rsel = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
     } else if constexpr (NR == 4) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) x[i] = (h5 ? v[i + 2] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 2], 32, 64);
-        z = (h4 ? x[1] : x[0]) + __shfl_xor(h4 ? x[0] : x[1], 16, 64);
-        z += __shfl_xor(z, 8, 64);
+        for (int i = 0; i < 2; i++) x[i] = (h5 ? v[i + 2] : v[i]) + vmx_lane_xor<32>(h5 ? v[i] : v[i + 2]);
+        z = (h4 ? x[1] : x[0]) + vmx_lane_xor<16>(h4 ? x[0] : x[1]);
+        z += vmx_lane_xor<8>(z);
         rsel = (h5 ? 2 : 0) + (h4 ? 1 : 0);
     } else {
-        z = (h5 ? v[1] : v[0]) + __shfl_xor(h5 ? v[0] : v[1], 32, 64);
-        z += __shfl_xor(z, 16, 64);
-        z += __shfl_xor(z, 8, 64);
+        z = (h5 ? v[1] : v[0]) + vmx_lane_xor<32>(h5 ? v[0] : v[1]);
+        z += vmx_lane_xor<16>(z);
+        z += vmx_lane_xor<8>(z);
         rsel = h5 ? 1 : 0;
     }
-    z += __shfl_xor(z, 4, 64);
-    z += __shfl_xor(z, 2, 64);
-    z += __shfl_xor(z, 1, 64);
+    z += vmx_lane_xor<4>(z);
+    z += vmx_lane_xor<2>(z);
+    z += vmx_lane_xor<1>(z);
     return z;
 }
 
@@ -375,43 +375,57 @@ __device__ __forceinline__ void pk_norm_request(PkNormIn &r, const PkArgs &a, in
 // n_h_out, a buffer other than n_h_in (the other workgroups may still be reading that one).  Ends with the LDS stores
 // issued, not yet waited for: the caller's barrier does that.
 __device__ __forceinline__ void pk_norm_prologue(const PkNormIn &r, const PkArgs &a, int n_in, int tid, int8_t *aq_s, float *ad_s, float *red) {
-    const int nchunk = n_in >> 3, wave = tid >> 6, nw = blockDim.x >> 6;
-    const bool live = tid < nchunk;
+    const int nchunk = n_in >> 3, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nlive = (nchunk + 63) >> 6;   // waves that own chunks; the others only keep the barriers company
+    const bool wlive = wave < nlive, live = tid < nchunk;
+    // the per-wave sums of the workgroup in wave order (one vector read per four waves, not a loop of dependent reads)
+    auto block_total = [&](const float *rd) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(rd);
+        const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+        const float x[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) t += w < nlive ? x[w] : 0.f;
+        return t;
+    };
     float ov[8] = {r.oa.x, r.oa.y, r.oa.z, r.oa.w, r.ob.x, r.ob.y, r.ob.z, r.ob.w};
-    float v1 = 0.f;
+    if (wlive) {
+        float v1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { ov[j] = pk_rbf(ov[j]); v1 += live ? ov[j] * ov[j] : 0.f; }
-    v1 = vmx_wave_sum(v1);
-    if ((tid & 63) == 0) red[wave] = v1;
-    __syncthreads();
-    float t1 = 0.f;
-    for (int w = 0; w < nw; w++) t1 += red[w];
-    const float inv1 = rsqrtf(t1 / (float)n_in + a.n_eps);
-    float wv[8], hr[8], hv[8];
-    pk_unpack8(r.wp, wv);
-    pk_unpack8(r.h, hr);
-    float v2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        hv[j] = pk_rbf(pk_rbf(ov[j] * inv1 * wv[j]) + hr[j]);
-        if (a.n_scalar) hv[j] = pk_rbf(hv[j] * vmx_bf16_to_f32(r.sc));   // layer_scalar of the layer whose tail this is
-        v2 += live ? hv[j] * hv[j] : 0.f;
+        for (int j = 0; j < 8; j++) { ov[j] = pk_rbf(ov[j]); v1 += live ? ov[j] * ov[j] : 0.f; }
+        v1 = vmx_wave_sum(v1);
+        if ((tid & 63) == 0) red[wave] = v1;
     }
-    if (blockIdx.x == 0 && live) *reinterpret_cast<uint4 *>(a.n_h_out + 8 * tid) = pk_pack8(hv);
-    v2 = vmx_wave_sum(v2);
-    if ((tid & 63) == 0) red[16 + wave] = v2;
     __syncthreads();
-    float t2 = 0.f;
-    for (int w = 0; w < nw; w++) t2 += red[16 + w];
-    const float inv2 = rsqrtf(t2 / (float)n_in + a.n_eps);
-    pk_unpack8(r.wn, wv);
-    float xr[8];
+    float hv[8];
+    if (wlive) {
+        const float inv1 = rsqrtf(block_total(red) / (float)n_in + a.n_eps);
+        float wv[8], hr[8];
+        pk_unpack8(r.wp, wv);
+        pk_unpack8(r.h, hr);
+        float v2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; j++) xr[j] = pk_rbf(hv[j] * inv2 * wv[j]);
-    // four consecutive threads hold one 32-value block (nchunk % 4 == 0: a group is all live or all not)
-    const int ci = live ? tid : nchunk - 1;
-    float scratch_d;
-    vmx_q8_1_emit8(xr, live ? aq_s + 8 * ci : aq_s + n_in, live ? ad_s + (ci >> 2) : &scratch_d, (ci & 3) == 0);
+        for (int j = 0; j < 8; j++) {
+            hv[j] = pk_rbf(pk_rbf(ov[j] * inv1 * wv[j]) + hr[j]);
+            if (a.n_scalar) hv[j] = pk_rbf(hv[j] * vmx_bf16_to_f32(r.sc));   // layer_scalar of the layer whose tail this is
+            v2 += live ? hv[j] * hv[j] : 0.f;
+        }
+        if (blockIdx.x == 0 && live) *reinterpret_cast<uint4 *>(a.n_h_out + 8 * tid) = pk_pack8(hv);
+        v2 = vmx_wave_sum(v2);
+        if ((tid & 63) == 0) red[16 + wave] = v2;
+    }
+    __syncthreads();
+    if (wlive) {
+        const float inv2 = rsqrtf(block_total(red + 16) / (float)n_in + a.n_eps);
+        float wv[8], xr[8];
+        pk_unpack8(r.wn, wv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) xr[j] = pk_rbf(hv[j] * inv2 * wv[j]);
+        // four consecutive threads hold one 32-value block (nchunk % 4 == 0: a group is all live or all not)
+        const int ci = live ? tid : nchunk - 1;
+        float scratch_d;
+        vmx_q8_1_emit8(xr, live ? aq_s + 8 * ci : aq_s + n_in, live ? ad_s + (ci >> 2) : &scratch_d, (ci & 3) == 0);
+    }
 }
 
 // One wave = one work item = PPW row pairs of one unit (rows 2 PPW c .. 2 PPW (c + 1) - 1 of row group g, K-slice s; item
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(1024) void iq_pk_mmvq_kernel(PkArgs a, const int8_t
             const float r = vmx_bf16_to_f32(rb);
             float amax = fabsf(r);
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            for (int o = 1; o < 32; o <<= 1) amax = fmaxf(amax, vmx_lane_xor_m(amax, o));
             const float d = amax / 127.0f;
             const int q = amax != 0.0f ? (int)roundf(r / d) : 0;
             if (col < a.seg[0].n_out) {

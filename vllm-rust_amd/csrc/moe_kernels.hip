@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void topk_softmax_kernel(const void *__restric
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
+            const float ov = vmx_lane_xor_m(bv, off);
+            const int oi = vmx_lane_xor_m(bi, off);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         if (lane == 0) { w_out[(int64_t)t * k + ki] = bv; id_out[(int64_t)t * k + ki] = bi; }
@@ -236,10 +236,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t *__restrict__
             h_resid[(int64_t)t * hidden + i] = hn;
             float sq = vmx_bf16_to_f32(hn);
             sq *= sq;
-            sq += __shfl_xor(sq, 1, 64);
-            sq += __shfl_xor(sq, 2, 64);
-            sq += __shfl_xor(sq, 4, 64);
-            sq += __shfl_xor(sq, 8, 64);
+            sq = vmx_row16_sum(sq);
             if ((i & 15) == 0) ssq[(int64_t)t * (hidden >> 4) + (i >> 4)] = sq;
         }
     }

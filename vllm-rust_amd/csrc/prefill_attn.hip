@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
                 for (int r = 0; r < 16; r++) tmax = fmaxf(tmax, s[u][r]);
             tmax = fmaxf(tmax * c2, -1e30f);   // scaled-log2 domain; a row without a visible token stays at the floor
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = fmaxf(tmax, vmx_lane_xor<32>(tmax));
             // The running maximum follows the tile maxima lazily: it moves (and the accumulators are rescaled) only when a row's
             // maximum has grown by more than 2^8 since the last move -- weights stay below 2^8, sums and products are f32, and
             // the rounding of P is relative, so nothing is lost; in the steady state of a long context no tile rescales.  The
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
         if (more) commit((tile + 1) & 1);
         __syncthreads();
     }
-    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float l = l_run + vmx_lane_xor<32>(l_run);
     if (wave_live && qi < q_len) {
         const float inv = vsc / l;
         uint16_t *o = out + ((int64_t)qi * num_heads + head) * HD + 4 * hi;

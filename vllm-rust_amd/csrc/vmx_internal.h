@@ -101,16 +101,103 @@ template <bool F16> __device__ __forceinline__ uint4 vmx_pack16x8(const float f[
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Cross-lane exchanges without the LDS pipe (ds_bpermute costs a round trip of ~100 clocks per step): DPP row operations inside
+// a row of 16 lanes, v_permlane16_swap / v_permlane32_swap across rows.
+template <int CTRL> __device__ __forceinline__ float vmx_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int VMX_DPP_XOR1 = 0xB1, VMX_DPP_XOR2 = 0x4E;        // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int VMX_DPP_ROR4 = 0x124, VMX_DPP_ROR8 = 0x128;      // row_ror:4, row_ror:8 (= lane ^ 8)
+constexpr int VMX_DPP_HALF_MIRROR = 0x141;                     // lane -> 7 - lane inside each 8 lanes
+// The values of lane and lane ^ 32 (MASK 32) or lane ^ 16 (MASK 16) as an unordered pair {a, b}: combine them with a
+// commutative operation.
+template <int MASK> __device__ __forceinline__ void vmx_swap_pair(float v, float &a, float &b) {
+    static_assert(MASK == 16 || MASK == 32, "row exchanges only");
+    // written as assembly: the compiler's builtin hands back the first result register for both halves of its result pair.
+    // The swap needs its operands written two wait states earlier (s_nop 1).
+    a = v;
+    b = v;
+    if constexpr (MASK == 32) asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = low half everywhere, b = high half
+    else asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));                          // a = even rows, b = odd rows
+}
+// Butterfly over the whole wave in the order lane ^ 32, 16, 8, 4, 2, 1; every lane ends with the same bits.  The step for
+// lane ^ 4 is a rotation by 4: after the lane ^ 8 step lanes i and i ^ 8 hold equal values, so (i + 4) mod 16 serves as i ^ 4.
 __device__ __forceinline__ float vmx_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    float a, b;
+    vmx_swap_pair<32>(v, a, b); v = a + b;
+    vmx_swap_pair<16>(v, a, b); v = a + b;
+    v += vmx_dpp<VMX_DPP_ROR8>(v);
+    v += vmx_dpp<VMX_DPP_ROR4>(v);
+    v += vmx_dpp<VMX_DPP_XOR2>(v);
+    v += vmx_dpp<VMX_DPP_XOR1>(v);
     return v;
 }
 
 __device__ __forceinline__ float vmx_wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    float a, b;
+    vmx_swap_pair<32>(v, a, b); v = fmaxf(a, b);
+    vmx_swap_pair<16>(v, a, b); v = fmaxf(a, b);
+    v = fmaxf(v, vmx_dpp<VMX_DPP_ROR8>(v));
+    v = fmaxf(v, vmx_dpp<VMX_DPP_ROR4>(v));
+    v = fmaxf(v, vmx_dpp<VMX_DPP_XOR2>(v));
+    v = fmaxf(v, vmx_dpp<VMX_DPP_XOR1>(v));
     return v;
+}
+
+// The value of lane ^ M for a compile-time M, without the LDS crossbar.  M = 4: two masked row shifts (lanes with bit 2 clear
+// take lane + 4, the others lane - 4).
+template <int M> __device__ __forceinline__ float vmx_lane_xor(float v) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "one lane bit");
+    if constexpr (M == 1) return vmx_dpp<VMX_DPP_XOR1>(v);
+    else if constexpr (M == 2) return vmx_dpp<VMX_DPP_XOR2>(v);
+    else if constexpr (M == 4) {
+        const int x = __builtin_bit_cast(int, v);
+        int t = __builtin_amdgcn_update_dpp(x, x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+        t = __builtin_amdgcn_update_dpp(t, x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+        return __builtin_bit_cast(float, t);
+    } else if constexpr (M == 8) return vmx_dpp<VMX_DPP_ROR8>(v);
+    else {
+        float a, b;
+        vmx_swap_pair<M>(v, a, b);
+        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        return (lane & M) ? a : b;
+    }
+}
+template <int M> __device__ __forceinline__ int vmx_lane_xor(int v) { return __builtin_bit_cast(int, vmx_lane_xor<M>(__builtin_bit_cast(float, v))); }
+// ... for an M that is a constant only after loop unrolling
+__device__ __forceinline__ float vmx_lane_xor_m(float v, int m) {
+    switch (m) {
+        case 1: return vmx_lane_xor<1>(v);
+        case 2: return vmx_lane_xor<2>(v);
+        case 4: return vmx_lane_xor<4>(v);
+        case 8: return vmx_lane_xor<8>(v);
+        case 16: return vmx_lane_xor<16>(v);
+        default: return vmx_lane_xor<32>(v);
+    }
+}
+__device__ __forceinline__ int vmx_lane_xor_m(int v, int m) { return __builtin_bit_cast(int, vmx_lane_xor_m(__builtin_bit_cast(float, v), m)); }
+// Butterflies over each row of 16 lanes in the order lane ^ 1, 2, 4, 8 (every lane of a row ends with the same bits).  The
+// lane ^ 4 step is the mirror inside 8 lanes: after the first two steps the four lanes of a quad hold equal values.
+__device__ __forceinline__ float vmx_row16_sum(float v) {
+    v += vmx_dpp<VMX_DPP_XOR1>(v);
+    v += vmx_dpp<VMX_DPP_XOR2>(v);
+    v += vmx_dpp<VMX_DPP_HALF_MIRROR>(v);
+    v += vmx_dpp<VMX_DPP_ROR8>(v);
+    return v;
+}
+__device__ __forceinline__ float vmx_row16_max(float v) {
+    v = fmaxf(v, vmx_dpp<VMX_DPP_XOR1>(v));
+    v = fmaxf(v, vmx_dpp<VMX_DPP_XOR2>(v));
+    v = fmaxf(v, vmx_dpp<VMX_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, vmx_dpp<VMX_DPP_ROR8>(v));
+    return v;
+}
+// ... and over 32 lanes (lane ^ 1 .. 16)
+__device__ __forceinline__ float vmx_row32_max(float v) {
+    v = vmx_row16_max(v);
+    float a, b;
+    vmx_swap_pair<16>(v, a, b);
+    return fmaxf(a, b);
 }
 
 // Sum over a 256-thread workgroup (4 waves); `red` is 4 floats of LDS.  Ends synchronised.
@@ -130,8 +217,8 @@ __device__ __forceinline__ void vmx_q8_1_emit8(const float v[8], int8_t *aq8, fl
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; j++) amax = fmaxf(amax, fabsf(v[j]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, vmx_dpp<VMX_DPP_XOR1>(amax));
+    amax = fmaxf(amax, vmx_dpp<VMX_DPP_XOR2>(amax));
     const float d = amax / 127.0f;
     uint32_t w[2] = {0u, 0u};
     if (amax != 0.0f) {
