@@ -526,6 +526,133 @@ __device__ __forceinline__ void int4_gemm_body_looped(const uint4 *__restrict__ 
     }
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in its body
+template <int... I, class F> __device__ __forceinline__ void ring_static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void ring_static_for(F &&f) { ring_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+#ifndef VMX_RING_D
+#define VMX_RING_D 3
+#endif
+constexpr int RING_D = VMX_RING_D;   // passes a request runs ahead of its use
+// 5..16 activation rows, ring form.  The looped body above waits for an L2 round trip per staging batch (8 of them on a
+// 4096-deep slice at 16 rows) with its matrix work in between: a wave spends most of its life waiting.  Here
+//   * a pass is 4 k-blocks (one per wave); its 16 x 512 activation tile is requested D passes ahead into registers (16 per
+//     lane and pass) and written to one of two 16 KB LDS stages one pass ahead, so the round trips overlap each other and
+//     the matrix work; one barrier per pass;
+//   * weights and scale|zero words are requested D passes ahead as well; the loop is fully unrolled, every request is a plain
+//     load, so the compiler's per-use wait counts are exact (loads retire in issue order);
+//   * a workgroup owns CT column tiles that share every staged tile and every A fragment;
+//   * a row is 1 KiB unpadded; position p of row r holds the row's 16-byte chunk p ^ (r & 15), so the 16 rows a fragment read
+//     touches lie in 16 different bank groups;
+//   * the row sums of the zero-point term come from the matrix cores (the tile times a matrix of ones).
+// K % (512 * UPW) == 0, (N / 16) % CT == 0; rows past M replicate row M - 1 (never stored).
+template <int UPW, bool GLU, int CT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void int4_gemm_ring_kernel(
+    const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ, const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+    uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N, int K, int group, int slice_rows) {
+    constexpr int PASSES = UPW, D = RING_D, ROWB = 4 * KB * 2;   // bytes per staged row
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *xs = smem;                                        // [2][16][ROWB]
+    float *red = reinterpret_cast<float *>(smem);                    // [CT][4][64][4], after the last pass
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 15, h = lane >> 4;
+    const int n_tiles = N / NT, kblocks = K / KB, G = K / group;
+    const int n_groups = n_tiles / CT;
+    const int nt0 = ((int)blockIdx.x % n_groups) * CT, ks = (int)blockIdx.x / n_groups;
+    const int kb_wg = ks * 4 * UPW;
+
+    // staging: request j of a wave is row 4 j + wave of the tile, lane l its chunk l.  Every address is a wave-uniform base
+    // plus a 32-bit lane offset.
+    const char *xrow_u[4];
+    uint32_t xdst[4];   // byte offset of the lane's chunk inside a stage
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = 4 * j + wave;
+        xrow_u[j] = reinterpret_cast<const char *>(x + (int64_t)min(row, M - 1) * K + (int64_t)kb_wg * KB);
+        xdst[j] = (uint32_t)(row * ROWB + ((lane ^ (row & 15)) << 4));
+    }
+    const char *w_u[CT];
+    const char *z_u[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+        w_u[t] = reinterpret_cast<const char *>(W + ((int64_t)(nt0 + t) * kblocks + kb_wg + wave) * 64);
+        z_u[t] = reinterpret_cast<const char *>(SZ + (int64_t)(nt0 + t) * G * 16);
+    }
+    const uint32_t woff = (uint32_t)lane << 4, zoff = (uint32_t)nl << 2;
+    typedef unsigned int ring_u32x4 __attribute__((ext_vector_type(4)));
+    ring_u32x4 tq[D][4];
+    uint4 wq[D][CT];
+    uint32_t zq[D][CT];
+    auto issue = [&](auto pc) {
+        constexpr int p = decltype(pc)::value, r = p % D;
+#pragma unroll
+        for (int j = 0; j < 4; j++) tq[r][j] = *reinterpret_cast<const ring_u32x4 *>(xrow_u[j] + (size_t)p * ROWB + woff);
+#pragma unroll
+        for (int t = 0; t < CT; t++) {
+            wq[r][t] = ld_weights(reinterpret_cast<const uint4 *>(w_u[t] + (size_t)p * 4 * 64 * 16 + woff));
+            zq[r][t] = *reinterpret_cast<const uint32_t *>(z_u[t] + (size_t)((((kb_wg + 4 * p + wave) * KB) / group) * 16) * 4 + zoff);
+        }
+    };
+    auto write_tile = [&](auto pc) {
+        constexpr int p = decltype(pc)::value, r = p % D;
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<ring_u32x4 *>(xs + (p & 1) * 16 * ROWB + xdst[j]) = tq[r][j];
+    };
+    ring_static_for<(D < PASSES ? D : PASSES)>([&](auto pc) { issue(pc); });
+    write_tile(std::integral_constant<int, 0>{});
+    const int rowc = min(nl, M - 1);
+    uint32_t fa[4];   // byte offsets of this lane's four A fragments inside a stage
+#pragma unroll
+    for (int i = 0; i < 4; i++) fa[i] = (uint32_t)rowc * ROWB + (uint32_t)(((wave * 16 + 4 * i + h) ^ rowc) << 4);
+    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    vmx_f32x4 fin[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) fin[t] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+    ring_static_for<PASSES>([&](auto pc) {
+        constexpr int p = decltype(pc)::value, r = p % D;
+        __syncthreads();   // tile p is in its stage; every wave has left pass p - 1 (the other stage)
+        vmx_f32x4 acc[CT], acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < CT; t++) acc[t] = vmx_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 au = *reinterpret_cast<const uint4 *>(xs + (p & 1) * 16 * ROWB + fa[i]);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, ones), acc1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < CT; t++) {
+                const uint4 wv = wq[r][t];
+                const uint32_t w = i == 0 ? wv.x : i == 1 ? wv.y : i == 2 ? wv.z : wv.w;
+                uint4 bu;
+                bu.x = (w & 0x000F000Fu) | 0x43004300u;
+                bu.y = ((w >> 4) & 0x000F000Fu) | 0x43004300u;
+                bu.z = ((w >> 8) & 0x000F000Fu) | 0x43004300u;
+                bu.w = ((w >> 12) & 0x000F000Fu) | 0x43004300u;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, bu), acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < CT; t++) {
+            const uint32_t szw = zq[r][t];
+            const float sc = __uint_as_float(szw << 16);
+            const float zo = __uint_as_float(szw & 0xFFFF0000u);
+            fin[t][0] += sc * (acc[t][0] - zo * acc1[0]);
+            fin[t][1] += sc * (acc[t][1] - zo * acc1[1]);
+            fin[t][2] += sc * (acc[t][2] - zo * acc1[2]);
+            fin[t][3] += sc * (acc[t][3] - zo * acc1[3]);
+        }
+        if constexpr (p + 1 < PASSES) write_tile(std::integral_constant<int, p + 1>{});   // requested D - 1 passes ago; into the stage every wave left before the barrier above
+        if constexpr (p + D < PASSES) issue(std::integral_constant<int, p + D>{});        // into the registers this pass and that write have just used
+    });
+    __syncthreads();   // the last tile has been read: the stages become the waves' exchange buffer
+#pragma unroll
+    for (int t = 0; t < CT; t++)
+        *reinterpret_cast<float4 *>(red + ((t * 4 + wave) * 64 + lane) * 4) = make_float4(fin[t][0], fin[t][1], fin[t][2], fin[t][3]);
+    __syncthreads();
+    for (int t = wave; t < CT; t += 4)
+        int4_gemm_tile_store<GLU>(red + t * 4 * 64 * 4, bias, y, partial, (int64_t)slice_rows * N, M, N, nt0 + t, ks, nullptr);
+}
+
 template <int UPW, bool TAIL, int CT = 1>
 __global__ __launch_bounds__(256) void int4_gemm_looped_kernel(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
                                                                 const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
@@ -1434,6 +1561,19 @@ inline int looped_ct(int M, int N) {
     return (ct == 2 && (N / NT) % 2 == 0) ? 2 : 1;
 }
 
+// Ring form (5..16 rows, whole passes of 512 k): column tiles per workgroup, 0 = not eligible.  Two workgroups fit a compute
+// unit (64 KB of stages each), so the tile count is chosen to give at most 512 workgroups, as many as possible.
+constexpr size_t RING_LDS = 2 * 16 * 4 * KB * 2;
+inline int ring_ct(int M, int N, int K, const GemmPlan &p) {
+    static const int on = vmx_tune("VMX_INT4_RING", 1), force_ct = vmx_tune("VMX_INT4_RING_CT", 0), max_wgs = vmx_tune("VMX_INT4_RING_MAX_WGS", 512);
+    if (!on || M < 5 || M > 16 || (p.upw != 4 && p.upw != 8) || (K / KB) % (4 * p.upw) != 0) return 0;
+    const int n_tiles = N / NT;
+    if (force_ct >= 1 && force_ct <= 3 && n_tiles % force_ct == 0) return force_ct;
+    for (int ct = 1; ct <= 3; ct++)
+        if (n_tiles % ct == 0 && (n_tiles / ct) * p.splits <= max_wgs) return ct;
+    return n_tiles % 3 == 0 ? 3 : (n_tiles % 2 == 0 ? 2 : 1);
+}
+
 inline size_t gemm_lds_bytes(int M, int upw) {
     return (size_t)M * (4 * upw * KB + 8) * 2 + (size_t)4 * upw * 16 * 4 + 4 * 64 * 4 * 4 + (size_t)4 * upw * 16 * 4;
 }
@@ -1441,6 +1581,17 @@ inline size_t gemm_lds_bytes(int M, int upw) {
 int launch_gemm(const GemmPlan &p, const uint4 *W, const uint32_t *SZ, const uint16_t *x, const uint16_t *bias, uint16_t *y,
                 float *partial, int M, int N, int K, int group, hipStream_t st, int slice_rows = 0) {
     if (slice_rows <= 0) slice_rows = M;
+    if (const int rct = ring_ct(M, N, K, p)) {
+        const dim3 rgrid((unsigned)((N / NT / rct) * p.splits));
+#define RING_C(U, C) hipLaunchKernelGGL((int4_gemm_ring_kernel<U, false, C>), rgrid, dim3(256), RING_LDS, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows)
+#define RING(U) do { if (rct == 3) RING_C(U, 3); else if (rct == 2) RING_C(U, 2); else RING_C(U, 1); } while (0)
+        if (p.upw == 8) RING(8);
+        else RING(4);
+#undef RING
+#undef RING_C
+        VMX_CHECK_LAUNCH("int4_gemm(ring)");
+        return VMX_OK;
+    }
     if (use_looped(M, p.upw)) {
         const int ct = looped_ct(M, N);
         const size_t ll = gemm_lds_bytes_looped(M, p.upw, ct);
@@ -1824,6 +1975,16 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
         const int mm = M - m0 < 16 ? M - m0 : 16;
         const uint16_t *xc = x + (int64_t)m0 * K;
         uint16_t *ac = act + (int64_t)m0 * (N / 2);
+        if (const int rct = ring_ct(mm, N, K, p)) {
+            const dim3 rgrid((unsigned)(N / NT / rct));
+#define GRING_C(U, C) hipLaunchKernelGGL((int4_gemm_ring_kernel<U, true, C>), rgrid, block, RING_LDS, st, W, SZ, xc, nullptr, ac, nullptr, mm, N, K, group, mm)
+#define GRING(U) do { if (rct == 3) GRING_C(U, 3); else if (rct == 2) GRING_C(U, 2); else GRING_C(U, 1); } while (0)
+            if (p.upw == 8) GRING(8);
+            else GRING(4);
+#undef GRING
+#undef GRING_C
+            continue;
+        }
         if (use_looped(mm, p.upw)) {
             const int ct = looped_ct(mm, N);
             const size_t ll = gemm_lds_bytes_looped(mm, p.upw, ct);
