@@ -785,6 +785,21 @@ __global__ __launch_bounds__(64 * NW) void fused_decode_attn_kernel(
 //      workgroup to its waves in contiguous sub-ranges, each walked with the online softmax of attn_walk;
 //   C  the waves' states are merged through LDS and the partition's normalised output, max logit and sum go to
 //      tmp_out / max_logits / exp_sums [seq][head][P] (a partition without tokens writes sum 0 and a zero row).
+#ifdef VMX_ATTN_STAMPS
+// build-time measurement variant: 100 MHz wall-clock stamps of the last split_decode_attn_kernel launch, 8 u64 per wave
+__device__ unsigned long long vmx_attn_stamp_buf[4096 * 8];
+#define ATTN_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        unsigned long long t__;                                                                         \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                 \
+        if ((threadIdx.x & 63) == 0) {                                                                  \
+            const int w__ = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + (threadIdx.x >> 6); \
+            if (w__ < 4096) vmx_attn_stamp_buf[w__ * 8 + (i)] = t__;                                    \
+        }                                                                                               \
+    } while (0)
+#else
+#define ATTN_STAMP(i) do {} while (0)
+#endif
 template <int HD, int QPK, int FP8, int NW>
 __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
     float *__restrict__ tmp_out, float *__restrict__ exp_sums, float *__restrict__ max_logits, const float *__restrict__ partial, int splits,
@@ -813,6 +828,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
     const float ksc = (FP8 && k_scale_ptr) ? *k_scale_ptr : 1.0f;
     const float vsc = (FP8 && v_scale_ptr) ? *v_scale_ptr : 1.0f;
 
+    ATTN_STAMP(0);
     // ---- A (loads): head `wave` of this KV head's q heads, then k, then v (NW >= nq + 2 waves, checked on the host)
     const bool has_head = wave < nq + 2;
     const bool is_q = wave < nq, is_k = wave == nq;
@@ -830,6 +846,8 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
         for (int j = 0; j < EPL; j++) nwf[j] = nw ? vmx_ld16<FP8 == 3>(nw[lane + 64 * j]) : 1.0f;
         attn_sum_splits<EPL>(partial + base + lane, splits, slice, v);
     }
+    asm volatile("" ::"v"(v[0]));   // the split sums have landed
+    ATTN_STAMP(1);
     // rotation factors of this lane's pairs (position known after the first round trip)
     const int half = rot_dim >> 1;
     const float *cs = cos_sin + (int64_t)pos * rot_dim;
@@ -848,11 +866,12 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
     // ---- tiles of this workgroup / wave (needs seq_len), and the wave's first tile if it lies before the new token
     const int start = (window > 0 && seq_len > window) ? seq_len - window : 0;
     const int T = (seq_len - start + 15) >> 4;                  // tiles of this sequence
-    const int tpp = (T + P - 1) / P;                            // tiles per workgroup
-    const int g0 = part * tpp, g1 = min(g0 + tpp, T);           // this workgroup's tiles
+    // this workgroup's tiles: P contiguous ranges of T/P tiles, rounded down or up (fewer tiles than workgroups: one each for
+    // the first T); inside the workgroup the same deal over its waves, so no wave walks more than one tile above the average
+    const int g0 = T >= P ? (int)((int64_t)part * T / P) : min(part, T), g1 = T >= P ? (int)((int64_t)(part + 1) * T / P) : min(part + 1, T);
     const bool owner = seq_len > 0 && g0 < T && g1 == T;        // its range ends with the tile of the new token
-    const int tpw = (max(g1 - g0, 0) + NW - 1) / NW;            // tiles per wave
-    const int w0 = g0 + wave * tpw, w1 = min(w0 + tpw, g1);
+    const int ng = g1 - g0;
+    const int w0 = ng >= NW ? g0 + wave * ng / NW : g0 + min(wave, ng), w1 = ng >= NW ? g0 + (wave + 1) * ng / NW : g0 + min(wave + 1, ng);
     const bool active = seq_len > 0 && w0 < w1;
     const int p0 = start + 16 * w0, p1 = min(start + 16 * w1, seq_len);
     // block-table entries in a register: every token of the walk lies in the first 64 blocks
@@ -864,6 +883,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
         else attn_tile_load<HD, FP8, false>(tile, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, lane);
     }
 
+    ATTN_STAMP(2);
     // ---- A (arithmetic): bf16 round, optional per-head RMSNorm, NeoX RoPE; q -> LDS, k and v -> cache (owner only)
     if (has_head && g0 < T && (is_q || owner)) {
         if constexpr (HD == 128) {   // EXL3: the sums are the trellis GEMM before its output transform; a head is one Hadamard block
@@ -919,9 +939,11 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
             }
         }
     }
+    ATTN_STAMP(3);
     __syncthreads();
 
     // ---- B
+    ATTN_STAMP(4);
     float m_run[4], s_run[4];
     float o[QPK][NP][2];
     if (active) {   // wave-uniform
@@ -938,6 +960,8 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
             attn_walk<HD, QPK, FP8, false>(qa, k_cache, v_cache, bt_row, p0, p1, block_size, (int64_t)Hkv * HD, kvh, scale * ksc, vsc, lane,
                                            m_run, s_run, o, tile, pre);
     }
+    asm volatile("" ::"v"(o[0][0][0]), "v"(s_run[0]));
+    ATTN_STAMP(5);
     const bool lane_live = (HD >= 128) || (lane < 32);
 #pragma unroll
     for (int h = 0; h < QPK; h++) {
@@ -957,7 +981,8 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
     __syncthreads();
 
     // ---- C: this workgroup's partition result
-    const int nwv = g0 < g1 ? min(NW, (g1 - g0 + tpw - 1) / tpw) : 0;   // waves that saw tokens
+    ATTN_STAMP(6);
+    const int nwv = min(NW, ng);   // waves that saw tokens (the first ones)
     for (int idx = tid; idx < nq * HD; idx += 64 * NW) {
         const int h = idx / HD, d = idx % HD;
         float val = 0.f, gmax = -FLT_MAX, gsum = 0.f;
@@ -965,13 +990,23 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
             val = mo[h * HD + d];
             gmax = mm[h];
             gsum = ms[h];
-        } else if (nwv > 1) {
-            for (int w = 0; w < nwv; w++) gmax = fmaxf(gmax, mm[w * QPK + h]);
+        } else if (nwv > 1) {   // every wave's entry is read at once (a loop over nwv waits for each LDS read in turn)
+            float mw[NW], sw[NW], ow[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const bool on = w < nwv;
+                mw[w] = on ? mm[w * QPK + h] : -FLT_MAX;
+                sw[w] = on ? ms[w * QPK + h] : 0.f;
+                ow[w] = on ? mo[(w * QPK + h) * HD + d] : 0.f;
+            }
+#pragma unroll
+            for (int w = 0; w < NW; w++) gmax = fmaxf(gmax, mw[w]);
             float acc = 0.f;
-            for (int w = 0; w < nwv; w++) {
-                const float wt = ms[w * QPK + h] * __expf(mm[w * QPK + h] - gmax);
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const float wt = sw[w] * __expf(mw[w] - gmax);
                 gsum += wt;
-                acc += mo[(w * QPK + h) * HD + d] * wt;
+                acc += ow[w] * wt;
             }
             val = acc * (1.0f / (gsum + 1e-6f));
         }
@@ -979,6 +1014,7 @@ __global__ __launch_bounds__(64 * NW) void split_decode_attn_kernel(
         tmp_out[po * HD + d] = val;
         if (d == 0) { max_logits[po] = gmax; exp_sums[po] = gsum; }
     }
+    ATTN_STAMP(7);
 }
 
 // waves per workgroup: 16 where a thread may hold 128 registers' worth of tiles, 8 for 256-wide heads; context bound = 4 tiles
@@ -1359,6 +1395,13 @@ static int g_fused_attn_enabled = -1;   // -1: not decided yet (environment VMX_
 
 // Measurement / parity aid: switch the one-launch short-context attention off (0) or on (1) for the calls that follow, so
 // that both forms can be compared on the same inputs in one process.
+#ifdef VMX_ATTN_STAMPS
+extern "C" int vmx_debug_attn_stamps_read(void *dst, size_t bytes) {
+    VMX_CHECK_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(vmx_attn_stamp_buf), bytes < sizeof(vmx_attn_stamp_buf) ? bytes : sizeof(vmx_attn_stamp_buf)));
+    return VMX_OK;
+}
+#endif
+
 extern "C" int vmx_debug_set_fused_attention(int enable) {
     g_fused_attn_enabled = enable ? 1 : 0;
     return VMX_OK;

@@ -1561,17 +1561,18 @@ inline int looped_ct(int M, int N) {
     return (ct == 2 && (N / NT) % 2 == 0) ? 2 : 1;
 }
 
-// Ring form (5..16 rows, whole passes of 512 k): column tiles per workgroup, 0 = not eligible.  Two workgroups fit a compute
-// unit (64 KB of stages each), so the tile count is chosen to give at most 512 workgroups, as many as possible.
+// Ring form (5..16 rows, whole passes of 512 k): column tiles per workgroup, 0 = not eligible.  The most tiles (at most 3:
+// registers) that still leave a workgroup for every compute unit (Qwen3-8B AWQ at 16 rows, same box: 3 / 2 / 1 tiles
+// 6367 / 6155 / 5821 tok/s aggregate).
 constexpr size_t RING_LDS = 2 * 16 * 4 * KB * 2;
 inline int ring_ct(int M, int N, int K, const GemmPlan &p) {
-    static const int on = vmx_tune("VMX_INT4_RING", 1), force_ct = vmx_tune("VMX_INT4_RING_CT", 0), max_wgs = vmx_tune("VMX_INT4_RING_MAX_WGS", 512);
+    static const int on = vmx_tune("VMX_INT4_RING", 1), force_ct = vmx_tune("VMX_INT4_RING_CT", 0);
     if (!on || M < 5 || M > 16 || (p.upw != 4 && p.upw != 8) || (K / KB) % (4 * p.upw) != 0) return 0;
-    const int n_tiles = N / NT;
+    const int n_tiles = N / NT, cus = vmx_num_cus();
     if (force_ct >= 1 && force_ct <= 3 && n_tiles % force_ct == 0) return force_ct;
-    for (int ct = 1; ct <= 3; ct++)
-        if (n_tiles % ct == 0 && (n_tiles / ct) * p.splits <= max_wgs) return ct;
-    return n_tiles % 3 == 0 ? 3 : (n_tiles % 2 == 0 ? 2 : 1);
+    for (int ct = 3; ct > 1; ct--)
+        if (n_tiles % ct == 0 && (n_tiles / ct) * p.splits >= cus) return ct;
+    return 1;
 }
 
 inline size_t gemm_lds_bytes(int M, int upw) {
@@ -1711,11 +1712,14 @@ extern "C" int vmx_int4_dequant_bf16(const void *packed, uint16_t *dense, int K,
     return VMX_OK;
 }
 
-// rows beyond one MFMA row tile and whole 128-column groups: the tiled kernel (VMX_INT4_NO_TILED=1 keeps the 16-row passes)
-static bool tiled_ok(int M, int N) {
+// Rows from which the prompt-shaped (tiled) kernel takes over from 16-row launches of the small-M kernels: 17 where those are
+// the looped form, 49 where they are the ring form (Qwen3-8B shapes, whole call at 24 / 32 / 48 / 64 rows: down 26 / 27 / 41 / 53 us
+// in 16-row ring launches against 53 / 53 / 55 / 56 us tiled, gate|up 28 / 32 / 49 / 61 against 59 / 59 / 59 / 60).
+// VMX_INT4_NO_TILED=1 keeps the 16-row launches, VMX_INT4_TILED_MIN_M overrides both thresholds (measurement).
+static bool tiled_ok(int M, int N, int K) {
     static const bool off = vmx_tune("VMX_INT4_NO_TILED", 0) != 0;
-    // rows from which the tiled kernel takes over (VMX_INT4_TILED_MIN_M overrides, for measurement)
-    static const int min_m = vmx_tune("VMX_INT4_TILED_MIN_M", 17);
+    static const int force_min_m = vmx_tune("VMX_INT4_TILED_MIN_M", 0);
+    const int min_m = force_min_m > 0 ? force_min_m : (ring_ct(16, N, K, plan_gemm(N, K)) ? 49 : 17);
     return !off && M >= min_m && N % 128 == 0;
 }
 
@@ -1747,7 +1751,7 @@ int vmx_int4_gemm_partial(const void *packed, const uint16_t *x, float *partial,
     const GemmPlan p = plan_gemm(N, K);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
-    if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, the same split-K slices as the small-M plan
+    if (tiled_ok(M, N, K)) {   // prompt chunk: 64 x 128 output tiles, the same split-K slices as the small-M plan
         const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
         launch_tiled<false, false>(W, SZ, x, partial, nullptr, M, N, K, group, kbs, M, Int4GroupedArgs{}, (M + PF_BM - 1) / PF_BM, p.splits, st);
         VMX_CHECK_LAUNCH("int4_gemm(tiled)");
@@ -1964,7 +1968,7 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
     VMX_REQUIRE(p.splits == 1, "int4_gemm_glu: linear [%d -> %d] is split over k", K, N);
     const uint4 *W = (const uint4 *)packed;
     const uint32_t *SZ = (const uint32_t *)((const char *)packed + sz_offset_bytes(K, N));
-    if (tiled_ok(M, N)) {
+    if (tiled_ok(M, N, K)) {
         launch_tiled<true, false>(W, SZ, x, nullptr, act, M, N, K, group, K / KB, M, Int4GroupedArgs{}, (M + PF_BM - 1) / PF_BM, 1, st);
         VMX_CHECK_LAUNCH("int4_gemm(tiled glu)");
         return VMX_OK;
@@ -2123,7 +2127,7 @@ int vmx_awq_convert_into(const uint32_t *awq_qweight, const uint32_t *awq_qzeros
 extern "C" size_t vmx_int4_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % KB || N % NT) return 0;
     const GemmPlan p = plan_gemm(N, K);
-    if (tiled_ok(M, N)) return (size_t)p.splits * M * N * sizeof(float);   // prompt-shaped M: f32 slices of every row
+    if (tiled_ok(M, N, K)) return (size_t)p.splits * M * N * sizeof(float);   // prompt-shaped M: f32 slices of every row
     return p.splits > 1 ? (size_t)p.splits * (M < 16 ? M : 16) * N * sizeof(float) : 0;
 }
 
@@ -2142,7 +2146,7 @@ extern "C" int vmx_int4_gemm_bf16(uint16_t *y, const uint16_t *x, const void *pa
     hipStream_t st = vmx_stream(stream);
     float *partial = (float *)workspace;
     (void)mc;
-    if (tiled_ok(M, N)) {   // prompt chunk: 64 x 128 output tiles, then the slices are summed (+ bias) into bf16
+    if (tiled_ok(M, N, K)) {   // prompt chunk: 64 x 128 output tiles, then the slices are summed (+ bias) into bf16
         const int kblocks = K / KB, row_tiles = (M + PF_BM - 1) / PF_BM;
         // split-K only while the tiles alone leave compute units idle (the plan's slice count is sized for one row tile)
         int splits = p.splits;
