@@ -1512,8 +1512,9 @@ int run_layers(vmx_qwen3 *m, const int32_t *input_ids, const int32_t *positions,
             // QuantizedMoELayer::forward (models/mixtral_quantized.rs:138-195): dense router, softmax (bf16) -> top-k -> renormalise,
             // out = sum_j bf16(expert_j(x) * w_j), experts = down(silu(gate x) * up x); no host read of the routing
             uint16_t *rl = (uint16_t *)m->router_logits.p;
-            for (int r0 = 0; r0 < B; r0 += 16) {
-                const int mr = B - r0 < 16 ? B - r0 : 16;
+            const int rstep = (c.num_experts <= 16 && B >= 2) ? B : 16;   // up to 16 experts: one launch, a workgroup per row
+            for (int r0 = 0; r0 < B; r0 += rstep) {
+                const int mr = B - r0 < rstep ? B - r0 : rstep;
                 if (int rc = vmx_dense_gemv_launch(rl + (size_t)r0 * c.num_experts, x + (size_t)r0 * H, (const uint16_t *)L.router.p, nullptr, mr,
                                                    c.num_experts, H, st))
                     return rc;

@@ -135,6 +135,47 @@ __global__ __launch_bounds__(256) void dense_gemm16_kernel(uint16_t *__restrict_
     }
 }
 
+// A handful of output columns (a mixture-of-experts router: N = 8) for several rows: the matrix-core kernel above would run
+// as ONE workgroup walking all of K (19 us at 16 rows of 4096).  Here a workgroup owns one activation row and all N <= 16
+// weight rows; a thread multiplies its 8-element chunks of the row with the same chunks of every weight row, then the
+// workgroup adds up.  f32 accumulation, chunk order per thread, threads summed by wave then across the four waves.
+template <bool F16>
+__global__ __launch_bounds__(256) void dense_fewcols_kernel(uint16_t *__restrict__ y, const uint16_t *__restrict__ x,
+                                                             const uint16_t *__restrict__ W, const uint16_t *__restrict__ bias, int N,
+                                                             int K) {
+    __shared__ float red[4][16];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chunks = K >> 3;
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    for (int c = tid; c < chunks; c += 256) {
+        const uint4 xv = reinterpret_cast<const uint4 *>(x + (int64_t)m * K)[c];
+        uint4 wv[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) wv[e] = reinterpret_cast<const uint4 *>(W + (int64_t)min(e, N - 1) * K)[c];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            float a = acc[e];
+            a = dot2<F16>(wv[e].x, xv.x, a);
+            a = dot2<F16>(wv[e].y, xv.y, a);
+            a = dot2<F16>(wv[e].z, xv.z, a);
+            a = dot2<F16>(wv[e].w, xv.w, a);
+            acc[e] = a;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const float v = vmx_wave_sum(acc[e]);
+        if (lane == 0) red[wave][e] = v;
+    }
+    __syncthreads();
+    if (tid < N) {
+        float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (bias) v += vmx_ld16<F16>(bias[tid]);
+        y[(int64_t)m * N + tid] = vmx_st16<F16>(v);
+    }
+}
+
 __global__ __launch_bounds__(256) void embedding_lookup_kernel(uint16_t *__restrict__ out, const uint16_t *__restrict__ table,
                                                                 const int32_t *__restrict__ ids, int hidden, int vocab) {
     const int t = blockIdx.x;
@@ -149,6 +190,11 @@ __global__ __launch_bounds__(256) void embedding_lookup_kernel(uint16_t *__restr
 
 template <bool F16>
 static int dense_gemv_launch_t(uint16_t *y, const uint16_t *x, const uint16_t *W, const uint16_t *bias, int M, int N, int K, hipStream_t st) {
+    if (M >= 2 && N <= 16) {   // a few output columns: one workgroup per row
+        hipLaunchKernelGGL((dense_fewcols_kernel<F16>), dim3(M), dim3(256), 0, st, y, x, W, bias, N, K);
+        VMX_CHECK_LAUNCH("dense_fewcols");
+        return VMX_OK;
+    }
     static const int mfma_min_m = vmx_tune("VMX_DENSE_MFMA_MIN_M", 5);   // 0 disables
     if (mfma_min_m > 0 && M >= mfma_min_m && K % 128 == 0) {   // GEMM-shaped: matrix cores, activations staged in k-passes
         int g16 = ((N + 15) / 16 + 3) / 4;   // 4 waves x one 16-row tile of W per round
