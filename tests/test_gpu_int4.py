@@ -109,6 +109,13 @@ def test_gemm_reference_lcg_cases(gpu, m):
     (100, 2048, 3072, 128, True, False),   # two row blocks, split-K slices summed
     (64, 12288, 1024, 128, False, True),   # long k, three slices, bias
     (40, 1024, 208, 128, True, False),     # N not a multiple of 128: passes of 16 rows
+    # 5..16 rows with K a whole number of 512-deep passes: the ring form (tiles staged ahead through registers and LDS)
+    (5, 4096, 6144, 128, True, True),      # q|k|v: two k slices, three column tiles per workgroup, rows 5..15 of the tile idle
+    (9, 12288, 4096, 128, True, False),    # down: three k slices, two column tiles per workgroup
+    (13, 4096, 4112, 128, False, True),    # 257 column tiles: one per workgroup, symmetric, bias
+    (16, 2048, 1024, 256, True, False),    # group of two k-blocks, short k (four passes), small grid
+    (24, 4096, 2048, 128, True, True),     # 16 + 8 rows: two ring launches below the prompt kernel's threshold
+    (48, 4096, 1024, 128, True, False),    # three ring launches, k slices summed per launch
 ])
 def test_gemm_model_shapes(gpu, M, K, N, group, zeros, bias):
     from oracle import oracle as orc
