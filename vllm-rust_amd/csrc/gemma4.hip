@@ -897,11 +897,15 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
                                 vmx_split_decode_attention_parts_wide(hd, Hq / Hkv, L.rot, max_seq_len, L.window) > 0;
         if (split_attn) {
             VmxAttnParts ap;
+            // workgroups per (sequence, KV head): 8 for a few rows; with many rows every compute unit has work at fewer, and each
+            // partition repeats the per-head norms and rotation of its q heads (0 = the kernel's own choice)
+            static const int p_many = vmx_tune("VMX_G4_SPLIT_P_MANY", 2), p_some = vmx_tune("VMX_G4_SPLIT_P_SOME", 4);
+            const int split_p = B >= 12 ? p_many : (B >= 5 ? p_some : 0);
             if (int rc = vmx_split_decode_attention(&ap, m->attn_ws.p, proj, 1, L.k_cache.p, L.v_cache.p, (const uint16_t *)L.q_norm.p,
                                                     (const uint16_t *)L.k_norm.p, c.rms_norm_eps,
                                                     (const float *)(L.sliding ? m->cos_sin_s.p : m->cos_sin_f.p), positions, slot_mapping,
                                                     block_tables, seq_lens, 1.0f, B, Hq, Hkv, hd, L.rot, max_blocks_per_seq, max_seq_len,
-                                                    c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, 1, st))
+                                                    c.block_size, L.window, c.kv_cache_dtype, ks, ks + 1, 1, st, nullptr, split_p))
                 return rc;
             if (int rc = vmx_paged_attention_merge(attn, &ap, seq_lens, B, Hq, hd, L.window, st, aq_of(m), ad_of(m, B, NQ))) return rc;
         } else if (fused_attn) {
