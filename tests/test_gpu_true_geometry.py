@@ -230,7 +230,7 @@ def test_qwen3_0_6b_tied(gpu):
     _qwen3_case(gpu, spec, "load_synthetic", start_lens=[0, 15, 255, 1023], steps=3, first_ids=[9, 8, 7, 6])
 
 
-@pytest.mark.parametrize("B,kv_dtype", [(1, 0), (4, 0), (1, 1), (4, 1)])
+@pytest.mark.parametrize("B,kv_dtype", [(1, 0), (4, 0), (1, 1), (4, 1), (6, 0), (13, 1)])
 def test_gemma4_12b_layers(gpu, B, kv_dtype):
     """Gemma-4-12B layers: hidden 3840, 16 query heads, one sliding layer (8 x 256, window 1024) and one full layer
     (1 x 512, proportional partial rotary), intermediate 15360, the UD-IQ3_XXS type mix, Q3_K token embedding / tied lm_head,
@@ -240,7 +240,7 @@ def test_gemma4_12b_layers(gpu, B, kv_dtype):
     from tests.model_oracle import OracleGemma4
     from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
     vmx, torch = gpu
-    spec = Gemma4Spec(3840, 2, 16, 15360, VOCAB, full_every=2, max_position=2048, num_blocks=320, max_batch=B, max_seq_len=2048,
+    spec = Gemma4Spec(3840, 2, 16, 15360, VOCAB, full_every=2, max_position=2048, num_blocks=max(320, 96 * B), max_batch=B, max_seq_len=2048,
                       embed_ggml_type=11, kv_cache_dtype=kv_dtype)
     model = QuantizedGemma4ForCausalLM(spec)
     try:
@@ -251,7 +251,9 @@ def test_gemma4_12b_layers(gpu, B, kv_dtype):
             hd, kvh, _, _, _ = spec.layer_geom(li)
             shapes.append((spec.num_blocks, spec.block_size, kvh, hd))
         _fill_kv(torch, model, ref, spec.num_layers, shapes, spec.kv_cache_dtype, seed=3, k_std=0.08)
-        starts = [1023] if B == 1 else [15, 300, 1022, 1100]
-        _decode_and_compare(torch, model, ref, spec, starts, 3, [17, 900, 4000, 8000][:B], bar=2e-2 if kv_dtype == 0 else 5e-2)
+        # 6 and 13 rows: the matrix-core MMVQ and the sliding-layer attention with 4 / 2 workgroups per KV head
+        starts = [1023] if B == 1 else [15, 300, 1022, 1100, 0, 63, 512, 1400, 257, 1024, 31, 800, 1200][:B]
+        first = [17, 900, 4000, 8000, 5, 77, 1234, 4321, 2, 3000, 650, 7000, 42][:B]
+        _decode_and_compare(torch, model, ref, spec, starts, 3 if B <= 4 else 2, first, bar=2e-2 if kv_dtype == 0 else 5e-2)
     finally:
         model.close()
