@@ -182,9 +182,10 @@ struct MpArgs {
     int nseg;
 };
 
-// Workgroup = 16 waves = RT row-tile pairs (32 weight rows each) x KS slices of K; wave (rt, ks).  The KS partial sums of a
-// row-tile pair are added through LDS in slice order.
-template <int T, int KS, bool DBG>
+// Workgroup = 16 waves = RT row-tile sets (TPW 16-row tiles each) x KS slices of K; wave (rt, ks).  The KS partial sums of a
+// set are added through LDS in slice order.  TPW = 2 shares a wave's activation fragments between two tiles; TPW = 1 is for
+// tensors with so few rows that pairs would leave compute units without a workgroup.
+template <int T, int KS, bool DBG, int TPW>
 __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, int wg, const int8_t *__restrict__ aq, const float *__restrict__ ad,
                                         int n_in, int M, int ldy, int32_t *__restrict__ dbg) {
     constexpr int RT = 16 / KS;
@@ -193,7 +194,7 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
     const int ks = wave % KS, rt = wave / KS;
     const int nsb = n_in >> 8, G = n_in >> 5;
     const int tiles = (sg.n_out + MP_ROWS - 1) / MP_ROWS;
-    const int tile0 = (wg * RT + rt) * 2;             // this wave's two 16-row tiles
+    const int tile0 = (wg * RT + rt) * TPW;           // this wave's 16-row tiles
     // K slice of this wave: super-blocks [sb0, sb0 + nb)
     const int base = nsb / KS, rem = nsb % KS;
     const int nb = base + (ks < rem ? 1 : 0), sb0 = ks * base + (ks < rem ? ks : rem);
@@ -201,16 +202,16 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
     float *ad_s = reinterpret_cast<float *>(smem + MpLds<T>::AD_OFF + wave * 512);
     __syncthreads();
 
-    const bool tile_ok[2] = {tile0 < tiles, tile0 + 1 < tiles};
+    const bool tile_ok[2] = {tile0 < tiles, TPW > 1 && tile0 + 1 < tiles};
     const int8_t *arow = aq + (int64_t)min(o, M - 1) * n_in + 8 * kg;      // A operand: lane (m = o, kg)
     const float *adrow = ad + (int64_t)min(o, M - 1) * G + kg;             // staging of a_d: lane (m = o, g = kg, kg + 4)
     mp_i32x4 zero = {0, 0, 0, 0};
     float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int b = 0; b < nb; b++) {
         const int sb = sb0 + b;
-        MpRaw<T> raw[2];
+        MpRaw<T> raw[TPW];
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < TPW; t++)
             mp_load<T>(raw[t], sg.w + ((int64_t)min(tile0 + t, tiles - 1) * nsb + sb) * Mp<T>::BYTES, lane);
         long au[8];
 #pragma unroll
@@ -220,15 +221,15 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
         ad_s[kg * 16 + o] = ad0;            // [g][m]
         ad_s[(kg + 4) * 16 + o] = ad1;
         __builtin_amdgcn_wave_barrier();
-        float dw[2];
+        float dw[TPW];
 #pragma unroll
-        for (int t = 0; t < 2; t++) dw[t] = vmx_f16_to_f32((uint16_t)raw[t].d);
+        for (int t = 0; t < TPW; t++) dw[t] = vmx_f16_to_f32((uint16_t)raw[t].d);
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const float4 a4 = *reinterpret_cast<const float4 *>(ad_s + s * 16 + 4 * kg);   // a_d of this lane's four rows m = 4 kg + j
             const float adv[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
+            for (int t = 0; t < TPW; t++) {
                 uint32_t w0, w1;
                 int ls0, ls1;
                 mp_decode<T>(raw[t], s, kg, copy, smem, w0, w1, ls0, ls1);
@@ -282,11 +283,11 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
     __syncthreads();   // every wave is done with the tables: their space now holds the partial sums
     float4 *red = reinterpret_cast<float4 *>(smem);
 #pragma unroll
-    for (int t = 0; t < 2; t++) red[(wave * 2 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    for (int t = 0; t < TPW; t++) red[(wave * 2 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     __syncthreads();
     if (ks != 0) return;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < TPW; t++) {
         float4 v = red[((rt * KS) * 2 + t) * 64 + lane];
         for (int k = 1; k < KS; k++) {
             const float4 u = red[((rt * KS + k) * 2 + t) * 64 + lane];
@@ -303,7 +304,7 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
     }
 }
 
-template <int KS, bool DBG>
+template <int KS, bool DBG, int TPW = 2>
 __global__ __launch_bounds__(1024) void iq_mma_kernel(MpArgs a, const int8_t *__restrict__ aq, const float *__restrict__ ad, int n_in, int M,
                                                        int ldy, int32_t *__restrict__ dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -312,9 +313,9 @@ __global__ __launch_bounds__(1024) void iq_mma_kernel(MpArgs a, const int8_t *__
         if ((int)blockIdx.x >= a.seg[i].wg0) si = i;
     const MpSeg sg = a.seg[si];
     const int wg = blockIdx.x - sg.wg0;
-    if (sg.type == 18) mp_body<18, KS, DBG>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
-    else if (sg.type == 21) mp_body<21, KS, DBG>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
-    else mp_body<22, KS, DBG>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
+    if (sg.type == 18) mp_body<18, KS, DBG, TPW>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
+    else if (sg.type == 21) mp_body<21, KS, DBG, TPW>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
+    else mp_body<22, KS, DBG, TPW>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
 }
 
 int mp_lds_bytes(int t) { return t == 18 ? MpLds<18>::TOTAL : t == 21 ? MpLds<21>::TOTAL : MpLds<22>::TOTAL; }
@@ -337,23 +338,31 @@ int mp_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
     a.nseg = nseg;
     int total_rows = 0, lds = 0;
     for (int i = 0; i < nseg; i++) total_rows += segs[i].n_out;
-    const int ks = mp_pick_ks(total_rows, n_in >> 8), rows_per_wg = 32 * (16 / ks);
+    const int ks = mp_pick_ks(total_rows, n_in >> 8);
+    // one tile per wave where tile pairs would leave compute units without a workgroup (Gemma-4-12B at 16 rows: q|k|v 128, o_proj
+    // and down 120 workgroups of pairs on 256 compute units)
+    static const int tpw_force = vmx_tune("VMX_IQ_MMA_TPW", 0);
+    const int pair_wgs = (total_rows + 32 * (16 / ks) - 1) / (32 * (16 / ks));
+    const int tpw = DBG ? 2 : (tpw_force == 1 || tpw_force == 2 ? tpw_force : (pair_wgs < vmx_num_cus() ? 1 : 2));
+    const int rows_per_wg = 16 * tpw * (16 / ks);
     int wg = 0;
     for (int i = 0; i < nseg; i++) {
         a.seg[i] = MpSeg{(const uint8_t *)segs[i].w, y ? y + segs[i].y_off : nullptr, segs[i].ggml_type, segs[i].n_out, wg};
         wg += (segs[i].n_out + rows_per_wg - 1) / rows_per_wg;
         lds = lds > mp_lds_bytes(segs[i].ggml_type) ? lds : mp_lds_bytes(segs[i].ggml_type);
     }
-#define MP_GO(KSV)                                                                                                          \
+#define MP_GO_T(KSV, TPWV)                                                                                                  \
     do {                                                                                                                    \
         if (lds > 64 * 1024)                                                                                                \
-            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)iq_mma_kernel<KSV, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        hipLaunchKernelGGL((iq_mma_kernel<KSV, DBG>), dim3(wg), dim3(1024), lds, st, a, aq, ad, n_in, m, ldy, dbg);          \
+            VMX_CHECK_HIP(hipFuncSetAttribute((const void *)iq_mma_kernel<KSV, DBG, TPWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL((iq_mma_kernel<KSV, DBG, TPWV>), dim3(wg), dim3(1024), lds, st, a, aq, ad, n_in, m, ldy, dbg);    \
     } while (0)
+#define MP_GO(KSV) do { if (tpw == 1) MP_GO_T(KSV, (DBG ? 2 : 1)); else MP_GO_T(KSV, 2); } while (0)
     if (ks == 4) MP_GO(4);
     else if (ks == 8) MP_GO(8);
     else MP_GO(16);
 #undef MP_GO
+#undef MP_GO_T
     VMX_CHECK_LAUNCH("iq_mmvq(mma)");
     return VMX_OK;
 }
