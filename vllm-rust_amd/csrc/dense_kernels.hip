@@ -97,29 +97,40 @@ __global__ __launch_bounds__(256) void dense_gemm16_kernel(uint16_t *__restrict_
         const int row = min(tile * 16 + nl, N - 1);
         const uint16_t *wrow = W + (int64_t)row * K;
         vmx_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < K; k0 += PK) {
-            const int pk = min(PK, K - k0);   // K % 128 == 0 (checked on the host)
-            if (k0 || rd) __syncthreads();    // the previous pass has been read by every wave
-            for (int c = tid; c < 16 * (PK / 8); c += 256) {
-                const int m = c / (PK / 8), cc = c % (PK / 8);
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (m < M && cc * 8 < pk) v = *reinterpret_cast<const uint4 *>(x + (int64_t)m * K + k0 + cc * 8);
-                *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = v;
+        // the weights of 128-deep block i + 1 are requested before block i is multiplied: with load and use in the same iteration
+        // a wave has one block (4 KB) in flight and the launch runs at the memory latency, not the memory rate
+        const int nblk = K >> 7;
+        uint4 wn[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) wn[j] = *reinterpret_cast<const uint4 *>(wrow + 32 * g + 8 * j);
+        for (int blk = 0; blk < nblk; blk++) {
+            const int k0 = (blk >> 3) * PK, b = (blk & 7) * 128;
+            if ((blk & 7) == 0) {
+                const int pk = min(PK, K - k0);   // K % 128 == 0 (checked on the host)
+                if (blk || rd) __syncthreads();   // the previous pass has been read by every wave
+                for (int c = tid; c < 16 * (PK / 8); c += 256) {
+                    const int m = c / (PK / 8), cc = c % (PK / 8);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (m < M && cc * 8 < pk) v = *reinterpret_cast<const uint4 *>(x + (int64_t)m * K + k0 + cc * 8);
+                    *reinterpret_cast<uint4 *>(xs + m * XROW + cc * 8) = v;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            for (int b = 0; b < pk; b += 128) {
-                uint4 wv[4];
+            uint4 wv[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) wv[j] = *reinterpret_cast<const uint4 *>(wrow + k0 + b + 32 * g + 8 * j);
+            for (int j = 0; j < 4; j++) wv[j] = wn[j];
+            if (blk + 1 < nblk) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint4 au = *reinterpret_cast<const uint4 *>(xs + nl * XROW + b + 32 * g + 8 * j);
-                    if constexpr (F16)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, au), __builtin_bit_cast(f16x8_t, wv[j]), acc, 0, 0, 0);
-                    else
+                for (int j = 0; j < 4; j++) wn[j] = *reinterpret_cast<const uint4 *>(wrow + (blk + 1) * 128 + 32 * g + 8 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint4 au = *reinterpret_cast<const uint4 *>(xs + nl * XROW + b + 32 * g + 8 * j);
+                if constexpr (F16)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, au), __builtin_bit_cast(f16x8_t, wv[j]), acc, 0, 0, 0);
+                else
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vmx_bf16x8, au), __builtin_bit_cast(vmx_bf16x8, wv[j]), acc,
                                                                   0, 0, 0);
-                }
             }
         }
         // lane holds activation rows m = 4 g + r of output column (W row) tile * 16 + nl
@@ -198,7 +209,7 @@ static int dense_gemv_launch_t(uint16_t *y, const uint16_t *x, const uint16_t *W
     static const int mfma_min_m = vmx_tune("VMX_DENSE_MFMA_MIN_M", 5);   // 0 disables
     if (mfma_min_m > 0 && M >= mfma_min_m && K % 128 == 0) {   // GEMM-shaped: matrix cores, activations staged in k-passes
         int g16 = ((N + 15) / 16 + 3) / 4;   // 4 waves x one 16-row tile of W per round
-        if (g16 > 2048) g16 = 2048;
+        if (g16 > 4096) g16 = 4096;   // one round of 16-row tiles for vocabularies up to 262144 (151936 rows at 16 activation rows: 286 -> 276 us)
         hipLaunchKernelGGL((dense_gemm16_kernel<F16>), dim3(g16), dim3(256), 0, st, y, x, W, bias, M, N, K);
         VMX_CHECK_LAUNCH("dense_gemm16");
         return VMX_OK;
