@@ -547,10 +547,13 @@ constexpr int RING_D = VMX_RING_D;   // passes a request runs ahead of its use
 //     touches lie in 16 different bank groups;
 //   * the row sums of the zero-point term come from the matrix cores (the tile times a matrix of ones).
 // K % (512 * UPW) == 0, (N / 16) % CT == 0; rows past M replicate row M - 1 (never stored).
+// xmap / omap (token-grouped experts, LDS): activation row and output row of block row m.
 template <int UPW, bool GLU, int CT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void int4_gemm_ring_kernel(
-    const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ, const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
-    uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N, int K, int group, int slice_rows) {
+__device__ __forceinline__ void int4_gemm_ring_body(const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ,
+                                                    const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+                                                    uint16_t *__restrict__ y, float *__restrict__ partial, int64_t slice_stride, int M,
+                                                    int N, int K, int group, int block, const int32_t *xmap = nullptr,
+                                                    const int32_t *omap = nullptr) {
     constexpr int PASSES = UPW, D = RING_D, ROWB = 4 * KB * 2;   // bytes per staged row
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *xs = smem;                                        // [2][16][ROWB]
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int nl = lane & 15, h = lane >> 4;
     const int n_tiles = N / NT, kblocks = K / KB, G = K / group;
     const int n_groups = n_tiles / CT;
-    const int nt0 = ((int)blockIdx.x % n_groups) * CT, ks = (int)blockIdx.x / n_groups;
+    const int nt0 = (block % n_groups) * CT, ks = block / n_groups;
     const int kb_wg = ks * 4 * UPW;
 
     // staging: request j of a wave is row 4 j + wave of the tile, lane l its chunk l.  Every address is a wave-uniform base
@@ -568,8 +571,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     uint32_t xdst[4];   // byte offset of the lane's chunk inside a stage
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int row = 4 * j + wave;
-        xrow_u[j] = reinterpret_cast<const char *>(x + (int64_t)min(row, M - 1) * K + (int64_t)kb_wg * KB);
+        const int row = 4 * j + wave, rsrc = min(row, M - 1);
+        xrow_u[j] = reinterpret_cast<const char *>(x + (int64_t)(xmap ? __builtin_amdgcn_readfirstlane(xmap[rsrc]) : rsrc) * K + (int64_t)kb_wg * KB);
         xdst[j] = (uint32_t)(row * ROWB + ((lane ^ (row & 15)) << 4));
     }
     const char *w_u[CT];
@@ -650,7 +653,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         *reinterpret_cast<float4 *>(red + ((t * 4 + wave) * 64 + lane) * 4) = make_float4(fin[t][0], fin[t][1], fin[t][2], fin[t][3]);
     __syncthreads();
     for (int t = wave; t < CT; t += 4)
-        int4_gemm_tile_store<GLU>(red + t * 4 * 64 * 4, bias, y, partial, (int64_t)slice_rows * N, M, N, nt0 + t, ks, nullptr);
+        int4_gemm_tile_store<GLU>(red + t * 4 * 64 * 4, bias, y, partial, slice_stride, M, N, nt0 + t, ks, omap);
+}
+
+template <int UPW, bool GLU, int CT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void int4_gemm_ring_kernel(
+    const uint4 *__restrict__ W, const uint32_t *__restrict__ SZ, const uint16_t *__restrict__ x, const uint16_t *__restrict__ bias,
+    uint16_t *__restrict__ y, float *__restrict__ partial, int M, int N, int K, int group, int slice_rows) {
+    int4_gemm_ring_body<UPW, GLU, CT>(W, SZ, x, bias, y, partial, (int64_t)slice_rows * N, M, N, K, group, (int)blockIdx.x);
 }
 
 template <int UPW, bool TAIL, int CT = 1>
@@ -1476,6 +1486,37 @@ __global__ __launch_bounds__(256) void int4_gemm_grouped16_kernel(Int4GroupedArg
     int4_gemm_body_looped<UPW, TAIL, GLU>(W, SZ, x, nullptr, act, partial, (int64_t)ga.numel * N, M, N, K, group, blockIdx.x, xmap, omap);
 }
 
+// The same row blocks through the ring form (slices of whole 512-deep passes): the looped body waits for an L2 round trip per
+// staging pass, and a 16-sequence decode step of an 8-expert model is thousands of such workgroups in a dozen rounds.
+template <int UPW, bool GLU, int CT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void int4_gemm_grouped16_ring_kernel(
+    Int4GroupedArgs ga, const uint16_t *__restrict__ x, float *__restrict__ partial, uint16_t *__restrict__ act, int N, int K, int group) {
+    __shared__ int32_t xmap[16], omap[16];
+    __shared__ int m_s;
+    const int row0 = blockIdx.y * 16, tid = threadIdx.x;
+    if (row0 >= ga.total_post_pad[0]) return;
+    int e = ga.block_expert[blockIdx.y];
+    e = e < 0 ? 0 : (e >= ga.num_experts ? ga.num_experts - 1 : e);
+    const char *packed = static_cast<const char *>(ga.table[e]);
+    if (!packed) return;   // expert held by another rank
+    if (tid < 64) {
+        const int p = tid < 16 ? ga.sorted[row0 + tid] : -1;
+        const bool valid = tid < 16 && p >= 0 && p < ga.numel;
+        if (tid < 16) {
+            xmap[tid] = valid ? p / ga.x_row_div : 0;
+            omap[tid] = valid ? p : 0;
+        }
+        const unsigned long long mask = __ballot(valid);   // the valid pairs of a block come first
+        if (tid == 0) m_s = __popcll(mask);
+    }
+    __syncthreads();
+    const int M = m_s;
+    if (M == 0) return;
+    const uint4 *W = reinterpret_cast<const uint4 *>(packed);
+    const uint32_t *SZ = reinterpret_cast<const uint32_t *>(packed + sz_offset_bytes(K, N));
+    int4_gemm_ring_body<UPW, GLU, CT>(W, SZ, x, nullptr, act, partial, (int64_t)ga.numel * N, M, N, K, group, (int)blockIdx.x, xmap, omap);
+}
+
 // Grouped form for mixture-of-experts decode: blockIdx.y = p selects one (token, expert slot) pair;
 // its weights are packed_table[expert_ids[p]], its activation row is x[p / x_row_div] and it writes
 // row p of partial[splits][pairs][N].  M = 1 per pair.
@@ -2083,6 +2124,24 @@ int vmx_int4_gemm_token_grouped(const void *const *packed_table, const int32_t *
     const int kblocks = K / KB, kbs = (kblocks + p.splits - 1) / p.splits;
     Int4GroupedArgs ga{packed_table, sorted, block_expert, total_post_pad, pairs, x_row_div, num_experts};
     if (block_rows == 16) {
+        // ring form where the plan's k slices are whole 512-deep passes (4, 7 or 8 of them) and the tiles pair up
+        static const int ring_on = vmx_tune("VMX_INT4_RING_GROUPED", 1);
+        const int per_slice = kblocks % p.splits == 0 ? kblocks / p.splits : 0;
+        const int rupw = per_slice % 4 == 0 ? per_slice / 4 : 0;
+        if (ring_on && vmx_tune("VMX_INT4_RING", 1) && (rupw == 4 || rupw == 7 || rupw == 8) && (N / NT) % 2 == 0) {
+            const dim3 rgrid((unsigned)((N / NT / 2) * p.splits), (unsigned)max_blocks);
+#define G16R(U)                                                                                                                       \
+            do {                                                                                                                      \
+                if (act) hipLaunchKernelGGL((int4_gemm_grouped16_ring_kernel<U, true, 2>), rgrid, dim3(256), RING_LDS, st, ga, x, partial, act, N, K, group); \
+                else hipLaunchKernelGGL((int4_gemm_grouped16_ring_kernel<U, false, 2>), rgrid, dim3(256), RING_LDS, st, ga, x, partial, act, N, K, group);    \
+            } while (0)
+            if (rupw == 8) G16R(8);
+            else if (rupw == 7) G16R(7);
+            else G16R(4);
+#undef G16R
+            VMX_CHECK_LAUNCH("int4_gemm(token grouped, ring)");
+            return VMX_OK;
+        }
         const size_t lds = gemm_lds_bytes_looped(16, p.upw);
         const dim3 grid16((unsigned)((N / NT) * p.splits), (unsigned)max_blocks);
         const bool tail = kblocks % (4 * p.upw) != 0;
