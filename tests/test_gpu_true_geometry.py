@@ -220,6 +220,11 @@ def test_mixtral_8x7b_moe_layers(gpu):
                       max_position=2048, num_blocks=200, max_batch=4, max_seq_len=1024)
     _qwen3_case(gpu, spec3, "load_synthetic_moe", start_lens=[300], steps=3, first_ids=[5], bar=3e-2)
     _qwen3_case(gpu, spec3, "load_synthetic_moe", start_lens=[0, 15, 16, 700], steps=2, first_ids=[1, 2, 3, 4], bar=3e-2)
+    # eight rows = sixteen (token, slot) pairs: the experts' weights streamed once per 16-row block of their pairs (ring form)
+    spec8 = Qwen3Spec(4096, 2, 32, 8, 128, 14336, VOCAB, rms_norm_eps=1e-5, rope_theta=1e6, qk_norm=False, num_experts=8, experts_per_tok=2,
+                      max_position=2048, num_blocks=400, max_batch=8, max_seq_len=1024)
+    _qwen3_case(gpu, spec8, "load_synthetic_moe", start_lens=[0, 15, 16, 700, 33, 250, 511, 64], steps=2,
+                first_ids=[1, 2, 3, 4, 5, 6, 7, 8], bar=3e-2)
 
 
 def test_qwen3_0_6b_tied(gpu):
