@@ -1608,7 +1608,7 @@ inline int looped_ct(int M, int N) {
 constexpr size_t RING_LDS = 2 * 16 * 4 * KB * 2;
 inline int ring_ct(int M, int N, int K, const GemmPlan &p) {
     static const int on = vmx_tune("VMX_INT4_RING", 1), force_ct = vmx_tune("VMX_INT4_RING_CT", 0);
-    if (!on || M < 5 || M > 16 || (p.upw != 4 && p.upw != 8) || (K / KB) % (4 * p.upw) != 0) return 0;
+    if (!on || M < 5 || M > 16 || (p.upw != 2 && p.upw != 4 && p.upw != 8) || (K / KB) % (4 * p.upw) != 0) return 0;
     const int n_tiles = N / NT, cus = vmx_num_cus();
     if (force_ct >= 1 && force_ct <= 3 && n_tiles % force_ct == 0) return force_ct;
     for (int ct = 3; ct > 1; ct--)
@@ -1628,7 +1628,8 @@ int launch_gemm(const GemmPlan &p, const uint4 *W, const uint32_t *SZ, const uin
 #define RING_C(U, C) hipLaunchKernelGGL((int4_gemm_ring_kernel<U, false, C>), rgrid, dim3(256), RING_LDS, st, W, SZ, x, bias, y, partial, M, N, K, group, slice_rows)
 #define RING(U) do { if (rct == 3) RING_C(U, 3); else if (rct == 2) RING_C(U, 2); else RING_C(U, 1); } while (0)
         if (p.upw == 8) RING(8);
-        else RING(4);
+        else if (p.upw == 4) RING(4);
+        else RING(2);
 #undef RING
 #undef RING_C
         VMX_CHECK_LAUNCH("int4_gemm(ring)");
@@ -2020,7 +2021,7 @@ int vmx_int4_gemm_glu(const void *packed, const uint16_t *x, uint16_t *act, int 
         const int mm = M - m0 < 16 ? M - m0 : 16;
         const uint16_t *xc = x + (int64_t)m0 * K;
         uint16_t *ac = act + (int64_t)m0 * (N / 2);
-        if (const int rct = ring_ct(mm, N, K, p)) {
+        if (const int rct = p.upw >= 4 ? ring_ct(mm, N, K, p) : 0) {
             const dim3 rgrid((unsigned)(N / NT / rct));
 #define GRING_C(U, C) hipLaunchKernelGGL((int4_gemm_ring_kernel<U, true, C>), rgrid, block, RING_LDS, st, W, SZ, xc, nullptr, ac, nullptr, mm, N, K, group, mm)
 #define GRING(U) do { if (rct == 3) GRING_C(U, 3); else if (rct == 2) GRING_C(U, 2); else GRING_C(U, 1); } while (0)
