@@ -1,5 +1,5 @@
 """Per-wave timeline of the decode attention launch (split_decode_attn_kernel) of a Qwen3-8B-shaped layer: build variant
-libvmx_stamps.so (attention_kernels.hip compiled with -DVMX_ATTN_STAMPS), run as
+libvmx_stamps.so (make -C vllm-rust_amd/csrc STAMPS=1), run as
 VMX_LIB_VARIANT=stamps python tools/attn_stamps.py [context]."""
 import ctypes as C
 import sys

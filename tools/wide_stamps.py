@@ -1,4 +1,4 @@
-"""Per-wave timeline of the gate|up int4 GEMM of a Qwen3-8B-shaped layer (build variant libvmx_stamps.so, made with
+"""Per-wave timeline of the gate|up int4 GEMM of a Qwen3-8B-shaped layer (build variant libvmx_stamps.so, made with make STAMPS=1:
 -DVMX_WIDE_STAMPS): run as  VMX_LIB_VARIANT=stamps python tools/wide_stamps.py [mask]   (mask 4 = gate|up, 1 = q|k|v)."""
 import ctypes as C
 import sys
