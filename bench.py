@@ -694,7 +694,7 @@ class _Dist:
         self.dist.all_gather_object(flags, bool(ok))
         return all(flags)
 
-    def make_comm(self, allow_p2p=True):
+    def make_comm(self):
         """(communicator, description of the all-reduce path, note).  The transport is agreed between the ranks."""
         from vllm_rust_amd.parallel import Communicator, LocalCommunicator
         if self.local:
@@ -705,8 +705,6 @@ class _Dist:
             # no RCCL between processes that share a GPU: prompts of at most 32 rows so that every all-reduce fits the staging slot
             return LocalCommunicator(self.rank, self.world, exchange, max_bytes=256 * 1024), "one-shot over peer-mapped memory (ranks share one GPU)", ""
         comm = Communicator(self.rank, self.world)
-        if not allow_p2p:
-            return comm, "RCCL", "peer-mapped path switched off after it failed in this run"
         if os.environ.get("VMX_NO_P2P_ALLREDUCE", "0") not in ("", "0"):
             return comm, "RCCL", "peer-mapped path switched off (VMX_NO_P2P_ALLREDUCE)"
         if comm.enable_p2p(64 * 1024):   # the 8 KiB row-parallel sums go over peer-mapped memory in one step; RCCL keeps the rest
@@ -854,45 +852,10 @@ def main():
             comm_note = comm_note or "communicator set-up failed on a peer rank"
         else:
             spec = shard_spec(full_spec, rank, world)   # this rank's heads / MLP columns / lm_head rows
-    # The tensor-parallel job is tried with the agreed transport; if any rank's run fails or its communicator reports an error (a
-    # peer-mapped exchange that missed a flag poisons its result and the communicator), every rank drops the job and tries once
-    # more over RCCL alone, then falls back to replicas -- the line always says which path produced the number.
-    result, comm_state = None, None
-    attempts = ["agreed"] + (["rccl"] if mode == "tp" and not d.local else [])
-    for attempt in attempts:
-        if mode != "tp":
-            break
-        ok, err = True, ""
-        try:
-            if attempt == "rccl":
-                comm, allreduce_path, note2 = d.make_comm(allow_p2p=False)
-                comm_note = (comm_note + "; " if comm_note else "") + note2
-            result = run_decode_job(d, args, spec, full_spec, comm, exl3, seed_per_rank=False)
-            comm_state = {"p2p_timeouts": comm.p2p_timeouts(), "error_code": comm.error_code()}
-            ok = comm_state["error_code"] == 0 and comm_state["p2p_timeouts"] == 0
-            if not ok:
-                err = f"communicator error {comm_state} on rank {rank}"
-        except Exception as e:   # noqa: BLE001 - reported in the line; the other ranks learn of it through all_agree
-            ok, err = False, f"tensor-parallel run failed on rank {rank}: {e!r}"
-        if d.all_agree(ok):
-            break
-        comm_note = (comm_note + "; " if comm_note else "") + (err or f"tensor-parallel run over '{allreduce_path}' failed on a peer rank")
-        if result is not None:
-            result[2].close()
-        result = None
-        try:
-            if comm is not None:
-                comm.close()
-        except Exception:   # noqa: BLE001
-            pass
-        comm = None
-        torch.cuda.empty_cache()
-    if mode == "tp" and result is None:   # no working tensor-parallel path: replicas, and the line says why
-        comm, mode, spec = None, "replicas", full_spec
-        plan = dict(plan, mode="replicas", scaling="weak", tp=1, secondary=None)
-    if result is None:
-        result = run_decode_job(d, args, spec, full_spec, comm, exl3, seed_per_rank=mode == "replicas")
-    elapsed, prefill_s, model, graph, side = result
+    elapsed, prefill_s, model, graph, side = run_decode_job(d, args, spec, full_spec, comm, exl3, seed_per_rank=mode == "replicas")
+    comm_state = None
+    if comm is not None:
+        comm_state = {"p2p_timeouts": comm.p2p_timeouts(), "error_code": comm.error_code()}
 
     # ---- N > 1, tensor-parallel primary: the N-replica job as a secondary (full model per rank, no collective)
     replicas = None
