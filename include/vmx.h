@@ -709,6 +709,11 @@ int vmx_debug_stream_read(const void *p, size_t bytes, int upw, void *sink, void
  * spreads consecutive workgroup ids over the 8 dies, each with its own L2). */
 int vmx_debug_xcc_ids(int *out, int n_wgs, int wg_threads, void *stream);
 
+/* Self-check of the kernels' register-only cross-lane exchanges (DPP row operations, v_permlane16/32_swap) against the LDS
+ * crossbar forms they replace: out64[lane] = number of helpers whose result differs in any bit on that lane (all zero when
+ * they agree).  No counterpart in the reference: test infrastructure of this library. */
+int vmx_debug_lane_ops_check(int *out64, unsigned seed, void *stream);
+
 /* Measurement / parity aid: the executors run q/k/v post-processing + attention + merge as ONE launch for contexts of up to
  * 1024 tokens and head_dim <= 128, as three launches otherwise; enable = 0 forces the three-launch form (default on, or off
  * when the environment has VMX_NO_FUSED_ATTN=1). */

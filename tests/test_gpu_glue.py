@@ -486,3 +486,17 @@ def test_paged_attention_f16(gpu, H, KVH, D):
         assert np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()) <= 1e-3 + 2 ** -11
     from vllm_rust_amd._lib import lib
     assert lib.vmx_paged_attention_f16(None, None, None, None, None, None, 1.0, 1, 4, 4, 1, 16, 64, 16, 0, None, 0, None) != 0
+
+
+def test_register_only_lane_exchanges_equal_the_lds_crossbar_forms():
+    """The wave / row butterflies and lane exchanges every kernel reduces with (DPP row operations, v_permlane swaps) give the
+    bits of the __shfl_xor forms they replaced, on values whose sums depend on the order of the additions."""
+    import torch
+    import vllm_rust_amd as vmx
+    from vllm_rust_amd._lib import check, lib
+    vmx.init(0)
+    out = torch.full((64,), -1, dtype=torch.int32, device="cuda")
+    for seed in (1, 12345, 987654321):
+        check(lib.vmx_debug_lane_ops_check(out.data_ptr(), seed, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert out.cpu().tolist() == [0] * 64

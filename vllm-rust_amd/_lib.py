@@ -161,6 +161,7 @@ _SIGS = {
     "vmx_qwen3_debug_kv": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
     "vmx_debug_stream_read": (_i, [_p, _sz, _i, _p, _p]),
     "vmx_debug_xcc_ids": (_i, [_p, _i, _i, _p]),
+    "vmx_debug_lane_ops_check": (_i, [_p, C.c_uint, _p]),
     "vmx_decode_advance": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "vmx_qwen3_load_gptq_expert": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "vmx_qwen3_prefill": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),

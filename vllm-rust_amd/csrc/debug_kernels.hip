@@ -21,7 +21,42 @@ __global__ void xcc_id_kernel(int *__restrict__ out) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     if (threadIdx.x == 0) out[blockIdx.x] = (int)(v & 0xF);
 }
+// Every register-only cross-lane helper of vmx_internal.h against its ds_bpermute form (__shfl_xor), on values whose sums
+// round differently in a different order: out[lane] = number of helpers whose bits differ on that lane.
+__global__ void lane_ops_check_kernel(int *__restrict__ out, unsigned seed) {
+    const int l = threadIdx.x & 63;
+    int bad = 0;
+    bad += vmx_lane_xor<1>(l + 100) != (l ^ 1) + 100;
+    bad += vmx_lane_xor<2>(l + 100) != (l ^ 2) + 100;
+    bad += vmx_lane_xor<4>(l + 100) != (l ^ 4) + 100;
+    bad += vmx_lane_xor<8>(l + 100) != (l ^ 8) + 100;
+    bad += vmx_lane_xor<16>(l + 100) != (l ^ 16) + 100;
+    bad += vmx_lane_xor<32>(l + 100) != (l ^ 32) + 100;
+    for (int m = 1; m < 64; m <<= 1) bad += vmx_lane_xor_m(l + 7, m) != (l ^ m) + 7;
+    for (unsigned round = 0; round < 32; round++) {
+        unsigned h = (seed + round * 64u + (unsigned)l) * 2654435761u;
+        h ^= h >> 15;
+        const float v = (float)(h & 0xFFFFu) * ((h >> 16) % 5u == 0u ? 37.25f : 0.001953125f) - 11.0f;
+        float ws = v, wm = v, rs = v, rm = v;
+        for (int off = 32; off > 0; off >>= 1) { ws += __shfl_xor(ws, off, 64); wm = fmaxf(wm, __shfl_xor(wm, off, 64)); }
+        for (int off = 1; off < 16; off <<= 1) { rs += __shfl_xor(rs, off, 64); rm = fmaxf(rm, __shfl_xor(rm, off, 64)); }
+        const float rm32 = fmaxf(rm, __shfl_xor(rm, 16, 64));
+        bad += __float_as_uint(vmx_wave_sum(v)) != __float_as_uint(ws);
+        bad += __float_as_uint(vmx_wave_max(v)) != __float_as_uint(wm);
+        bad += __float_as_uint(vmx_row16_sum(v)) != __float_as_uint(rs);
+        bad += __float_as_uint(vmx_row16_max(v)) != __float_as_uint(rm);
+        bad += __float_as_uint(vmx_row32_max(v)) != __float_as_uint(rm32);
+    }
+    out[l] = bad;
+}
 }  // namespace
+
+extern "C" int vmx_debug_lane_ops_check(int *out64, unsigned seed, void *stream) {
+    VMX_REQUIRE(out64, "debug_lane_ops_check: null pointer");
+    hipLaunchKernelGGL(lane_ops_check_kernel, dim3(1), dim3(64), 0, vmx_stream(stream), out64, seed);
+    VMX_CHECK_LAUNCH("debug_lane_ops_check");
+    return VMX_OK;
+}
 
 extern "C" int vmx_debug_xcc_ids(int *out, int n_wgs, int wg_threads, void *stream) {
     VMX_REQUIRE(out && n_wgs > 0 && wg_threads > 0 && wg_threads <= 1024, "debug_xcc_ids: bad arguments");
