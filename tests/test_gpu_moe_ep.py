@@ -50,7 +50,7 @@ def _worker(rank, world, conns, result_q, round_robin):
             x = (torch.randn((max(T, 1), H), generator=g)).to(torch.bfloat16).cuda()
             logits = torch.randn((max(T, 1), E), generator=g).cuda()
             w, ids = vmx.topk_softmax(logits, K, True, True)
-            if T == 0:   # this rank routes nothing this round: every id out of range
+            if T == 0:   # this rank routes nothing in this call: every id out of range
                 ids = torch.full_like(ids, -1)
             got = vmx.moe_ep_int4_forward(x, w, ids, l13, l2, E, H, I, G, comm, cap_rows, round_robin=round_robin)
             torch.cuda.synchronize()
