@@ -412,7 +412,7 @@ int8_t *aq_of(vmx_gemma4 *m) { return (int8_t *)(m->q8_alt ? m->q8_alt : m->q8.p
 float *ad_of(vmx_gemma4 *m, int tokens, int k) { return (float *)((char *)aq_of(m) + (((size_t)tokens * k + 255) & ~(size_t)255)); }
 
 // Projections that share the q8_1 activations (1..3 of them: q|k|v, gate|up, or a single one), outputs at y + off[i]
-int g_mma_min_rows = 5;   // rows from which the matrix-core MMVQ takes over from the per-row kernels (tests: vmx_debug_iq_mma_min_rows)
+int g_mma_min_rows = 3;   // rows from which the matrix-core MMVQ takes over from the per-row kernels (Gemma-4-12B: 3 rows 602 -> 628, 4 rows 724 -> 800 tok/s against the threshold 5; 2 rows 477 -> 437; tests: vmx_debug_iq_mma_min_rows)
 
 int mmvq_group(vmx_gemma4 *m, const IqLin *const *lins, const int *offs, int n, float *y, int ldy, int tokens, hipStream_t st) {
     VmxMmvqSeg raw[3], pk[3];
