@@ -166,6 +166,12 @@ size_t vmx_kquant_gemm_workspace_bytes(int m, int n_out, int n_in);
 int vmx_kquant_gemm_f32(int ggml_type, const void *w, const float *x, float *y, int m, int n_out, int n_in, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The same product for 1..16 rows of bf16 activations over a Q3_K table (the tied lm_head of a GGUF Gemma at several concurrent
+ * sequences: the reference casts the hidden state to f32 and runs qmm.forward, gguf/mod.rs:197): y[m, n_out] f32 =
+ * x[m, n_in] @ dequant(W)^T with the table streamed once for all rows; the integer part of a weight times the bf16 activation is
+ * exact on the matrix cores and d * scale multiplies the f32 group sums.  n_in a multiple of 256, at most 4096. */
+int vmx_q3k_rows16_bf16(const void *w, const uint16_t *x, float *y, int n_out, int n_in, int m, void *stream);
+
 /* ------------------------------------------------------- AWQ / GPTQ int4 */
 
 /* Replaces awq_to_gptq_qweight_int4 (crates/core/kernels/marlin_gemm.cu:491;

@@ -103,3 +103,35 @@ def test_q3k_lm_head_gemv(gpu, n_out, n_in):
     exp = (x.astype(np.float64) @ ref.astype(np.float64).T)[0]
     assert np.all(got[n_out:] == 7.0)                      # nothing written past the last row
     assert np.sqrt(((got[:n_out] - exp) ** 2).sum() / (exp ** 2).sum()) <= 1e-5
+
+
+@pytest.mark.parametrize("n_out,n_in,m", [(1003, 3840, 16), (37, 256, 2), (4100, 2048, 5), (9, 4096, 13), (70000, 256, 16), (20000, 3840, 7), (16, 512, 1)])
+def test_q3k_rows_on_the_matrix_cores(gpu, n_out, n_in, m):
+    """Up to 16 bf16 activation rows over a Q3_K table in one pass (integer part exact on the matrix cores, d * scale on
+    the f32 group sums) against the float64 product of the oracle's dequantised table; ragged row counts, rows past m and
+    columns past n_out untouched; the one-row kernel's answer on the same rows agrees to f32 summation order."""
+    from oracle import oracle as orc
+    from vllm_rust_amd._lib import lib, check
+    vmx, torch = gpu
+    rng = np.random.default_rng(n_out + n_in + m)
+    raw = _blocks(rng, 11, n_out * n_in // 256)
+    ref = orc.ggml_dequant(11, raw).reshape(n_out, n_in)
+    xb = torch.from_numpy(rng.standard_normal((m, n_in)).astype(np.float32)).to(torch.bfloat16)
+    x = xb.float().numpy()
+    w, xd = torch.from_numpy(raw).cuda(), xb.cuda()
+    y = torch.full((m * n_out + 8,), 7.0, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.vmx_q3k_rows16_bf16(w.data_ptr(), xd.data_ptr(), y.data_ptr(), n_out, n_in, m, st))
+    got = y.cpu().numpy()
+    assert np.all(got[m * n_out:] == 7.0)
+    got = got[:m * n_out].reshape(m, n_out)
+    exp = x.astype(np.float64) @ ref.astype(np.float64).T
+    assert np.sqrt(((got - exp) ** 2).sum() / (exp ** 2).sum()) <= 1e-5
+    assert np.abs(got - exp).max() <= 2e-5 * np.abs(exp).max()
+    y1 = torch.empty((1, n_out), dtype=torch.float32, device="cuda")
+    x1 = xb[m - 1:m].float().cuda()
+    check(lib.vmx_kquant_gemv_f32(11, w.data_ptr(), x1.data_ptr(), y1.data_ptr(), n_out, n_in, 1, st))
+    assert np.abs(y1.cpu().numpy()[0] - got[m - 1]).max() <= 2e-5 * np.abs(exp).max()
+    assert lib.vmx_q3k_rows16_bf16(w.data_ptr(), xd.data_ptr(), y.data_ptr(), n_out, n_in, 17, st) != 0
+    assert lib.vmx_q3k_rows16_bf16(w.data_ptr(), xd.data_ptr(), y.data_ptr(), n_out, 8192, m, st) != 0
+    assert lib.vmx_q3k_rows16_bf16(w.data_ptr(), xd.data_ptr(), y.data_ptr(), n_out, 384, m, st) != 0

@@ -58,6 +58,7 @@ _SIGS = {
     "vmx_ggml_block_elems": (_i, [_i]),
     "vmx_kquant_dequantize_f32": (_i, [_i, _p, _p, _i64, _p]),
     "vmx_kquant_gemv_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p]),
+    "vmx_q3k_rows16_bf16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "vmx_kquant_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "vmx_kquant_gemm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vmx_awq_to_gptq_qweight": (_i, [_p, _p, _i, _i, _p]),

@@ -1034,6 +1034,25 @@ int g4_run_head(vmx_gemma4 *m, const uint16_t *x, int rows, int32_t *out_ids, ui
                                inv_cap, cap);
     } else {   // tied lm_head over the quantized table (QMatMul, :1849-1865): f32 activations, f32 result cast back to bf16
         float *xf = (float *)m->x_f32.p, *lf = (float *)m->logits_f32.p;
+        static const int q3_mma = vmx_tune("VMX_G4_Q3K_MMA_HEAD", 1);
+        if (q3_mma && c.embed_ggml_type == 11 && vmx_q3k_gemm16_ok(VL, H, B < 16 ? B : 16)) {
+            // several rows over a Q3_K table: one pass of the table on the matrix cores per 16 rows (exact products of the bf16
+            // activations with the integer weights) instead of one pass per row
+            const size_t row_bytes = (size_t)(H / 256) * 110;
+            for (int b0 = 0; b0 < B; b0 += 16) {
+                const int mb = B - b0 < 16 ? B - b0 : 16;
+                if (mb < 2) {
+                    hipLaunchKernelGGL(g4_bf16_to_f32_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, x + (int64_t)b0 * H, xf, (int64_t)H);
+                    if (int rc = vmx_kquant_gemv_f32(11, (const char *)m->embed.p + (size_t)v0 * row_bytes, xf, lf + (int64_t)b0 * VL, VL, H, 1, stream))
+                        return rc;
+                } else if (int rc = vmx_q3k_gemm16_bf16((const char *)m->embed.p + (size_t)v0 * row_bytes, x + (int64_t)b0 * H, lf + (int64_t)b0 * VL, VL,
+                                                        H, mb, st))
+                    return rc;
+            }
+            hipLaunchKernelGGL(g4_logits_kernel, dim3((unsigned)((nlog + 255) / 256)), dim3(256), 0, st, logits, (const float *)lf, nlog, inv_cap, cap);
+            VMX_CHECK_LAUNCH("gemma4(lm_head)");
+            goto head_done;
+        }
         hipLaunchKernelGGL(g4_bf16_to_f32_kernel, dim3((unsigned)(((int64_t)B * H + 255) / 256)), dim3(256), 0, st, x, xf, (int64_t)B * H);
         for (int b0 = 0; b0 < B; b0 += 8) {
             const int mb = B - b0 < 8 ? B - b0 : 8;
@@ -1046,6 +1065,7 @@ int g4_run_head(vmx_gemma4 *m, const uint16_t *x, int rows, int32_t *out_ids, ui
                            cap);
     }
     VMX_CHECK_LAUNCH("gemma4(lm_head)");
+head_done:
     if (out_ids) {
         if (!tp) {
             if (int rc = vmx_argmax_bf16(out_ids, logits, B, VL, m->argmax_ws.p, m->argmax_ws.bytes, stream)) return rc;

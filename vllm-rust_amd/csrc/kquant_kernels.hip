@@ -263,6 +263,96 @@ __global__ __launch_bounds__(256) void q3k_gemv_m1_kernel(const uint8_t *__restr
     }
 }
 
+// Q3_K table x 2..16 bf16 activation rows on the matrix cores (the tied lm_head of a GGUF Gemma at several concurrent
+// sequences; the one-row kernel above would stream the 432 MB table once per row).  A weight is d * scale * (t - 4) with
+// t = q2 | hbit << 2 in 0..7: bf16(t - 4) is exact and comes from two byte-table lookups (v_perm_b32), so a 16-weight group
+// (one scale) is one v_mfma_f32_16x16x16_bf16 with exact products, and  d * scale  is applied to its f32 sums.  One
+// 16-wave workgroup per compute unit keeps all activation rows in LDS (16 x K bf16) and every wave walks 16-row tiles of
+// the table, the next super-block's bytes requested before the current one is decoded.  f32 accumulation in group order.
+__global__ __launch_bounds__(1024) void q3k_gemm16_kernel(const uint8_t *__restrict__ w, const uint16_t *__restrict__ x, float *__restrict__ y,
+                                                           int n_out, int nb, int M) {
+    extern __shared__ __align__(16) uint16_t q3_xs[];
+    typedef short q3_s4 __attribute__((ext_vector_type(4)));
+    const int K = nb * 256, XROW = K + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int cpr = K >> 3, nch = 16 * cpr;
+    for (int c0 = 0; c0 < nch; c0 += 8 * 1024) {   // eight chunks per thread requested before the first is stored
+        uint4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = c0 + i * 1024 + tid, m = c / cpr, cc = c % cpr;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (c < nch && m < M) v[i] = *reinterpret_cast<const uint4 *>(x + (int64_t)m * K + cc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = c0 + i * 1024 + tid, m = c / cpr, cc = c % cpr;
+            if (c < nch) *reinterpret_cast<uint4 *>(q3_xs + m * XROW + cc * 8) = v[i];
+        }
+    }
+    __syncthreads();
+    const int tiles = (n_out + 15) >> 4, waves_total = gridDim.x * 16;
+    const uint16_t *xa = q3_xs + r * XROW + 4 * kg;   // A operand: lane (activation row r, k-group kg)
+    const int64_t row_bytes = (int64_t)nb * 110;
+    struct Raw { uint32_t qs[2][2], hm[2], s0, s1, s2, d; };
+    for (int tile = blockIdx.x * 16 + wave; tile < tiles; tile += waves_total) {
+        const uint8_t *rp = w + (int64_t)min(tile * 16 + r, n_out - 1) * row_bytes;   // B operand: lane (table row r of the tile, kg)
+        auto load = [&](int sb, Raw &o) {
+            const uint8_t *b = rp + sb * 110;
+#pragma unroll
+            for (int hi = 0; hi < 2; hi++) {
+                o.hm[hi] = ldw(b + 16 * hi + 4 * kg);
+#pragma unroll
+                for (int n = 0; n < 2; n++) o.qs[n][hi] = ldw(b + 32 + 32 * n + 16 * hi + 4 * kg);
+            }
+            o.s0 = ldw(b + 96); o.s1 = ldw(b + 100); o.s2 = ldw(b + 104);
+            o.d = reinterpret_cast<const u16a2 *>(b + 108)->v;
+        };
+        vmx_f32x4 fin = {0.f, 0.f, 0.f, 0.f};
+        Raw nxt;
+        load(0, nxt);
+        for (int sb = 0; sb < nb; sb++) {
+            const Raw cur = nxt;
+            if (sb + 1 < nb) load(sb + 1, nxt);
+            uint32_t aux[4];
+            aux[0] = (cur.s0 & 0x0f0f0f0fu) | (((cur.s2 >> 0) & 0x03030303u) << 4);
+            aux[1] = (cur.s1 & 0x0f0f0f0fu) | (((cur.s2 >> 2) & 0x03030303u) << 4);
+            aux[2] = ((cur.s0 >> 4) & 0x0f0f0f0fu) | (((cur.s2 >> 4) & 0x03030303u) << 4);
+            aux[3] = ((cur.s1 >> 4) & 0x0f0f0f0fu) | (((cur.s2 >> 6) & 0x03030303u) << 4);
+            const float dd = vmx_f16_to_f32((uint16_t)cur.d);
+            const uint16_t *xsb = xa + sb * 256;
+#pragma unroll
+            for (int g = 0; g < 8; g++) {   // g = 4 n + j: weights 128 n + 32 j + 16 hi + (0..15), scale 2 g + hi
+                const int n = g >> 2, j = g & 3;
+#pragma unroll
+                for (int hi = 0; hi < 2; hi++) {
+                    const uint32_t q4 = (cur.qs[n][hi] >> (2 * j)) & 0x03030303u;
+                    const uint32_t t4 = q4 | (((cur.hm[hi] >> g) & 0x01010101u) << 2);
+                    const uint32_t hib = __builtin_amdgcn_perm(0x40403F00u, 0xBFC0C0C0u, t4);   // high / low bytes of bf16(t - 4)
+                    const uint32_t lob = __builtin_amdgcn_perm(0x40008000u, 0x80004080u, t4);
+                    const uint2 bw = make_uint2(__builtin_amdgcn_perm(hib, lob, 0x05010400u), __builtin_amdgcn_perm(hib, lob, 0x07030602u));
+                    const uint2 aw = *reinterpret_cast<const uint2 *>(xsb + 32 * g + 16 * hi);
+                    const vmx_f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(q3_s4, aw), __builtin_bit_cast(q3_s4, bw),
+                                                                                   vmx_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const int sc = (int)((aux[g >> 1] >> (8 * (((2 * g) & 3) + hi))) & 0xFFu) - 32;
+                    const float fsc = dd * (float)sc;
+                    fin[0] = fmaf(fsc, acc[0], fin[0]);
+                    fin[1] = fmaf(fsc, acc[1], fin[1]);
+                    fin[2] = fmaf(fsc, acc[2], fin[2]);
+                    fin[3] = fmaf(fsc, acc[3], fin[3]);
+                }
+            }
+        }
+        const int col = tile * 16 + r;   // lane holds activation rows 4 kg + i of table row `col`
+        if (col < n_out) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * kg + i < M) y[(int64_t)(4 * kg + i) * n_out + col] = fin[i];
+        }
+    }
+}
+
 // out[t, :] = bf16(bf16(dequant(table row ids[t])) * scale): QuantizedEmbedding::forward (gather the row's blocks,
 // dequantise, cast to the model dtype; crates/core/src/quantization/gguf/mod.rs:546-600) followed by the model's
 // embedding normaliser in bf16.  Out-of-range ids give a zero row.  One thread per 32-weight sub-block.
@@ -380,4 +470,25 @@ int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_
 #undef CALL
     VMX_CHECK_LAUNCH("kquant_gather");
     return VMX_OK;
+}
+
+// y [m][n_out] f32 = x [m][n_in] (bf16) x dequant(W)^T for a Q3_K table, 2..16 rows, n_in <= 4096 (the activation rows stay in
+// LDS): see q3k_gemm16_kernel.  Internal (the Gemma 4 executor's tied lm_head at several concurrent sequences).
+bool vmx_q3k_gemm16_ok(int n_out, int n_in, int m) { return m >= 2 && m <= 16 && n_in % 256 == 0 && n_in <= 4096 && n_out >= 16 * 16 * vmx_num_cus(); }
+int vmx_q3k_gemm16_bf16(const void *w, const uint16_t *x, float *y, int n_out, int n_in, int m, hipStream_t st) {
+    VMX_REQUIRE(w && x && y && m >= 1 && m <= 16 && n_out >= 1 && n_in >= 256 && n_in % 256 == 0 && n_in <= 4096,
+                "q3k_gemm16: shape [%d x %d -> %d] not supported (1..16 rows, n_in a multiple of 256 up to 4096)", m, n_in, n_out);
+    const int lds = 16 * (n_in + 16) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VMX_CHECK_HIP(hipFuncSetAttribute((const void *)q3k_gemm16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (4096 + 16) * 2));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(q3k_gemm16_kernel, dim3(vmx_num_cus()), dim3(1024), lds, st, (const uint8_t *)w, x, y, n_out, n_in / 256, m);
+    VMX_CHECK_LAUNCH("q3k_gemm16");
+    return VMX_OK;
+}
+
+extern "C" int vmx_q3k_rows16_bf16(const void *w, const uint16_t *x, float *y, int n_out, int n_in, int m, void *stream) {
+    return vmx_q3k_gemm16_bf16(w, x, y, n_out, n_in, m, (hipStream_t)stream);
 }

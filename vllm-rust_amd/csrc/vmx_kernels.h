@@ -166,3 +166,6 @@ int vmx_dense_gemv_launch(uint16_t *y, const uint16_t *x, const uint16_t *W, con
 // bf16 matrix-core GEMM y = bf16(bf16(x @ W^T) + bias), W [N, K] bf16 (fp8_kernels.hip)
 int vmx_bf16_gemm_nt(uint16_t *y, const uint16_t *x, const uint16_t *w, const uint16_t *bias, int M, int N, int K, hipStream_t st);
 
+// Q3_K table x 2..16 bf16 rows on the matrix cores (kquant_kernels.hip); f32 out [m][n_out]
+bool vmx_q3k_gemm16_ok(int n_out, int n_in, int m);
+int vmx_q3k_gemm16_bf16(const void *w, const uint16_t *x, float *y, int n_out, int n_in, int m, hipStream_t st);
