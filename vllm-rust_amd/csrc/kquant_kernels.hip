@@ -273,6 +273,7 @@ __global__ __launch_bounds__(1024) void q3k_gemm16_kernel(const uint8_t *__restr
                                                            int n_out, int nb, int M) {
     extern __shared__ __align__(16) uint16_t q3_xs[];
     typedef short q3_s4 __attribute__((ext_vector_type(4)));
+    typedef float q3_f2 __attribute__((ext_vector_type(2)));
     const int K = nb * 256, XROW = K + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(1024) void q3k_gemm16_kernel(const uint8_t *__restr
             o.s0 = ldw(b + 96); o.s1 = ldw(b + 100); o.s2 = ldw(b + 104);
             o.d = reinterpret_cast<const u16a2 *>(b + 108)->v;
         };
-        vmx_f32x4 fin = {0.f, 0.f, 0.f, 0.f};
+        q3_f2 fin_lo = {0.f, 0.f}, fin_hi = {0.f, 0.f};
         Raw nxt;
         load(0, nxt);
         for (int sb = 0; sb < nb; sb++) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(1024) void q3k_gemm16_kernel(const uint8_t *__restr
             aux[1] = (cur.s1 & 0x0f0f0f0fu) | (((cur.s2 >> 2) & 0x03030303u) << 4);
             aux[2] = ((cur.s0 >> 4) & 0x0f0f0f0fu) | (((cur.s2 >> 4) & 0x03030303u) << 4);
             aux[3] = ((cur.s1 >> 4) & 0x0f0f0f0fu) | (((cur.s2 >> 6) & 0x03030303u) << 4);
-            const float dd = vmx_f16_to_f32((uint16_t)cur.d);
+            const float dd = vmx_f16_to_f32((uint16_t)cur.d), dd32 = -32.0f * dd;
             const uint16_t *xsb = xa + sb * 256;
 #pragma unroll
             for (int g = 0; g < 8; g++) {   // g = 4 n + j: weights 128 n + 32 j + 16 hi + (0..15), scale 2 g + hi
@@ -335,17 +336,17 @@ __global__ __launch_bounds__(1024) void q3k_gemm16_kernel(const uint8_t *__restr
                     const uint2 aw = *reinterpret_cast<const uint2 *>(xsb + 32 * g + 16 * hi);
                     const vmx_f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(q3_s4, aw), __builtin_bit_cast(q3_s4, bw),
                                                                                    vmx_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    const int sc = (int)((aux[g >> 1] >> (8 * (((2 * g) & 3) + hi))) & 0xFFu) - 32;
-                    const float fsc = dd * (float)sc;
-                    fin[0] = fmaf(fsc, acc[0], fin[0]);
-                    fin[1] = fmaf(fsc, acc[1], fin[1]);
-                    fin[2] = fmaf(fsc, acc[2], fin[2]);
-                    fin[3] = fmaf(fsc, acc[3], fin[3]);
+                    // d * (scale - 32) is exact in f32 (11-bit x 6-bit), so byte -> float -> one fma gives the same bits
+                    const float fsc = fmaf((float)((aux[g >> 1] >> (8 * (((2 * g) & 3) + hi))) & 0xFFu), dd, dd32);
+                    const q3_f2 f2 = {fsc, fsc};
+                    fin_lo = __builtin_elementwise_fma(f2, acc.lo, fin_lo);   // v_pk_fma_f32
+                    fin_hi = __builtin_elementwise_fma(f2, acc.hi, fin_hi);
                 }
             }
         }
         const int col = tile * 16 + r;   // lane holds activation rows 4 kg + i of table row `col`
         if (col < n_out) {
+            const float fin[4] = {fin_lo.x, fin_lo.y, fin_hi.x, fin_hi.y};
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 if (4 * kg + i < M) y[(int64_t)(4 * kg + i) * n_out + col] = fin[i];
@@ -474,7 +475,7 @@ int vmx_kquant_gather_scaled_bf16(int ggml_type, const void *table, const int32_
 
 // y [m][n_out] f32 = x [m][n_in] (bf16) x dequant(W)^T for a Q3_K table, 2..16 rows, n_in <= 4096 (the activation rows stay in
 // LDS): see q3k_gemm16_kernel.  Internal (the Gemma 4 executor's tied lm_head at several concurrent sequences).
-bool vmx_q3k_gemm16_ok(int n_out, int n_in, int m) { return m >= 2 && m <= 16 && n_in % 256 == 0 && n_in <= 4096 && n_out >= 16 * 16 * vmx_num_cus(); }
+bool vmx_q3k_gemm16_ok(int n_out, int n_in, int m) { return m >= 2 && m <= 16 && n_in % 256 == 0 && n_in <= 4096 && n_out >= 16 * vmx_num_cus(); }
 int vmx_q3k_gemm16_bf16(const void *w, const uint16_t *x, float *y, int n_out, int n_in, int m, hipStream_t st) {
     VMX_REQUIRE(w && x && y && m >= 1 && m <= 16 && n_out >= 1 && n_in >= 256 && n_in % 256 == 0 && n_in <= 4096,
                 "q3k_gemm16: shape [%d x %d -> %d] not supported (1..16 rows, n_in a multiple of 256 up to 4096)", m, n_in, n_out);
