@@ -132,8 +132,11 @@ int vmx_iq_mmvq_mma_f32(int ggml_type, const void *packed, const int8_t *aq, con
                         void *stream);
 int vmx_iq_subdots_mma_i32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, int32_t *out, int n_out, int n_in,
                            int m, void *stream);
-/* Parity / measurement aid: rows from which the Gemma 4 executor's I-quant linears take the matrix-core form (default 5: up to four rows the per-row kernels are faster; 17 = never). */
+/* Parity / measurement aid: rows from which the Gemma 4 executor's I-quant linears take the matrix-core form (default 3: up to two rows the per-row kernels are faster; 17 = never). */
 int vmx_debug_iq_mma_min_rows(int rows);
+/* Test hook (no counterpart in the reference): 0 = the Gemma executor's matrix-core gate|up launch writes its f32 projections and
+ * the stand-alone GeGLU + q8_1 kernel follows, 1 (default) = both inside the launch's epilogue; the two give the same bits. */
+int vmx_debug_gemma4_mma_geglu(int on);
 /* Measurement / test aid: on != 0 sends the Gemma 4 executor's prompt-sized linears through the two-term bf16 split even for
  * the types that have the exact one-pass integer form (A/B runs and the test that compares the two). */
 int vmx_debug_gemma4_split_always(int on);

@@ -262,3 +262,44 @@ def test_gemma4_12b_layers(gpu, B, kv_dtype):
         _decode_and_compare(torch, model, ref, spec, starts, 3 if B <= 4 else 2, first, bar=2e-2 if kv_dtype == 0 else 5e-2)
     finally:
         model.close()
+
+
+def test_gemma4_matrix_core_geglu_epilogue_same_bits(gpu):
+    """gate|up on the matrix cores with the GeGLU + q8_1 epilogue against the same launch followed by the stand-alone GeGLU
+    kernel: same K-slice order and the same roundings, so logits and the residual stream must agree bit for bit (7 rows on the
+    Gemma-4-12B layer geometry; the oracle comparison of the fused form is test_gemma4_12b_layers at 6 and 13 rows)."""
+    from vllm_rust_amd._lib import lib
+    from vllm_rust_amd.gemma4 import Gemma4Spec, QuantizedGemma4ForCausalLM
+    vmx, torch = gpu
+    B = 7
+    spec = Gemma4Spec(3840, 2, 16, 15360, VOCAB, full_every=2, max_position=2048, num_blocks=96 * B, max_batch=B, max_seq_len=2048,
+                      embed_ggml_type=11, kv_cache_dtype=0)
+    model = QuantizedGemma4ForCausalLM(spec)
+    try:
+        model.load_synthetic(seed=22)
+        g = torch.Generator(device="cuda").manual_seed(4)
+        for li in range(spec.num_layers):
+            hd, kvh, _, _, _ = spec.layer_geom(li)
+            for which in (0, 1):
+                t = (torch.randn((spec.num_blocks, spec.block_size, kvh, hd), device="cuda", generator=g) * (0.08 if which == 0 else 1.0)).to(torch.bfloat16)
+                model.debug_kv(li, which, t.contiguous(), True)
+        bs = spec.block_size
+        pos = np.asarray([15, 300, 1022, 1100, 0, 63, 512], np.int32)
+        mb = (int(pos.max()) + 1 + bs - 1) // bs + 1
+        bt = np.random.default_rng(6).permutation(spec.num_blocks)[:B * mb].reshape(B, mb).astype(np.int32)
+        ids = np.asarray([17, 900, 4000, 8000, 5, 77, 1234], np.int32)
+        slots = (bt[np.arange(B), pos // bs] * bs + pos % bs).astype(np.int32)
+        sl = pos + 1
+        res = []
+        for on in (1, 0):
+            assert lib.vmx_debug_gemma4_mma_geglu(on) == 0
+            logits = torch.empty((B, spec.vocab_size), dtype=torch.bfloat16, device="cuda")
+            model.forward_decode_batch(*(torch.from_numpy(a).cuda() for a in (ids, pos, slots, bt, sl)), max_seq_len=int(sl.max()), logits=logits)
+            torch.cuda.synchronize()
+            res.append((logits.clone(), model.debug_read(0, (B, spec.hidden_size)).clone()))
+        assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16))
+        assert torch.equal(res[0][1].view(torch.int16), res[1][1].view(torch.int16))
+        assert bool(torch.isfinite(res[0][0].float()).all())
+    finally:
+        lib.vmx_debug_gemma4_mma_geglu(1)
+        model.close()

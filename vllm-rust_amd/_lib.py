@@ -51,6 +51,7 @@ _SIGS = {
     "vmx_iq_mmvq_mma_f32": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vmx_iq_subdots_mma_i32": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vmx_debug_iq_mma_min_rows": (_i, [_i]),
+    "vmx_debug_gemma4_mma_geglu": (_i, [_i]),
     "vmx_debug_gemma4_split_always": (_i, [_i]),
     "vmx_iq_subdots_packed_i32": (_i, [_i, _p, _p, _p, _i, _i, _p]),
     "vmx_gather_dequant_q6k_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),

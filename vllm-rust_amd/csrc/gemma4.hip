@@ -444,6 +444,18 @@ int mmvq(vmx_gemma4 *m, const IqLin &l, float *y, int ldy, int tokens, hipStream
     return vmx_iq_mmvq_ld(l.ggml_type, l.raw.p, aq_of(m), ad_of(m, tokens, l.in_features), y, l.out_features, l.in_features, tokens, ldy, st);
 }
 
+bool g_mma_geglu = true;   // gate|up + GeGLU + q8_1 in one matrix-core launch where the shapes allow (tests: vmx_debug_gemma4_mma_geglu)
+
+// the conditions under which mmvq_group would send gate|up to the matrix cores, plus those of the fused epilogue
+bool mma_geglu_ok(vmx_gemma4 *m, const G4Layer &L, int H, int tokens) {
+    const IqLin &g = L.lin[VMX_L_GATE], &u = L.lin[VMX_L_UP];
+    if (!g_mma_geglu || m->q8_alt || tokens < g_mma_min_rows || tokens > 16 || !g.mma.p || !u.mma.p) return false;
+    const VmxMmvqSeg pk[2] = {{g.packed.p, g.ggml_type, g.out_features, 0}, {u.packed.p, u.ggml_type, u.out_features, g.out_features}};
+    if (vmx_iq_packed_preferred(pk, 2, H, tokens)) return false;
+    const VmxMmvqSeg gm = {g.mma.p, g.ggml_type, g.out_features, 0}, um = {u.mma.p, u.ggml_type, u.out_features, 0};
+    return vmx_iq_mma_geglu_ok(&gm, &um, H, tokens);
+}
+
 bool g_split_always = false;   // measurement: prompt-sized linears always through the two-term bf16 split (vmx_debug_gemma4_split_always)
 
 // A linear on `rows` token rows: the q8_1 MMVQ up to IQ_GEMV_MAX_M = 16 rows (activations already quantised in m->q8), beyond that
@@ -694,7 +706,8 @@ extern "C" int vmx_gemma4_create(const vmx_gemma4_config *cfg, const int *layer_
         kmax = (size_t)max_nq > kmax ? (size_t)max_nq : kmax;
         kmax = (size_t)P > kmax ? (size_t)P : kmax;
         TRY(m->q8.alloc(R * kmax + 256 + R * (kmax / 32) * 4));
-        TRY(m->q8b.alloc(kmax + 256 + (kmax / 32) * 4));   // one row: the fused gate|up launch reads q8 and writes this
+        const size_t r16 = (size_t)(R < 16 ? R : 16);       // up to 16 rows: the fused gate|up launches read q8 and write this
+        TRY(m->q8b.alloc(r16 * kmax + 256 + r16 * (kmax / 32) * 4));
         TRY(m->h2.alloc((size_t)H * 2));                   // one row of the residual stream, written by the norm-fused gate|up launch
     }
     {
@@ -972,6 +985,19 @@ int g4_run_layers(vmx_gemma4 *m, const int32_t *input_ids, const int32_t *positi
             const int rc_glu = vmx_iq_mmvq_packed_geglu(&gate_pk, &up_pk, (const int8_t *)m->q8.p,
                                                         (const float *)((const char *)m->q8.p + (((size_t)H + 255) & ~(size_t)255)), act,
                                                         aq_of(m), ad_of(m, B, I), H, st);
+            if (rc_glu) {
+                m->q8_alt = nullptr;
+                return rc_glu;
+            }
+        } else if (mma_geglu_ok(m, L, H, B)) {
+            // several rows on the matrix cores: both projections, the GeGLU and q8_1 of the result in one launch; it reads q8_1(x)
+            // from q8 while other workgroups already write q8_1(act), so the result goes to q8b (read from there by down)
+            const VmxMmvqSeg gate_mm = {L.lin[VMX_L_GATE].mma.p, L.lin[VMX_L_GATE].ggml_type, L.lin[VMX_L_GATE].out_features, 0};
+            const VmxMmvqSeg up_mm = {L.lin[VMX_L_UP].mma.p, L.lin[VMX_L_UP].ggml_type, L.lin[VMX_L_UP].out_features, 0};
+            const int8_t *aq_in = (const int8_t *)m->q8.p;
+            const float *ad_in = (const float *)((const char *)m->q8.p + (((size_t)B * H + 255) & ~(size_t)255));
+            m->q8_alt = m->q8b.p;
+            const int rc_glu = vmx_iq_mmvq_mma_geglu(&gate_mm, &up_mm, aq_in, ad_in, act, aq_of(m), ad_of(m, B, I), H, B, st);
             if (rc_glu) {
                 m->q8_alt = nullptr;
                 return rc_glu;
@@ -1285,7 +1311,14 @@ extern "C" int vmx_gemma4_debug_read(vmx_gemma4 *m, int which, void *dst, size_t
     return VMX_OK;
 }
 
-// Parity / measurement aid: rows from which the Gemma executor's I-quant linears run on the int8 matrix cores (default 5;
+// Parity aid: 0 = gate|up on the matrix cores writes its f32 projections and the stand-alone GeGLU kernel follows (the fused
+// epilogue must give the same bits), 1 = the default.
+extern "C" int vmx_debug_gemma4_mma_geglu(int on) {
+    g_mma_geglu = on != 0;
+    return VMX_OK;
+}
+
+// Parity / measurement aid: rows from which the Gemma executor's I-quant linears run on the int8 matrix cores (default 3;
 // 17 = never, i.e. the per-row kernels for every batch size).
 extern "C" int vmx_debug_iq_mma_min_rows(int rows) {
     VMX_REQUIRE(rows >= 2 && rows <= 17, "debug_iq_mma_min_rows: %d (2 .. 17)", rows);

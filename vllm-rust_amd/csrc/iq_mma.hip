@@ -185,16 +185,27 @@ struct MpArgs {
 // Workgroup = 16 waves = RT row-tile sets (TPW 16-row tiles each) x KS slices of K; wave (rt, ks).  The KS partial sums of a
 // set are added through LDS in slice order.  TPW = 2 shares a wave's activation fragments between two tiles; TPW = 1 is for
 // tensors with so few rows that pairs would leave compute units without a workgroup.
-template <int T, int KS, bool DBG, int TPW>
+// GLU (TPW = 2): tile 0 of a wave is a tile of the gate tensor, tile 1 the same tile of the up tensor (glu.w_up, same type and
+// shape); the epilogue forms act = bf16(bf16(gelu_erf(bf16(gate))) * bf16(up)) and its q8_1 blocks (32 rows = the tiles of two
+// neighbouring tile sets of the workgroup, so KS <= 8) instead of writing the two f32 projections.
+struct MpGlu {
+    const uint8_t *w_up;
+    uint16_t *act;     // [M][n_out] bf16
+    int8_t *aq_out;    // [M][n_out]
+    float *ad_out;     // [M][n_out / 32]
+};
+
+template <int T, int KS, bool DBG, int TPW, bool GLU = false>
 __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, int wg, const int8_t *__restrict__ aq, const float *__restrict__ ad,
-                                        int n_in, int M, int ldy, int32_t *__restrict__ dbg) {
+                                        int n_in, int M, int ldy, int32_t *__restrict__ dbg, const MpGlu *glu = nullptr) {
+    static_assert(!GLU || (TPW == 2 && KS <= 8 && !DBG), "the GeGLU epilogue pairs a gate and an up tile per wave and two tile sets per q8_1 block");
     constexpr int RT = 16 / KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int o = lane & 15, kg = lane >> 4, copy = lane & (Mp<T>::COPIES - 1);
     const int ks = wave % KS, rt = wave / KS;
     const int nsb = n_in >> 8, G = n_in >> 5;
     const int tiles = (sg.n_out + MP_ROWS - 1) / MP_ROWS;
-    const int tile0 = (wg * RT + rt) * TPW;           // this wave's 16-row tiles
+    const int tile0 = GLU ? wg * RT + rt : (wg * RT + rt) * TPW;           // this wave's 16-row tiles
     // K slice of this wave: super-blocks [sb0, sb0 + nb)
     const int base = nsb / KS, rem = nsb % KS;
     const int nb = base + (ks < rem ? 1 : 0), sb0 = ks * base + (ks < rem ? ks : rem);
@@ -202,7 +213,7 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
     float *ad_s = reinterpret_cast<float *>(smem + MpLds<T>::AD_OFF + wave * 512);
     __syncthreads();
 
-    const bool tile_ok[2] = {tile0 < tiles, TPW > 1 && tile0 + 1 < tiles};
+    const bool tile_ok[2] = {tile0 < tiles, GLU ? tile0 < tiles : (TPW > 1 && tile0 + 1 < tiles)};
     const int8_t *arow = aq + (int64_t)min(o, M - 1) * n_in + 8 * kg;      // A operand: lane (m = o, kg)
     const float *adrow = ad + (int64_t)min(o, M - 1) * G + kg;             // staging of a_d: lane (m = o, g = kg, kg + 4)
     mp_i32x4 zero = {0, 0, 0, 0};
@@ -212,7 +223,7 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
         MpRaw<T> raw[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; t++)
-            mp_load<T>(raw[t], sg.w + ((int64_t)min(tile0 + t, tiles - 1) * nsb + sb) * Mp<T>::BYTES, lane);
+            mp_load<T>(raw[t], (GLU && t == 1 ? glu->w_up : sg.w) + ((int64_t)min(GLU ? tile0 : tile0 + t, tiles - 1) * nsb + sb) * Mp<T>::BYTES, lane);
         long au[8];
 #pragma unroll
         for (int s = 0; s < 8; s++) au[s] = *reinterpret_cast<const long *>(arow + 256 * sb + 32 * s);
@@ -285,6 +296,44 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
 #pragma unroll
     for (int t = 0; t < TPW; t++) red[(wave * 2 + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     __syncthreads();
+    if constexpr (GLU) {
+        float *pm = reinterpret_cast<float *>(smem + MpLds<T>::TOTAL);   // [RT][16]: |act| maxima of (tile set, activation row)
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ks == 0) {
+            float4 g = red[((rt * KS) * 2 + 0) * 64 + lane], u = red[((rt * KS) * 2 + 1) * 64 + lane];
+            for (int k = 1; k < KS; k++) {
+                const float4 g2 = red[((rt * KS + k) * 2 + 0) * 64 + lane], u2 = red[((rt * KS + k) * 2 + 1) * 64 + lane];
+                g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+                u.x += u2.x; u.y += u2.y; u.z += u2.z; u.w += u2.w;
+            }
+            const float gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float gg = vmx_bf16_to_f32(vmx_f32_to_bf16(gv[j]));
+                const float ge = vmx_bf16_to_f32(vmx_f32_to_bf16(0.5f * gg * (1.0f + erff(gg * 0.70710678118654752f))));
+                a4[j] = vmx_bf16_to_f32(vmx_f32_to_bf16(ge * vmx_bf16_to_f32(vmx_f32_to_bf16(uv[j]))));
+                const float am = vmx_row16_max(fabsf(a4[j]));
+                if (o == 0) pm[rt * 16 + kg * 4 + j] = am;
+            }
+        }
+        __syncthreads();
+        if (ks == 0 && tile_ok[0]) {
+            const int row = tile0 * MP_ROWS + o;   // n_out % 32 == 0: every row of a valid tile exists, and so does the block's other tile
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int mi = 4 * kg + j;
+                if (mi < M) {
+                    // q8_1 as in vmx_q8_1_emit8: d = amax / 127, q = roundf(v / d), an all-zero block has d = 0 and q = 0
+                    const float amax = fmaxf(pm[rt * 16 + kg * 4 + j], pm[(rt ^ 1) * 16 + kg * 4 + j]);
+                    const float d = amax / 127.0f;
+                    glu->aq_out[(int64_t)mi * sg.n_out + row] = amax != 0.0f ? (int8_t)(int)roundf(a4[j] / d) : (int8_t)0;
+                    glu->act[(int64_t)mi * sg.n_out + row] = vmx_f32_to_bf16(a4[j]);
+                    if ((rt & 1) == 0 && o == 0) glu->ad_out[(int64_t)mi * (sg.n_out >> 5) + (row >> 5)] = d;
+                }
+            }
+        }
+        return;
+    }
     if (ks != 0) return;
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
@@ -316,6 +365,15 @@ __global__ __launch_bounds__(1024) void iq_mma_kernel(MpArgs a, const int8_t *__
     if (sg.type == 18) mp_body<18, KS, DBG, TPW>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
     else if (sg.type == 21) mp_body<21, KS, DBG, TPW>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
     else mp_body<22, KS, DBG, TPW>(smem, sg, wg, aq, ad, n_in, M, ldy, dbg);
+}
+
+template <int KS>
+__global__ __launch_bounds__(1024) void iq_mma_geglu_kernel(MpSeg gate, MpGlu glu, const int8_t *__restrict__ aq, const float *__restrict__ ad, int n_in,
+                                                             int M) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (gate.type == 18) mp_body<18, KS, false, 2, true>(smem, gate, blockIdx.x, aq, ad, n_in, M, 0, nullptr, &glu);
+    else if (gate.type == 21) mp_body<21, KS, false, 2, true>(smem, gate, blockIdx.x, aq, ad, n_in, M, 0, nullptr, &glu);
+    else mp_body<22, KS, false, 2, true>(smem, gate, blockIdx.x, aq, ad, n_in, M, 0, nullptr, &glu);
 }
 
 int mp_lds_bytes(int t) { return t == 18 ? MpLds<18>::TOTAL : t == 21 ? MpLds<21>::TOTAL : MpLds<22>::TOTAL; }
@@ -394,6 +452,33 @@ extern "C" int vmx_iq_mma_pack(int ggml_type, const void *raw, void *packed, int
 // up to three tensors that share the activation rows (q|k|v, gate|up): segs[i].w = 16-row-tile form, outputs at y + segs[i].y_off
 int vmx_iq_mmvq_mma_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int m, int ldy, hipStream_t st) {
     return mp_launch<false>(segs, nseg, aq, ad, y, n_in, m, ldy, nullptr, st);
+}
+
+// gate|up + GeGLU + q8_1 of the result in one launch (2 .. 16 rows): both tensors of one type and shape, whole 32-row q8_1 blocks,
+// at least one super-block per K slice.  The values are those of vmx_iq_mmvq_mma_multi followed by the stand-alone GeGLU kernel,
+// bit for bit (same slice order, same roundings).
+bool vmx_iq_mma_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, int n_in, int m) {
+    return gate && up && gate->w && up->w && mp_supported(gate->ggml_type) && gate->ggml_type == up->ggml_type && gate->n_out == up->n_out &&
+           gate->n_out > 0 && gate->n_out % 32 == 0 && n_in > 0 && n_in % 256 == 0 && (n_in >> 8) >= 8 && m >= 1 && m <= 16;
+}
+int vmx_iq_mmvq_mma_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const int8_t *aq, const float *ad, uint16_t *act, int8_t *aq_out,
+                          float *ad_out, int n_in, int m, hipStream_t st) {
+    VMX_REQUIRE(vmx_iq_mma_geglu_ok(gate, up, n_in, m) && aq && ad && act && aq_out && ad_out, "iq_mmvq_mma_geglu: unsupported shapes or null pointer");
+    VMX_REQUIRE((const void *)aq != (const void *)aq_out, "iq_mmvq_mma_geglu: the q8_1 result must not overwrite the q8_1 input");
+    const int ks = mp_pick_ks(2 * gate->n_out, n_in >> 8) == 4 ? 4 : 8;
+    const int rt = 16 / ks, tiles = gate->n_out / MP_ROWS, wgs = (tiles + rt - 1) / rt;
+    const int lds = mp_lds_bytes(gate->ggml_type) + 256;
+    const MpSeg g = {(const uint8_t *)gate->w, nullptr, gate->ggml_type, gate->n_out, 0};
+    const MpGlu glu = {(const uint8_t *)up->w, act, aq_out, ad_out};
+    if (ks == 4) {
+        if (lds > 64 * 1024) VMX_CHECK_HIP(hipFuncSetAttribute((const void *)iq_mma_geglu_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(iq_mma_geglu_kernel<4>, dim3(wgs), dim3(1024), lds, st, g, glu, aq, ad, n_in, m);
+    } else {
+        if (lds > 64 * 1024) VMX_CHECK_HIP(hipFuncSetAttribute((const void *)iq_mma_geglu_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(iq_mma_geglu_kernel<8>, dim3(wgs), dim3(1024), lds, st, g, glu, aq, ad, n_in, m);
+    }
+    VMX_CHECK_LAUNCH("iq_mmvq(mma, geglu)");
+    return VMX_OK;
 }
 
 extern "C" int vmx_iq_mmvq_mma_f32(int ggml_type, const void *packed, const int8_t *aq, const float *ad, float *y, int n_out, int n_in, int m,

@@ -142,6 +142,9 @@ int vmx_iq_mmvq_packed_geglu(const VmxMmvqSeg *gate_packed, const VmxMmvqSeg *up
 
 // iq_mma.hip: the same MMVQ for 2 .. 16 activation rows on the int8 matrix cores over the 16-row-tile form (vmx_iq_mma_pack)
 bool vmx_iq_mma_supported(int ggml_type);
+bool vmx_iq_mma_geglu_ok(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, int n_in, int m);
+int vmx_iq_mmvq_mma_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const int8_t *aq, const float *ad, uint16_t *act, int8_t *aq_out,
+                          float *ad_out, int n_in, int m, hipStream_t st);
 int vmx_iq_mmvq_mma_multi(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int m, int ldy, hipStream_t st);
 
 // kquant_kernels.hip
