@@ -236,11 +236,12 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
 #pragma unroll
         for (int t = 0; t < TPW; t++) dw[t] = vmx_f16_to_f32((uint16_t)raw[t].d);
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
+        for (int t = 0; t < TPW; t++) {
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
             const float4 a4 = *reinterpret_cast<const float4 *>(ad_s + s * 16 + 4 * kg);   // a_d of this lane's four rows m = 4 kg + j
             const float adv[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int t = 0; t < TPW; t++) {
+            {
                 uint32_t w0, w1;
                 int ls0, ls1;
                 mp_decode<T>(raw[t], s, kg, copy, smem, w0, w1, ls0, ls1);
@@ -287,6 +288,7 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
             // one sub-block (of both tiles) at a time: without the fence the scheduler interleaves all sixteen decodes of a
             // super-block and the kernel needs twice the registers a 16-wave workgroup may have
             __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     if constexpr (DBG) return;
