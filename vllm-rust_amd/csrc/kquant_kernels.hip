@@ -324,23 +324,28 @@ __global__ __launch_bounds__(1024) void q3k_gemm16_kernel(const uint8_t *__restr
             const float dd = vmx_f16_to_f32((uint16_t)cur.d), dd32 = -32.0f * dd;
             const uint16_t *xsb = xa + sb * 256;
 #pragma unroll
-            for (int g = 0; g < 8; g++) {   // g = 4 n + j: weights 128 n + 32 j + 16 hi + (0..15), scale 2 g + hi
-                const int n = g >> 2, j = g & 3;
+            for (int n = 0; n < 2; n++) {   // eight independent MFMAs in flight, then their eight scalings: no wait per group
+                vmx_f32x4 acc[8];
 #pragma unroll
-                for (int hi = 0; hi < 2; hi++) {
+                for (int u = 0; u < 8; u++) {   // u = 2 j + hi; g = 4 n + j: weights 128 n + 32 j + 16 hi + (0..15), scale 2 g + hi
+                    const int j = u >> 1, hi = u & 1, g = 4 * n + j;
                     const uint32_t q4 = (cur.qs[n][hi] >> (2 * j)) & 0x03030303u;
                     const uint32_t t4 = q4 | (((cur.hm[hi] >> g) & 0x01010101u) << 2);
                     const uint32_t hib = __builtin_amdgcn_perm(0x40403F00u, 0xBFC0C0C0u, t4);   // high / low bytes of bf16(t - 4)
                     const uint32_t lob = __builtin_amdgcn_perm(0x40008000u, 0x80004080u, t4);
                     const uint2 bw = make_uint2(__builtin_amdgcn_perm(hib, lob, 0x05010400u), __builtin_amdgcn_perm(hib, lob, 0x07030602u));
                     const uint2 aw = *reinterpret_cast<const uint2 *>(xsb + 32 * g + 16 * hi);
-                    const vmx_f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(q3_s4, aw), __builtin_bit_cast(q3_s4, bw),
-                                                                                   vmx_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(q3_s4, aw), __builtin_bit_cast(q3_s4, bw),
+                                                                       vmx_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = u >> 1, hi = u & 1, g = 4 * n + j;
                     // d * (scale - 32) is exact in f32 (11-bit x 6-bit), so byte -> float -> one fma gives the same bits
                     const float fsc = fmaf((float)((aux[g >> 1] >> (8 * (((2 * g) & 3) + hi))) & 0xFFu), dd, dd32);
                     const q3_f2 f2 = {fsc, fsc};
-                    fin_lo = __builtin_elementwise_fma(f2, acc.lo, fin_lo);   // v_pk_fma_f32
-                    fin_hi = __builtin_elementwise_fma(f2, acc.hi, fin_hi);
+                    fin_lo = __builtin_elementwise_fma(f2, acc[u].lo, fin_lo);   // v_pk_fma_f32
+                    fin_hi = __builtin_elementwise_fma(f2, acc[u].hi, fin_hi);
                 }
             }
         }
