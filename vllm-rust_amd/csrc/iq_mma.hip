@@ -237,42 +237,35 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
         for (int t = 0; t < TPW; t++) dw[t] = vmx_f16_to_f32((uint16_t)raw[t].d);
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(ad_s + s * 16 + 4 * kg);   // a_d of this lane's four rows m = 4 kg + j
-            const float adv[4] = {a4.x, a4.y, a4.z, a4.w};
-            {
-                uint32_t w0, w1;
-                int ls0, ls1;
-                mp_decode<T>(raw[t], s, kg, copy, smem, w0, w1, ls0, ls1);
-                const long bw = (long)(((unsigned long long)w1 << 32) | w0);
+            // software pipeline of depth one: the matrix-core product of sub-block s is issued, then sub-block s - 1 (whose product
+            // has landed meanwhile) takes its integer scale step and the two f32 scales; sums stay in sub-block order
+            mp_i32x4 cc[2][2];
+            int lsv[2][2];
+            float4 adq[2];
+            auto finish = [&](int s) {
+                const int q = s & 1;
+                const float adv[4] = {adq[q].x, adq[q].y, adq[q].z, adq[q].w};   // a_d of this lane's four rows m = 4 kg + j
+                const int ls0 = lsv[q][0], ls1 = lsv[q][1];
                 float sub[4];
                 if constexpr (T == 22) {
-                    // the halves of a sub-block (weights 0..15 / 16..31 = k-groups 0, 1 / 2, 3) carry their own scale nibbles
-                    const long b_lo = kg < 2 ? bw : 0l, b_hi = kg < 2 ? 0l : bw;
-                    const mp_i32x4 c0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(au[s], b_lo, zero, 0, 0, 0);
-                    const mp_i32x4 c1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(au[s], b_hi, zero, 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {   // (s0 ls0 + s1 ls1 + (s0 + s1) / 2) / 4, C truncating divisions as shifts
-                        const int s0 = c0[j], s1 = c1[j], h = s0 + s1;
+                        const int s0 = cc[q][0][j], s1 = cc[q][1][j], h = s0 + s1;
                         const int half = (h + (int)((uint32_t)h >> 31)) >> 1;
                         const int v = __mul24(s0, ls0) + __mul24(s1, ls1) + half;
                         sub[j] = (float)((v + (int)(((uint32_t)(v >> 31)) >> 30)) >> 2);
                     }
+                } else if constexpr (T == 18) {
+                    // (ls * sumi + sumi / 2) / 2 with C truncating divisions == trunc((2 ls + 1) * sumi / 4): 2 ls + 1 is odd, so
+                    // the product has the parity of sumi and dropping that bit towards zero first cannot change the quotient;
+                    // |product| < 2^23: exact in f32
+                    const float f = 0.25f * (float)(2 * ls0 + 1);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sub[j] = truncf((float)cc[q][0][j] * f);
                 } else {
-                    const mp_i32x4 c = __builtin_amdgcn_mfma_i32_16x16x32_i8(au[s], bw, zero, 0, 0, 0);
-                    if constexpr (T == 18) {
-                        // (ls * sumi + sumi / 2) / 2 with C truncating divisions == trunc((2 ls + 1) * sumi / 4): 2 ls + 1 is odd, so
-                        // the product has the parity of sumi and dropping that bit towards zero first cannot change the quotient;
-                        // |product| < 2^23: exact in f32
-                        const float f = 0.25f * (float)(2 * ls0 + 1);
+                    const float f = (float)(2 * ls0 + 1);
 #pragma unroll
-                        for (int j = 0; j < 4; j++) sub[j] = truncf((float)c[j] * f);
-                    } else {
-                        const float f = (float)(2 * ls0 + 1);
-#pragma unroll
-                        for (int j = 0; j < 4; j++) sub[j] = (float)c[j] * f;
-                    }
+                    for (int j = 0; j < 4; j++) sub[j] = (float)cc[q][0][j] * f;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[t][j] += dw[t] * adv[j] * sub[j];
@@ -284,11 +277,28 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
                         if (tile_ok[t] && row < sg.n_out && mi < M) dbg[((int64_t)row * M + mi) * G + sb * 8 + s] = (int)sub[j];
                     }
                 }
+            };
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int q = s & 1;
+                adq[q] = *reinterpret_cast<const float4 *>(ad_s + s * 16 + 4 * kg);
+                uint32_t w0, w1;
+                mp_decode<T>(raw[t], s, kg, copy, smem, w0, w1, lsv[q][0], lsv[q][1]);
+                const long bw = (long)(((unsigned long long)w1 << 32) | w0);
+                if constexpr (T == 22) {
+                    // the halves of a sub-block (weights 0..15 / 16..31 = k-groups 0, 1 / 2, 3) carry their own scale nibbles
+                    const long b_lo = kg < 2 ? bw : 0l, b_hi = kg < 2 ? 0l : bw;
+                    cc[q][0] = __builtin_amdgcn_mfma_i32_16x16x32_i8(au[s], b_lo, zero, 0, 0, 0);
+                    cc[q][1] = __builtin_amdgcn_mfma_i32_16x16x32_i8(au[s], b_hi, zero, 0, 0, 0);
+                } else {
+                    cc[q][0] = __builtin_amdgcn_mfma_i32_16x16x32_i8(au[s], bw, zero, 0, 0, 0);
+                }
+                if (s > 0) finish(s - 1);
+                // one sub-block at a time: without the fence the scheduler interleaves all the decodes of a super-block and the
+                // kernel needs twice the registers a 16-wave workgroup may have
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // one sub-block (of both tiles) at a time: without the fence the scheduler interleaves all sixteen decodes of a
-            // super-block and the kernel needs twice the registers a 16-wave workgroup may have
-            __builtin_amdgcn_sched_barrier(0);
-            }
+            finish(7);
         }
     }
     if constexpr (DBG) return;
