@@ -115,14 +115,25 @@ template <int T> struct MpLds {
 
 template <int T> __device__ __forceinline__ void mp_build_tables(unsigned char *smem, int tid) {
     constexpr int C = Mp<T>::COPIES;
+    // every entry of a thread is requested before the first one is stored: one memory round trip, not one per pass
+    constexpr int PASSES = Mp<T>::GRID_N * C / 1024;
+    static_assert(Mp<T>::GRID_N * C % 1024 == 0, "whole passes of the 1024 threads");
     if constexpr (Mp<T>::GRID_ENTRY == 4) {
         const uint32_t *src = T == 18 ? iq3xxs_grid : iq3s_grid;
         uint32_t *g = reinterpret_cast<uint32_t *>(smem);
-        for (int i = tid; i < Mp<T>::GRID_N * C; i += 1024) g[i] = src[i / C];
+        uint32_t v[PASSES];
+#pragma unroll
+        for (int k = 0; k < PASSES; k++) v[k] = src[(tid + 1024 * k) / C];
+#pragma unroll
+        for (int k = 0; k < PASSES; k++) g[tid + 1024 * k] = v[k];
     } else {
         const uint2 *src = reinterpret_cast<const uint2 *>(iq2s_grid);
         uint2 *g = reinterpret_cast<uint2 *>(smem);
-        for (int i = tid; i < Mp<T>::GRID_N * C; i += 1024) g[i] = src[i / C];
+        uint2 v[PASSES];
+#pragma unroll
+        for (int k = 0; k < PASSES; k++) v[k] = src[(tid + 1024 * k) / C];
+#pragma unroll
+        for (int k = 0; k < PASSES; k++) g[tid + 1024 * k] = v[k];
     }
     if (tid < 256) {
         const uint32_t s8 = (uint32_t)tid;
