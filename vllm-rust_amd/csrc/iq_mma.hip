@@ -253,6 +253,7 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
             mp_i32x4 cc[2][2];
             int lsv[2][2];
             float4 adq[2];
+            float blk[4] = {0.f, 0.f, 0.f, 0.f};   // sum over the super-block's sub-blocks of a_d * sub-dot; the weight's d multiplies it once
             auto finish = [&](int s) {
                 const int q = s & 1;
                 const float adv[4] = {adq[q].x, adq[q].y, adq[q].z, adq[q].w};   // a_d of this lane's four rows m = 4 kg + j
@@ -279,7 +280,7 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
                     for (int j = 0; j < 4; j++) sub[j] = (float)cc[q][0][j] * f;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[t][j] += dw[t] * adv[j] * sub[j];
+                for (int j = 0; j < 4; j++) blk[j] = fmaf(adv[j], sub[j], blk[j]);
                 if constexpr (DBG) {
                     const int row = (tile0 + t) * MP_ROWS + o;
 #pragma unroll
@@ -310,6 +311,8 @@ __device__ __forceinline__ void mp_body(unsigned char *smem, const MpSeg &sg, in
                 __builtin_amdgcn_sched_barrier(0);
             }
             finish(7);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[t][j] = fmaf(dw[t], blk[j], acc[t][j]);
         }
     }
     if constexpr (DBG) return;
@@ -412,6 +415,16 @@ int mp_pick_ks(int total_rows, int nsb) {
     return 16;
 }
 
+// K slices per workgroup of the fused gate|up + GeGLU launch: four (four tile sets per workgroup) where that still gives three
+// quarters of the compute units a workgroup, else eight.  A compute unit holds one of these workgroups at a time, so a launch that
+// fits in one round pays the table build, the first loads and the slice sums once: Gemma-4-12B gate|up at 16 rows, 240 workgroups
+// of four slices against 480 of eight, 5.35 -> 5.23 ms per step.
+int mp_glu_ks(int n_out) {
+    static const int ks_force = vmx_tune("VMX_IQ_MMA_GLU_KS", 0);
+    const int tiles4 = (n_out / MP_ROWS + 3) / 4;
+    return ks_force == 4 || ks_force == 8 ? ks_force : (4 * tiles4 >= 3 * vmx_num_cus() ? 4 : 8);
+}
+
 template <bool DBG>
 int mp_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *ad, float *y, int n_in, int m, int ldy, int32_t *dbg,
               hipStream_t st) {
@@ -419,7 +432,11 @@ int mp_launch(const VmxMmvqSeg *segs, int nseg, const int8_t *aq, const float *a
     a.nseg = nseg;
     int total_rows = 0, lds = 0;
     for (int i = 0; i < nseg; i++) total_rows += segs[i].n_out;
-    const int ks = mp_pick_ks(total_rows, n_in >> 8);
+    // a gate|up pair (two tensors of one type and shape) takes the K slices of the fused GeGLU launch, so that the two forms add
+    // the same sub-blocks in the same order and agree bit for bit
+    const bool glu_pair = !DBG && nseg == 2 && segs[0].ggml_type == segs[1].ggml_type && segs[0].n_out == segs[1].n_out &&
+                          segs[0].n_out % 32 == 0 && (n_in >> 8) >= 8;
+    const int ks = glu_pair ? mp_glu_ks(segs[0].n_out) : mp_pick_ks(total_rows, n_in >> 8);
     // one tile per wave where tile pairs would leave compute units without a workgroup (Gemma-4-12B at 16 rows: q|k|v 128, o_proj
     // and down 120 workgroups of pairs on 256 compute units)
     static const int tpw_force = vmx_tune("VMX_IQ_MMA_TPW", 0);
@@ -488,13 +505,7 @@ int vmx_iq_mmvq_mma_geglu(const VmxMmvqSeg *gate, const VmxMmvqSeg *up, const in
                           float *ad_out, int n_in, int m, hipStream_t st) {
     VMX_REQUIRE(vmx_iq_mma_geglu_ok(gate, up, n_in, m) && aq && ad && act && aq_out && ad_out, "iq_mmvq_mma_geglu: unsupported shapes or null pointer");
     VMX_REQUIRE((const void *)aq != (const void *)aq_out, "iq_mmvq_mma_geglu: the q8_1 result must not overwrite the q8_1 input");
-    // K slices per workgroup: four (four tile sets per workgroup) where that still gives three quarters of the compute units a
-    // workgroup, else eight.  A compute unit holds one of these workgroups at a time, so a launch that fits in one round pays the
-    // table build, the first loads and the slice sums once: Gemma-4-12B gate|up at 16 rows, 240 workgroups of four slices against
-    // 480 of eight, 5.35 -> 5.23 ms per step.
-    static const int ks_force = vmx_tune("VMX_IQ_MMA_GLU_KS", 0);
-    const int tiles4 = (gate->n_out / MP_ROWS + 3) / 4;
-    const int ks = ks_force == 4 || ks_force == 8 ? ks_force : (4 * tiles4 >= 3 * vmx_num_cus() ? 4 : 8);
+    const int ks = mp_glu_ks(gate->n_out);
     const int rt = 16 / ks, tiles = gate->n_out / MP_ROWS, wgs = (tiles + rt - 1) / rt;
     const int lds = mp_lds_bytes(gate->ggml_type) + 256;
     const MpSeg g = {(const uint8_t *)gate->w, nullptr, gate->ggml_type, gate->n_out, 0};
